@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload chamfer|fps|ball_group]
+
+Default workload = BASELINE.json configs[1]: Chamfer forward+backward, B=32 (per GPU), N=M=16384,
+C=3, fp32, synthetic area-uniform unit-sphere clouds, through the public autograd API
+(pytorch_points_amd.network.model_loss.nndistance -> _ext.losses -> C ABI -> HIP kernels).
+A "step" is one forward + one backward over that batch, inputs resident in HBM.
+
+Metric: point-pairs/s = n_gpus * 2*B*N*M / t(step) (both directions counted).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL): the batch is
+sharded, B=32 per rank (weak scaling); each step also all-gathers the per-shard (dist, idx) over
+xGMI as BASELINE.json's north_star specifies.  Timing = barrier + synchronize on both sides, MAX
+over ranks; rank 0 prints ONE JSON line.
+
+The JSON line also carries
+  roofline      HBM roofline of the dominant kernel (the forward scan): algorithmic bytes per
+                launch / its average duration, HIP events on the launch stream inside the timed loop
+  valu          the roof that actually binds that kernel (fp32 VALU issue)
+  cpu_baseline  the CPU oracle (a port of the reference semantics; the reference has no CPU
+                path) timed on this host's cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
+VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz fp32 lane-ops/s (same table)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="chamfer", choices=["chamfer", "fps", "ball_group"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--variant", type=int, default=0, help="forward kernel variant (0 = automatic)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        return dist, world, rank, local
+    if args.gpus > 1:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
+                         "(one rank per GPU)" % args.gpus)
+    torch.cuda.set_device(0)
+    return None, 1, 0, 0
+
+
+def timed_region(dist, fn, steps, warmup, device):
+    """W untimed steps, then exactly K steps between barrier+synchronize; MAX over ranks (seconds)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+# ------------------------------------------------------------------------------------- chamfer
+def cpu_baseline_chamfer(N, C):
+    """Oracle fwd+bwd on a bounded sample of the workload (same N=M, fewer batch elements)."""
+    import oracle
+    from pytorch_points_amd import synthetic as S
+    oracle.build()
+    x1 = S.unit_sphere(0, 1, N, C)
+    x2 = S.unit_sphere(1, 1, N, C)
+
+    def run(a, b):
+        bb = a.shape[0]
+        d1, i1, d2, i2 = oracle.chamfer_forward(a, b)
+        g = np.full((bb, N), 1.0 / (bb * N), np.float32)
+        oracle.chamfer_backward(a, b, g, g, i1, i2)
+
+    run(x1[:, :256], x2[:, :256])  # thread-pool warm-up
+    t0 = time.perf_counter()
+    run(x1, x2)
+    t1 = time.perf_counter() - t0
+    bs = int(max(1, min(32, round(12.0 / max(t1, 1e-3)))))
+    a = np.ascontiguousarray(np.repeat(x1, bs, 0))
+    b = np.ascontiguousarray(np.repeat(x2, bs, 0))
+    t0 = time.perf_counter()
+    run(a, b)
+    dt = time.perf_counter() - t0
+    return {"value": 2.0 * bs * N * N / dt, "unit": "pairs/s", "cores": oracle.num_threads(),
+            "kind": "port", "sample": "Chamfer fwd+bwd B=%d N=M=%d C=%d (oracle/pp_oracle.c, OpenMP, "
+            "AVX2+FMA), %.2f s" % (bs, N, C, dt)}
+
+
+def bench_chamfer(args, dist, world, rank, device):
+    from pytorch_points_amd import _lib, synthetic as S
+    from pytorch_points_amd.network.model_loss import nndistance
+    import ctypes
+    B = args.batch or 32
+    N = args.points or 16384
+    M, C = N, 3
+    if args.variant:
+        fn = _lib.lib().pp_debug_set_nmdistance_variant
+        fn.argtypes = [ctypes.c_int]
+        fn.restype = None
+        fn(args.variant)
+    # rank r owns batch elements [r*B, (r+1)*B) of the global batch; seeds 0 / 1 as SURVEY.md §8d
+    x1 = torch.from_numpy(S.unit_sphere(0, world * B, N, C)[rank * B:(rank + 1) * B].copy()).to(device)
+    x2 = torch.from_numpy(S.unit_sphere(1, world * B, M, C)[rank * B:(rank + 1) * B].copy()).to(device)
+    x1.requires_grad_(True)
+    x2.requires_grad_(True)
+    g1 = torch.full((B, N), 1.0 / (B * N), device=device)   # gradient of dist.mean()
+    g2 = torch.full((B, M), 1.0 / (B * M), device=device)
+    gathered = None
+    if dist is not None:
+        gathered = [torch.empty(world * B, N, dtype=torch.float32, device=device) for _ in range(2)] + \
+                   [torch.empty(world * B, N, dtype=torch.int32, device=device) for _ in range(2)]
+    fwd_events = []
+
+    def step():
+        x1.grad = None
+        x2.grad = None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        d1, d2, i1, i2 = nndistance(x1, x2)
+        e1.record()
+        fwd_events.append((e0, e1))
+        if dist is not None:   # all-gather of the per-shard (dist, idx) over xGMI (RCCL)
+            for out, src in zip(gathered, (d1.detach(), d2.detach(), i1, i2)):
+                dist.all_gather_into_tensor(out, src)
+        torch.autograd.backward([d1, d2], [g1, g2])
+
+    for _ in range(args.warmup):
+        step()
+    fwd_events.clear()
+    dt = timed_region(dist, step, args.steps, 0, device)
+    torch.cuda.synchronize()
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events[-args.steps:]]))
+
+    pairs_per_step = 2.0 * B * N * M * world
+    ms = dt / args.steps * 1e3
+    alg_bytes_fwd = 4.0 * C * B * (N + M) + 8.0 * B * (N + M)
+    hbm_gbs = alg_bytes_fwd / (fwd_ms * 1e-3) / 1e9
+    # VALU lane-ops actually issued per pair by the kernel: 3 sub + 1 mul + 2 fma + 1/2 min3 + 13/32
+    # per-group bookkeeping (DESIGN.md "nmdist_fwd_c3_kernel")
+    laneops = 2.0 * B * N * M * 6.90625
+    out = {
+        "metric": "chamfer_fwd_bwd_point_pairs_per_s", "value": pairs_per_step / (dt / args.steps),
+        "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Chamfer fwd+bwd B=%d/GPU N=M=%d C=3 fp32, area-uniform unit sphere"
+                               % (B, N), "global_batch": B * world,
+                   "parallelism": "batch-shard x%d%s" % (world, " + RCCL all-gather(dist,idx)" if world > 1 else "")},
+        "fwd_ms": fwd_ms,
+        "roofline": {"bound": "hbm", "kernel": "nmdist_fwd_c3_kernel", "achieved": hbm_gbs,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                     "traffic": None,
+                     "note": "exact brute force is fp32-VALU-bound (6500 flop/B); see 'valu'"},
+        "valu": {"achieved": laneops / (fwd_ms * 1e-3), "peak": VALU_PEAK_LANEOPS,
+                 "unit": "lane-ops/s", "frac": laneops / (fwd_ms * 1e-3) / VALU_PEAK_LANEOPS,
+                 "pairs_per_s_fwd": 2.0 * B * N * M / (fwd_ms * 1e-3)},
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_chamfer(N, C)
+    return out
+
+
+# ------------------------------------------------------------------------ fps + gather (config 3)
+def bench_fps(args, dist, world, rank, device):
+    from pytorch_points_amd import synthetic as S
+    from pytorch_points_amd.network.geo_operations import furthest_point_sample
+    B = args.batch or 16
+    N = args.points or 65536
+    npoint = 4096
+    x = torch.from_numpy(S.unit_sphere(0, B, N)).to(device)
+
+    def step():
+        furthest_point_sample(x, npoint, NCHW=False, seedIdx=0)
+
+    dt = timed_region(dist, step, args.steps, args.warmup, device)
+    ms = dt / args.steps * 1e3
+    updates = float(B) * (npoint - 1) * N * world
+    alg_bytes = 12.0 * B * N + 4.0 * B * npoint
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {"metric": "fps_point_updates_per_s", "value": updates / (dt / args.steps), "unit": "updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "furthest_point_sample + gather_points B=%d N=%d npoint=%d" % (B, N, npoint),
+                       "parallelism": "replicas x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "fps_block_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "note": "serial chain of npoint-1 dependent steps: latency-bound, not HBM-bound"},
+            "us_per_pick": ms * 1e3 / (npoint - 1)}
+
+
+# ------------------------------------------------------------- ball_query + group_points (config 4)
+def bench_ball_group(args, dist, world, rank, device):
+    from pytorch_points_amd import synthetic as S
+    from pytorch_points_amd.network.operations import ball_query, grouping_operation
+    B = args.batch or 32
+    N = args.points or 16384
+    C, ns, r = 128, 64, 0.1
+    x = torch.from_numpy(S.unit_sphere(0, B, N)).to(device)
+    centres = x[:, ::4].contiguous()                       # npoint = N/4 = 4096
+    npoint = centres.shape[1]
+    feats = torch.from_numpy(S.normal(2, (B, C, N))).to(device)
+    ev = []
+
+    def step():
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        idx = ball_query(r, ns, x, centres)
+        e[1].record()
+        grouping_operation(feats, idx)
+        e[2].record()
+        ev.append(e)
+
+    dt = timed_region(dist, step, args.steps, args.warmup, device)
+    torch.cuda.synchronize()
+    bq_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev[-args.steps:]]))
+    gp_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev[-args.steps:]]))
+    ms = dt / args.steps * 1e3
+    gp_bytes = 4.0 * B * C * N + 4.0 * B * npoint * ns + 4.0 * B * C * npoint * ns
+    gbs = gp_bytes / (gp_ms * 1e-3) / 1e9
+    return {"metric": "group_points_output_bytes_per_s", "value": 4.0 * B * C * npoint * ns * world / (gp_ms * 1e-3),
+            "unit": "B/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ball_query r=%.2f nsample=%d + group_points B=%d N=%d npoint=%d C=%d"
+                                   % (r, ns, B, N, npoint, C), "parallelism": "batch-shard x%d" % world},
+            "ball_query_ms": bq_ms, "group_points_ms": gp_ms,
+            "ball_query_pairs_per_s": float(B) * npoint * N / (bq_ms * 1e-3),
+            "roofline": {"bound": "hbm", "kernel": "group_points_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    dist, world, rank, local = init_dist(args)
+    device = torch.device("cuda", local)
+    fn = {"chamfer": bench_chamfer, "fps": bench_fps, "ball_group": bench_ball_group}[args.workload]
+    out = fn(args, dist, world, rank, device)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

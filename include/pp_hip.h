@@ -1,0 +1,128 @@
+/*
+ * pp_hip.h -- C ABI of libpp_hip.so, the MI355X (gfx950) implementation of the pytorch_points
+ * `_ext` hot path.
+ *
+ * Each entry point replaces one function of the reference's pybind modules
+ * `pytorch_points._ext.losses` (_ext/nmdistance.cpp:30-34) and `pytorch_points._ext.sampling`
+ * (_ext/sampling.cpp:205-216); the reference interface each one stands in for is cited beside it
+ * (paths relative to /root/reference/pytorch_points/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous memory; fp32 data, int32 indices;
+ *   - the caller allocates every output and every workspace; nothing is allocated, retained or
+ *     synchronised inside the library; no global mutable state (thread-safe);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); all work is
+ *     enqueued on it, on the device that is current when the call is made;
+ *   - return value: 0 on success, otherwise a hipError_t value (PP_EINVAL = hipErrorInvalidValue
+ *     for bad sizes / null pointers).  Never exit()s, never prints.
+ *   - NaN coordinates are outside the contract (the reference's behaviour for them is an
+ *     artefact of its 512-point chunking).
+ */
+#ifndef PP_HIP_H
+#define PP_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_OK 0
+#define PP_EINVAL 1 /* == hipErrorInvalidValue */
+
+/* library / build identification: "pp_hip <version> gfx950" */
+const char* pp_version(void);
+
+/* ---- _ext.losses ------------------------------------------------------------------------- */
+
+/* Replaces losses.nmdistance_forward(xyz1,xyz2,dist1,dist2,idx1,idx2)
+ *   (_ext/nmdistance.cpp:13-15 -> chamfer_cuda_forward, _ext/nmdistance_cuda.cu:118-140).
+ * xyz1 (B,N,C), xyz2 (B,M,C) -> dist1,idx1 (B,N): nearest xyz2 point of every xyz1 point
+ * (squared distance, lowest index on exact ties); dist2,idx2 (B,M): the converse.
+ * N == 0 or M == 0: outputs are zero-filled (what the reference's Python wrapper leaves). */
+int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, float* dist1, int* idx1,
+                              float* dist2, int* idx2, int B, int N, int M, int C, void* stream);
+
+/* Replaces losses.labeled_nmdistance_forward(xyz1,xyz2,label1,label2,dist1,dist2,idx1,idx2)
+ *   (_ext/nmdistance.cpp:17-20 -> labeled_chamfer_cuda_forward, _ext/nmdistance_cuda.cu:142-166).
+ * label1 (B,N), label2 (B,M) as fp32.  Unmatched query: idx -1, dist 0. */
+int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float* xyz2, const float* label1,
+                                      const float* label2, float* dist1, int* idx1, float* dist2,
+                                      int* idx2, int B, int N, int M, int C, void* stream);
+
+/* Replaces losses.nmdistance_backward(xyz1,xyz2,gradxyz1,gradxyz2,graddist1,graddist2,idx1,idx2)
+ *   (_ext/nmdistance.cpp:23-27 -> chamfer_cuda_backward, _ext/nmdistance_cuda.cu:195-221).
+ * gradxyz1 (B,N,C), gradxyz2 (B,M,C) are fully overwritten (the reference zeroes them first). */
+int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2, const float* graddist1,
+                               const float* graddist2, const int* idx1, const int* idx2,
+                               float* gradxyz1, float* gradxyz2, int B, int N, int M, int C,
+                               void* stream);
+
+/* ---- _ext.sampling ----------------------------------------------------------------------- */
+
+/* Replaces sampling.furthest_sampling(m, seedIdx, input, temp, idx)
+ *   (_ext/sampling.cpp:68-82 -> furthest_sampling_cuda_forward, _ext/sampling_cuda.cu:235-325).
+ * xyz (B,N,3); temp (B,N) in/out running min squared distance (caller pre-fills 1e10,
+ * network/geo_operations.py:33); idx (B,npoint) out, idx[:,0] = seed_idx.
+ * workspace: pp_furthest_sampling_workspace_bytes(...) bytes of scratch (may be NULL if that is 0). */
+size_t pp_furthest_sampling_workspace_bytes(int B, int N, int npoint);
+int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx, int B, int N, int npoint,
+                             int seed_idx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Replaces sampling.gather_forward(b,c,n,npoints,points,idx,out)
+ *   (_ext/sampling.cpp:19-28 -> _ext/sampling_cuda.cu:9-45).  points (B,C,N), idx (B,M) -> out (B,C,M) */
+int pp_gather_forward_f32(const float* points, const int* idx, float* out, int B, int C, int N,
+                          int M, void* stream);
+
+/* Replaces sampling.gather_backward(b,c,n,npoints,grad_out,idx,grad_points)
+ *   (_ext/sampling.cpp:31-41 -> _ext/sampling_cuda.cu:47-84).  ACCUMULATES into grad_points (B,C,N),
+ * which the caller zero-fills (network/operations.py:76-77). */
+int pp_gather_backward_f32(const float* grad_out, const int* idx, float* grad_points, int B, int C,
+                           int N, int M, void* stream);
+
+/* Replaces sampling.ball_query(new_xyz, xyz, radius, nsample)
+ *   (_ext/sampling.cpp:85-104 -> _ext/sampling_cuda.cu:340-397).
+ * new_xyz (B,M,3) centres, xyz (B,N,3) -> idx (B,M,nsample), fully written (rows with no hit are
+ * written as zeros, which is what the reference's zero-filled allocation leaves). */
+int pp_ball_query_f32(const float* new_xyz, const float* xyz, int* idx, int B, int N, int M,
+                      float radius, int nsample, void* stream);
+
+/* Replaces sampling.group_points(points, idx)
+ *   (_ext/sampling.cpp:113-138 -> _ext/sampling_cuda.cu:447-478).
+ * points (B,C,N), idx (B,npoint,nsample) -> out (B,C,npoint,nsample), fully written. */
+int pp_group_points_f32(const float* points, const int* idx, float* out, int B, int C, int N,
+                        int npoint, int nsample, void* stream);
+
+/* Replaces sampling.group_points_grad(grad_out, idx, n)
+ *   (_ext/sampling.cpp:140-161 -> _ext/sampling_cuda.cu:482-513).
+ * ACCUMULATES into grad_points (B,C,N), which the caller zero-fills. */
+int pp_group_points_grad_f32(const float* grad_out, const int* idx, float* grad_points, int B,
+                             int C, int N, int npoint, int nsample, void* stream);
+
+/* Replaces sampling.three_nn_wrapper(b,n,m,unknown,known,dist2,idx)
+ *   (_ext/sampling.cpp:163-172 -> _ext/interpolate_gpu.cu:9-74).
+ * unknown (B,N,3), known (B,M,3) -> dist2 (B,N,3) squared distances ascending, idx (B,N,3).
+ * M < 3: unused slots hold +inf / index 0. */
+int pp_three_nn_f32(const float* unknown, const float* known, float* dist2, int* idx, int B, int N,
+                    int M, void* stream);
+
+/* Replaces sampling.three_interpolate_wrapper(b,c,m,n,points,idx,weight,out)
+ *   (_ext/sampling.cpp:175-188 -> _ext/interpolate_gpu.cu:77-117).
+ * points (B,C,M), idx (B,N,3), weight (B,N,3) -> out (B,C,N) */
+int pp_three_interpolate_f32(const float* points, const int* idx, const float* weight, float* out,
+                             int B, int C, int M, int N, void* stream);
+
+/* Replaces sampling.three_interpolate_grad_wrapper(b,c,n,m,grad_out,idx,weight,grad_points)
+ *   (_ext/sampling.cpp:190-203 -> _ext/interpolate_gpu.cu:120-160).
+ * ACCUMULATES into grad_points (B,C,M), which the caller zero-fills
+ * (network/pointnet2_utils.py:82). */
+int pp_three_interpolate_grad_f32(const float* grad_out, const int* idx, const float* weight,
+                                  float* grad_points, int B, int C, int N, int M, void* stream);
+
+/* cuda_utils.h:11-16 opt_n_threads -- the FPS tie-break depends on it, so it is part of the ABI */
+int pp_opt_n_threads(int work_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PP_HIP_H */

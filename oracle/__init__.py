@@ -1,0 +1,218 @@
+"""CPU oracle for the pytorch_points `_ext` hot path -- TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: the reference holds no tests/golden vectors for this path and cannot be built or
+imported in this image (see oracle/pp_oracle.c header and DESIGN.md).  The C restatement in
+``pp_oracle.c`` follows the reference kernels line by line and is cross-checked against the
+independent fp64 brute force in ``oracle/bruteforce.py``.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package.  Nothing in ``pytorch_points_amd`` does.
+
+numpy in, numpy out; every wrapper mirrors one C function of ``pp_oracle.c``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "pp_oracle.c")
+_SO = os.path.join(_HERE, "libpp_oracle.so")
+
+# x86-64-v3 (AVX2 + FMA) rather than -march=native: the .so is built in the dev container and
+# travels to the GPU box, whose host CPU may be a different micro-architecture.
+# -ffp-contract=off: every fused multiply-add in the canonical arithmetic is an explicit fmaf.
+_CFLAGS = ["-O3", "-march=x86-64-v3", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+           "-fPIC", "-shared", "-std=c11", "-Wall"]
+
+
+def build(force=False):
+    """Compile pp_oracle.c -> libpp_oracle.so with gcc (no-op when up to date)."""
+    if (not force and os.path.exists(_SO)
+            and os.path.getmtime(_SO) >= os.path.getmtime(_SRC)):
+        return _SO
+    cmd = ["gcc", *_CFLAGS, _SRC, "-o", _SO, "-lm"]
+    subprocess.run(cmd, check=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO) or (os.path.exists(_SRC) and
+                                       os.path.getmtime(_SO) < os.path.getmtime(_SRC)):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.oracle_opt_n_threads.restype = ctypes.c_int
+        _lib.oracle_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())
+
+
+def opt_n_threads(work_size):
+    return int(lib().oracle_opt_n_threads(ctypes.c_int(int(work_size))))
+
+
+def chamfer_forward(xyz1, xyz2, structural=False):
+    """-> dist1 (B,N) f32, idx1 (B,N) i32, dist2 (B,M) f32, idx2 (B,M) i32"""
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    b, n, c = xyz1.shape
+    _, m, c2 = xyz2.shape
+    assert c == c2 and xyz2.shape[0] == b
+    # zeros: what the reference's Python wrapper allocates (network/model_loss.py:412-416); they
+    # survive only when n == 0 or m == 0.
+    d1 = np.zeros((b, n), np.float32)
+    d2 = np.zeros((b, m), np.float32)
+    i1 = np.zeros((b, n), np.int32)
+    i2 = np.zeros((b, m), np.int32)
+    fn = lib().oracle_chamfer_forward_structural if structural else lib().oracle_chamfer_forward
+    fn(p1, p2, _p(d1), _p(i1), _p(d2), _p(i2), b, n, m, c)
+    return d1, i1, d2, i2
+
+
+def labeled_chamfer_forward(xyz1, xyz2, label1, label2):
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    label1, l1 = _f(label1)  # labels are cast to the xyz dtype (network/model_loss.py:452-453)
+    label2, l2 = _f(label2)
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = np.zeros((b, n), np.float32)
+    d2 = np.zeros((b, m), np.float32)
+    i1 = np.zeros((b, n), np.int32)
+    i2 = np.zeros((b, m), np.int32)
+    lib().oracle_labeled_chamfer_forward(p1, p2, l1, l2, _p(d1), _p(i1), _p(d2), _p(i2), b, n, m, c)
+    return d1, i1, d2, i2
+
+
+def chamfer_backward(xyz1, xyz2, graddist1, graddist2, idx1, idx2):
+    """-> gradxyz1 (B,N,C), gradxyz2 (B,M,C)"""
+    xyz1, p1 = _f(xyz1)
+    xyz2, p2 = _f(xyz2)
+    graddist1, g1 = _f(graddist1)
+    graddist2, g2 = _f(graddist2)
+    idx1, q1 = _i(idx1)
+    idx2, q2 = _i(idx2)
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    gx1 = np.zeros_like(xyz1)
+    gx2 = np.zeros_like(xyz2)
+    lib().oracle_chamfer_backward(p1, p2, g1, g2, q1, q2, _p(gx1), _p(gx2), b, n, m, c)
+    return gx1, gx2
+
+
+def furthest_sampling(xyz, npoint, seed_idx=0, temp=None):
+    """-> idx (B,npoint) i32, temp (B,N) f32 after the call"""
+    xyz, px = _f(xyz)
+    b, n, three = xyz.shape
+    assert three == 3
+    if temp is None:
+        temp = np.full((b, n), 1e10, np.float32)  # network/geo_operations.py:33
+    temp = np.array(temp, dtype=np.float32, copy=True, order="C")
+    idx = np.zeros((b, npoint), np.int32)
+    lib().oracle_furthest_sampling(px, _p(temp), _p(idx), b, n, int(npoint), int(seed_idx))
+    return idx, temp
+
+
+def gather_forward(points, idx):
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = np.zeros((b, c, m), np.float32)
+    lib().oracle_gather_forward(pp, pi, _p(out), b, c, n, m)
+    return out
+
+
+def gather_backward(grad_out, idx, n):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    b, c, m = grad_out.shape
+    gp = np.zeros((b, c, n), np.float32)
+    lib().oracle_gather_backward(pg, pi, _p(gp), b, c, int(n), m)
+    return gp
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """argument order of the native function (sampling.cpp:85): (new_xyz, xyz, radius, nsample)"""
+    new_xyz, pn = _f(new_xyz)
+    xyz, px = _f(xyz)
+    b, m, _ = new_xyz.shape
+    n = xyz.shape[1]
+    idx = np.zeros((b, m, nsample), np.int32)
+    lib().oracle_ball_query(pn, px, _p(idx), b, n, m, ctypes.c_float(radius), int(nsample))
+    return idx
+
+
+def group_points(points, idx):
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    b, c, n = points.shape
+    _, npoints, nsample = idx.shape
+    out = np.zeros((b, c, npoints, nsample), np.float32)
+    lib().oracle_group_points(pp, pi, _p(out), b, c, n, npoints, nsample)
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    b, c, npoints, nsample = grad_out.shape
+    gp = np.zeros((b, c, n), np.float32)
+    lib().oracle_group_points_grad(pg, pi, _p(gp), b, c, int(n), npoints, nsample)
+    return gp
+
+
+def three_nn(unknown, known):
+    """-> dist2 (B,N,3) f32 (squared, before the wrapper's sqrt), idx (B,N,3) i32"""
+    unknown, pu = _f(unknown)
+    known, pk = _f(known)
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = np.zeros((b, n, 3), np.float32)
+    idx = np.zeros((b, n, 3), np.int32)
+    lib().oracle_three_nn(pu, pk, _p(d2), _p(idx), b, n, m)
+    return d2, idx
+
+
+def three_interpolate(points, idx, weight):
+    points, pp = _f(points)
+    idx, pi = _i(idx)
+    weight, pw = _f(weight)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = np.zeros((b, c, n), np.float32)
+    lib().oracle_three_interpolate(pp, pi, pw, _p(out), b, c, m, n)
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    grad_out, pg = _f(grad_out)
+    idx, pi = _i(idx)
+    weight, pw = _f(weight)
+    b, c, n = grad_out.shape
+    gp = np.zeros((b, c, m), np.float32)
+    lib().oracle_three_interpolate_grad(pg, pi, pw, _p(gp), b, c, n, int(m))
+    return gp

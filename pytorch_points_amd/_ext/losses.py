@@ -1,0 +1,79 @@
+"""``pytorch_points._ext.losses`` (reference: _ext/nmdistance.cpp:30-34).
+
+Same names, same positional arguments, same ``int`` return (1 = ok, as chamfer_cuda_forward
+returns on success, _ext/nmdistance_cuda.cu:137).  Unlike the reference, which checks nothing
+here, inputs are validated and failures raise RuntimeError.
+"""
+from .. import _lib
+
+
+def _shapes(xyz1, xyz2):
+    if xyz1.dim() != 3 or xyz2.dim() != 3:
+        raise RuntimeError("xyz1 and xyz2 must be (B, N, C) and (B, M, C)")
+    b, n, c = xyz1.shape
+    b2, m, c2 = xyz2.shape
+    if b != b2 or c != c2:  # CHECK_EQ(xyz2.size(2), c), _ext/nmdistance_cuda.cu:124
+        raise RuntimeError("xyz1 %s and xyz2 %s disagree in batch or point dimension"
+                           % (tuple(xyz1.shape), tuple(xyz2.shape)))
+    return b, n, m, c
+
+
+def nmdistance_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
+    """chamfer_forward (_ext/nmdistance.cpp:13-15): fills dist1/idx1 (B,N), dist2/idx2 (B,M)."""
+    b, n, m, c = _shapes(xyz1, xyz2)
+    floats = (("xyz1", xyz1), ("xyz2", xyz2), ("dist1", dist1), ("dist2", dist2))
+    ints = (("idx1", idx1), ("idx2", idx2))
+    dev = _lib.require_cuda(*floats, *ints)
+    _lib.require_contiguous(*floats, *ints)
+    _lib.require_float(*floats)
+    _lib.require_int(*ints)
+    if dist1.numel() != b * n or idx1.numel() != b * n or dist2.numel() != b * m or idx2.numel() != b * m:
+        raise RuntimeError("output tensors must be (B, N) and (B, M)")
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_nmdistance_forward_f32(
+            _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(idx1), _lib.ptr(dist2),
+            _lib.ptr(idx2), b, n, m, c, stream), "nmdistance_forward")
+    return 1
+
+
+def labeled_nmdistance_forward(xyz1, xyz2, label1, label2, dist1, dist2, idx1, idx2):
+    """labeled_chamfer_forward (_ext/nmdistance.cpp:17-20).  Labels are converted to the xyz dtype
+    as the reference does (``label.toType(xyz1.scalar_type())``, _ext/nmdistance_cuda.cu:153)."""
+    b, n, m, c = _shapes(xyz1, xyz2)
+    label1 = label1.to(dtype=xyz1.dtype).contiguous()
+    label2 = label2.to(dtype=xyz1.dtype).contiguous()
+    floats = (("xyz1", xyz1), ("xyz2", xyz2), ("label1", label1), ("label2", label2),
+              ("dist1", dist1), ("dist2", dist2))
+    ints = (("idx1", idx1), ("idx2", idx2))
+    dev = _lib.require_cuda(*floats, *ints)
+    _lib.require_contiguous(*floats, *ints)
+    _lib.require_float(*floats)
+    _lib.require_int(*ints)
+    if label1.numel() != b * n or label2.numel() != b * m:
+        raise RuntimeError("labels must be (B, N) and (B, M)")
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_labeled_nmdistance_forward_f32(
+            _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(label1), _lib.ptr(label2), _lib.ptr(dist1),
+            _lib.ptr(idx1), _lib.ptr(dist2), _lib.ptr(idx2), b, n, m, c, stream),
+            "labeled_nmdistance_forward")
+    return 1
+
+
+def nmdistance_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+    """chamfer_backward (_ext/nmdistance.cpp:23-27): overwrites gradxyz1 (B,N,C), gradxyz2 (B,M,C)."""
+    b, n, m, c = _shapes(xyz1, xyz2)
+    floats = (("xyz1", xyz1), ("xyz2", xyz2), ("gradxyz1", gradxyz1), ("gradxyz2", gradxyz2),
+              ("graddist1", graddist1), ("graddist2", graddist2))
+    ints = (("idx1", idx1), ("idx2", idx2))
+    dev = _lib.require_cuda(*floats, *ints)
+    _lib.require_contiguous(*floats, *ints)
+    _lib.require_float(*floats)
+    _lib.require_int(*ints)
+    if gradxyz1.shape != xyz1.shape or gradxyz2.shape != xyz2.shape:
+        raise RuntimeError("gradxyz tensors must have the shapes of xyz1 / xyz2")
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_nmdistance_backward_f32(
+            _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(graddist1), _lib.ptr(graddist2),
+            _lib.ptr(idx1), _lib.ptr(idx2), _lib.ptr(gradxyz1), _lib.ptr(gradxyz2), b, n, m, c,
+            stream), "nmdistance_backward")
+    return 1

@@ -1,0 +1,186 @@
+"""``pytorch_points._ext.sampling`` (reference: _ext/sampling.cpp:205-216).
+
+Same nine names and positional signatures as the pybind module.  Ownership follows the reference:
+``ball_query``, ``group_points`` and ``group_points_grad`` allocate and return their output on the
+input's device (sampling.cpp:93-94,123-125,148-150); everything else writes into caller-allocated
+tensors.  Precondition failures raise RuntimeError (the reference's AT_ASSERTM / TORCH_CHECK);
+launch failures raise RuntimeError instead of the reference's ``exit(-1)``.
+"""
+import torch
+
+from .. import _lib
+
+_fps_workspace = {}
+
+
+def _workspace(device, nbytes):
+    if nbytes == 0:
+        return None
+    buf = _fps_workspace.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _fps_workspace[device] = buf
+    return buf
+
+
+def furthest_sampling(m, seedIdx, input, temp, idx):
+    """furthest_sampling_forward (sampling.cpp:68-82): input (B,N,3), temp (B,N) in/out, idx (B,m)
+    out; returns idx."""
+    dev = _lib.require_cuda(("input", input), ("temp", temp), ("idx", idx))
+    _lib.require_contiguous(("input", input), ("temp", temp), ("idx", idx))  # CHECK_INPUT :76-77
+    _lib.require_float(("input", input), ("temp", temp))
+    _lib.require_int(("idx", idx))
+    if input.dim() != 3 or input.size(2) != 3:
+        raise RuntimeError("input must be (B, N, 3)")
+    b, n, _ = input.shape
+    if temp.numel() != b * n or idx.numel() != b * int(m):
+        raise RuntimeError("temp must be (B, N) and idx (B, m)")
+    L = _lib.lib()
+    nbytes = int(L.pp_furthest_sampling_workspace_bytes(b, n, int(m)))
+    ws = _workspace(dev, nbytes)
+    with _lib.on_device(dev) as stream:
+        _lib.check(L.pp_furthest_sampling_f32(
+            _lib.ptr(input), _lib.ptr(temp), _lib.ptr(idx), b, n, int(m), int(seedIdx),
+            _lib.ptr(ws) if ws is not None else None, nbytes, stream), "furthest_sampling")
+    return idx
+
+
+def gather_forward(b, c, n, npoints, points, idx, out):
+    """gather_points_wrapper_fast (sampling.cpp:19-28): out[b,c,m] = points[b,c,idx[b,m]]"""
+    dev = _lib.require_cuda(("points", points), ("idx", idx), ("out", out))
+    _lib.require_contiguous(("points", points), ("idx", idx), ("out", out))
+    _lib.require_float(("points", points), ("out", out))
+    _lib.require_int(("idx", idx))
+    if points.numel() != b * c * n or idx.numel() != b * npoints or out.numel() != b * c * npoints:
+        raise RuntimeError("gather_forward: tensor sizes do not match (b, c, n, npoints)")
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_gather_forward_f32(
+            _lib.ptr(points), _lib.ptr(idx), _lib.ptr(out), b, c, n, npoints, stream),
+            "gather_forward")
+    return 1
+
+
+def gather_backward(b, c, n, npoints, grad_out, idx, grad_points):
+    """gather_points_grad_wrapper_fast (sampling.cpp:31-41): scatter-add into grad_points."""
+    dev = _lib.require_cuda(("grad_out", grad_out), ("idx", idx), ("grad_points", grad_points))
+    _lib.require_contiguous(("grad_out", grad_out), ("idx", idx), ("grad_points", grad_points))
+    _lib.require_float(("grad_out", grad_out), ("grad_points", grad_points))
+    _lib.require_int(("idx", idx))
+    if (grad_out.numel() != b * c * npoints or idx.numel() != b * npoints
+            or grad_points.numel() != b * c * n):
+        raise RuntimeError("gather_backward: tensor sizes do not match (b, c, n, npoints)")
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_gather_backward_f32(
+            _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_points), b, c, n, npoints, stream),
+            "gather_backward")
+    return 1
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """ball_query_wrapper_fast (sampling.cpp:85-104): new_xyz (B,M,3) centres, xyz (B,N,3) ->
+    int32 idx (B,M,nsample)."""
+    dev = _lib.require_cuda(("new_xyz", new_xyz), ("xyz", xyz))
+    _lib.require_contiguous(("new_xyz", new_xyz), ("xyz", xyz))
+    _lib.require_float(("new_xyz", new_xyz), ("xyz", xyz))
+    if new_xyz.dim() != 3 or xyz.dim() != 3 or new_xyz.size(2) != 3 or xyz.size(2) != 3 \
+            or new_xyz.size(0) != xyz.size(0):
+        raise RuntimeError("new_xyz must be (B, M, 3) and xyz (B, N, 3)")
+    b, m, _ = new_xyz.shape
+    n = xyz.size(1)
+    nsample = int(nsample)
+    idx = torch.empty(b, m, nsample, dtype=torch.int32, device=dev)  # kernel writes every slot
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_ball_query_f32(
+            _lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), b, n, m, float(radius), nsample,
+            stream), "ball_query")
+    return idx
+
+
+def group_points(points, idx):
+    """group_points (sampling.cpp:113-138): points (B,C,N), idx (B,npoint,nsample) ->
+    (B,C,npoint,nsample)."""
+    _lib.require_contiguous(("points", points), ("idx", idx))
+    _lib.require_float(("points", points))
+    _lib.require_int(("idx", idx))
+    if not points.is_cuda:
+        raise RuntimeError("CPU not supported")  # sampling.cpp:132
+    dev = _lib.require_cuda(("points", points), ("idx", idx))
+    if points.dim() != 3 or idx.dim() != 3 or points.size(0) != idx.size(0):
+        raise RuntimeError("points must be (B, C, N) and idx (B, npoint, nsample)")
+    b, c, n = points.shape
+    _, npoint, nsample = idx.shape
+    out = torch.empty(b, c, npoint, nsample, dtype=torch.float32, device=dev)  # fully written
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_group_points_f32(
+            _lib.ptr(points), _lib.ptr(idx), _lib.ptr(out), b, c, n, npoint, nsample, stream),
+            "group_points")
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    """group_points_grad (sampling.cpp:140-161): grad_out (B,C,npoint,nsample) -> (B,C,n)."""
+    _lib.require_contiguous(("grad_out", grad_out), ("idx", idx))
+    _lib.require_float(("grad_out", grad_out))
+    _lib.require_int(("idx", idx))
+    if not grad_out.is_cuda:
+        raise RuntimeError("CPU not supported")  # sampling.cpp:157
+    dev = _lib.require_cuda(("grad_out", grad_out), ("idx", idx))
+    if grad_out.dim() != 4 or idx.dim() != 3:
+        raise RuntimeError("grad_out must be (B, C, npoint, nsample) and idx (B, npoint, nsample)")
+    b, c, npoint, nsample = grad_out.shape
+    out = torch.zeros(b, c, int(n), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_group_points_grad_f32(
+            _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(out), b, c, int(n), npoint, nsample,
+            stream), "group_points_grad")
+    return out
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    """three_nn_wrapper_fast (sampling.cpp:163-172): fills dist2 (B,N,3) squared, idx (B,N,3)."""
+    floats = (("unknown", unknown), ("known", known), ("dist2", dist2))
+    dev = _lib.require_cuda(*floats, ("idx", idx))
+    _lib.require_contiguous(*floats, ("idx", idx))
+    _lib.require_float(*floats)
+    _lib.require_int(("idx", idx))
+    if unknown.numel() != b * n * 3 or known.numel() != b * m * 3 or dist2.numel() != b * n * 3 \
+            or idx.numel() != b * n * 3:
+        raise RuntimeError("three_nn_wrapper: tensor sizes do not match (b, n, m)")
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_three_nn_f32(
+            _lib.ptr(unknown), _lib.ptr(known), _lib.ptr(dist2), _lib.ptr(idx), b, n, m, stream),
+            "three_nn_wrapper")
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    """three_interpolate_wrapper_fast (sampling.cpp:175-188): points (B,C,M), idx/weight (B,N,3)
+    -> out (B,C,N)."""
+    floats = (("points", points), ("weight", weight), ("out", out))
+    dev = _lib.require_cuda(*floats, ("idx", idx))
+    _lib.require_contiguous(*floats, ("idx", idx))
+    _lib.require_float(*floats)
+    _lib.require_int(("idx", idx))
+    if points.numel() != b * c * m or idx.numel() != b * n * 3 or weight.numel() != b * n * 3 \
+            or out.numel() != b * c * n:
+        raise RuntimeError("three_interpolate_wrapper: tensor sizes do not match (b, c, m, n)")
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_three_interpolate_f32(
+            _lib.ptr(points), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(out), b, c, m, n, stream),
+            "three_interpolate_wrapper")
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    """three_interpolate_grad_wrapper_fast (sampling.cpp:190-203): scatter-add into grad_points
+    (B,C,M)."""
+    floats = (("grad_out", grad_out), ("weight", weight), ("grad_points", grad_points))
+    dev = _lib.require_cuda(*floats, ("idx", idx))
+    _lib.require_contiguous(*floats, ("idx", idx))
+    _lib.require_float(*floats)
+    _lib.require_int(("idx", idx))
+    if grad_out.numel() != b * c * n or idx.numel() != b * n * 3 or weight.numel() != b * n * 3 \
+            or grad_points.numel() != b * c * m:
+        raise RuntimeError("three_interpolate_grad_wrapper: tensor sizes do not match (b, c, n, m)")
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_three_interpolate_grad_f32(
+            _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(grad_points), b, c, n, m,
+            stream), "three_interpolate_grad_wrapper")

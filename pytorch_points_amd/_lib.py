@@ -1,0 +1,122 @@
+"""ctypes binding of libpp_hip.so (C ABI: include/pp_hip.h).
+
+There is NO fallback: if the HIP library is missing or an entry point is absent, importing an
+operator raises.  Tensors are passed as raw device pointers, the stream as torch's current HIP
+stream on the tensor's device, under a device guard (the reference launches Chamfer and FPS on the
+legacy default stream with no guard -- SURVEY.md F10; this is a deliberate correction).
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _build
+
+_c_void_p, _c_int, _c_float, _c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_P, _I, _F = _c_void_p, _c_int, _c_float
+
+# name -> argtypes (return type is int unless listed in _RESTYPES); must match include/pp_hip.h
+SIGNATURES = {
+    "pp_version": [],
+    "pp_opt_n_threads": [_I],
+    "pp_nmdistance_forward_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_labeled_nmdistance_forward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_nmdistance_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_furthest_sampling_workspace_bytes": [_I, _I, _I],
+    "pp_furthest_sampling_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
+    "pp_gather_forward_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_gather_backward_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_ball_query_f32": [_P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "pp_group_points_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "pp_group_points_grad_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "pp_three_nn_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "pp_three_interpolate_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_three_interpolate_grad_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+}
+_RESTYPES = {"pp_version": ctypes.c_char_p, "pp_furthest_sampling_workspace_bytes": _c_size_t}
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB
+
+
+def lib():
+    """The loaded library.  Raises RuntimeError if libpp_hip.so is absent (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "pytorch_points_amd: %s not found. Build it with `python -m pytorch_points_amd._build` "
+                "(hipcc, gfx950). There is no CPU fallback." % path)
+        handle = ctypes.CDLL(path)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, _c_int)
+        _lib = handle
+    return _lib
+
+
+def version():
+    return lib().pp_version().decode()
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("pytorch_points_amd: %s failed with HIP error %d" % (what, code))
+
+
+def require_cuda(*named):
+    """The reference's CHECK_CUDA (_ext/utils.h:5): every tensor on a GPU, all on the same one."""
+    dev = None
+    for name, t in named:
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % name)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("%s is on %s, expected %s" % (name, t.device, dev))
+    return dev
+
+
+def require_contiguous(*named):
+    """CHECK_CONTIGUOUS (_ext/utils.h:6)"""
+    for name, t in named:
+        if not t.is_contiguous():
+            raise RuntimeError("%s must be contiguous" % name)
+
+
+def require_float(*named):
+    """CHECK_IS_FLOAT (_ext/utils.h:15-19); fp32 is the only floating type in scope."""
+    for name, t in named:
+        if t.dtype != torch.float32:
+            raise RuntimeError("%s must be a float tensor" % name)
+
+
+def require_int(*named):
+    """CHECK_IS_INT (_ext/utils.h:9-13)"""
+    for name, t in named:
+        if t.dtype != torch.int32:
+            raise RuntimeError("%s must be an int tensor" % name)
+
+
+def ptr(t):
+    return _c_void_p(t.data_ptr())
+
+
+class on_device(object):
+    """Device guard + current stream handle for a launch."""
+
+    def __init__(self, device):
+        self._guard = torch.cuda.device(device)
+        self.device = device
+
+    def __enter__(self):
+        self._guard.__enter__()
+        return _c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __exit__(self, *exc):
+        return self._guard.__exit__(*exc)

@@ -1,0 +1,426 @@
+// chamfer.hip -- nearest-neighbour (Chamfer) distance forward / labeled forward / backward for
+// gfx950.  Replaces the reference's _ext/nmdistance_cuda.cu (NmDistanceKernel :7-49,
+// LabeledNmDistanceKernel :55-115, NmDistanceGradKernel :168-185 and their launchers).
+//
+// Forward, C == 3 (the hot kernel)
+//   * one lane owns Q queries (coordinates in VGPRs); a workgroup = 4 waves = 64*Q queries; the
+//     four waves scan the four quarters of the reference cloud and merge through LDS, so a
+//     (batch, direction) pair yields 4x the waves of a one-wave-per-tile split;
+//   * the reference point is wave-uniform: it is fetched with scalar loads (s_load) into SGPRs
+//     and used directly as the SGPR operand of v_sub_f32 -- no LDS staging, no per-pair vector
+//     memory traffic;
+//   * exact "min, lowest index on ties" without a compare+2 selects per pair: reference points
+//     are scanned in groups of G; inside a group only the running minimum is kept (v_min3_f32,
+//     one op per two pairs) and after the group one compare/select records the id of the FIRST
+//     group that lowered the minimum.  After the scan each query recomputes the G distances of
+//     its recorded group (bit-identical arithmetic) and takes the first one equal to the minimum.
+//     VALU cost per pair: 3 sub + 1 mul + 2 fma + 1/2 min3 + 2/G  (6.75 at G = 8) instead of 9.
+//   * both directions (xyz1->xyz2, xyz2->xyz1) are one launch; virtual block ids are dealt to the
+//     8 XCDs in contiguous ranges so that workgroups sharing a reference cloud share an L2.
+#include "pp_common.h"
+
+namespace {
+
+using pp::chamfer_d3;
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+
+template <int Q, int G>
+__global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
+    int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M,
+    int tiles1, int tiles2, int total, int per_xcd) {
+  static_assert(G % 2 == 0, "groups are consumed two reference points per v_min3");
+  constexpr int TQ = 64 * Q;  // queries per workgroup
+  __shared__ float s_best[kWavesPerBlock][TQ];
+  __shared__ int s_idx[kWavesPerBlock][TQ];
+
+  const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
+  if (V >= total) return;  // uniform per workgroup
+  const int per_b = tiles1 + tiles2;
+  const int b = V / per_b;
+  const int r = V - b * per_b;
+  const bool second = r >= tiles1;
+  const int tile = second ? r - tiles1 : r;
+  const int nq = second ? M : N;
+  const int nr = second ? N : M;
+  const float* __restrict__ qry = (second ? xyz2 : xyz1) + (size_t)b * nq * 3;
+  const float* __restrict__ ref = (second ? xyz1 : xyz2) + (size_t)b * nr * 3;
+
+  const int wave = pp::wave_id_uniform();
+  const int lane = threadIdx.x & 63;
+
+  float qx[Q], qy[Q], qz[Q], best[Q];
+  int gid[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    int j = tile * TQ + i * 64 + lane;
+    j = j < nq ? j : nq - 1;  // clamp: out-of-range lanes compute a valid query, never stored
+    qx[i] = qry[3 * (size_t)j + 0];
+    qy[i] = qry[3 * (size_t)j + 1];
+    qz[i] = qry[3 * (size_t)j + 2];
+    best[i] = __builtin_inff();
+    gid[i] = -1;
+  }
+
+  // ---- grouped scan of this wave's quarter of the reference cloud -----------------------------
+  const int ngroups = nr / G;
+  const int g0 = (int)(((long long)ngroups * wave) / kWavesPerBlock);
+  const int g1 = (int)(((long long)ngroups * (wave + 1)) / kWavesPerBlock);
+  for (int g = g0; g < g1; ++g) {
+    const float* __restrict__ rp = ref + (size_t)g * (G * 3);  // wave-uniform -> s_load
+    float rr[G * 3];
+#pragma unroll
+    for (int e = 0; e < G * 3; ++e) rr[e] = rp[e];
+    float nb[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) nb[i] = best[i];
+#pragma unroll
+    for (int p = 0; p < G; p += 2) {
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const float da = chamfer_d3(rr[3 * p + 0], rr[3 * p + 1], rr[3 * p + 2], qx[i], qy[i], qz[i]);
+        const float db = chamfer_d3(rr[3 * p + 3], rr[3 * p + 4], rr[3 * p + 5], qx[i], qy[i], qz[i]);
+        nb[i] = pp::min3(da, db, nb[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      gid[i] = nb[i] < best[i] ? g : gid[i];  // first group that attains the running minimum
+      best[i] = nb[i];
+    }
+  }
+
+  // ---- recover the index inside the recorded group ------------------------------------------
+  int bidx[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    int k = 0;
+    if (gid[i] >= 0) {
+      const int k0 = gid[i] * G;
+      const float* rp = ref + 3 * (size_t)k0;
+#pragma unroll
+      for (int p = G - 1; p >= 0; --p) {  // descending: the last hit kept is the lowest index
+        const float d = chamfer_d3(rp[3 * p + 0], rp[3 * p + 1], rp[3 * p + 2], qx[i], qy[i], qz[i]);
+        k = d == best[i] ? k0 + p : k;
+      }
+    }
+    bidx[i] = k;
+  }
+
+  // ---- tail (nr % G points, highest indices): exact compare/select, done by the last wave ------
+  if (wave == kWavesPerBlock - 1) {
+    for (int k = ngroups * G; k < nr; ++k) {
+      const float rx = ref[3 * (size_t)k + 0], ry = ref[3 * (size_t)k + 1], rz = ref[3 * (size_t)k + 2];
+#pragma unroll
+      for (int i = 0; i < Q; ++i) {
+        const float d = chamfer_d3(rx, ry, rz, qx[i], qy[i], qz[i]);
+        const bool lt = d < best[i];
+        best[i] = lt ? d : best[i];
+        bidx[i] = lt ? k : bidx[i];
+      }
+    }
+  }
+
+  // ---- merge the four quarters (ascending index ranges => strict < keeps the lowest index) ----
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    s_best[wave][i * 64 + lane] = best[i];
+    s_idx[wave][i * 64 + lane] = bidx[i];
+  }
+  __syncthreads();
+  float* __restrict__ od = (second ? dist2 : dist1) + (size_t)b * nq;
+  int* __restrict__ oi = (second ? idx2 : idx1) + (size_t)b * nq;
+  for (int e = threadIdx.x; e < TQ; e += kBlock) {
+    float bb = s_best[0][e];
+    int bi = s_idx[0][e];
+#pragma unroll
+    for (int w = 1; w < kWavesPerBlock; ++w) {
+      const float c = s_best[w][e];
+      const int ci = s_idx[w][e];
+      const bool lt = c < bb;
+      bb = lt ? c : bb;
+      bi = lt ? ci : bi;
+    }
+    const int j = tile * TQ + e;
+    if (j < nq) {
+      od[j] = bb;
+      oi[j] = bi;
+    }
+  }
+}
+
+// Generic point dimension (C != 3): one lane per query, reference point wave-uniform, plain
+// compare/select.  CT > 0: compile-time C, query in registers; CT == 0: run-time C, query re-read
+// from memory (L1) for every reference point.  Correctness path, not a tuned one.
+template <int CT>
+__global__ __launch_bounds__(256) void nmdist_fwd_generic_kernel(
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
+    int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M, int C,
+    int tiles1, int tiles2) {
+  const int c = CT > 0 ? CT : C;
+  const int per_b = tiles1 + tiles2;
+  const int b = blockIdx.x / per_b;
+  const int r = blockIdx.x - b * per_b;
+  const bool second = r >= tiles1;
+  const int tile = second ? r - tiles1 : r;
+  const int nq = second ? M : N;
+  const int nr = second ? N : M;
+  const float* __restrict__ qry = (second ? xyz2 : xyz1) + (size_t)b * nq * c;
+  const float* __restrict__ ref = (second ? xyz1 : xyz2) + (size_t)b * nr * c;
+  const int j = tile * 256 + threadIdx.x;
+  if (j >= nq) return;
+  const float* qp = qry + (size_t)j * c;
+  float q[CT > 0 ? CT : 1];
+  if (CT > 0) {
+#pragma unroll
+    for (int e = 0; e < CT; ++e) q[e] = qp[e];
+  }
+  float best = __builtin_inff();
+  int bi = 0;
+  for (int k = 0; k < nr; ++k) {
+    const float* rp = ref + (size_t)k * c;
+    float d = 0.0f;
+    if (CT > 0) {
+#pragma unroll
+      for (int e = 0; e < CT; ++e) {
+        const float t = rp[e] - q[e];
+        d = __builtin_fmaf(t, t, d);
+      }
+    } else {
+      for (int e = 0; e < c; ++e) {
+        const float t = rp[e] - qp[e];
+        d = __builtin_fmaf(t, t, d);
+      }
+    }
+    const bool lt = d < best;
+    best = lt ? d : best;
+    bi = lt ? k : bi;
+  }
+  ((second ? dist2 : dist1) + (size_t)b * nq)[j] = best;
+  ((second ? idx2 : idx1) + (size_t)b * nq)[j] = bi;
+}
+
+// Labeled forward (ref _ext/nmdistance_cuda.cu:55-115): candidates restricted to equal labels
+// (compared as floats, :89); no candidate -> idx -1, dist 0 (:110-113).
+__global__ __launch_bounds__(256) void labeled_nmdist_fwd_kernel(
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, const float* __restrict__ label1,
+    const float* __restrict__ label2, float* __restrict__ dist1, int* __restrict__ idx1,
+    float* __restrict__ dist2, int* __restrict__ idx2, int N, int M, int C, int tiles1, int tiles2) {
+  const int per_b = tiles1 + tiles2;
+  const int b = blockIdx.x / per_b;
+  const int r = blockIdx.x - b * per_b;
+  const bool second = r >= tiles1;
+  const int tile = second ? r - tiles1 : r;
+  const int nq = second ? M : N;
+  const int nr = second ? N : M;
+  const float* __restrict__ qry = (second ? xyz2 : xyz1) + (size_t)b * nq * C;
+  const float* __restrict__ ref = (second ? xyz1 : xyz2) + (size_t)b * nr * C;
+  const float* __restrict__ ql = (second ? label2 : label1) + (size_t)b * nq;
+  const float* __restrict__ rl = (second ? label1 : label2) + (size_t)b * nr;
+  const int j = tile * 256 + threadIdx.x;
+  if (j >= nq) return;
+  const float* qp = qry + (size_t)j * C;
+  const float l1 = ql[j];
+  float best = __builtin_inff();
+  int bi = -1;
+  if (C == 3) {
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    for (int k = 0; k < nr; ++k) {
+      const float d = chamfer_d3(ref[3 * (size_t)k], ref[3 * (size_t)k + 1], ref[3 * (size_t)k + 2], qx, qy, qz);
+      const bool take = (l1 == rl[k]) && (bi < 0 || d < best);
+      best = take ? d : best;
+      bi = take ? k : bi;
+    }
+  } else {
+    for (int k = 0; k < nr; ++k) {
+      const float* rp = ref + (size_t)k * C;
+      float d = 0.0f;
+      for (int e = 0; e < C; ++e) {
+        const float t = rp[e] - qp[e];
+        d = __builtin_fmaf(t, t, d);
+      }
+      const bool take = (l1 == rl[k]) && (bi < 0 || d < best);
+      best = take ? d : best;
+      bi = take ? k : bi;
+    }
+  }
+  ((second ? dist2 : dist1) + (size_t)b * nq)[j] = bi < 0 ? 0.0f : best;
+  ((second ? idx2 : idx1) + (size_t)b * nq)[j] = bi;
+}
+
+// Backward (ref _ext/nmdistance_cuda.cu:168-185,195-221).  Two passes on one stream:
+//   own:     gradxyzA[j] = 2*gdA[j] * (xA[j] - xB[idxA[j]])           plain stores, one writer per row
+//            (this overwrites, so the reference's zero_() of the outputs is folded in)
+//   scatter: gradxyzB[idxA[j]] -= the same value                      fp32 atomics
+// for A,B = (1,2) and (2,1).  g = gd*2 then g*(xa-xb): two roundings in the reference's order (:176,:179).
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void nmdist_bwd_kernel(
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, const float* __restrict__ gd1,
+    const float* __restrict__ gd2, const int* __restrict__ idx1, const int* __restrict__ idx2,
+    float* __restrict__ gx1, float* __restrict__ gx2, int N, int M, int C, long long total1,
+    long long total2) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total1 + total2) return;
+  const bool second = t >= total1;
+  const long long p = second ? t - total1 : t;  // flat (b, j)
+  const int na = second ? M : N, nb = second ? N : M;
+  const long long b = p / na;
+  const float* __restrict__ xa = (second ? xyz2 : xyz1) + p * C;
+  const int j2 = (second ? idx2 : idx1)[p];
+  float* __restrict__ ga = (second ? gx2 : gx1) + p * C;
+  if (j2 < 0) {  // labeled variant: no neighbour (:175)
+    if (!SCATTER)
+      for (int e = 0; e < C; ++e) ga[e] = 0.0f;
+    return;
+  }
+  const float g = (second ? gd2 : gd1)[p] * 2;
+  const float* __restrict__ xb = (second ? xyz1 : xyz2) + (b * nb + j2) * C;
+  float* __restrict__ gb = (second ? gx1 : gx2) + (b * nb + j2) * C;
+  for (int e = 0; e < C; ++e) {
+    const float v = g * (xa[e] - xb[e]);
+    if (SCATTER)
+      atomicAdd(gb + e, -v);
+    else
+      ga[e] = v;
+  }
+}
+
+__global__ void fill_zero_kernel(float* __restrict__ a, int* __restrict__ b, long long n) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) {
+    a[t] = 0.0f;
+    b[t] = 0;
+  }
+}
+
+template <int Q, int G>
+int launch_fwd_c3(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
+                  int* idx2, int B, int N, int M, hipStream_t s) {
+  constexpr int TQ = 64 * Q;
+  const int tiles1 = (N + TQ - 1) / TQ, tiles2 = (M + TQ - 1) / TQ;
+  const long long total = (long long)B * (tiles1 + tiles2);
+  if (total > 0x7fffff00LL) return PP_EINVAL;
+  const int per_xcd = (int)((total + 7) / 8);
+  nmdist_fwd_c3_kernel<Q, G><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
+      xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, tiles1, tiles2, (int)total, per_xcd);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+
+template <int CT>
+int launch_fwd_generic(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
+                       int* idx2, int B, int N, int M, int C, hipStream_t s) {
+  const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
+  const long long total = (long long)B * (tiles1 + tiles2);
+  if (total > 0x7fffff00LL) return PP_EINVAL;
+  nmdist_fwd_generic_kernel<CT><<<dim3((unsigned)total), dim3(256), 0, s>>>(
+      xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, C, tiles1, tiles2);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+
+int zero_outputs(float* dist1, int* idx1, float* dist2, int* idx2, int B, int N, int M,
+                 hipStream_t s) {
+  const long long n1 = (long long)B * N, n2 = (long long)B * M;
+  if (n1 > 0) {
+    fill_zero_kernel<<<dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s>>>(dist1, idx1, n1);
+    PP_RETURN_IF_LAUNCH_FAILED();
+  }
+  if (n2 > 0) {
+    fill_zero_kernel<<<dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s>>>(dist2, idx2, n2);
+    PP_RETURN_IF_LAUNCH_FAILED();
+  }
+  return PP_OK;
+}
+
+}  // namespace
+
+// Tuning override for benchmarking variants in one process (bench.py --variant); 0 = automatic.
+static int g_fwd_variant = 0;
+extern "C" void pp_debug_set_nmdistance_variant(int v) { g_fwd_variant = v; }
+
+extern "C" int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, float* dist1,
+                                         int* idx1, float* dist2, int* idx2, int B, int N, int M,
+                                         int C, void* stream) {
+  if (B < 0 || N < 0 || M < 0 || C < 1) return PP_EINVAL;
+  if (B == 0 || (N == 0 && M == 0)) return PP_OK;
+  if (!dist1 || !idx1 || !dist2 || !idx2) return PP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0 || M == 0) return zero_outputs(dist1, idx1, dist2, idx2, B, N, M, s);
+  if (!xyz1 || !xyz2) return PP_EINVAL;
+  if (C == 3) {
+    // queries per lane: enough workgroups to give every CU (256) several, else a smaller tile
+    const long long q = (long long)B * ((long long)N + M);
+    int variant = g_fwd_variant;
+    if (variant == 0) variant = q >= 4LL * 256 * 1024 ? 4 : (q >= 2LL * 256 * 512 ? 2 : 1);
+    switch (variant) {
+      case 4: return launch_fwd_c3<4, 8>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 2: return launch_fwd_c3<2, 8>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 1: return launch_fwd_c3<1, 8>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 8: return launch_fwd_c3<8, 8>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 416: return launch_fwd_c3<4, 16>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 216: return launch_fwd_c3<2, 16>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 44: return launch_fwd_c3<4, 4>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      default: return PP_EINVAL;
+    }
+  }
+  switch (C) {
+    case 1: return launch_fwd_generic<1>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
+    case 2: return launch_fwd_generic<2>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
+    case 4: return launch_fwd_generic<4>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
+    default: return launch_fwd_generic<0>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
+  }
+}
+
+extern "C" int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float* xyz2,
+                                                 const float* label1, const float* label2,
+                                                 float* dist1, int* idx1, float* dist2, int* idx2,
+                                                 int B, int N, int M, int C, void* stream) {
+  if (B < 0 || N < 0 || M < 0 || C < 1) return PP_EINVAL;
+  if (B == 0 || (N == 0 && M == 0)) return PP_OK;
+  if (!dist1 || !idx1 || !dist2 || !idx2) return PP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  // M == 0: the reference's kernel leaves dist 0 / idx 0 from the wrapper's zeros, then its
+  // post-pass (:110-113) sees idx 0 (not < 0) -- so zeros, like the unlabeled case.
+  if (N == 0 || M == 0) return zero_outputs(dist1, idx1, dist2, idx2, B, N, M, s);
+  if (!xyz1 || !xyz2 || !label1 || !label2) return PP_EINVAL;
+  const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
+  const long long total = (long long)B * (tiles1 + tiles2);
+  if (total > 0x7fffff00LL) return PP_EINVAL;
+  labeled_nmdist_fwd_kernel<<<dim3((unsigned)total), dim3(256), 0, s>>>(
+      xyz1, xyz2, label1, label2, dist1, idx1, dist2, idx2, N, M, C, tiles1, tiles2);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+
+extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
+                                          const float* graddist1, const float* graddist2,
+                                          const int* idx1, const int* idx2, float* gradxyz1,
+                                          float* gradxyz2, int B, int N, int M, int C,
+                                          void* stream) {
+  if (B < 0 || N < 0 || M < 0 || C < 1) return PP_EINVAL;
+  const long long t1 = (long long)B * N, t2 = (long long)B * M;
+  if (t1 + t2 == 0) return PP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (N == 0 || M == 0) {
+    // no pairs: gradients are zero (the reference zeroes and its loops do not run)
+    float* g = N == 0 ? gradxyz2 : gradxyz1;
+    const long long n = (N == 0 ? t2 : t1) * C;
+    if (!g) return PP_EINVAL;
+    hipError_t e = hipMemsetAsync(g, 0, (size_t)n * sizeof(float), s);
+    return (int)e;
+  }
+  if (!xyz1 || !xyz2 || !graddist1 || !graddist2 || !idx1 || !idx2 || !gradxyz1 || !gradxyz2)
+    return PP_EINVAL;
+  const long long blocks = (t1 + t2 + 255) / 256;
+  if (blocks > 0x7fffff00LL) return PP_EINVAL;
+  nmdist_bwd_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(
+      xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, C, t1, t2);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  nmdist_bwd_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(
+      xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, C, t1, t2);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}

@@ -1,0 +1,57 @@
+// pp_common.h -- shared device helpers for libpp_hip.so (gfx950 only).
+//
+// Canonical fp32 arithmetic (DESIGN.md "Arithmetic contract"): the library is compiled with
+// -ffp-contract=off and every fused multiply-add is an explicit __builtin_fmaf, so the rounding
+// sequence is fixed by the source, not by the optimiser:
+//   distc (Chamfer, ref _ext/nmdistance_cuda.cu:31-35):  t_c = ref_c - query_c;
+//         d = t_0*t_0; d = fma(t_1,t_1,d); d = fma(t_2,t_2,d) ...
+//   dist3 (FPS / ball_query / three_nn, ref _ext/sampling_cuda.cu:202,364, interpolate_gpu.cu:36):
+//         fma(dz,dz, fma(dx,dx, dy*dy))
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pp_hip.h"
+
+#define PP_WAVE 64
+
+#define PP_RETURN_IF_LAUNCH_FAILED()        \
+  do {                                      \
+    hipError_t e__ = hipGetLastError();     \
+    if (e__ != hipSuccess) return (int)e__; \
+  } while (0)
+
+namespace pp {
+
+__device__ __forceinline__ float chamfer_d3(float rx, float ry, float rz, float qx, float qy,
+                                            float qz) {
+  const float t0 = rx - qx, t1 = ry - qy, t2 = rz - qz;
+  return __builtin_fmaf(t2, t2, __builtin_fmaf(t1, t1, t0 * t0));
+}
+
+__device__ __forceinline__ float dist3(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+}
+
+// v_min3_f32: one VALU op for two candidates.  Operands are results of fma/mul chains (never
+// signalling NaNs), so no canonicalisation is needed; spelled in asm so that the compiler cannot
+// split it back into two v_min_f32 or insert v_max canonicalisations.
+__device__ __forceinline__ float min3(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+__device__ __forceinline__ int wave_id_uniform() {
+  return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
+// Blocks b and b+8 share an XCD (its private 4 MiB L2) under the observed round-robin dispatch;
+// remap so that each XCD walks a contiguous range of virtual block ids.  Speed only: any
+// placement gives the same results.  per_xcd = ceil(total / 8); grid = 8 * per_xcd.
+__device__ __forceinline__ int xcd_virtual_block(int linear, int per_xcd) {
+  return (linear & 7) * per_xcd + (linear >> 3);
+}
+
+}  // namespace pp

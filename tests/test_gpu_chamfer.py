@@ -1,0 +1,204 @@
+"""GPU parity: HIP Chamfer (through the autograd API -> _ext shim -> C ABI) vs the CPU oracle.
+
+Bar (BASELINE.json north_star): indices bit-exact, distances within 1e-5 -- in fact the canonical
+arithmetic makes the distances bit-exact too, and that is what is asserted."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import bruteforce as bf
+from pytorch_points_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+DIST_TOL = 1e-5  # the stated fp32 tolerance; the assertions below are stricter (bitwise)
+
+
+def _clouds(b, n, m, c, dup=False):
+    x1 = S.unit_sphere(0, b, n, c)
+    x2 = S.unit_sphere(1, b, m, c)
+    if dup:  # duplicated points: exact ties must resolve to the lowest index
+        x2[:, m // 2:] = x2[:, : m - m // 2]
+        x1[:, ::7] = x2[:, : len(range(0, n, 7))] if m >= len(range(0, n, 7)) else x1[:, ::7]
+    return x1, x2
+
+
+def _run(cuda, x1, x2):
+    from pytorch_points_amd.network.model_loss import nndistance
+    t1 = torch.from_numpy(x1).to(cuda)
+    t2 = torch.from_numpy(x2).to(cuda)
+    d1, d2, i1, i2 = nndistance(t1, t2)
+    torch.cuda.synchronize()
+    return d1.cpu().numpy(), i1.cpu().numpy(), d2.cpu().numpy(), i2.cpu().numpy()
+
+
+SHAPES = [(2, 1024, 1024, 3), (1, 1000, 777, 3), (2, 300, 1500, 3), (1, 64, 64, 2), (1, 513, 511, 5),
+          (3, 7, 5, 3), (1, 1, 1, 3), (2, 2050, 33, 3), (1, 129, 4099, 4), (1, 40, 50, 1)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("dup", [False, True])
+def test_forward_matches_oracle(cuda, shape, dup):
+    b, n, m, c = shape
+    x1, x2 = _clouds(b, n, m, c, dup)
+    got = _run(cuda, x1, x2)
+    exp = oracle.chamfer_forward(x1, x2)
+    for g, e, name in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
+        assert g.dtype == e.dtype and g.shape == e.shape
+        assert np.array_equal(g, e), "%s differs at %d places" % (name, int((g != e).sum()))
+
+
+@pytest.mark.parametrize("variant", [1, 2, 4, 8, 416, 216, 44])
+@pytest.mark.parametrize("shape", [(2, 1024, 1024, 3), (1, 1000, 777, 3), (2, 300, 1500, 3), (1, 5, 3, 3)])
+def test_forward_every_kernel_variant(cuda, variant, shape):
+    """Every (queries-per-lane, group) instantiation of the C==3 kernel gives the same bits."""
+    from pytorch_points_amd import _lib
+    b, n, m, c = shape
+    x1, x2 = _clouds(b, n, m, c, dup=True)
+    exp = oracle.chamfer_forward(x1, x2)
+    setter = _lib.lib().pp_debug_set_nmdistance_variant
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(variant)
+    try:
+        got = _run(cuda, x1, x2)
+    finally:
+        setter(0)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+
+
+def test_forward_api_contract(cuda):
+    from pytorch_points_amd.network.model_loss import nndistance
+    x1 = torch.from_numpy(S.unit_sphere(0, 2, 100)).to(cuda).requires_grad_(True)
+    x2 = torch.from_numpy(S.unit_sphere(1, 2, 90)).to(cuda).requires_grad_(True)
+    d1, d2, i1, i2 = nndistance(x1, x2)
+    assert d1.shape == (2, 100) and d2.shape == (2, 90) and i1.shape == (2, 100) and i2.shape == (2, 90)
+    assert d1.dtype == torch.float32 and i1.dtype == torch.int32 and i2.dtype == torch.int32
+    assert d1.device == x1.device and i1.device == x1.device
+    assert d1.requires_grad and d2.requires_grad and not i1.requires_grad and not i2.requires_grad
+    # non-contiguous input is made contiguous (reference model_loss.py:405-406)
+    xt = torch.from_numpy(S.unit_sphere(0, 2, 100)).to(cuda).transpose(1, 2).contiguous().transpose(1, 2)
+    assert not xt.is_contiguous()
+    e1, _, j1, _ = nndistance(xt, x2.detach())
+    assert torch.equal(e1, d1.detach()) and torch.equal(j1, i1)
+
+
+def test_forward_empty(cuda):
+    from pytorch_points_amd.network.model_loss import nndistance
+    x1 = torch.zeros(2, 0, 3, device=cuda)
+    x2 = torch.from_numpy(S.unit_sphere(1, 2, 9)).to(cuda)
+    d1, d2, i1, i2 = nndistance(x1, x2)
+    assert d1.shape == (2, 0) and d2.shape == (2, 9)
+    assert float(d2.abs().sum()) == 0 and int(i2.abs().sum()) == 0  # the wrapper's zeros survive
+    e = oracle.chamfer_forward(np.zeros((2, 0, 3), np.float32), x2.cpu().numpy())
+    assert np.array_equal(e[2], d2.cpu().numpy())
+
+
+@pytest.mark.parametrize("shape", [(2, 1024, 1024, 3), (1, 1000, 777, 3), (1, 64, 64, 2), (1, 513, 511, 5)])
+def test_backward_matches_oracle_and_fp64(cuda, shape):
+    from pytorch_points_amd.network.model_loss import nndistance
+    b, n, m, c = shape
+    x1, x2 = _clouds(b, n, m, c)
+    t1 = torch.from_numpy(x1).to(cuda).requires_grad_(True)
+    t2 = torch.from_numpy(x2).to(cuda).requires_grad_(True)
+    d1, d2, i1, i2 = nndistance(t1, t2)
+    w1 = torch.from_numpy(S.normal(5, (b, n))).to(cuda)
+    w2 = torch.from_numpy(S.normal(6, (b, m))).to(cuda)
+    ((d1 * w1).sum() + (d2 * w2).sum()).backward()
+    g1, g2 = t1.grad.cpu().numpy(), t2.grad.cpu().numpy()
+    i1n, i2n = i1.cpu().numpy(), i2.cpu().numpy()
+    e1, e2 = oracle.chamfer_backward(x1, x2, w1.cpu().numpy(), w2.cpu().numpy(), i1n, i2n)
+    f1, f2 = bf.chamfer_grad64(x1, x2, w1.cpu().numpy(), w2.cpu().numpy(), i1n, i2n)
+    scale = max(np.abs(f1).max(), np.abs(f2).max())
+    # fp32 atomics: order-dependent rounding -> tolerance, not bits (rtol 1e-5 of the fp64 formula)
+    assert np.abs(g1 - f1).max() <= 1e-5 * scale and np.abs(g2 - f2).max() <= 1e-5 * scale
+    assert np.abs(g1 - e1).max() <= 1e-5 * scale and np.abs(g2 - e2).max() <= 1e-5 * scale
+
+
+def test_backward_equals_torch_autograd(cuda):
+    """Gradient of sum(dist) through the op == torch autograd of the same formula on fixed idx."""
+    from pytorch_points_amd.network.model_loss import nndistance
+    x1, x2 = _clouds(2, 500, 400, 3)
+    t1 = torch.from_numpy(x1).to(cuda).requires_grad_(True)
+    t2 = torch.from_numpy(x2).to(cuda).requires_grad_(True)
+    d1, d2, i1, i2 = nndistance(t1, t2)
+    (d1.mean() + d2.mean()).backward()
+    a1 = t1.detach().double().requires_grad_(True)
+    a2 = t2.detach().double().requires_grad_(True)
+    r1 = ((a1 - torch.gather(a2, 1, i1.long()[..., None].expand(-1, -1, 3))) ** 2).sum(-1)
+    r2 = ((a2 - torch.gather(a1, 1, i2.long()[..., None].expand(-1, -1, 3))) ** 2).sum(-1)
+    (r1.mean() + r2.mean()).backward()
+    assert torch.allclose(t1.grad.double(), a1.grad, rtol=1e-5, atol=1e-9)
+    assert torch.allclose(t2.grad.double(), a2.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_labeled_matches_oracle(cuda):
+    from pytorch_points_amd.network.model_loss import labeled_nndistance
+    b, n, m = 1, 512, 700
+    x1, x2 = _clouds(b, n, m, 3)
+    l1 = (S.uniform01(7, (b, n)).reshape(b, n) * 4).astype(np.int64)          # labels 0..3
+    l2 = (S.uniform01(8, (b, m)).reshape(b, m) * 3).astype(np.int64)          # label 3 missing
+    t1 = torch.from_numpy(x1).to(cuda).requires_grad_(True)
+    t2 = torch.from_numpy(x2).to(cuda).requires_grad_(True)
+    d1, d2, i1, i2 = labeled_nndistance(t1, t2, torch.from_numpy(l1).to(cuda), torch.from_numpy(l2).to(cuda))
+    e = oracle.labeled_chamfer_forward(x1, x2, l1, l2)
+    got = [d1.detach().cpu().numpy(), i1.cpu().numpy(), d2.detach().cpu().numpy(), i2.cpu().numpy()]
+    for g, x in zip(got, e):
+        assert np.array_equal(g, x)
+    assert (got[1] == -1).any() and (got[0][got[1] == -1] == 0).all()
+    (d1.sum() + d2.sum()).backward()
+    e1, e2 = oracle.chamfer_backward(x1, x2, np.ones((b, n), np.float32), np.ones((b, m), np.float32), e[1], e[3])
+    assert np.allclose(t1.grad.cpu().numpy(), e1, rtol=1e-5, atol=1e-6)
+    assert np.allclose(t2.grad.cpu().numpy(), e2, rtol=1e-5, atol=1e-6)
+
+
+def test_rejects_bad_inputs(cuda):
+    from pytorch_points_amd._ext import losses
+    x = torch.zeros(1, 4, 3, device=cuda)
+    d = torch.zeros(1, 4, device=cuda)
+    i = torch.zeros(1, 4, dtype=torch.int32, device=cuda)
+    with pytest.raises(RuntimeError):
+        losses.nmdistance_forward(x.cpu(), x, d, d, i, i)
+    with pytest.raises(RuntimeError):
+        losses.nmdistance_forward(x.double(), x.double(), d, d, i, i)
+    with pytest.raises(RuntimeError):
+        losses.nmdistance_forward(x, x, d, d, i.long(), i)
+    with pytest.raises(RuntimeError):
+        losses.nmdistance_forward(x, torch.zeros(1, 4, 2, device=cuda), d, d, i, i)
+    assert losses.nmdistance_forward(x, x, d, d.clone(), i, i.clone()) == 1
+
+
+def test_full_size_c2_properties(cuda):
+    """BASELINE config 2 (B=32, N=M=16384): full comparison with the oracle on 2 of the 32 batch
+    elements, and size-independent properties on all of them."""
+    from pytorch_points_amd.network.model_loss import nndistance
+    B, N = 32, 16384
+    x1 = S.unit_sphere(0, B, N)
+    x2 = S.unit_sphere(1, B, N)
+    t1 = torch.from_numpy(x1).to(cuda)
+    t2 = torch.from_numpy(x2).to(cuda)
+    d1, d2, i1, i2 = nndistance(t1, t2)
+    sel = [0, 31]
+    e = oracle.chamfer_forward(x1[sel], x2[sel])
+    assert np.array_equal(d1[sel].cpu().numpy(), e[0]) and np.array_equal(i1[sel].cpu().numpy(), e[1])
+    assert np.array_equal(d2[sel].cpu().numpy(), e[2]) and np.array_equal(i2[sel].cpu().numpy(), e[3])
+    # (1) the returned distance is the distance to the returned index
+    nb = torch.gather(t2, 1, i1.long()[..., None].expand(-1, -1, 3))
+    assert torch.allclose(((t1 - nb) ** 2).sum(-1), d1, rtol=1e-5, atol=1e-7)
+    # (2) batch elements are independent: a shard gives the same bits as the whole
+    s1, s2, j1, j2 = nndistance(t1[8:12].contiguous(), t2[8:12].contiguous())
+    assert torch.equal(s1, d1[8:12]) and torch.equal(j1, i1[8:12]) and torch.equal(s2, d2[8:12]) and torch.equal(j2, i2[8:12])
+    # (3) swapping the clouds swaps the outputs
+    r1, r2, k1, k2 = nndistance(t2, t1)
+    assert torch.equal(r1, d2) and torch.equal(k1, i2) and torch.equal(r2, d1) and torch.equal(k2, i1)
+    # (4) permuting the reference cloud permutes indices and keeps distances (no ties in this data)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(0)).to(cuda)
+    p1, _, q1, _ = nndistance(t1[:4].contiguous(), t2[:4, perm].contiguous())
+    assert torch.equal(p1, d1[:4]) and torch.equal(perm[q1.long()], i1[:4].long())
+    # (5) deterministic
+    u1, u2, v1, v2 = nndistance(t1, t2)
+    assert torch.equal(u1, d1) and torch.equal(v1, i1) and torch.equal(u2, d2) and torch.equal(v2, i2)

@@ -1,0 +1,216 @@
+"""GPU parity: FPS, gather, ball_query, group_points, three_nn, three_interpolate vs the CPU oracle
+and vs torch identities.  Indices bit-exact; gathers bit-exact; scatter-adds (fp32
+atomics) within 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pytorch_points_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+# ---------------------------------------------------------------- furthest point sampling + gather
+@pytest.mark.parametrize("b,n,m,seed", [(2, 2048, 256, 0), (1, 300, 64, 7), (1, 5000, 128, 0),
+                                        (3, 1024, 1024, 3), (1, 70, 70, 0), (2, 1, 1, 0), (1, 513, 40, 512)])
+def test_fps_matches_oracle(cuda, b, n, m, seed):
+    from pytorch_points_amd.network.geo_operations import furthest_point_sample
+    x = S.unit_sphere(10, b, n)
+    idx, pc = furthest_point_sample(_t(x, cuda), m, NCHW=False, seedIdx=seed)
+    e_idx, _ = oracle.furthest_sampling(x, m, seed)
+    assert idx.dtype == torch.int32 and idx.shape == (b, m) and pc.shape == (b, m, 3)
+    assert np.array_equal(idx.cpu().numpy(), e_idx)
+    assert np.array_equal(pc.cpu().numpy(), np.take_along_axis(x, e_idx[..., None].astype(np.int64), 1))
+    assert (idx[:, 0] == seed).all()
+    # NCHW layout: (B,3,N) in, (B,3,npoint) out
+    idx2, pc2 = furthest_point_sample(_t(x, cuda).transpose(1, 2).contiguous(), m, NCHW=True, seedIdx=seed)
+    assert torch.equal(idx2, idx) and torch.equal(pc2, pc.transpose(1, 2))
+
+
+def test_fps_ties_and_degenerate(cuda):
+    """Exact ties (duplicated points, all-equal points) follow the reference's thread-order rule."""
+    from pytorch_points_amd._ext import sampling
+    x = S.unit_sphere(11, 2, 1500)
+    x[:, 700:1400] = x[:, :700]          # every point of the first 700 has an exact twin
+    x[1, :] = x[1, 0]                    # batch 1: all points identical -> index 0 repeated
+    m = 200
+    xt = _t(x, cuda)
+    idx = torch.empty(2, m, dtype=torch.int32, device=cuda)
+    temp = torch.full((2, 1500), 1e10, dtype=torch.float32, device=cuda)
+    out = sampling.furthest_sampling(m, 5, xt, temp, idx)
+    assert out is idx
+    e_idx, e_temp = oracle.furthest_sampling(x, m, 5)
+    assert np.array_equal(idx.cpu().numpy(), e_idx)
+    assert np.array_equal(temp.cpu().numpy(), e_temp)     # temp is an in/out argument
+    assert (e_idx[1, 1:] == 0).all()
+
+
+def test_fps_large_n_paths(cuda):
+    """N > 1024 (several points per thread) and N > 65536 (temp kept in global memory)."""
+    from pytorch_points_amd.network.geo_operations import furthest_point_sample
+    for n, m in [(20000, 64), (70000, 24)]:
+        x = S.unit_sphere(12, 1, n)
+        idx, _ = furthest_point_sample(_t(x, cuda), m, NCHW=False)
+        e_idx, _ = oracle.furthest_sampling(x, m, 0)
+        assert np.array_equal(idx.cpu().numpy(), e_idx)
+
+
+def test_gather_matches_torch_and_backward(cuda):
+    from pytorch_points_amd.network.operations import gather_points
+    b, c, n, m = 3, 37, 500, 123
+    f = _t(S.normal(20, (b, c, n)), cuda).requires_grad_(True)
+    idx = _t((S.uniform01(21, (b, m)).reshape(b, m) * n).astype(np.int32), cuda)
+    out = gather_points(f, idx)
+    ref = torch.gather(f, 2, idx.long()[:, None, :].expand(-1, c, -1))
+    assert torch.equal(out, ref)
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.gather_forward(f.detach().cpu().numpy(), idx.cpu().numpy()))
+    w = _t(S.normal(22, (b, c, m)), cuda)
+    (out * w).sum().backward()
+    g = f.grad.clone()
+    f.grad = None
+    (ref * w).sum().backward()
+    assert torch.allclose(g, f.grad, rtol=1e-5, atol=1e-6)
+    # int64 idx is accepted and converted (reference operations.py:55)
+    assert torch.equal(gather_points(f.detach(), idx.long()), out.detach())
+
+
+# ----------------------------------------------------------------------------------- ball query
+@pytest.mark.parametrize("r", [0.05, 0.2, 0.5])
+@pytest.mark.parametrize("ns", [16, 64])
+def test_ball_query_matches_oracle(cuda, r, ns):
+    from pytorch_points_amd.network.operations import ball_query
+    x = S.unit_sphere(30, 2, 2048)
+    fidx, _ = oracle.furthest_sampling(x, 256, 0)
+    centres = np.take_along_axis(x, fidx[..., None].astype(np.int64), 1)
+    idx = ball_query(r, ns, _t(x, cuda), _t(centres, cuda))
+    assert idx.dtype == torch.int32 and idx.shape == (2, 256, ns) and not idx.requires_grad
+    assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(centres, x, r, ns))
+
+
+@pytest.mark.parametrize("b,n,m,r,ns", [(1, 100, 70, 0.3, 5), (2, 1000, 300, 1e-4, 8), (1, 37, 3, 10.0, 200),
+                                        (1, 2000, 515, 0.25, 33), (1, 9, 1, 0.5, 1), (1, 64, 64, 0.4, 300)])
+def test_ball_query_edges(cuda, b, n, m, r, ns):
+    """odd sizes; empty balls (all-zero rows); full balls (early exit); nsample beyond the LDS
+    staging limit (direct-store path)."""
+    from pytorch_points_amd._ext import sampling
+    x = S.unit_sphere(31, b, n)
+    c = S.unit_sphere(32, b, m)
+    idx = sampling.ball_query(_t(c, cuda), _t(x, cuda), r, ns)
+    assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(c, x, r, ns))
+
+
+# --------------------------------------------------------------------------------- group points
+@pytest.mark.parametrize("b,c,n,npoint,ns", [(2, 8, 2048, 256, 16), (1, 3, 100, 7, 5), (2, 67, 500, 33, 12), (1, 1, 10, 1, 1)])
+def test_group_points_matches_torch_and_backward(cuda, b, c, n, npoint, ns):
+    from pytorch_points_amd.network.operations import grouping_operation
+    f = _t(S.normal(40, (b, c, n)), cuda).requires_grad_(True)
+    idx = _t((S.uniform01(41, (b, npoint, ns)).reshape(b, npoint, ns) * n).astype(np.int32), cuda)
+    out = grouping_operation(f, idx)
+    ref = torch.gather(f, 2, idx.long().reshape(b, 1, -1).expand(-1, c, -1)).reshape(b, c, npoint, ns)
+    assert out.shape == (b, c, npoint, ns) and torch.equal(out, ref)
+    assert np.array_equal(out.detach().cpu().numpy(), oracle.group_points(f.detach().cpu().numpy(), idx.cpu().numpy()))
+    w = _t(S.normal(42, (b, c, npoint, ns)), cuda)
+    (out * w).sum().backward()
+    g = f.grad.clone()
+    f.grad = None
+    (ref * w).sum().backward()
+    assert torch.allclose(g, f.grad, rtol=1e-5, atol=1e-5)
+    e = oracle.group_points_grad(w.cpu().numpy(), idx.cpu().numpy(), n)
+    assert np.allclose(g.cpu().numpy(), e, rtol=1e-5, atol=1e-5)
+
+
+def test_group_points_preconditions(cuda):
+    from pytorch_points_amd._ext import sampling
+    f = torch.zeros(1, 2, 8, device=cuda)
+    idx = torch.zeros(1, 2, 2, dtype=torch.int32, device=cuda)
+    with pytest.raises(RuntimeError):
+        sampling.group_points(f, idx.long())            # CHECK_IS_INT
+    with pytest.raises(RuntimeError):
+        sampling.group_points(f.transpose(1, 2), idx)   # CHECK_CONTIGUOUS
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        sampling.group_points(f.cpu(), idx.cpu())
+
+
+def test_query_and_group_composed(cuda):
+    from pytorch_points_amd.network.operations import QueryAndGroup
+    from pytorch_points_amd.network import pointnet2_utils
+    b, n, npoint, c, r, ns = 2, 1024, 128, 6, 0.3, 16
+    x = S.unit_sphere(50, b, n)
+    centres = x[:, ::8].copy()
+    feats = S.normal(51, (b, c, n))
+    qg = QueryAndGroup(r, ns, use_xyz=True)
+    out = qg(_t(x, cuda), _t(centres, cuda), _t(feats, cuda))
+    idx = oracle.ball_query(centres, x, r, ns)
+    gx = oracle.group_points(np.ascontiguousarray(x.transpose(0, 2, 1)), idx) - centres.transpose(0, 2, 1)[..., None]
+    gf = oracle.group_points(feats, idx)
+    exp = np.concatenate([gx, gf], 1)
+    assert out.shape == (b, 3 + c, npoint, ns)
+    assert np.array_equal(out.cpu().numpy(), exp)
+    assert pointnet2_utils.QueryAndGroup is QueryAndGroup
+    out2 = QueryAndGroup(r, ns, use_xyz=True)(_t(x, cuda), _t(centres, cuda), None)
+    assert np.array_equal(out2.cpu().numpy(), gx)
+    ga = pointnet2_utils.GroupAll()(_t(x, cuda), None, _t(feats, cuda))
+    assert ga.shape == (b, 3 + c, 1, n)
+
+
+# --------------------------------------------------------------------- three_nn / three_interpolate
+@pytest.mark.parametrize("b,n,m", [(2, 2048, 256), (1, 10, 2), (1, 300, 3), (1, 5, 1), (2, 1000, 1000)])
+def test_three_nn_matches_oracle(cuda, b, n, m):
+    from pytorch_points_amd.network.pointnet2_utils import three_nn
+    u = S.unit_sphere(60, b, n)
+    k = S.unit_sphere(61, b, m)
+    if m >= 6:
+        k[:, m // 2:m // 2 + 3] = k[:, :3]          # exact ties: the earlier index wins at every rank
+    dist, idx = three_nn(_t(u, cuda), _t(k, cuda))
+    e_d2, e_idx = oracle.three_nn(u, k)
+    assert idx.dtype == torch.int32 and np.array_equal(idx.cpu().numpy(), e_idx)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(dist.cpu().numpy(), np.sqrt(e_d2))     # wrapper returns sqrt (ref :33)
+    if m < 3:
+        assert np.isinf(dist.cpu().numpy()[..., m:]).all() and (e_idx[..., m:] == 0).all()
+
+
+def test_three_interpolate_forward_backward(cuda):
+    from pytorch_points_amd.network.pointnet2_utils import three_interpolate
+    b, c, m, n = 2, 19, 256, 777
+    feats = _t(S.normal(70, (b, c, m)), cuda).requires_grad_(True)
+    idx = _t((S.uniform01(71, (b, n, 3)).reshape(b, n, 3) * m).astype(np.int32), cuda)
+    w = S.uniform01(72, (b, n, 3)).reshape(b, n, 3).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    wt = _t(w, cuda)
+    out = three_interpolate(feats, idx, wt)
+    e = oracle.three_interpolate(feats.detach().cpu().numpy(), idx.cpu().numpy(), w)
+    assert np.array_equal(out.detach().cpu().numpy(), e)             # canonical fma order: bit-exact
+    g = torch.gather(feats.unsqueeze(2).expand(-1, -1, n, -1), 3, idx.long()[:, None].expand(-1, c, -1, -1))
+    ref = (g * wt[:, None]).sum(-1)
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+    go = _t(S.normal(73, (b, c, n)), cuda)
+    (out * go).sum().backward()
+    gr = feats.grad.clone()
+    feats.grad = None
+    (ref * go).sum().backward()
+    assert torch.allclose(gr, feats.grad, rtol=1e-5, atol=1e-5)
+    eg = oracle.three_interpolate_grad(go.cpu().numpy(), idx.cpu().numpy(), w, m)
+    assert np.allclose(gr.cpu().numpy(), eg, rtol=1e-5, atol=1e-5)
+
+
+def test_fp_module_style_pipeline(cuda):
+    """three_nn -> inverse-distance weights -> three_interpolate, as PointnetFPModule does
+    (reference network/pointnet2_modules.py:136-141)."""
+    from pytorch_points_amd.network.pointnet2_utils import three_nn, three_interpolate
+    b, n, m, c = 2, 600, 150, 8
+    unknown = _t(S.unit_sphere(80, b, n), cuda)
+    known = _t(S.unit_sphere(81, b, m), cuda)
+    kf = _t(S.normal(82, (b, c, m)), cuda)
+    dist, idx = three_nn(unknown, known)
+    dist_recip = 1.0 / (dist + 1e-8)
+    weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+    out = three_interpolate(kf, idx, weight)
+    assert out.shape == (b, c, n) and torch.isfinite(out).all()
+    e = oracle.three_interpolate(kf.cpu().numpy(), idx.cpu().numpy(), weight.cpu().numpy())
+    assert np.array_equal(out.cpu().numpy(), e)
