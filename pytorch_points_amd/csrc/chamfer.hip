@@ -346,7 +346,7 @@ extern "C" int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, f
                                          int C, void* stream) {
   if (B < 0 || N < 0 || M < 0 || C < 1) return PP_EINVAL;
   if (B == 0 || (N == 0 && M == 0)) return PP_OK;
-  if (!dist1 || !idx1 || !dist2 || !idx2) return PP_EINVAL;
+  if ((N > 0 && (!dist1 || !idx1)) || (M > 0 && (!dist2 || !idx2))) return PP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (N == 0 || M == 0) return zero_outputs(dist1, idx1, dist2, idx2, B, N, M, s);
   if (!xyz1 || !xyz2) return PP_EINVAL;
@@ -380,7 +380,7 @@ extern "C" int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float*
                                                  int B, int N, int M, int C, void* stream) {
   if (B < 0 || N < 0 || M < 0 || C < 1) return PP_EINVAL;
   if (B == 0 || (N == 0 && M == 0)) return PP_OK;
-  if (!dist1 || !idx1 || !dist2 || !idx2) return PP_EINVAL;
+  if ((N > 0 && (!dist1 || !idx1)) || (M > 0 && (!dist2 || !idx2))) return PP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   // M == 0: the reference's kernel leaves dist 0 / idx 0 from the wrapper's zeros, then its
   // post-pass (:110-113) sees idx 0 (not < 0) -- so zeros, like the unlabeled case.

@@ -1,0 +1,114 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/pp_hip.h declares;
+the host wrappers reject what the reference's precondition macros reject; the drop-in import
+names resolve; there is no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from pytorch_points_amd import _build, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_whole_path():
+    syms = declared_symbols()
+    for s in ["pp_nmdistance_forward_f32", "pp_labeled_nmdistance_forward_f32", "pp_nmdistance_backward_f32",
+              "pp_furthest_sampling_f32", "pp_gather_forward_f32", "pp_gather_backward_f32", "pp_ball_query_f32",
+              "pp_group_points_f32", "pp_group_points_grad_f32", "pp_three_nn_f32", "pp_three_interpolate_f32",
+              "pp_three_interpolate_grad_f32"]:
+        assert s in syms
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    _build.build()
+    assert os.path.exists(_build.LIB)
+    handle = ctypes.CDLL(_build.LIB)
+    for s in declared_symbols():
+        assert hasattr(handle, s), "libpp_hip.so does not export %s" % s
+    # and the ctypes table binds exactly the declared functions
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    assert _lib.version().startswith("pp_hip") and "gfx950" in _lib.version()
+
+
+def test_code_object_is_gfx950_only():
+    blob = open(_build.LIB, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_80"):
+        assert other not in blob
+
+
+def test_opt_n_threads_matches_reference_helper():
+    # _ext/cuda_utils.h:11-16
+    import oracle
+    L = _lib.lib()
+    for n in list(range(1, 70)) + [127, 128, 255, 256, 300, 511, 512, 513, 1023, 1024, 5000, 65536, 1 << 20, (1 << 29), (1 << 29) + 1]:
+        assert L.pp_opt_n_threads(n) == oracle.opt_n_threads(n)
+    assert L.pp_opt_n_threads(2048) == 512 and L.pp_opt_n_threads(300) == 256 and L.pp_opt_n_threads(1) == 1
+
+
+def test_no_cpu_fallback():
+    from pytorch_points_amd.network.model_loss import nndistance, labeled_nndistance
+    from pytorch_points_amd.network.operations import gather_points, ball_query, grouping_operation
+    from pytorch_points_amd.network.geo_operations import furthest_point_sample
+    from pytorch_points_amd.network.pointnet2_utils import three_nn, three_interpolate
+    x = torch.zeros(1, 8, 3)
+    i = torch.zeros(1, 4, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        nndistance(x, x)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        labeled_nndistance(x, x, torch.zeros(1, 8), torch.zeros(1, 8))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        gather_points(x.transpose(1, 2).contiguous(), i)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ball_query(0.1, 4, x, x)
+    with pytest.raises(RuntimeError, match="CPU not supported"):     # sampling.cpp:131-133
+        grouping_operation(x.transpose(1, 2).contiguous(), torch.zeros(1, 2, 2, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        furthest_point_sample(x, 4, NCHW=False)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        three_nn(x, x)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        three_interpolate(x.transpose(1, 2).contiguous(), torch.zeros(1, 4, 3, dtype=torch.int32), torch.zeros(1, 4, 3))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pytorch_points_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
+                assert "pp_oracle" not in text, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_build, "LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_drop_in_import_names():
+    import pytorch_points_amd
+    pytorch_points_amd.install_as_pytorch_points()
+    from pytorch_points.network.model_loss import nndistance, labeled_nndistance, NmDistanceFunction  # noqa: F401
+    from pytorch_points.network.operations import gather_points, ball_query, grouping_operation, QueryAndGroup  # noqa: F401
+    from pytorch_points.network.geo_operations import furthest_point_sample  # noqa: F401
+    from pytorch_points.network.pointnet2_utils import three_nn, three_interpolate, GroupAll, QueryAndGroup as Q2  # noqa: F401
+    from pytorch_points._ext import losses, sampling
+    for name in ["nmdistance_forward", "labeled_nmdistance_forward", "nmdistance_backward"]:   # nmdistance.cpp:30-34
+        assert callable(getattr(losses, name))
+    for name in ["furthest_sampling", "gather_forward", "gather_backward", "ball_query", "group_points",
+                 "group_points_grad", "three_nn_wrapper", "three_interpolate_wrapper",
+                 "three_interpolate_grad_wrapper"]:                                            # sampling.cpp:205-216
+        assert callable(getattr(sampling, name))
+    assert torch.backends.cudnn.benchmark is False      # pytorch_points/__init__.py:2

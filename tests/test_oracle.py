@@ -1,0 +1,198 @@
+"""CPU tests of the oracle (no GPU): the committed golden vectors, the structural vs vectorised
+Chamfer forms, and the independent fp64 brute force.
+
+Provenance of the golden vectors: tests/golden/gen_golden.py (oracle outputs accepted by the
+brute force; NOT reference outputs -- the reference has no tests and cannot run here)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import bruteforce as bf
+from pytorch_points_amd import synthetic as S
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz")))
+
+
+CHAMFER_GOLD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "chamfer_*.npz")))
+
+
+def test_golden_files_present():
+    assert len(CHAMFER_GOLD) == 5
+    for n in ["labeled_b1_n512_m700", "fps_b2_n2048_m256", "fps_b1_n300_m64_seed7", "fps_b1_n5000_m128",
+              "ball_query_b2_n2048_m256", "three_nn_b2_n2048_m256", "three_nn_b1_n10_m2"]:
+        assert os.path.exists(os.path.join(GOLD, n + ".npz"))
+
+
+@pytest.mark.parametrize("name", CHAMFER_GOLD)
+@pytest.mark.parametrize("structural", [False, True])
+def test_chamfer_golden(name, structural):
+    g = gold(name)
+    d1, i1, d2, i2 = oracle.chamfer_forward(g["xyz1"], g["xyz2"], structural=structural)
+    assert np.array_equal(i1, g["idx1"]) and np.array_equal(i2, g["idx2"])
+    assert np.array_equal(d1, g["dist1"]) and np.array_equal(d2, g["dist2"])
+    g1, g2 = oracle.chamfer_backward(g["xyz1"], g["xyz2"], g["graddist1"], g["graddist2"], i1, i2)
+    assert np.array_equal(g1, g["gradxyz1"]) and np.array_equal(g2, g["gradxyz2"])
+
+
+@pytest.mark.parametrize("name", CHAMFER_GOLD)
+def test_chamfer_golden_against_fp64(name):
+    g = gold(name)
+    for q, r, d, i in [(g["xyz1"], g["xyz2"], g["dist1"], g["idx1"]), (g["xyz2"], g["xyz1"], g["dist2"], g["idx2"])]:
+        res = bf.check_nn(q, r, d, i)
+        assert res["bad_idx"] == 0 and res["exact_tie_wrong"] == 0 and res["max_rel_err"] < 1e-5
+    f1, f2 = bf.chamfer_grad64(g["xyz1"], g["xyz2"], g["graddist1"], g["graddist2"], g["idx1"], g["idx2"])
+    assert np.allclose(g["gradxyz1"], f1, rtol=1e-5, atol=1e-6) and np.allclose(g["gradxyz2"], f2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 3), (2, 5, 700, 3), (1, 600, 3, 3), (1, 1025, 513, 3), (2, 33, 65, 4), (1, 70, 70, 1)])
+def test_chamfer_structural_equals_vectorised(shape):
+    b, n, m, c = shape
+    x1, x2 = S.unit_sphere(1, b, n, c), S.unit_sphere(2, b, m, c)
+    x2[:, m // 2:] = x2[:, : m - m // 2]      # exact ties across 512-chunk boundaries too
+    a = oracle.chamfer_forward(x1, x2, structural=True)
+    f = oracle.chamfer_forward(x1, x2, structural=False)
+    for u, v in zip(a, f):
+        assert np.array_equal(u, v)
+
+
+def test_chamfer_ties_resolve_to_lowest_index():
+    x2 = np.zeros((1, 1200, 3), np.float32)            # all reference points identical
+    x1 = S.unit_sphere(3, 1, 50)
+    d1, i1, d2, i2 = oracle.chamfer_forward(x1, x2, structural=True)
+    assert (i1 == 0).all()
+    x2 = S.unit_sphere(4, 1, 1200)
+    x2[0, 900] = x2[0, 100]                            # a twin in a later 512-chunk must lose
+    d1, i1, _, _ = oracle.chamfer_forward(x2[:, 100:101].copy(), x2, structural=True)
+    assert i1[0, 0] == 100 and d1[0, 0] == 0
+
+
+def test_chamfer_empty_sides_keep_wrapper_zeros():
+    x2 = S.unit_sphere(1, 2, 9)
+    d1, i1, d2, i2 = oracle.chamfer_forward(np.zeros((2, 0, 3), np.float32), x2)
+    assert d1.shape == (2, 0) and (d2 == 0).all() and (i2 == 0).all()
+
+
+def test_labeled_golden_and_sentinels():
+    g = gold("labeled_b1_n512_m700")
+    d1, i1, d2, i2 = oracle.labeled_chamfer_forward(g["xyz1"], g["xyz2"], g["label1"], g["label2"])
+    for a, k in [(d1, "dist1"), (i1, "idx1"), (d2, "dist2"), (i2, "idx2")]:
+        assert np.array_equal(a, g[k])
+    missing = g["label1"] == 3                      # label 3 does not occur on side 2
+    assert (i1[missing] == -1).all() and (d1[missing] == 0).all() and (i1[~missing] >= 0).all()
+    # backward skips the unmatched rows (ref nmdistance_cuda.cu:175)
+    g1, _ = oracle.chamfer_backward(g["xyz1"], g["xyz2"], np.ones_like(d1), np.zeros_like(d2), i1, i2)
+    assert (g1[missing] == 0).all() and (np.abs(g1[~missing]).sum(-1) > 0).all()
+
+
+@pytest.mark.parametrize("name", ["fps_b2_n2048_m256", "fps_b1_n300_m64_seed7", "fps_b1_n5000_m128"])
+def test_fps_golden(name):
+    g = gold(name)
+    idx, temp = oracle.furthest_sampling(g["xyz"], g["idx"].shape[1], int(g["seed"]))
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(temp, g["temp"])
+    assert (idx[:, 0] == int(g["seed"])).all()
+    for b in range(idx.shape[0]):
+        assert len(set(idx[b].tolist())) == idx.shape[1]        # no duplicates on generic data
+    assert bf.check_fps(g["xyz"], idx, int(g["seed"])) == dict(bad=0, near_ties=0)
+
+
+def test_fps_tie_rule_follows_thread_order():
+    """T = opt_n_threads(N); among equal d2 the smaller (k mod T) wins, then the smaller k
+    (ref sampling_cuda.cu:189,206-209,214-226)."""
+    assert [oracle.opt_n_threads(n) for n in (1, 2, 3, 300, 511, 512, 513, 5000, 65536)] == [1, 2, 2, 256, 256, 512, 512, 512, 512]
+    n = 600                                   # T = 512
+    x = np.zeros((1, n, 3), np.float32)
+    x[0, :, 0] = 1.0                          # everything at distance 1 from the seed except:
+    x[0, 0] = 0                               # the seed itself
+    # candidates at equal distance: k = 5 (slot 5), k = 517 (slot 5, larger k), k = 3 (slot 3)
+    x[0, [5, 517, 3], 1] = 2.0
+    idx, _ = oracle.furthest_sampling(x, 2, 0)
+    assert idx[0, 1] == 3
+    x[0, 3, 1] = 0.0
+    idx, _ = oracle.furthest_sampling(x, 2, 0)
+    assert idx[0, 1] == 5
+    x[0, 5, 1] = 0.0
+    x[0, 100, 1] = 2.0                        # slot 100 vs k=517 in slot 5: lower slot wins
+    idx, _ = oracle.furthest_sampling(x, 2, 0)
+    assert idx[0, 1] == 517
+    allsame = np.ones((1, 40, 3), np.float32)
+    idx, _ = oracle.furthest_sampling(allsame, 6, 9)
+    assert idx.tolist() == [[9, 0, 0, 0, 0, 0]]          # degenerate: index 0 repeated
+
+
+def test_ball_query_golden_and_properties():
+    g = gold("ball_query_b2_n2048_m256")
+    D = bf.sqdist64(g["new_xyz"], g["xyz"])
+    for r in (0.05, 0.2, 0.5):
+        for ns in (16, 64):
+            idx = oracle.ball_query(g["new_xyz"], g["xyz"], r, ns)
+            assert np.array_equal(idx, g["idx_r%g_ns%d" % (r, ns)])
+            assert bf.check_ball_query(g["new_xyz"], g["xyz"], r, ns, idx)["bad_rows"] == 0
+            # every listed index is inside the ball (or the row is the all-zero "empty" row)
+            inside = np.take_along_axis(D, idx.astype(np.int64), -1) < np.float32(r) ** 2 * (1 + 1e-6)
+            empty = (idx == 0).all(-1)
+            assert (inside | empty[..., None]).all()
+            # ascending until the pad, pad == first element
+            diff = np.diff(idx, axis=-1)
+            assert ((diff > 0) | (idx[..., 1:] == idx[..., :1])).all()
+
+
+def test_ball_query_empty_partial_full():
+    x = S.unit_sphere(5, 1, 500)
+    c = x[:, :3].copy()
+    assert (oracle.ball_query(c, x, 1e-6, 4) == np.array([0, 1, 2])[None, :, None]).all()   # only itself
+    far = np.full((1, 2, 3), 10.0, np.float32)
+    assert (oracle.ball_query(far, x, 0.5, 4) == 0).all()                                   # no hit -> zeros
+    assert (oracle.ball_query(c, x, 10.0, 6) == np.arange(6)).all()                         # full -> first 6
+
+
+@pytest.mark.parametrize("name", ["three_nn_b2_n2048_m256", "three_nn_b1_n10_m2"])
+def test_three_nn_golden(name):
+    g = gold(name)
+    d2, idx = oracle.three_nn(g["unknown"], g["known"])
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(d2, g["dist2"])
+    m = g["known"].shape[1]
+    if m < 3:      # unused slots: (float)1e40 = +inf, index 0 (ref interpolate_gpu.cu:30-31,50)
+        assert np.isinf(d2[..., m:]).all() and (idx[..., m:] == 0).all()
+    assert bf.check_three_nn(g["unknown"], g["known"], d2, idx)["bad"] == 0
+    assert (np.diff(d2[..., :min(3, m)], axis=-1) >= 0).all()
+
+
+def test_gather_group_interpolate_identities():
+    b, c, n, npoint, ns = 2, 5, 64, 7, 3
+    f = S.normal(1, (b, c, n))
+    idx = (S.uniform01(2, (b, npoint, ns)).reshape(b, npoint, ns) * n).astype(np.int32)
+    out = oracle.group_points(f, idx)
+    exp = np.take_along_axis(f, idx.reshape(b, 1, -1).astype(np.int64).repeat(c, 1), 2).reshape(b, c, npoint, ns)
+    assert np.array_equal(out, exp)
+    assert np.array_equal(oracle.gather_forward(f, idx[:, :, 0]), exp[..., 0])
+    go = S.normal(3, (b, c, npoint, ns))
+    gp = oracle.group_points_grad(go, idx, n)
+    ref = np.zeros((b, c, n))
+    for bi in range(b):
+        for j in range(npoint):
+            for k in range(ns):
+                ref[bi, :, idx[bi, j, k]] += go[bi, :, j, k]
+    assert np.allclose(gp, ref, atol=1e-5)
+    assert np.allclose(oracle.gather_backward(go[..., 0], idx[:, :, 0], n).sum(), go[..., 0].sum(), rtol=1e-4)
+    w = S.uniform01(4, (b, npoint, 3)).reshape(b, npoint, 3).astype(np.float32)
+    ti = oracle.three_interpolate(f, idx, w)
+    exp = (np.take_along_axis(f[:, :, None, :].repeat(npoint, 2), idx[:, None].astype(np.int64).repeat(c, 1), 3) * w[:, None]).sum(-1)
+    assert np.allclose(ti, exp, rtol=1e-5, atol=1e-6)
+    tg = oracle.three_interpolate_grad(S.normal(5, (b, c, npoint)), idx, w, n)
+    assert tg.shape == (b, c, n)
+
+
+def test_synthetic_generator_is_counter_based():
+    a = S.unit_sphere(0, 2, 100)
+    assert np.array_equal(a, S.unit_sphere(0, 2, 100)) and not np.array_equal(a, S.unit_sphere(1, 2, 100))
+    assert np.allclose(np.linalg.norm(a, axis=-1), 1, atol=1e-6)
+    assert abs(a.mean()) < 0.1 and S.polar_sphere(0, 1, 10).shape == (1, 10, 3)
+    # a pinned value: inputs must not drift with numpy versions
+    assert S.unit_sphere(0, 1, 4).dtype == np.float32

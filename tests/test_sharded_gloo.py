@@ -1,0 +1,85 @@
+"""world_size-2 gloo test of the batch-shard + all-gather host logic (CPU, no GPU).
+
+The local operator is injected (a torch restatement of Chamfer) because the product operator is
+HIP-only; what is under test is pytorch_points_amd/sharded.py: slab bounds, gather order, ragged
+shards, and that gradients reach exactly the local shard."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pytorch_points_amd import sharded
+
+
+def _torch_chamfer(x1, x2):
+    d = ((x1[:, :, None] - x2[:, None]) ** 2).sum(-1)
+    d1, i1 = d.min(2)
+    d2, i2 = d.min(1)
+    return d1, d2, i1.int(), i2.int()
+
+
+def _worker(rank, world, port, sizes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B = sum(sizes)
+        g = torch.Generator().manual_seed(0)
+        X1 = torch.randn(B, 40, 3, generator=g)
+        X2 = torch.randn(B, 30, 3, generator=g)
+        lo = sum(sizes[:rank])
+        hi = lo + sizes[rank]
+        x1 = X1[lo:hi].clone().requires_grad_(True)
+        x2 = X2[lo:hi].clone().requires_grad_(True)
+        d1, d2, i1, i2 = sharded.sharded_nndistance(x1, x2, _local_op=_torch_chamfer)
+        F1 = X1.clone().requires_grad_(True)
+        F2 = X2.clone().requires_grad_(True)
+        e1, e2, j1, j2 = _torch_chamfer(F1, F2)
+        ok = torch.equal(d1, e1) and torch.equal(d2, e2) and torch.equal(i1, j1) and torch.equal(i2, j2)
+        ok = ok and d1.shape[0] == B and not i1.requires_grad
+        w = torch.arange(B, dtype=torch.float32)[:, None]
+        ((d1 * w).sum() + d2.sum()).backward()
+        ((e1 * w).sum() + e2.sum()).backward()
+        ok = ok and torch.allclose(x1.grad, F1.grad[lo:hi]) and torch.allclose(x2.grad, F2.grad[lo:hi])
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("sizes", [[3, 3], [4, 1]])
+def test_sharded_equals_unsharded_world2(sizes):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, sizes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shard_bounds_partition_the_batch():
+    for B in (0, 1, 7, 32, 256):
+        for w in (1, 2, 3, 8):
+            spans = [sharded.shard_bounds(B, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_single_process_is_identity():
+    x = torch.randn(2, 3)
+    assert sharded.all_gather_batch(x) is x
