@@ -170,9 +170,9 @@ def bench_chamfer(args, dist, world, rank, device):
     ms = dt / args.steps * 1e3
     alg_bytes_fwd = 4.0 * C * B * (N + M) + 8.0 * B * (N + M)
     hbm_gbs = alg_bytes_fwd / (fwd_ms * 1e-3) / 1e9
-    # VALU lane-ops actually issued per pair by the kernel: 3 sub + 1 mul + 2 fma + 1/2 min3 + 13/32
+    # VALU lane-ops actually issued per pair by the kernel: 3 sub + 1 mul + 2 fma + 1/2 min3 + 13/64
     # per-group bookkeeping (DESIGN.md "nmdist_fwd_c3_kernel")
-    laneops = 2.0 * B * N * M * 6.90625
+    laneops = 2.0 * B * N * M * 6.703125
     out = {
         "metric": "chamfer_fwd_bwd_point_pairs_per_s", "value": pairs_per_step / (dt / args.steps),
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

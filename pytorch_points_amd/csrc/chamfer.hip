@@ -14,7 +14,9 @@
 //     one op per two pairs) and after the group one compare/select records the id of the FIRST
 //     group that lowered the minimum.  After the scan each query recomputes the G distances of
 //     its recorded group (bit-identical arithmetic) and takes the first one equal to the minimum.
-//     VALU cost per pair: 3 sub + 1 mul + 2 fma + 1/2 min3 + 2/G  (6.75 at G = 8) instead of 9.
+//     VALU cost per pair: 3 sub + 1 mul + 2 fma + 1/2 min3 + ~13/(Q*G) bookkeeping instead of 9
+//     (and v_cmp/v_cndmask/v_min3 issue at half the rate of add/mul/fma on gfx950, so the saving
+//     in issue cycles is larger than in instruction count: 14 cycles per pair per SIMD vs 24).
 //   * both directions (xyz1->xyz2, xyz2->xyz1) are one launch; virtual block ids are dealt to the
 //     8 XCDs in contiguous ranges so that workgroups sharing a reference cloud share an L2.
 #include "pp_common.h"
@@ -26,7 +28,12 @@ using pp::chamfer_d3;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = 64 * kWavesPerBlock;
 
-template <int Q, int G>
+// PK: the distance arithmetic of two queries is issued as packed fp32 (v_pk_add/mul/fma_f32 on
+// register pairs, the wave-uniform reference coordinate broadcast from an SGPR).  Same IEEE
+// operations per element, so the bits do not change; measured on MI355X a v_sub_f32 with an SGPR
+// operand issues at half the rate of the VGPR-only form while v_pk_add_f32 with an SGPR source
+// does two subtractions in the same slot (tools/valu_microbench2.hip, DESIGN.md "VALU roof").
+template <int Q, int G, bool PK>
 __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
     int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M,
@@ -76,13 +83,28 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     float nb[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) nb[i] = best[i];
+    if constexpr (PK) {
+      static_assert(!PK || Q % 2 == 0, "packed form pairs the queries of a lane");
 #pragma unroll
-    for (int p = 0; p < G; p += 2) {
+      for (int p = 0; p < G; p += 2) {
 #pragma unroll
-      for (int i = 0; i < Q; ++i) {
-        const float da = chamfer_d3(rr[3 * p + 0], rr[3 * p + 1], rr[3 * p + 2], qx[i], qy[i], qz[i]);
-        const float db = chamfer_d3(rr[3 * p + 3], rr[3 * p + 4], rr[3 * p + 5], qx[i], qy[i], qz[i]);
-        nb[i] = pp::min3(da, db, nb[i]);
+        for (int i = 0; i < Q; i += 2) {
+          const pp::f2 x2 = {qx[i], qx[i + 1]}, y2 = {qy[i], qy[i + 1]}, z2 = {qz[i], qz[i + 1]};
+          const pp::f2 da = pp::chamfer_d3_pk(rr[3 * p + 0], rr[3 * p + 1], rr[3 * p + 2], x2, y2, z2);
+          const pp::f2 db = pp::chamfer_d3_pk(rr[3 * p + 3], rr[3 * p + 4], rr[3 * p + 5], x2, y2, z2);
+          nb[i] = pp::min3(da.x, db.x, nb[i]);
+          nb[i + 1] = pp::min3(da.y, db.y, nb[i + 1]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < G; p += 2) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+          const float da = chamfer_d3(rr[3 * p + 0], rr[3 * p + 1], rr[3 * p + 2], qx[i], qy[i], qz[i]);
+          const float db = chamfer_d3(rr[3 * p + 3], rr[3 * p + 4], rr[3 * p + 5], qx[i], qy[i], qz[i]);
+          nb[i] = pp::min3(da, db, nb[i]);
+        }
       }
     }
 #pragma unroll
@@ -295,7 +317,7 @@ __global__ void fill_zero_kernel(float* __restrict__ a, int* __restrict__ b, lon
   }
 }
 
-template <int Q, int G>
+template <int Q, int G, bool PK = false>
 int launch_fwd_c3(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
                   int* idx2, int B, int N, int M, hipStream_t s) {
   constexpr int TQ = 64 * Q;
@@ -303,7 +325,7 @@ int launch_fwd_c3(const float* xyz1, const float* xyz2, float* dist1, int* idx1,
   const long long total = (long long)B * (tiles1 + tiles2);
   if (total > 0x7fffff00LL) return PP_EINVAL;
   const int per_xcd = (int)((total + 7) / 8);
-  nmdist_fwd_c3_kernel<Q, G><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
+  nmdist_fwd_c3_kernel<Q, G, PK><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
       xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, tiles1, tiles2, (int)total, per_xcd);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
@@ -354,7 +376,7 @@ extern "C" int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, f
     // queries per lane: enough workgroups to give every CU (256) several, else a smaller tile
     const long long q = (long long)B * ((long long)N + M);
     int variant = g_fwd_variant;
-    if (variant == 0) variant = q >= 4LL * 256 * 1024 ? 4 : (q >= 2LL * 256 * 512 ? 2 : 1);
+    if (variant == 0) variant = q >= 4LL * 256 * 1024 ? 1416 : (q >= 2LL * 256 * 512 ? 1002 : 1);
     switch (variant) {
       case 4: return launch_fwd_c3<4, 8>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
       case 2: return launch_fwd_c3<2, 8>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
@@ -363,6 +385,11 @@ extern "C" int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, f
       case 416: return launch_fwd_c3<4, 16>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
       case 216: return launch_fwd_c3<2, 16>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
       case 44: return launch_fwd_c3<4, 4>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 1002: return launch_fwd_c3<2, 8, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 1004: return launch_fwd_c3<4, 8, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 1008: return launch_fwd_c3<8, 8, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 1416: return launch_fwd_c3<4, 16, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 1816: return launch_fwd_c3<8, 16, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
       default: return PP_EINVAL;
     }
   }

@@ -29,6 +29,15 @@ __device__ __forceinline__ float chamfer_d3(float rx, float ry, float rz, float 
   return __builtin_fmaf(t2, t2, __builtin_fmaf(t1, t1, t0 * t0));
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// two queries against one wave-uniform reference point, element-wise the same operations as
+// chamfer_d3 (v_pk_add_f32 with the SGPR broadcast, v_pk_mul_f32, v_pk_fma_f32)
+__device__ __forceinline__ f2 chamfer_d3_pk(float rx, float ry, float rz, f2 qx, f2 qy, f2 qz) {
+  const f2 t0 = (f2)(rx) - qx, t1 = (f2)(ry) - qy, t2 = (f2)(rz) - qz;
+  return __builtin_elementwise_fma(t2, t2, __builtin_elementwise_fma(t1, t1, t0 * t0));
+}
+
 __device__ __forceinline__ float dist3(float ax, float ay, float az, float bx, float by, float bz) {
   const float dx = ax - bx, dy = ay - by, dz = az - bz;
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
