@@ -218,7 +218,7 @@ def bench_fps(args, dist, world, rank, device):
             "data": "synthetic",
             "config": {"workload": "furthest_point_sample + gather_points B=%d N=%d npoint=%d" % (B, N, npoint),
                        "parallelism": "replicas x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "fps_block_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "fps_cluster_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                          "note": "serial chain of npoint-1 dependent steps: latency-bound, not HBM-bound"},
             "us_per_pick": ms * 1e3 / (npoint - 1)}

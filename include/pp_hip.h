@@ -66,6 +66,9 @@ int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2, const float
  * network/geo_operations.py:33); idx (B,npoint) out, idx[:,0] = seed_idx.
  * workspace: pp_furthest_sampling_workspace_bytes(...) bytes of scratch (may be NULL if that is 0). */
 size_t pp_furthest_sampling_workspace_bytes(int B, int N, int npoint);
+/* Debug/test aid (synchronises `stream`): 0 = ok, 1 = a bounded inter-workgroup wait of an earlier
+ * pp_furthest_sampling_f32 call on this workspace timed out (its indices are invalid). */
+int pp_furthest_sampling_status(const void* workspace, void* stream);
 int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx, int B, int N, int npoint,
                              int seed_idx, void* workspace, size_t workspace_bytes, void* stream);
 

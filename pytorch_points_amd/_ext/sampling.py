@@ -23,6 +23,16 @@ def _workspace(device, nbytes):
     return buf
 
 
+def furthest_sampling_status(device):
+    """Test/debug aid: 0 if no inter-workgroup wait of the FPS cluster kernel has timed out on this
+    device's workspace since its last call (synchronises the current stream)."""
+    ws = _fps_workspace.get(torch.device(device))
+    if ws is None:
+        return 0
+    with _lib.on_device(ws.device) as stream:
+        return int(_lib.lib().pp_furthest_sampling_status(_lib.ptr(ws), stream))
+
+
 def furthest_sampling(m, seedIdx, input, temp, idx):
     """furthest_sampling_forward (sampling.cpp:68-82): input (B,N,3), temp (B,N) in/out, idx (B,m)
     out; returns idx."""

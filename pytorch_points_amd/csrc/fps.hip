@@ -119,6 +119,154 @@ __global__ __launch_bounds__(kFpsThreads) void fps_block_kernel(const float* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v2: a CLUSTER of CL workgroups (one per CU) per batch element.  Each workgroup keeps its slice
+// of the cloud -- coordinates AND running minima -- in registers for the whole call (R points per
+// thread, 512 threads), so a step touches no memory except:
+//   * one 8-byte granule per workgroup per step, {float_bits(d2) : 32 | ~tie_rank : 24 | tag : 8},
+//     published with an agent-scope relaxed store (sc1, write-through) into a 2-deep ring indexed
+//     by step parity, and polled by CL lanes of wave 0 of every workgroup of the cluster with
+//     agent-scope relaxed loads until all CL tags equal the step's tag;
+//   * the coordinates of the winner, read from the immutable input (scalar load, L2).
+// The granule IS the flag (no separate flag, no fence: nothing else is handed over).  Two ring
+// slots suffice: a workgroup can publish step j+2 only after it has read every member's step j+1
+// granule, which that member publishes only after it has read all of step j.  The ring is reset
+// by a hipMemsetAsync node in front of every launch (tag 0xFF never matches: tags are 7 bits).
+// Correctness does not depend on placement or dispatch order; it needs the B*CL workgroups to be
+// co-resident, which the launcher guarantees by keeping B*CL <= 256 (one 512-thread workgroup per
+// CU).  Every spin is bounded (2 s of s_memrealtime): on timeout the workgroup raises the error
+// word at the head of the workspace and leaves.
+// ------------------------------------------------------------------------------------------------
+constexpr int kClThreads = 512;
+constexpr int kClWaves = kClThreads / 64;
+constexpr unsigned long long kSpinLimitTicks = 200000000ull;  // 2 s at 100 MHz
+
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+
+struct ClusterGeom {
+  int cl;        // workgroups per batch element (power of two, <= 64)
+  int slice;     // points per workgroup (multiple of kClThreads)
+  int per_xcd8;  // cl * ceil(B / 8): blocks that share blockIdx % 8
+};
+
+template <int R>
+__global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
+    const float* __restrict__ xyz, float* __restrict__ temp, int* __restrict__ idx, int B, int N,
+    int npoint, int seed, TieOrder order, ClusterGeom geo, u64* __restrict__ ring,
+    unsigned* __restrict__ err) {
+  __shared__ u64 s_key[2][kClWaves];
+  __shared__ int s_old[2];
+  // members of one batch element share blockIdx % 8 (one XCD under round-robin dispatch): speed only
+  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+  const int b = x + 8 * (y / geo.cl);
+  const int c = y % geo.cl;
+  if (b >= B) return;
+  const float* __restrict__ p = xyz + (size_t)b * N * 3;
+  float* __restrict__ tmp = temp + (size_t)b * N;
+  int* __restrict__ out = idx + (size_t)b * npoint;
+  gu64* bring = (gu64*)(ring + (size_t)b * 2 * geo.cl);
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = pp::wave_id_uniform();
+  const int k0 = c * geo.slice;
+
+  float px[R], py[R], pz[R], td[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int k = k0 + t + kClThreads * i;
+    const bool ok = k < N && t + kClThreads * i < geo.slice;
+    const int kc = ok ? k : 0;
+    px[i] = p[3 * (size_t)kc + 0];
+    py[i] = p[3 * (size_t)kc + 1];
+    pz[i] = p[3 * (size_t)kc + 2];
+    // points outside the slice never win: -1 < every real d2 (>= 0); min(d, -1) stays -1
+    td[i] = ok ? tmp[kc] : -1.0f;
+  }
+  int old = seed;
+  if (c == 0 && t == 0) out[0] = old;
+  bool dead = false;
+  for (int j = 1; j < npoint; ++j) {
+    const float ox = p[3 * (size_t)old + 0], oy = p[3 * (size_t)old + 1], oz = p[3 * (size_t)old + 2];
+    const unsigned tag = (((unsigned)j & 63u) << 1) | 1u;  // odd, 7 bits: never 0, never 0xFF
+    u64 best = tag;  // a workgroup whose slice is empty still publishes a tagged (losing) granule
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int k = k0 + t + kClThreads * i;
+      const float d = dist3(px[i], py[i], pz[i], ox, oy, oz);
+      const float d2 = __builtin_fminf(d, td[i]);
+      td[i] = d2;
+      // negative (padding) entries produce a key below every real one
+      const u64 key = d2 < 0.0f ? 0ull
+                                : (((u64)__float_as_uint(d2) << 32) |
+                                   ((u64)(0xFFFFFFu - order.rank(k)) << 8) | tag);
+      best = key > best ? key : best;
+    }
+    best = wave_max_u64(best);
+    if (lane == 0) s_key[j & 1][wave] = best;
+    __syncthreads();
+    if (wave == 0) {
+      u64 m = s_key[j & 1][lane & (kClWaves - 1)];
+      m = wave_max_u64(m);  // every lane: this workgroup's best
+      gu64* slot = bring + (size_t)(j & 1) * geo.cl;
+      if (lane == 0) __hip_atomic_store(slot + c, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // poll the cluster's granules of this step
+      u64 v = m;
+      const bool poller = lane < geo.cl && lane != c;
+      const u64 t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        if (poller) v = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = !poller || (unsigned)(v & 0xFFu) == tag;
+        if (__all(ready)) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
+          dead = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (lane >= geo.cl) v = 0ull;
+      v = wave_max_u64(v);
+      const unsigned r = 0xFFFFFFu - (unsigned)((v >> 8) & 0xFFFFFFull);
+      if (lane == 0) s_old[j & 1] = dead ? -1 : order.unrank(r);
+    }
+    __syncthreads();
+    old = __builtin_amdgcn_readfirstlane(s_old[j & 1]);
+    if (old < 0) {  // timed out: flag and leave (uniform across the workgroup)
+      if (t == 0) atomicOr(err, 1u);
+      return;
+    }
+    if (c == 0 && t == 0) out[j] = old;
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int k = k0 + t + kClThreads * i;
+    if (k < N && t + kClThreads * i < geo.slice) tmp[k] = td[i];
+  }
+}
+
+template <int R>
+void launch_fps_cluster(const float* xyz, float* temp, int* idx, int B, int N, int npoint, int seed,
+                        TieOrder order, ClusterGeom geo, u64* ring, unsigned* err, hipStream_t s) {
+  const int groups8 = (B + 7) / 8;
+  fps_cluster_kernel<R><<<dim3(8 * groups8 * geo.cl), dim3(kClThreads), 0, s>>>(
+      xyz, temp, idx, B, N, npoint, seed, order, geo, ring, err);
+}
+
+// cluster size: as many workgroups per batch element as keeps B*CL <= 256 (co-residency), at
+// least 512 points each; 0 = do not use the cluster kernel
+int pick_cluster(int B, int N) {
+  if (N > (1 << 24) - 1024) return 0;  // tie rank (< N + 512) must fit 24 bits
+  int cl = 1;
+  while (cl * 2 <= 64 && (long long)8 * ((B + 7) / 8) * (cl * 2) <= 256 && (N + cl * 2 - 1) / (cl * 2) >= kClThreads)
+    cl *= 2;
+  if (cl < 2) return 0;
+  const int slice = ((N + cl - 1) / cl + kClThreads - 1) / kClThreads * kClThreads;
+  if (slice / kClThreads > 32) return 0;  // more than 32 points per thread: registers
+  return cl;
+}
+
+constexpr size_t kFpsErrBytes = 256;  // error word + padding in front of the ring
+
 template <int R>
 void launch_fps(const float* xyz, float* temp, int* idx, int B, int N, int npoint, int seed,
                 TieOrder order, hipStream_t s) {
@@ -127,15 +275,30 @@ void launch_fps(const float* xyz, float* temp, int* idx, int B, int N, int npoin
 
 }  // namespace
 
+static int g_fps_force_v1 = 0;
+extern "C" void pp_debug_set_fps_v1(int on) { g_fps_force_v1 = on; }
+
 extern "C" size_t pp_furthest_sampling_workspace_bytes(int B, int N, int npoint) {
-  (void)B; (void)N; (void)npoint;
-  return 0;
+  (void)npoint;
+  if (B <= 0 || N <= 0) return 0;
+  const int cl = pick_cluster(B, N);
+  if (cl == 0) return 0;
+  return kFpsErrBytes + (size_t)8 * ((B + 7) / 8) * 2 * cl * sizeof(u64);
+}
+
+// 0 = ok; 1 = a cluster spin timed out in some earlier call that used this workspace (the indices
+// of that call are invalid).  Synchronises the stream: a debugging / test aid, not a hot-path call.
+extern "C" int pp_furthest_sampling_status(const void* workspace, void* stream) {
+  if (!workspace) return 0;
+  unsigned v = 0;
+  if (hipMemcpyAsync(&v, workspace, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+  return (int)v;
 }
 
 extern "C" int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx, int B, int N,
                                         int npoint, int seed_idx, void* workspace,
                                         size_t workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes;
   if (B < 0 || N < 0 || npoint < 0) return PP_EINVAL;
   if (B == 0 || npoint <= 0) return PP_OK;  // ref: `if (m <= 0) return;` (sampling_cuda.cu:166)
   if (N == 0 || !xyz || !temp || !idx) return PP_EINVAL;
@@ -147,6 +310,31 @@ extern "C" int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx,
   order.t_shift = __builtin_ctz((unsigned)T);
   order.rows = (N + T - 1) / T;
   if ((long long)T * order.rows > 0xFFFFFFFELL) return PP_EINVAL;
+  const int cl = g_fps_force_v1 ? 0 : pick_cluster(B, N);
+  if (cl >= 2 && npoint > 1) {
+    const size_t need = pp_furthest_sampling_workspace_bytes(B, N, npoint);
+    if (!workspace || workspace_bytes < need) return PP_EINVAL;
+    ClusterGeom geo;
+    geo.cl = cl;
+    geo.slice = ((N + cl - 1) / cl + kClThreads - 1) / kClThreads * kClThreads;
+    geo.per_xcd8 = cl * ((B + 7) / 8);
+    // reset the error word and the ring (tag 0xFF never matches a step tag)
+    hipError_t e = hipMemsetAsync(workspace, 0, kFpsErrBytes, s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync((char*)workspace + kFpsErrBytes, 0xFF, need - kFpsErrBytes, s);
+    if (e != hipSuccess) return (int)e;
+    u64* ring = (u64*)((char*)workspace + kFpsErrBytes);
+    unsigned* err = (unsigned*)workspace;
+    const int r = geo.slice / kClThreads;
+    if (r <= 1) launch_fps_cluster<1>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
+    else if (r <= 2) launch_fps_cluster<2>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
+    else if (r <= 4) launch_fps_cluster<4>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
+    else if (r <= 8) launch_fps_cluster<8>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
+    else if (r <= 16) launch_fps_cluster<16>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
+    else launch_fps_cluster<32>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
+    PP_RETURN_IF_LAUNCH_FAILED();
+    return PP_OK;
+  }
   const int per_thread = (N + kFpsThreads - 1) / kFpsThreads;
   if (per_thread <= 1) launch_fps<1>(xyz, temp, idx, B, N, npoint, seed_idx, order, s);
   else if (per_thread <= 2) launch_fps<2>(xyz, temp, idx, B, N, npoint, seed_idx, order, s);

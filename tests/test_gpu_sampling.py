@@ -16,9 +16,25 @@ def _t(a, cuda):
 
 
 # ---------------------------------------------------------------- furthest point sampling + gather
+@pytest.fixture(params=["cluster", "single_block"])
+def fps_path(request, cuda):
+    """Run every FPS test on both decompositions: the CU-cluster kernel (default where it applies)
+    and the one-workgroup-per-batch kernel; afterwards no inter-workgroup wait may have timed out."""
+    import ctypes
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd._ext import sampling
+    setter = _lib.lib().pp_debug_set_fps_v1
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(1 if request.param == "single_block" else 0)
+    yield request.param
+    setter(0)
+    assert sampling.furthest_sampling_status(cuda) == 0
+
+
 @pytest.mark.parametrize("b,n,m,seed", [(2, 2048, 256, 0), (1, 300, 64, 7), (1, 5000, 128, 0),
                                         (3, 1024, 1024, 3), (1, 70, 70, 0), (2, 1, 1, 0), (1, 513, 40, 512)])
-def test_fps_matches_oracle(cuda, b, n, m, seed):
+def test_fps_matches_oracle(cuda, fps_path, b, n, m, seed):
     from pytorch_points_amd.network.geo_operations import furthest_point_sample
     x = S.unit_sphere(10, b, n)
     idx, pc = furthest_point_sample(_t(x, cuda), m, NCHW=False, seedIdx=seed)
@@ -32,7 +48,7 @@ def test_fps_matches_oracle(cuda, b, n, m, seed):
     assert torch.equal(idx2, idx) and torch.equal(pc2, pc.transpose(1, 2))
 
 
-def test_fps_ties_and_degenerate(cuda):
+def test_fps_ties_and_degenerate(cuda, fps_path):
     """Exact ties (duplicated points, all-equal points) follow the reference's thread-order rule."""
     from pytorch_points_amd._ext import sampling
     x = S.unit_sphere(11, 2, 1500)
@@ -50,7 +66,7 @@ def test_fps_ties_and_degenerate(cuda):
     assert (e_idx[1, 1:] == 0).all()
 
 
-def test_fps_large_n_paths(cuda):
+def test_fps_large_n_paths(cuda, fps_path):
     """N > 1024 (several points per thread) and N > 65536 (temp kept in global memory)."""
     from pytorch_points_amd.network.geo_operations import furthest_point_sample
     for n, m in [(20000, 64), (70000, 24)]:
@@ -58,6 +74,34 @@ def test_fps_large_n_paths(cuda):
         idx, _ = furthest_point_sample(_t(x, cuda), m, NCHW=False)
         e_idx, _ = oracle.furthest_sampling(x, m, 0)
         assert np.array_equal(idx.cpu().numpy(), e_idx)
+
+
+def test_fps_config3_full_size(cuda):
+    """BASELINE config 3 (B=16, N=65536 -> 4096): cluster kernel == single-block kernel on every
+    batch element, == oracle on one; repeated calls reuse the workspace ring safely."""
+    import ctypes
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd._ext import sampling
+    from pytorch_points_amd.network.geo_operations import furthest_point_sample
+    B, N, m = 16, 65536, 4096
+    x = S.unit_sphere(13, B, N)
+    xt = _t(x, cuda)
+    runs = [furthest_point_sample(xt, m, NCHW=False)[0] for _ in range(3)]
+    assert sampling.furthest_sampling_status(cuda) == 0
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    setter = _lib.lib().pp_debug_set_fps_v1
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(1)
+    try:
+        v1, _ = furthest_point_sample(xt[:3].contiguous(), m, NCHW=False)
+    finally:
+        setter(0)
+    assert torch.equal(runs[0][:3], v1)
+    e_idx, _ = oracle.furthest_sampling(x[:1], m, 0)
+    assert np.array_equal(runs[0][:1].cpu().numpy(), e_idx)
+    for b in range(B):
+        assert len(set(runs[0][b].tolist())) == m
 
 
 def test_gather_matches_torch_and_backward(cuda):
