@@ -30,6 +30,8 @@ __device__ __forceinline__ float chamfer_d3(float rx, float ry, float rz, float 
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
 
 // two queries against one wave-uniform reference point, element-wise the same operations as
 // chamfer_d3 (v_pk_add_f32 with the SGPR broadcast, v_pk_mul_f32, v_pk_fma_f32)

@@ -166,6 +166,224 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float* __restri
   }
 }
 
+// v2: the channel row points[b,c,:] (N floats) is staged in LDS once per workgroup and the gathers
+// become ds_read_b32 (random LDS addresses: ~3-4-way bank conflicts, still several times the rate
+// of 64-distinct-line global gathers).  A 512-thread workgroup owns 512*4*V consecutive (j,k)
+// positions of one batch element, keeps their indices in registers for all C channels (idx is
+// read from HBM exactly once) and streams 16-byte stores.  Two workgroups per CU (<= 64 KiB of LDS
+// each) overlap one's row load + barrier with the other's gather + store phase.  Workgroups of
+// one batch element share blockIdx % 8 (one XCD's L2 serves the row re-reads).
+// A 16-byte global load the compiler does not track: hipcc's waitcnt pass treats a vmcnt queue that
+// holds both loads and stores as unordered and drains it (vmcnt(0)) at the first use of a load
+// result -- which here would wait for the previous channel's 8 HBM stores every iteration.  The
+// hardware retires vector-memory operations in issue order, so the loads (issued before the
+// stores) are complete once at most `V` younger operations are outstanding: vm_wait<V>().
+__device__ __forceinline__ void load16_untracked(pp::f4& dst, const pp::f4* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N, int KR>
+__device__ __forceinline__ void vm_wait(pp::f4 (&r)[KR]) {
+  // names every destination so that no use of them can be scheduled above the wait
+  if constexpr (KR == 1)
+    asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(r[0]) : "i"(N));
+  else if constexpr (KR == 2)
+    asm volatile("s_waitcnt vmcnt(%c2)" : "+v"(r[0]), "+v"(r[1]) : "i"(N));
+  else if constexpr (KR == 4)
+    asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "i"(N));
+  else
+    asm volatile("s_waitcnt vmcnt(%c8)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                 : "i"(N));
+}
+
+template <int V, int KR, bool FULL>
+__device__ __forceinline__ void group_points_lds_loop(const pp::f4* __restrict__ row, float* __restrict__ out_b,
+                                                      float* s_row, const pp::i4 (&ii)[V], int C, int n4,
+                                                      long long P, long long p0, int t) {
+  // The row loads are unconditional (indices clamped to the row: surplus lanes re-load and
+  // re-write the last float4 with the same value).  Row c+1 is fetched into registers BEFORE the
+  // stores of row c are issued; in the FULL instantiation exactly V stores follow the loads, so
+  // vmcnt(V) retires the loads and leaves the stores in flight across the barriers.
+  static_assert(KR == 1 || KR == 2 || KR == 4 || KR == 8, "");
+  int ee[KR];
+  pp::f4 pre[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    ee[k] = min(t + 512 * k, n4 - 1);
+    load16_untracked(pre[k], row + ee[k]);
+  }
+  vm_wait<0, KR>(pre);
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();  // everyone is done gathering from the previous row
+    // FULL: exactly V stores were issued after the loads of this row; otherwise the count varies
+    // per wave and the queue is drained.  (c == 0: retired before the loop.)
+    if (c > 0) vm_wait<FULL ? V : 0, KR>(pre);
+#pragma unroll
+    for (int k = 0; k < KR; ++k) reinterpret_cast<pp::f4*>(s_row)[ee[k]] = pre[k];
+    __syncthreads();
+    // last iteration: harmless re-load of the same row (keeps the loop body branch-free)
+    const pp::f4* __restrict__ nrow = row + (size_t)(c + 1 < C ? c + 1 : c) * n4;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) load16_untracked(pre[k], nrow + ee[k]);
+    float* __restrict__ o = out_b + (size_t)c * P;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const long long p = p0 + (long long)v * 2048;
+      pp::f4 r;
+      r.x = s_row[ii[v].x];
+      r.y = s_row[ii[v].y];
+      r.z = s_row[ii[v].z];
+      r.w = s_row[ii[v].w];
+      if (FULL || p < P) *reinterpret_cast<pp::f4*>(o + p) = r;
+    }
+  }
+  vm_wait<0, KR>(pre);  // the surplus prefetch of the last iteration
+}
+
+template <int V, int KR>
+__global__ __launch_bounds__(512, 4) void group_points_lds_kernel(const float* __restrict__ points,
+                                                                  const int* __restrict__ idx,
+                                                                  float* __restrict__ out, int B, int C,
+                                                                  int N, long long P, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) float s_row[];
+  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+  const int b = x + 8 * (y / chunks);
+  const int chunk = y % chunks;
+  if (b >= B) return;
+  const int t = threadIdx.x;
+  const long long p0 = (long long)chunk * (512 * 4 * V) + t * 4;
+  const bool full = (long long)(chunk + 1) * (512 * 4 * V) <= P;  // every position of the chunk exists
+  pp::i4 ii[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const long long p = p0 + (long long)v * 2048;
+    ii[v] = p < P ? *reinterpret_cast<const pp::i4*>(idx + (size_t)b * P + p) : pp::i4{0, 0, 0, 0};
+  }
+  const pp::f4* __restrict__ row = reinterpret_cast<const pp::f4*>(points + (size_t)b * C * N);
+  float* __restrict__ out_b = out + (size_t)b * C * P;
+  if (full)
+    group_points_lds_loop<V, KR, true>(row, out_b, s_row, ii, C, N >> 2, P, p0, t);
+  else
+    group_points_lds_loop<V, KR, false>(row, out_b, s_row, ii, C, N >> 2, P, p0, t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v3: the same staging, done by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write)
+// into a 2-deep ring of row buffers, one 1024-thread workgroup per CU.  Row c+1 is in flight during
+// the whole gather/store phase of row c; one barrier per channel.  Every wait is counted by hand:
+// the DMA pieces of row c are older than the V stores of channel c-1, and vector-memory operations
+// retire in issue order, so `vmcnt(V)` retires the DMA and leaves the stores in flight
+// (a __syncthreads() here would make hipcc drain the queue: the guide's "Pipelining across
+// barriers").  Used when 2 * row bytes fit the LDS and every position chunk is full.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDmaThreads = 1024;
+constexpr int kDmaPieceF4 = kDmaThreads;  // float4 moved per workgroup pass (16 KiB)
+
+template <int V>
+__global__ __launch_bounds__(kDmaThreads) void group_points_dma_kernel(const float* __restrict__ points,
+                                                                       const int* __restrict__ idx,
+                                                                       float* __restrict__ out, int B, int C,
+                                                                       int N, long long P, int chunks,
+                                                                       int passes, int buf_floats) {
+  extern __shared__ __attribute__((aligned(16))) float s_ring[];  // [2][buf_floats]
+  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+  const int b = x + 8 * (y / chunks);
+  const int chunk = y % chunks;
+  if (b >= B) return;
+  const int t = threadIdx.x;
+  const int wave = pp::wave_id_uniform();
+  const long long p0 = (long long)chunk * (kDmaThreads * 4 * V) + t * 4;
+  pp::i4 ii[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+    ii[v] = *reinterpret_cast<const pp::i4*>(idx + (size_t)b * P + p0 + (long long)v * (kDmaThreads * 4));
+  const int n4 = N >> 2;
+  const pp::f4* __restrict__ row0 = reinterpret_cast<const pp::f4*>(points + (size_t)b * C * N);
+  float* __restrict__ out_b = out + (size_t)b * C * P;
+
+  // one DMA instruction moves 64 lanes x 16 B to  lds_base(wave-uniform) + lane*16
+  auto issue_row = [&](int c, int slot) {
+    const pp::f4* __restrict__ row = row0 + (size_t)c * n4;
+    for (int k = 0; k < passes; ++k) {
+      const int e = k * kDmaPieceF4 + t;              // float4 index inside the row image
+      const int src = e < n4 ? e : n4 - 1;            // surplus lanes land in the pad of the image
+      float* dst = s_ring + (size_t)slot * buf_floats + (size_t)(k * kDmaPieceF4 + wave * 64) * 4;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(row + src),
+          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  issue_row(0, 0);
+  for (int c = 0; c < C; ++c) {
+    // retire this wave's DMA pieces of row c (older than the V stores issued after them)
+    if (c == 0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(V) : "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's pieces landed; every wave left row c-1
+    asm volatile("" ::: "memory");
+    if (c + 1 < C) issue_row(c + 1, (c + 1) & 1);
+    const float* cur = s_ring + (size_t)(c & 1) * buf_floats;
+    float* __restrict__ o = out_b + (size_t)c * P;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      pp::f4 r;
+      r.x = cur[ii[v].x];
+      r.y = cur[ii[v].y];
+      r.z = cur[ii[v].z];
+      r.w = cur[ii[v].w];
+      *reinterpret_cast<pp::f4*>(o + p0 + (long long)v * (kDmaThreads * 4)) = r;
+    }
+    if (c + 1 >= C) break;
+  }
+}
+
+template <int V>
+bool launch_group_dma(const float* points, const int* idx, float* out, int B, int C, int N,
+                      long long P, hipStream_t s) {
+  const long long per_block = (long long)kDmaThreads * 4 * V;
+  if (P % per_block != 0) return false;  // this form has no ragged-tail path
+  const long long chunks = P / per_block;
+  const long long blocks = 8LL * ((B + 7) / 8) * chunks;
+  const int n4 = N / 4;
+  const int passes = (n4 + kDmaPieceF4 - 1) / kDmaPieceF4;
+  const int buf_floats = passes * kDmaPieceF4 * 4;
+  const size_t lds = (size_t)2 * buf_floats * sizeof(float);
+  if (lds > 160 * 1024 || chunks > 0x7fffffLL || blocks > 0x7fffffffLL) return false;
+  static bool attr_set[17] = {};
+  if (!attr_set[V]) {
+    if (hipFuncSetAttribute((const void*)group_points_dma_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return false;
+    attr_set[V] = true;
+  }
+  group_points_dma_kernel<V><<<dim3((unsigned)blocks), dim3(kDmaThreads), lds, s>>>(
+      points, idx, out, B, C, N, P, (int)chunks, passes, buf_floats);
+  return true;
+}
+
+template <int V>
+bool launch_group_lds(const float* points, const int* idx, float* out, int B, int C, int N,
+                      long long P, hipStream_t s) {
+  const long long per_block = 512LL * 4 * V;
+  const long long chunks = (P + per_block - 1) / per_block;
+  const long long blocks = 8LL * ((B + 7) / 8) * chunks;
+  if (chunks > 0x7fffffLL || blocks > 0x7fffffffLL) return false;
+  // KR = float4 per thread per staging pass: 512 * KR * 16 B >= row bytes
+  const dim3 grid((unsigned)blocks), block(512);
+  const size_t lds = (size_t)N * sizeof(float);
+  const int n4 = N / 4;
+  if (n4 <= 512 * 1)
+    group_points_lds_kernel<V, 1><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks);
+  else if (n4 <= 512 * 2)
+    group_points_lds_kernel<V, 2><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks);
+  else if (n4 <= 512 * 4)
+    group_points_lds_kernel<V, 4><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks);
+  else
+    group_points_lds_kernel<V, 8><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks);
+  return true;
+}
+
 // group_points backward: grad_points[b,c,idx[b,j,k]] += grad_out[b,c,j,k]  (ref :482-503)
 __global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __restrict__ grad_out,
                                                                 const int* __restrict__ idx,
@@ -338,6 +556,11 @@ extern "C" int pp_ball_query_f32(const float* new_xyz, const float* xyz, int* id
   return PP_OK;
 }
 
+// 0 = automatic; 1 = force the global-gather kernel; 2/4/8 = force the LDS-staged kernel with that
+// many index quads per thread (tests and tuning)
+static int g_group_variant = 0;
+extern "C" void pp_debug_set_group_points_variant(int v) { g_group_variant = v; }
+
 extern "C" int pp_group_points_f32(const float* points, const int* idx, float* out, int B, int C,
                                    int N, int npoint, int nsample, void* stream) {
   if (B < 0 || C < 0 || N < 0 || npoint < 0 || nsample < 0) return PP_EINVAL;
@@ -346,6 +569,32 @@ extern "C" int pp_group_points_f32(const float* points, const int* idx, float* o
   if (!points || !idx || !out || N == 0) return PP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const bool vec4 = (P % 4 == 0) && ((uintptr_t)idx % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  // LDS-staged form: row fits 64 KiB (two workgroups per CU), rows 16-byte aligned, enough channels
+  // to amortise keeping the indices in registers, enough positions to fill the chip
+  if (g_group_variant != 1 && vec4 && N % 4 == 0 && (uintptr_t)points % 16 == 0 &&
+      (size_t)N * sizeof(float) <= 64 * 1024 && C >= 4 && (long long)B * P >= 256LL * 2048) {
+    const long long per_cu = (long long)B * P / 512;  // positions per half-CU
+    bool ok = false;
+    // DMA ring form: full chunks only, one 1024-thread workgroup per CU
+    if (g_group_variant == 108 || (g_group_variant == 0 && (long long)B * P >= 256LL * 1024 * 4 * 8))
+      ok = launch_group_dma<8>(points, idx, out, B, C, N, P, s);
+    else if (g_group_variant == 104)
+      ok = launch_group_dma<4>(points, idx, out, B, C, N, P, s);
+    if (ok) {
+      PP_RETURN_IF_LAUNCH_FAILED();
+      return PP_OK;
+    }
+    if (g_group_variant == 8 || ((g_group_variant == 0 || g_group_variant > 100) && per_cu >= 512LL * 4 * 8))
+      ok = launch_group_lds<8>(points, idx, out, B, C, N, P, s);
+    else if (g_group_variant == 4 || (g_group_variant == 0 && per_cu >= 512LL * 4 * 4))
+      ok = launch_group_lds<4>(points, idx, out, B, C, N, P, s);
+    else
+      ok = launch_group_lds<2>(points, idx, out, B, C, N, P, s);
+    if (ok) {
+      PP_RETURN_IF_LAUNCH_FAILED();
+      return PP_OK;
+    }
+  }
   const long long threads = vec4 ? P / 4 : P;
   const long long cols = (threads + 255) / 256;
   const int cpb = pick_c_per_block(cols, B, C);

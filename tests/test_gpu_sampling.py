@@ -168,6 +168,31 @@ def test_group_points_matches_torch_and_backward(cuda, b, c, n, npoint, ns):
     assert np.allclose(g.cpu().numpy(), e, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 4, 8, 104, 108])
+@pytest.mark.parametrize("b,c,n,npoint,ns", [(9, 5, 1024, 600, 16), (2, 4, 16384, 2048, 64), (1, 7, 500, 4099, 32),
+                                             (3, 9, 10000, 1024, 64), (2, 6, 20480, 512, 64)])
+def test_group_points_every_kernel_variant(cuda, variant, b, c, n, npoint, ns):
+    """global-gather kernel and the LDS-staged kernel (2/4/8 index quads per thread) agree with
+    torch.gather, including ragged tails and batch counts that are not a multiple of 8."""
+    import ctypes
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd._ext import sampling
+    f = _t(S.normal(43, (b, c, n)), cuda)
+    idx = _t((S.uniform01(44, (b, npoint, ns)).reshape(b, npoint, ns) * n).astype(np.int32), cuda)
+    idx[:, 0, 0] = n - 1
+    idx[:, -1, -1] = 0
+    setter = _lib.lib().pp_debug_set_group_points_variant
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(variant)
+    try:
+        out = sampling.group_points(f, idx)
+    finally:
+        setter(0)
+    ref = torch.gather(f, 2, idx.long().reshape(b, 1, -1).expand(-1, c, -1)).reshape(b, c, npoint, ns)
+    assert torch.equal(out, ref)
+
+
 def test_group_points_preconditions(cuda):
     from pytorch_points_amd._ext import sampling
     f = torch.zeros(1, 2, 8, device=cuda)
