@@ -33,7 +33,7 @@ constexpr int kBlock = 64 * kWavesPerBlock;
 // operations per element, so the bits do not change; measured on MI355X a v_sub_f32 with an SGPR
 // operand issues at half the rate of the VGPR-only form while v_pk_add_f32 with an SGPR source
 // does two subtractions in the same slot (tools/valu_microbench2.hip, DESIGN.md "VALU roof").
-template <int Q, int G, bool PK>
+template <int Q, int G, bool PK, bool PF>
 __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
     int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M,
@@ -75,11 +75,12 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
   const int ngroups = nr / G;
   const int g0 = (int)(((long long)ngroups * wave) / kWavesPerBlock);
   const int g1 = (int)(((long long)ngroups * (wave + 1)) / kWavesPerBlock);
-  for (int g = g0; g < g1; ++g) {
+  auto load_group = [&](float (&rr)[G * 3], int g) {
     const float* __restrict__ rp = ref + (size_t)g * (G * 3);  // wave-uniform -> s_load
-    float rr[G * 3];
 #pragma unroll
     for (int e = 0; e < G * 3; ++e) rr[e] = rp[e];
+  };
+  auto scan_group = [&](const float (&rr)[G * 3], int g) {
     float nb[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) nb[i] = best[i];
@@ -111,6 +112,31 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     for (int i = 0; i < Q; ++i) {
       gid[i] = nb[i] < best[i] ? g : gid[i];  // first group that attains the running minimum
       best[i] = nb[i];
+    }
+  };
+  if constexpr (PF) {
+    // ping-pong SGPR sets: the scalar loads of group g+1 are in flight while group g is scanned.
+    // Scalar loads return out of order (only lgkmcnt(0) exists), so each set is "used" before the
+    // next loads are issued -- otherwise waiting for it would also wait for them.
+    if (g0 < g1) {
+      float ra[G * 3], rb[G * 3];
+      load_group(ra, g0);
+      int g = g0;
+      for (; g + 1 < g1; g += 2) {
+        load_group(rb, g + 1);
+        scan_group(ra, g);
+        asm volatile("" ::"s"(rb[0]), "s"(rb[G * 3 - 1]));
+        load_group(ra, g + 2 < g1 ? g + 2 : g1 - 1);
+        scan_group(rb, g + 1);
+        asm volatile("" ::"s"(ra[0]), "s"(ra[G * 3 - 1]));
+      }
+      if (g < g1) scan_group(ra, g);
+    }
+  } else {
+    for (int g = g0; g < g1; ++g) {
+      float rr[G * 3];
+      load_group(rr, g);
+      scan_group(rr, g);
     }
   }
 
@@ -317,7 +343,7 @@ __global__ void fill_zero_kernel(float* __restrict__ a, int* __restrict__ b, lon
   }
 }
 
-template <int Q, int G, bool PK = false>
+template <int Q, int G, bool PK = false, bool PF = false>
 int launch_fwd_c3(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
                   int* idx2, int B, int N, int M, hipStream_t s) {
   constexpr int TQ = 64 * Q;
@@ -325,7 +351,7 @@ int launch_fwd_c3(const float* xyz1, const float* xyz2, float* dist1, int* idx1,
   const long long total = (long long)B * (tiles1 + tiles2);
   if (total > 0x7fffff00LL) return PP_EINVAL;
   const int per_xcd = (int)((total + 7) / 8);
-  nmdist_fwd_c3_kernel<Q, G, PK><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
+  nmdist_fwd_c3_kernel<Q, G, PK, PF><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
       xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, tiles1, tiles2, (int)total, per_xcd);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
@@ -390,6 +416,11 @@ extern "C" int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, f
       case 1008: return launch_fwd_c3<8, 8, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
       case 1416: return launch_fwd_c3<4, 16, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
       case 1816: return launch_fwd_c3<8, 16, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 2004: return launch_fwd_c3<4, 8, true, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 2008: return launch_fwd_c3<8, 8, true, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 2002: return launch_fwd_c3<2, 8, true, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 2416: return launch_fwd_c3<4, 16, true, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
+      case 3004: return launch_fwd_c3<4, 8, false, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, s);
       default: return PP_EINVAL;
     }
   }

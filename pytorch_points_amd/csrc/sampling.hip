@@ -132,6 +132,128 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// ball_query v2: a workgroup = 64 centres x 4 waves; wave w scans the w-th quarter of the cloud
+// (4x the waves of v1 at the same problem size -- v1 leaves the chip at 2 waves per SIMD at
+// config 4) and records its in-radius indices, ascending, in its own LDS list (capped at nsample:
+// later entries can never be output).  The row is then the concatenation of the four lists in
+// quarter order, cut at nsample and padded with the first hit -- exactly the sequential scan's
+// result.  Lists are stored as IT = uint16 when N <= 65536 (32 KiB per workgroup at nsample = 64).
+// Per group of 8 scanned points the eight `d < r^2` tests become eight wave masks (v_cmp into
+// SGPRs); points nobody hit are skipped with scalar branches.
+// ------------------------------------------------------------------------------------------------
+template <typename IT>
+__global__ __launch_bounds__(256) void ball_query_split_kernel(const float* __restrict__ new_xyz,
+                                                               const float* __restrict__ xyz,
+                                                               int* __restrict__ idx, int N, int M,
+                                                               float radius2, int nsample,
+                                                               int tiles_per_b) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  IT* s_list = reinterpret_cast<IT*>(s_raw);                               // [4][64][nsample]
+  int* s_cnt = reinterpret_cast<int*>(s_raw + (size_t)4 * 64 * nsample * sizeof(IT));  // [4][64]
+  const int b = blockIdx.x / tiles_per_b;
+  const int tile = blockIdx.x - b * tiles_per_b;
+  const int wave = pp::wave_id_uniform();
+  const int lane = threadIdx.x & 63;
+  const int m0 = tile * 64;
+  const int m = m0 + lane;
+  const bool valid = m < M;
+  const int mc = valid ? m : M - 1;
+  const float* __restrict__ q = new_xyz + ((size_t)b * M + mc) * 3;
+  const float* __restrict__ p = xyz + (size_t)b * N * 3;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  IT* mylist = s_list + ((size_t)wave * 64 + lane) * nsample;
+
+  // quarter [k0, k1), boundaries on multiples of the group size
+  const int ngroups = N / kBqGroup;
+  const int g0 = (int)(((long long)ngroups * wave) / 4), g1 = (int)(((long long)ngroups * (wave + 1)) / 4);
+  int cnt = valid ? 0 : nsample;
+  auto load_group = [&](float (&rr)[kBqGroup * 3], int g) {
+    const float* __restrict__ rp = p + (size_t)g * (kBqGroup * 3);  // wave-uniform -> s_load
+#pragma unroll
+    for (int e = 0; e < kBqGroup * 3; ++e) rr[e] = rp[e];
+  };
+  auto scan_group = [&](const float (&rr)[kBqGroup * 3], int g) {
+    const int k = g * kBqGroup;
+    unsigned long long hit[kBqGroup];
+    unsigned long long any = 0;
+#pragma unroll
+    for (int e = 0; e < kBqGroup; ++e) {
+      const float d = dist3(qx, qy, qz, rr[3 * e], rr[3 * e + 1], rr[3 * e + 2]);
+      hit[e] = __ballot(d < radius2);
+      any |= hit[e];
+    }
+    if (any) {
+#pragma unroll
+      for (int e = 0; e < kBqGroup; ++e) {
+        if (hit[e]) {
+          if (((hit[e] >> lane) & 1ull) && cnt < nsample) {
+            mylist[cnt] = (IT)(k + e);
+            ++cnt;
+          }
+        }
+      }
+    }
+  };
+  // two groups per trip, the scalar loads of the next group issued before the current one is
+  // scanned (ping-pong SGPR sets): the s_load latency is covered by this wave's own VALU work
+  if (g0 < g1) {
+    float ra[kBqGroup * 3], rb[kBqGroup * 3];
+    load_group(ra, g0);
+    int g = g0;
+    for (; g + 1 < g1; g += 2) {
+      if (__all(cnt >= nsample)) break;
+      load_group(rb, g + 1);
+      scan_group(ra, g);
+      // scalar loads return out of order, so the only wait is lgkmcnt(0): make rb "used" here,
+      // before the next loads are issued, or waiting for rb would also wait for them
+      asm volatile("" ::"s"(rb[0]), "s"(rb[kBqGroup * 3 - 1]));
+      load_group(ra, g + 2 < g1 ? g + 2 : g1 - 1);
+      scan_group(rb, g + 1);
+      asm volatile("" ::"s"(ra[0]), "s"(ra[kBqGroup * 3 - 1]));
+    }
+    if (g < g1 && !__all(cnt >= nsample)) scan_group(ra, g);
+  }
+  if (wave == 3 && !__all(cnt >= nsample)) {  // tail points (N mod 8), highest indices
+    for (int k = ngroups * kBqGroup; k < N; ++k) {
+      const float d = dist3(qx, qy, qz, p[3 * (size_t)k], p[3 * (size_t)k + 1], p[3 * (size_t)k + 2]);
+      if (d < radius2 && cnt < nsample) {
+        mylist[cnt] = (IT)k;
+        ++cnt;
+      }
+    }
+  }
+  s_cnt[wave * 64 + lane] = valid ? cnt : 0;
+  __syncthreads();
+
+  // 64 rows x nsample ints, contiguous in the output
+  int* __restrict__ gout = idx + ((size_t)b * M + m0) * nsample;
+  const int nrows = min(64, M - m0);
+  const int total = nrows * nsample;
+  for (int f = threadIdx.x; f < total; f += 256) {
+    const int row = f / nsample;
+    const int slot = f - row * nsample;
+    const int c0 = s_cnt[row], c1 = s_cnt[64 + row], c2 = s_cnt[128 + row], c3 = s_cnt[192 + row];
+    const IT* l0 = s_list + (size_t)row * nsample;
+    const IT* l1 = l0 + (size_t)64 * nsample;
+    const IT* l2 = l1 + (size_t)64 * nsample;
+    const IT* l3 = l2 + (size_t)64 * nsample;
+    // first hit of the row = head of the first non-empty list (0 if the ball is empty)
+    int first = 0;
+    if (c0 > 0) first = (int)l0[0];
+    else if (c1 > 0) first = (int)l1[0];
+    else if (c2 > 0) first = (int)l2[0];
+    else if (c3 > 0) first = (int)l3[0];
+    int v = first;
+    int sidx = slot;
+    if (sidx < c0) v = (int)l0[sidx];
+    else if ((sidx -= c0) < c1) v = (int)l1[sidx];
+    else if ((sidx -= c1) < c2) v = (int)l2[sidx];
+    else if ((sidx -= c2) < c3) v = (int)l3[sidx];
+    gout[f] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // group_points: out[b,c,j,k] = points[b,c,idx[b,j,k]]        (ref sampling_cuda.cu:447-467)
 // A thread owns 4 consecutive (j,k) positions: one 16-byte idx load, then per channel four
 // gathers and one 16-byte store.  The reference launches B blocks; this fills the chip.
@@ -534,6 +656,10 @@ extern "C" int pp_gather_backward_f32(const float* grad_out, const int* idx, flo
   return PP_OK;
 }
 
+// 0 = automatic; 1 = force the one-wave-per-64-centres kernel (tests and tuning)
+static int g_ball_variant = 0;
+extern "C" void pp_debug_set_ball_query_variant(int v) { g_ball_variant = v; }
+
 extern "C" int pp_ball_query_f32(const float* new_xyz, const float* xyz, int* idx, int B, int N,
                                  int M, float radius, int nsample, void* stream) {
   if (B < 0 || N < 0 || M < 0 || nsample < 0) return PP_EINVAL;
@@ -541,6 +667,24 @@ extern "C" int pp_ball_query_f32(const float* new_xyz, const float* xyz, int* id
   if (!new_xyz || !idx || (N > 0 && !xyz)) return PP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const float radius2 = radius * radius;  // fp32, as the reference (sampling_cuda.cu:354)
+  // split form: 4 waves share 64 centres (one cloud quarter each); needs its lists in LDS and
+  // enough points for four quarters
+  if (g_ball_variant != 1 && N >= 4 * kBqGroup) {
+    const int tiles64 = (M + 63) / 64;
+    const long long blocks64 = (long long)B * tiles64;
+    const size_t esz = N <= 65536 ? sizeof(unsigned short) : sizeof(unsigned);
+    const size_t lds64 = (size_t)4 * 64 * nsample * esz + (size_t)4 * 64 * sizeof(int);
+    if (blocks64 <= 0x7fffffffLL && lds64 <= 64 * 1024) {
+      if (esz == 2)
+        ball_query_split_kernel<unsigned short><<<dim3((unsigned)blocks64), dim3(256), lds64, s>>>(
+            new_xyz, xyz, idx, N, M, radius2, nsample, tiles64);
+      else
+        ball_query_split_kernel<unsigned><<<dim3((unsigned)blocks64), dim3(256), lds64, s>>>(
+            new_xyz, xyz, idx, N, M, radius2, nsample, tiles64);
+      PP_RETURN_IF_LAUNCH_FAILED();
+      return PP_OK;
+    }
+  }
   const int tiles = (M + 255) / 256;
   const long long blocks = (long long)B * tiles;
   if (blocks > 0x7fffffffLL) return PP_EINVAL;

@@ -51,7 +51,7 @@ def test_forward_matches_oracle(cuda, shape, dup):
         assert np.array_equal(g, e), "%s differs at %d places" % (name, int((g != e).sum()))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 8, 416, 216, 44, 1002, 1004, 1008, 1416, 1816])
+@pytest.mark.parametrize("variant", [1, 2, 4, 8, 416, 216, 44, 1002, 1004, 1008, 1416, 1816, 2002, 2004, 2008, 3004])
 @pytest.mark.parametrize("shape", [(2, 1024, 1024, 3), (1, 1000, 777, 3), (2, 300, 1500, 3), (1, 5, 3, 3)])
 def test_forward_every_kernel_variant(cuda, variant, shape):
     """Every (queries-per-lane, group) instantiation of the C==3 kernel gives the same bits."""

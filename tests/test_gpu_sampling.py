@@ -124,9 +124,22 @@ def test_gather_matches_torch_and_backward(cuda):
 
 
 # ----------------------------------------------------------------------------------- ball query
+@pytest.fixture(params=["split", "single_wave"], autouse=False)
+def bq_path(request, cuda):
+    """both ball_query decompositions: 4 waves x cloud quarters (default) and one wave per centre tile"""
+    import ctypes
+    from pytorch_points_amd import _lib
+    setter = _lib.lib().pp_debug_set_ball_query_variant
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(1 if request.param == "single_wave" else 0)
+    yield request.param
+    setter(0)
+
+
 @pytest.mark.parametrize("r", [0.05, 0.2, 0.5])
 @pytest.mark.parametrize("ns", [16, 64])
-def test_ball_query_matches_oracle(cuda, r, ns):
+def test_ball_query_matches_oracle(cuda, bq_path, r, ns):
     from pytorch_points_amd.network.operations import ball_query
     x = S.unit_sphere(30, 2, 2048)
     fidx, _ = oracle.furthest_sampling(x, 256, 0)
@@ -137,8 +150,9 @@ def test_ball_query_matches_oracle(cuda, r, ns):
 
 
 @pytest.mark.parametrize("b,n,m,r,ns", [(1, 100, 70, 0.3, 5), (2, 1000, 300, 1e-4, 8), (1, 37, 3, 10.0, 200),
-                                        (1, 2000, 515, 0.25, 33), (1, 9, 1, 0.5, 1), (1, 64, 64, 0.4, 300)])
-def test_ball_query_edges(cuda, b, n, m, r, ns):
+                                        (1, 2000, 515, 0.25, 33), (1, 9, 1, 0.5, 1), (1, 64, 64, 0.4, 300),
+                                        (1, 70000, 130, 0.05, 40), (2, 4099, 777, 0.3, 128), (1, 33, 65, 2.0, 7)])
+def test_ball_query_edges(cuda, bq_path, b, n, m, r, ns):
     """odd sizes; empty balls (all-zero rows); full balls (early exit); nsample beyond the LDS
     staging limit (direct-store path)."""
     from pytorch_points_amd._ext import sampling
