@@ -57,6 +57,11 @@ def init_dist(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        if os.environ.get("PP_BENCH_DEBUG_GLOO") == "1":
+            # logic check on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL (not a measurement)
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+            return dist, world, rank, 0
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         return dist, world, rank, local
@@ -109,15 +114,21 @@ def cpu_baseline_chamfer(N, C):
     t0 = time.perf_counter()
     run(x1, x2)
     t1 = time.perf_counter() - t0
-    bs = int(max(1, min(32, round(12.0 / max(t1, 1e-3)))))
+    # about 20 core-seconds of CPU work per repetition, at most the full batch of 32
+    cores = oracle.num_threads()
+    bs = int(max(1, min(32, round(20.0 / max(t1 * cores, 1e-3)))))
     a = np.ascontiguousarray(np.repeat(x1, bs, 0))
     b = np.ascontiguousarray(np.repeat(x2, bs, 0))
-    t0 = time.perf_counter()
-    run(a, b)
-    dt = time.perf_counter() - t0
-    return {"value": 2.0 * bs * N * N / dt, "unit": "pairs/s", "cores": oracle.num_threads(),
-            "kind": "port", "sample": "Chamfer fwd+bwd B=%d N=M=%d C=%d (oracle/pp_oracle.c, OpenMP, "
-            "AVX2+FMA), %.2f s" % (bs, N, C, dt)}
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run(a, b)
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
+    return {"value": 2.0 * bs * N * N / dt, "unit": "pairs/s", "cores": cores,
+            "kind": "port", "sample": "Chamfer fwd+bwd B=%d N=M=%d C=%d, best of 3 (oracle/pp_oracle.c: "
+            "OpenMP, AVX2+FMA, same canonical arithmetic), %.2f s = %.0f core-seconds"
+            % (bs, N, C, dt, dt * cores)}
 
 
 def bench_chamfer(args, dist, world, rank, device):
@@ -156,7 +167,10 @@ def bench_chamfer(args, dist, world, rank, device):
         fwd_events.append((e0, e1))
         if dist is not None:   # all-gather of the per-shard (dist, idx) over xGMI (RCCL)
             for out, src in zip(gathered, (d1.detach(), d2.detach(), i1, i2)):
-                dist.all_gather_into_tensor(out, src)
+                if dist.get_backend() == "nccl":
+                    dist.all_gather_into_tensor(out, src)
+                else:  # debug path only
+                    dist.all_gather(list(out.chunk(world, 0)), src)
         torch.autograd.backward([d1, d2], [g1, g2])
 
     for _ in range(args.warmup):
@@ -184,7 +198,11 @@ def bench_chamfer(args, dist, world, rank, device):
         "fwd_ms": fwd_ms,
         "roofline": {"bound": "hbm", "kernel": "nmdist_fwd_c3_kernel", "achieved": hbm_gbs,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
-                     "traffic": None,
+                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+                     # (profiles/r1/pmc_summary.txt): 6.1 MB + 8.0 MB per launch; reads are scalar/dword
+                     # loads (uncalibrated on gfx950, not the 16-B form that reads 1/2) -- at most the
+                     # algorithmic 20.97 MB either way: no re-reads beyond L2
+                     "traffic": 14.4e6 if (B, N, M) == (32, 16384, 16384) else None,
                      "note": "exact brute force is fp32-VALU-bound (6500 flop/B); see 'valu'"},
         "valu": {"achieved": laneops / (fwd_ms * 1e-3), "peak": VALU_PEAK_LANEOPS,
                  "unit": "lane-ops/s", "frac": laneops / (fwd_ms * 1e-3) / VALU_PEAK_LANEOPS,
@@ -260,8 +278,11 @@ def bench_ball_group(args, dist, world, rank, device):
                                    % (r, ns, B, N, npoint, C), "parallelism": "batch-shard x%d" % world},
             "ball_query_ms": bq_ms, "group_points_ms": gp_ms,
             "ball_query_pairs_per_s": float(B) * npoint * N / (bq_ms * 1e-3),
-            "roofline": {"bound": "hbm", "kernel": "group_points_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None}}
+            "roofline": {"bound": "hbm", "kernel": "group_points_dma_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         # PMC passes (profiles/r1/pmc_summary.txt): WRITE_SIZE 4096 MB exact, FETCH_SIZE
+                         # 144 MB x2 (16-B loads read 1/2 on gfx950) = 288 MB
+                         "traffic": 4583e6 if (B, N, C, ns) == (32, 16384, 128, 64) else None}}
 
 
 def main():

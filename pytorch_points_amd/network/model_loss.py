@@ -22,10 +22,12 @@ class NmDistanceFunction(torch.autograd.Function):
         batchsize, n, _ = xyz1.size()
         _, m, _ = xyz2.size()
         assert xyz1.dtype == xyz2.dtype
-        dist1 = torch.zeros(batchsize, n, dtype=xyz1.dtype, device=xyz1.device)
-        dist2 = torch.zeros(batchsize, m, dtype=xyz1.dtype, device=xyz1.device)
-        idx1 = torch.zeros(batchsize, n, dtype=torch.int32, device=xyz1.device)
-        idx2 = torch.zeros(batchsize, m, dtype=torch.int32, device=xyz1.device)
+        # the kernel overwrites every element (and zero-fills them itself when n == 0 or m == 0, the
+        # only case in which the reference's zeros survive), so no fill launches are needed
+        dist1 = torch.empty(batchsize, n, dtype=xyz1.dtype, device=xyz1.device)
+        dist2 = torch.empty(batchsize, m, dtype=xyz1.dtype, device=xyz1.device)
+        idx1 = torch.empty(batchsize, n, dtype=torch.int32, device=xyz1.device)
+        idx2 = torch.empty(batchsize, m, dtype=torch.int32, device=xyz1.device)
         losses.nmdistance_forward(xyz1, xyz2, dist1, dist2, idx1, idx2)
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
@@ -59,10 +61,10 @@ class LabeledNmdistanceFunction(torch.autograd.Function):
         assert xyz1.dtype == xyz2.dtype
         label1 = label1.to(dtype=xyz1.dtype)
         label2 = label2.to(dtype=xyz1.dtype)
-        dist1 = torch.zeros(batchsize, n, dtype=xyz1.dtype, device=xyz1.device)
-        dist2 = torch.zeros(batchsize, m, dtype=xyz1.dtype, device=xyz1.device)
-        idx1 = torch.zeros(batchsize, n, dtype=torch.int32, device=xyz1.device)
-        idx2 = torch.zeros(batchsize, m, dtype=torch.int32, device=xyz1.device)
+        dist1 = torch.empty(batchsize, n, dtype=xyz1.dtype, device=xyz1.device)
+        dist2 = torch.empty(batchsize, m, dtype=xyz1.dtype, device=xyz1.device)
+        idx1 = torch.empty(batchsize, n, dtype=torch.int32, device=xyz1.device)
+        idx2 = torch.empty(batchsize, m, dtype=torch.int32, device=xyz1.device)
         losses.labeled_nmdistance_forward(xyz1, xyz2, label1, label2, dist1, dist2, idx1, idx2)
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)

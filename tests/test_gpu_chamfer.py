@@ -98,8 +98,20 @@ def test_forward_empty(cuda):
     assert np.array_equal(e[2], d2.cpu().numpy())
 
 
-@pytest.mark.parametrize("shape", [(2, 1024, 1024, 3), (1, 1000, 777, 3), (1, 64, 64, 2), (1, 513, 511, 5)])
-def test_backward_matches_oracle_and_fp64(cuda, shape):
+@pytest.fixture(params=["auto", "global_atomics", "lds_columns"])
+def bwd_path(request, cuda):
+    from pytorch_points_amd import _lib
+    setter = _lib.lib().pp_debug_set_nmdistance_backward_variant
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter({"auto": 0, "global_atomics": 1, "lds_columns": 2}[request.param])
+    yield request.param
+    setter(0)
+
+
+@pytest.mark.parametrize("shape", [(2, 1024, 1024, 3), (1, 1000, 777, 3), (1, 64, 64, 2), (1, 513, 511, 5),
+                                   (12, 2048, 3000, 3)])
+def test_backward_matches_oracle_and_fp64(cuda, bwd_path, shape):
     from pytorch_points_amd.network.model_loss import nndistance
     b, n, m, c = shape
     x1, x2 = _clouds(b, n, m, c)
@@ -136,7 +148,7 @@ def test_backward_equals_torch_autograd(cuda):
     assert torch.allclose(t2.grad.double(), a2.grad, rtol=1e-5, atol=1e-9)
 
 
-def test_labeled_matches_oracle(cuda):
+def test_labeled_matches_oracle(cuda, bwd_path):
     from pytorch_points_amd.network.model_loss import labeled_nndistance
     b, n, m = 1, 512, 700
     x1, x2 = _clouds(b, n, m, 3)
