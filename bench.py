@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--variant", type=int, default=0, help="forward kernel variant (0 = automatic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-backward", action="store_true", help="ball_group: also time group_points_grad")
     return ap.parse_args()
 
 
@@ -255,19 +256,27 @@ def bench_ball_group(args, dist, world, rank, device):
     feats = torch.from_numpy(S.normal(2, (B, C, N))).to(device)
     ev = []
 
+    from pytorch_points_amd._ext import sampling as _sampling
+    grad_out = None
+
     def step():
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        nonlocal grad_out
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
         idx = ball_query(r, ns, x, centres)
         e[1].record()
-        grouping_operation(feats, idx)
+        out = grouping_operation(feats, idx)
         e[2].record()
+        if args.with_backward:
+            _sampling.group_points_grad(out, idx, N)     # dL/dout := out (any dense gradient)
+        e[3].record()
         ev.append(e)
 
     dt = timed_region(dist, step, args.steps, args.warmup, device)
     torch.cuda.synchronize()
     bq_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev[-args.steps:]]))
     gp_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev[-args.steps:]]))
+    gpg_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev[-args.steps:]])) if args.with_backward else None
     ms = dt / args.steps * 1e3
     gp_bytes = 4.0 * B * C * N + 4.0 * B * npoint * ns + 4.0 * B * C * npoint * ns
     gbs = gp_bytes / (gp_ms * 1e-3) / 1e9
@@ -276,7 +285,7 @@ def bench_ball_group(args, dist, world, rank, device):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ball_query r=%.2f nsample=%d + group_points B=%d N=%d npoint=%d C=%d"
                                    % (r, ns, B, N, npoint, C), "parallelism": "batch-shard x%d" % world},
-            "ball_query_ms": bq_ms, "group_points_ms": gp_ms,
+            "ball_query_ms": bq_ms, "group_points_ms": gp_ms, "group_points_grad_ms": gpg_ms,
             "ball_query_pairs_per_s": float(B) * npoint * N / (bq_ms * 1e-3),
             "roofline": {"bound": "hbm", "kernel": "group_points_dma_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,

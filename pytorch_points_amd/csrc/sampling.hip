@@ -401,24 +401,40 @@ __global__ __launch_bounds__(512, 4) void group_points_lds_kernel(const float* _
 constexpr int kDmaThreads = 1024;
 constexpr int kDmaPieceF4 = kDmaThreads;  // float4 moved per workgroup pass (16 KiB)
 
-template <int V>
+// PACK16: indices are < 65536, two per register -- twice the positions per workgroup in the same
+// register budget, i.e. half the row re-reads.
+template <int V, bool PACK16>
 __global__ __launch_bounds__(kDmaThreads) void group_points_dma_kernel(const float* __restrict__ points,
                                                                        const int* __restrict__ idx,
                                                                        float* __restrict__ out, int B, int C,
                                                                        int N, long long P, int chunks,
-                                                                       int passes, int buf_floats) {
+                                                                       int passes, int buf_floats,
+                                                                       int cgroups, int c_per_group) {
   extern __shared__ __attribute__((aligned(16))) float s_ring[];  // [2][buf_floats]
+  // (batch, position chunk, channel group); workgroups of one batch element share blockIdx % 8
   const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
-  const int b = x + 8 * (y / chunks);
-  const int chunk = y % chunks;
-  if (b >= B) return;
+  const int per_b = chunks * cgroups;
+  const int b = x + 8 * (y / per_b);
+  const int rem = y % per_b;
+  const int chunk = rem / cgroups;
+  const int c_begin = (rem % cgroups) * c_per_group;
+  const int c_end = min(C, c_begin + c_per_group);
+  if (b >= B || c_begin >= c_end) return;
   const int t = threadIdx.x;
   const int wave = pp::wave_id_uniform();
   const long long p0 = (long long)chunk * (kDmaThreads * 4 * V) + t * 4;
-  pp::i4 ii[V];
+  constexpr int IW = PACK16 ? 2 : 4;  // registers per index quad
+  unsigned ii[V][IW];
 #pragma unroll
-  for (int v = 0; v < V; ++v)
-    ii[v] = *reinterpret_cast<const pp::i4*>(idx + (size_t)b * P + p0 + (long long)v * (kDmaThreads * 4));
+  for (int v = 0; v < V; ++v) {
+    const pp::i4 q = *reinterpret_cast<const pp::i4*>(idx + (size_t)b * P + p0 + (long long)v * (kDmaThreads * 4));
+    if constexpr (PACK16) {
+      ii[v][0] = (unsigned)q.x | ((unsigned)q.y << 16);
+      ii[v][1] = (unsigned)q.z | ((unsigned)q.w << 16);
+    } else {
+      ii[v][0] = q.x; ii[v][1] = q.y; ii[v][2] = q.z; ii[v][3] = q.w;
+    }
+  }
   const int n4 = N >> 2;
   const pp::f4* __restrict__ row0 = reinterpret_cast<const pp::f4*>(points + (size_t)b * C * N);
   float* __restrict__ out_b = out + (size_t)b * C * P;
@@ -435,52 +451,66 @@ __global__ __launch_bounds__(kDmaThreads) void group_points_dma_kernel(const flo
           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
   };
-  issue_row(0, 0);
-  for (int c = 0; c < C; ++c) {
+  issue_row(c_begin, 0);
+  for (int c = c_begin, it = 0; c < c_end; ++c, ++it) {
     // retire this wave's DMA pieces of row c (older than the V stores issued after them)
-    if (c == 0)
+    if (it == 0)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(V) : "memory");
     __builtin_amdgcn_s_barrier();  // every wave's pieces landed; every wave left row c-1
     asm volatile("" ::: "memory");
-    if (c + 1 < C) issue_row(c + 1, (c + 1) & 1);
-    const float* cur = s_ring + (size_t)(c & 1) * buf_floats;
+    if (c + 1 < c_end) issue_row(c + 1, (it + 1) & 1);
+    const float* cur = s_ring + (size_t)(it & 1) * buf_floats;
     float* __restrict__ o = out_b + (size_t)c * P;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       pp::f4 r;
-      r.x = cur[ii[v].x];
-      r.y = cur[ii[v].y];
-      r.z = cur[ii[v].z];
-      r.w = cur[ii[v].w];
+      if constexpr (PACK16) {
+        r.x = cur[ii[v][0] & 0xFFFFu];
+        r.y = cur[ii[v][0] >> 16];
+        r.z = cur[ii[v][1] & 0xFFFFu];
+        r.w = cur[ii[v][1] >> 16];
+      } else {
+        r.x = cur[ii[v][0]];
+        r.y = cur[ii[v][1]];
+        r.z = cur[ii[v][2]];
+        r.w = cur[ii[v][3]];
+      }
       *reinterpret_cast<pp::f4*>(o + p0 + (long long)v * (kDmaThreads * 4)) = r;
     }
-    if (c + 1 >= C) break;
   }
 }
 
-template <int V>
+template <int V, bool PACK16 = false>
 bool launch_group_dma(const float* points, const int* idx, float* out, int B, int C, int N,
                       long long P, hipStream_t s) {
   const long long per_block = (long long)kDmaThreads * 4 * V;
   if (P % per_block != 0) return false;  // this form has no ragged-tail path
   const long long chunks = P / per_block;
-  const long long blocks = 8LL * ((B + 7) / 8) * chunks;
+  // every byte a CU moves (row re-reads from L2 included) shares one ~10 B/clk path, so the rows are
+  // re-read as rarely as the registers allow (V) and the channels are split only as far as needed
+  // to give every CU a workgroup
+  const long long base = 8LL * ((B + 7) / 8) * chunks;
+  int cgroups = 1;
+  while (base * cgroups < 256 && cgroups * 2 <= C) cgroups *= 2;
+  const int c_per_group = (C + cgroups - 1) / cgroups;
+  const long long blocks = base * cgroups;
   const int n4 = N / 4;
   const int passes = (n4 + kDmaPieceF4 - 1) / kDmaPieceF4;
   const int buf_floats = passes * kDmaPieceF4 * 4;
   const size_t lds = (size_t)2 * buf_floats * sizeof(float);
   if (lds > 160 * 1024 || chunks > 0x7fffffLL || blocks > 0x7fffffffLL) return false;
-  static bool attr_set[17] = {};
-  if (!attr_set[V]) {
-    if (hipFuncSetAttribute((const void*)group_points_dma_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (PACK16 && N > 65536) return false;
+  static bool attr_set = false;  // one flag per instantiation of this function template
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)group_points_dma_kernel<V, PACK16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return false;
-    attr_set[V] = true;
+    attr_set = true;
   }
-  group_points_dma_kernel<V><<<dim3((unsigned)blocks), dim3(kDmaThreads), lds, s>>>(
-      points, idx, out, B, C, N, P, (int)chunks, passes, buf_floats);
+  group_points_dma_kernel<V, PACK16><<<dim3((unsigned)blocks), dim3(kDmaThreads), lds, s>>>(
+      points, idx, out, B, C, N, P, (int)chunks, passes, buf_floats, cgroups, c_per_group);
   return true;
 }
 
@@ -520,6 +550,40 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __r
   const int i = idx[(size_t)b * P + t];
   for (int c = c0; c < c1; ++c)
     atomicAdd(grad_points + ((size_t)b * C + c) * N + i, grad_out[((size_t)b * C + c) * P + t]);
+}
+
+// group_points backward without global atomics: one workgroup per (batch, channel) owns the column
+// grad_points[b,c,:] in LDS, streams grad_out[b,c,:,:] and idx[b,:,:] with 16-byte loads, adds with
+// ds_add_f32 and ADDS the column to the caller's (zero-filled) output once.  At config 4 the
+// reference's formulation is 1.07e9 scattered global atomics.  Workgroups of one batch element share
+// blockIdx % 8, so idx (re-read per channel) is served by one XCD's L2.
+__global__ __launch_bounds__(1024) void group_points_grad_lds_kernel(const float* __restrict__ grad_out,
+                                                                     const int* __restrict__ idx,
+                                                                     float* __restrict__ grad_points,
+                                                                     int B, int C, int N, long long P) {
+  extern __shared__ __attribute__((aligned(16))) float s_col[];
+  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+  const int b = x + 8 * (y / C);
+  const int c = y % C;
+  if (b >= B) return;
+  const int t = threadIdx.x;
+  for (int k = t; k < N; k += 1024) s_col[k] = 0.0f;
+  __syncthreads();
+  const float* __restrict__ go = grad_out + ((size_t)b * C + c) * P;
+  const int* __restrict__ ib = idx + (size_t)b * P;
+  const long long p4 = P >> 2;
+  for (long long e = t; e < p4; e += 1024) {
+    const pp::f4 g = reinterpret_cast<const pp::f4*>(go)[e];
+    const pp::i4 i = reinterpret_cast<const pp::i4*>(ib)[e];
+    atomicAdd(&s_col[i.x], g.x);
+    atomicAdd(&s_col[i.y], g.y);
+    atomicAdd(&s_col[i.z], g.z);
+    atomicAdd(&s_col[i.w], g.w);
+  }
+  for (long long e = (p4 << 2) + t; e < P; e += 1024) atomicAdd(&s_col[ib[e]], go[e]);
+  __syncthreads();
+  float* __restrict__ gp = grad_points + ((size_t)b * C + c) * N;
+  for (int k = t; k < N; k += 1024) gp[k] += s_col[k];  // accumulate: the ABI's contract
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -720,9 +784,13 @@ extern "C" int pp_group_points_f32(const float* points, const int* idx, float* o
     const long long per_cu = (long long)B * P / 512;  // positions per half-CU
     bool ok = false;
     // DMA ring form: full chunks only, one 1024-thread workgroup per CU
-    if (g_group_variant == 108 || (g_group_variant == 0 && (long long)B * P >= 256LL * 1024 * 4 * 8))
+    if (g_group_variant == 132)  // 16-bit packed indices, 32 quads per thread: spills at 1024 threads (kept for tuning)
+      ok = launch_group_dma<32, true>(points, idx, out, B, C, N, P, s);
+    if (!ok && (g_group_variant == 116 || (g_group_variant == 0 && C >= 8 && (long long)B * P * C >= 256LL * 1024 * 4 * 16 * 8)))
+      ok = launch_group_dma<16>(points, idx, out, B, C, N, P, s);
+    if (!ok && (g_group_variant == 108 || (g_group_variant == 0 && (long long)B * P >= 256LL * 1024 * 4 * 8)))
       ok = launch_group_dma<8>(points, idx, out, B, C, N, P, s);
-    else if (g_group_variant == 104)
+    else if (!ok && g_group_variant == 104)
       ok = launch_group_dma<4>(points, idx, out, B, C, N, P, s);
     if (ok) {
       PP_RETURN_IF_LAUNCH_FAILED();
@@ -753,6 +821,10 @@ extern "C" int pp_group_points_f32(const float* points, const int* idx, float* o
   return PP_OK;
 }
 
+// 0 = automatic; 1 = force global atomics; 2 = force the LDS-column form (tests and tuning)
+static int g_group_grad_variant = 0;
+extern "C" void pp_debug_set_group_points_grad_variant(int v) { g_group_grad_variant = v; }
+
 extern "C" int pp_group_points_grad_f32(const float* grad_out, const int* idx, float* grad_points,
                                         int B, int C, int N, int npoint, int nsample,
                                         void* stream) {
@@ -760,6 +832,23 @@ extern "C" int pp_group_points_grad_f32(const float* grad_out, const int* idx, f
   const long long P = (long long)npoint * nsample;
   if (B == 0 || C == 0 || P == 0) return PP_OK;
   if (!grad_out || !idx || !grad_points || N == 0) return PP_EINVAL;
+  // LDS-column form: the column fits the LDS, 16-byte aligned streams, enough work per column
+  if (g_group_grad_variant != 1 && (size_t)N * sizeof(float) <= 160 * 1024 &&
+      (uintptr_t)grad_out % 16 == 0 && (uintptr_t)idx % 16 == 0 && P % 4 == 0 &&
+      8LL * ((B + 7) / 8) * C <= 0x7fffffffLL && (g_group_grad_variant == 2 || P >= 4096)) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)group_points_grad_lds_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    group_points_grad_lds_kernel<<<dim3((unsigned)(8 * ((B + 7) / 8) * C)), dim3(1024),
+                                   (size_t)N * sizeof(float), (hipStream_t)stream>>>(
+        grad_out, idx, grad_points, B, C, N, P);
+    PP_RETURN_IF_LAUNCH_FAILED();
+    return PP_OK;
+  }
   const long long cols = (P + 255) / 256;
   const int cpb = pick_c_per_block(cols, B, C);
   const long long gy = (C + cpb - 1) / cpb;

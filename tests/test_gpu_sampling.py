@@ -163,8 +163,21 @@ def test_ball_query_edges(cuda, bq_path, b, n, m, r, ns):
 
 
 # --------------------------------------------------------------------------------- group points
-@pytest.mark.parametrize("b,c,n,npoint,ns", [(2, 8, 2048, 256, 16), (1, 3, 100, 7, 5), (2, 67, 500, 33, 12), (1, 1, 10, 1, 1)])
-def test_group_points_matches_torch_and_backward(cuda, b, c, n, npoint, ns):
+@pytest.fixture(params=["auto", "global_atomics", "lds_columns"])
+def group_grad_path(request, cuda):
+    import ctypes
+    from pytorch_points_amd import _lib
+    setter = _lib.lib().pp_debug_set_group_points_grad_variant
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter({"auto": 0, "global_atomics": 1, "lds_columns": 2}[request.param])
+    yield request.param
+    setter(0)
+
+
+@pytest.mark.parametrize("b,c,n,npoint,ns", [(2, 8, 2048, 256, 16), (1, 3, 100, 7, 5), (2, 67, 500, 33, 12), (1, 1, 10, 1, 1),
+                                             (9, 4, 4096, 512, 32)])
+def test_group_points_matches_torch_and_backward(cuda, group_grad_path, b, c, n, npoint, ns):
     from pytorch_points_amd.network.operations import grouping_operation
     f = _t(S.normal(40, (b, c, n)), cuda).requires_grad_(True)
     idx = _t((S.uniform01(41, (b, npoint, ns)).reshape(b, npoint, ns) * n).astype(np.int32), cuda)
@@ -182,9 +195,9 @@ def test_group_points_matches_torch_and_backward(cuda, b, c, n, npoint, ns):
     assert np.allclose(g.cpu().numpy(), e, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 8, 104, 108])
+@pytest.mark.parametrize("variant", [1, 2, 4, 8, 104, 108, 116, 132])
 @pytest.mark.parametrize("b,c,n,npoint,ns", [(9, 5, 1024, 600, 16), (2, 4, 16384, 2048, 64), (1, 7, 500, 4099, 32),
-                                             (3, 9, 10000, 1024, 64), (2, 6, 20480, 512, 64)])
+                                             (3, 9, 10000, 1024, 64), (2, 6, 20480, 512, 64), (2, 13, 4096, 2048, 32), (1, 16, 65536, 4096, 32)])
 def test_group_points_every_kernel_variant(cuda, variant, b, c, n, npoint, ns):
     """global-gather kernel and the LDS-staged kernel (2/4/8 index quads per thread) agree with
     torch.gather, including ragged tails and batch counts that are not a multiple of 8."""
