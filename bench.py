@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--variant", type=int, default=0, help="forward kernel variant (0 = automatic)")
+    ap.add_argument("--search", default="auto", choices=["auto", "bruteforce"],
+                    help="chamfer: auto = the operator's default (exact grid search, brute-force "
+                         "fallback); bruteforce = evaluate every pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-backward", action="store_true", help="ball_group: also time group_points_grad")
     return ap.parse_args()
@@ -139,6 +142,11 @@ def bench_chamfer(args, dist, world, rank, device):
     B = args.batch or 32
     N = args.points or 16384
     M, C = N, 3
+    if args.search == "bruteforce":
+        fs = _lib.lib().pp_debug_set_nmdistance_search
+        fs.argtypes = [ctypes.c_int]
+        fs.restype = None
+        fs(1)
     if args.variant:
         fn = _lib.lib().pp_debug_set_nmdistance_variant
         fn.argtypes = [ctypes.c_int]
@@ -156,6 +164,7 @@ def bench_chamfer(args, dist, world, rank, device):
         gathered = [torch.empty(world * B, N, dtype=torch.float32, device=device) for _ in range(2)] + \
                    [torch.empty(world * B, N, dtype=torch.int32, device=device) for _ in range(2)]
     fwd_events = []
+    pending = []   # (work handles, tensors kept alive) of the previous step's all-gather
 
     def step():
         x1.grad = None
@@ -166,28 +175,102 @@ def bench_chamfer(args, dist, world, rank, device):
         d1, d2, i1, i2 = nndistance(x1, x2)
         e1.record()
         fwd_events.append((e0, e1))
-        if dist is not None:   # all-gather of the per-shard (dist, idx) over xGMI (RCCL)
-            for out, src in zip(gathered, (d1.detach(), d2.detach(), i1, i2)):
+        if dist is not None:
+            # all-gather of the per-shard (dist, idx) over xGMI (RCCL), asynchronous: it runs on the
+            # collective stream beside this step's backward and the next step's forward, and is
+            # waited for before its buffers are reused (and before the timed region ends)
+            for w, _ in pending:
+                for h in w:
+                    h.wait()
+            pending.clear()
+            srcs = (d1.detach(), d2.detach(), i1, i2)
+            works = []
+            for out, src in zip(gathered, srcs):
                 if dist.get_backend() == "nccl":
-                    dist.all_gather_into_tensor(out, src)
+                    works.append(dist.all_gather_into_tensor(out, src, async_op=True))
                 else:  # debug path only
-                    dist.all_gather(list(out.chunk(world, 0)), src)
+                    works.append(dist.all_gather(list(out.chunk(world, 0)), src, async_op=True))
+            pending.append((works, srcs))
         torch.autograd.backward([d1, d2], [g1, g2])
+
+    def drain():
+        for w, _ in pending:
+            for h in w:
+                h.wait()
+        pending.clear()
 
     for _ in range(args.warmup):
         step()
+    drain()
     fwd_events.clear()
-    dt = timed_region(dist, step, args.steps, 0, device)
+
+    def timed_steps():
+        step()
+
+    # the last step's gather is part of the timed work: drained before the closing synchronize
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    drain()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events[-args.steps:]]))
+
+    # the same step with the search forced to the brute-force kernel (every pair evaluated)
+    brute = None
+    if args.search == "auto":
+        setter = _lib.lib().pp_debug_set_nmdistance_search
+        setter.argtypes = [ctypes.c_int]
+        setter.restype = None
+        setter(1)
+        try:
+            bev = []
+
+            def bstep():
+                x1.grad = None
+                x2.grad = None
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                d1, d2, i1, i2 = nndistance(x1, x2)
+                e1.record()
+                bev.append((e0, e1))
+                torch.autograd.backward([d1, d2], [g1, g2])
+
+            for _ in range(3):
+                bstep()
+            torch.cuda.synchronize()
+            bev.clear()
+            tb = time.perf_counter()
+            nb = max(5, min(args.steps, 20))
+            for _ in range(nb):
+                bstep()
+            torch.cuda.synchronize()
+            tb = (time.perf_counter() - tb) / nb
+            bfwd = float(np.mean([a.elapsed_time(b) for a, b in bev]))
+            brute = {"ms_per_step": tb * 1e3, "fwd_ms": bfwd, "pairs_per_s_per_gpu": 2.0 * B * N * M / tb}
+        finally:
+            setter(0)
 
     pairs_per_step = 2.0 * B * N * M * world
     ms = dt / args.steps * 1e3
     alg_bytes_fwd = 4.0 * C * B * (N + M) + 8.0 * B * (N + M)
     hbm_gbs = alg_bytes_fwd / (fwd_ms * 1e-3) / 1e9
-    # VALU lane-ops actually issued per pair by the kernel: 3 sub + 1 mul + 2 fma + 1/2 min3 + 13/64
+    # VALU lane-ops the brute-force kernel issues per pair: 3 sub + 1 mul + 2 fma + 1/2 min3 + 13/64
     # per-group bookkeeping (DESIGN.md "nmdist_fwd_c3_kernel")
     laneops = 2.0 * B * N * M * 6.703125
+    grid = args.search == "auto" and int(_lib.lib().pp_nmdistance_forward_workspace_bytes(B, N, M, C)) > 0
     out = {
         "metric": "chamfer_fwd_bwd_point_pairs_per_s", "value": pairs_per_step / (dt / args.steps),
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,20 +278,41 @@ def bench_chamfer(args, dist, world, rank, device):
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Chamfer fwd+bwd B=%d/GPU N=M=%d C=3 fp32, area-uniform unit sphere"
                                % (B, N), "global_batch": B * world,
-                   "parallelism": "batch-shard x%d%s" % (world, " + RCCL all-gather(dist,idx)" if world > 1 else "")},
+                   "search": ("exact uniform-grid search with brute-force fallback (operator default): "
+                              "outputs bit-identical to the brute force, most pairs pruned, value = "
+                              "2*B*N*M/t" if grid else "brute force: every pair evaluated"),
+                   "parallelism": "batch-shard x%d%s" % (world, " + RCCL all-gather(dist,idx), async" if world > 1 else "")},
         "fwd_ms": fwd_ms,
-        "roofline": {"bound": "hbm", "kernel": "nmdist_fwd_c3_kernel", "achieved": hbm_gbs,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
-                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-                     # (profiles/r1/pmc_summary.txt): 6.1 MB + 8.0 MB per launch; reads are scalar/dword
-                     # loads (uncalibrated on gfx950, not the 16-B form that reads 1/2) -- at most the
-                     # algorithmic 20.97 MB either way: no re-reads beyond L2
-                     "traffic": 14.4e6 if (B, N, M) == (32, 16384, 16384) else None,
-                     "note": "exact brute force is fp32-VALU-bound (6500 flop/B); see 'valu'"},
-        "valu": {"achieved": laneops / (fwd_ms * 1e-3), "peak": VALU_PEAK_LANEOPS,
-                 "unit": "lane-ops/s", "frac": laneops / (fwd_ms * 1e-3) / VALU_PEAK_LANEOPS,
-                 "pairs_per_s_fwd": 2.0 * B * N * M / (fwd_ms * 1e-3)},
     }
+    if grid:
+        # forward = grid_build_kernel + grid_query_kernel (the dominant one, ~2/3 of the forward) +
+        # the brute-force kernel over the unresolved list; timed together by the HIP events
+        out["roofline"] = {"bound": "hbm", "kernel": "grid_build_kernel + grid_query_kernel + list fallback",
+                           "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None,
+                           "note": "latency/L2-gather-bound search over a 29 MB workspace; 'bruteforce' "
+                                   "carries the every-pair kernel and its VALU roofline"}
+        if brute is not None:
+            bg = alg_bytes_fwd / (brute["fwd_ms"] * 1e-3) / 1e9
+            brute.update({
+                "roofline": {"bound": "hbm", "kernel": "nmdist_fwd_c3_kernel", "achieved": bg,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bg / HBM_PEAK_GBS,
+                             "traffic": 14.4e6 if (B, N, M) == (32, 16384, 16384) else None,
+                             "note": "6500 flop/B: VALU-bound, see valu"},
+                "valu": {"achieved": laneops / (brute["fwd_ms"] * 1e-3), "peak": VALU_PEAK_LANEOPS,
+                         "unit": "lane-ops/s", "frac": laneops / (brute["fwd_ms"] * 1e-3) / VALU_PEAK_LANEOPS}})
+            out["bruteforce"] = brute
+    else:
+        out["roofline"] = {"bound": "hbm", "kernel": "nmdist_fwd_c3_kernel", "achieved": hbm_gbs,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                           # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r1/pmc_summary.txt):
+                           # 6.1 MB + 8.0 MB per launch; reads are scalar/dword loads (uncalibrated on
+                           # gfx950) -- at most the algorithmic 20.97 MB either way: no re-reads beyond L2
+                           "traffic": 14.4e6 if (B, N, M) == (32, 16384, 16384) else None,
+                           "note": "exact brute force is fp32-VALU-bound (6500 flop/B); see 'valu'"}
+        out["valu"] = {"achieved": laneops / (fwd_ms * 1e-3), "peak": VALU_PEAK_LANEOPS,
+                       "unit": "lane-ops/s", "frac": laneops / (fwd_ms * 1e-3) / VALU_PEAK_LANEOPS,
+                       "pairs_per_s_fwd": 2.0 * B * N * M / (fwd_ms * 1e-3)}
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_chamfer(N, C)
     return out

@@ -43,6 +43,15 @@ const char* pp_version(void);
 int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, float* dist1, int* idx1,
                               float* dist2, int* idx2, int B, int N, int M, int C, void* stream);
 
+/* The same operation with a caller-provided scratch buffer.  With a workspace of at least
+ * pp_nmdistance_forward_workspace_bytes(...) bytes (0 = not applicable to these sizes) the search
+ * is an exact uniform-grid search with the brute force as its fallback -- bit-identical outputs,
+ * far fewer distance evaluations; with workspace == NULL it is pp_nmdistance_forward_f32. */
+size_t pp_nmdistance_forward_workspace_bytes(int B, int N, int M, int C);
+int pp_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2, float* dist1, int* idx1,
+                                 float* dist2, int* idx2, int B, int N, int M, int C,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* Replaces losses.labeled_nmdistance_forward(xyz1,xyz2,label1,label2,dist1,dist2,idx1,idx2)
  *   (_ext/nmdistance.cpp:17-20 -> labeled_chamfer_cuda_forward, _ext/nmdistance_cuda.cu:142-166).
  * label1 (B,N), label2 (B,M) as fp32.  Unmatched query: idx -1, dist 0. */

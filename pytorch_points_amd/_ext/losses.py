@@ -4,7 +4,25 @@ Same names, same positional arguments, same ``int`` return (1 = ok, as chamfer_c
 returns on success, _ext/nmdistance_cuda.cu:137).  Unlike the reference, which checks nothing
 here, inputs are validated and failures raise RuntimeError.
 """
+import os
+
+import torch
+
 from .. import _lib
+
+# scratch for the exact grid search, one growing buffer per device (reused across calls on the
+# device's streams in launch order, like any torch workspace)
+_nmd_workspace = {}
+
+
+def _workspace(device, nbytes):
+    if nbytes == 0:
+        return None
+    buf = _nmd_workspace.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _nmd_workspace[device] = buf
+    return buf
 
 
 def _shapes(xyz1, xyz2):
@@ -29,10 +47,15 @@ def nmdistance_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
     _lib.require_int(*ints)
     if dist1.numel() != b * n or idx1.numel() != b * n or dist2.numel() != b * m or idx2.numel() != b * m:
         raise RuntimeError("output tensors must be (B, N) and (B, M)")
+    L = _lib.lib()
+    nbytes = 0 if os.environ.get("PP_NMDISTANCE_SEARCH") == "bruteforce" else \
+        int(L.pp_nmdistance_forward_workspace_bytes(b, n, m, c))
+    ws = _workspace(dev, nbytes)
     with _lib.on_device(dev) as stream:
-        _lib.check(_lib.lib().pp_nmdistance_forward_f32(
+        _lib.check(L.pp_nmdistance_forward_ws_f32(
             _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(idx1), _lib.ptr(dist2),
-            _lib.ptr(idx2), b, n, m, c, stream), "nmdistance_forward")
+            _lib.ptr(idx2), b, n, m, c, _lib.ptr(ws) if ws is not None else None, nbytes, stream),
+            "nmdistance_forward")
     return 1
 
 

@@ -20,6 +20,8 @@ SIGNATURES = {
     "pp_version": [],
     "pp_opt_n_threads": [_I],
     "pp_nmdistance_forward_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_nmdistance_forward_workspace_bytes": [_I, _I, _I, _I],
+    "pp_nmdistance_forward_ws_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_labeled_nmdistance_forward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_nmdistance_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_furthest_sampling_workspace_bytes": [_I, _I, _I],
@@ -34,7 +36,8 @@ SIGNATURES = {
     "pp_three_interpolate_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_three_interpolate_grad_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
 }
-_RESTYPES = {"pp_version": ctypes.c_char_p, "pp_furthest_sampling_workspace_bytes": _c_size_t}
+_RESTYPES = {"pp_version": ctypes.c_char_p, "pp_furthest_sampling_workspace_bytes": _c_size_t,
+             "pp_nmdistance_forward_workspace_bytes": _c_size_t}
 
 _lib = None
 

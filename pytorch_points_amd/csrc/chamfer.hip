@@ -33,11 +33,15 @@ constexpr int kBlock = 64 * kWavesPerBlock;
 // operations per element, so the bits do not change; measured on MI355X a v_sub_f32 with an SGPR
 // operand issues at half the rate of the VGPR-only form while v_pk_add_f32 with an SGPR source
 // does two subtractions in the same slot (tools/valu_microbench2.hip, DESIGN.md "VALU roof").
-template <int Q, int G, bool PK, bool PF>
+// LIST: the queries of a set are not 0..nq-1 but the `qcount[set]` indices stored in
+// qlist[set's query offset ...] (the grid search's unresolved queries, chamfer_grid.hip); tiles
+// beyond the list exit at once.
+template <int Q, int G, bool PK, bool PF, bool LIST = false>
 __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
     int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M,
-    int tiles1, int tiles2, int total, int per_xcd) {
+    int tiles1, int tiles2, int total, int per_xcd, const int* __restrict__ qlist = nullptr,
+    const int* __restrict__ qcount = nullptr) {
   static_assert(G % 2 == 0, "groups are consumed two reference points per v_min3");
   constexpr int TQ = 64 * Q;  // queries per workgroup
   __shared__ float s_best[kWavesPerBlock][TQ];
@@ -57,13 +61,21 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
 
   const int wave = pp::wave_id_uniform();
   const int lane = threadIdx.x & 63;
+  int count = nq;
+  const int* __restrict__ ql = nullptr;
+  if constexpr (LIST) {
+    count = qcount[2 * b + (second ? 1 : 0)];
+    if (tile * TQ >= count) return;  // uniform per workgroup
+    ql = qlist + (size_t)b * ((size_t)N + M) + (second ? (size_t)N : 0);
+  }
 
   float qx[Q], qy[Q], qz[Q], best[Q];
   int gid[Q];
 #pragma unroll
   for (int i = 0; i < Q; ++i) {
     int j = tile * TQ + i * 64 + lane;
-    j = j < nq ? j : nq - 1;  // clamp: out-of-range lanes compute a valid query, never stored
+    j = j < count ? j : count - 1;  // clamp: out-of-range lanes compute a valid query, never stored
+    if constexpr (LIST) j = ql[j];
     qx[i] = qry[3 * (size_t)j + 0];
     qy[i] = qry[3 * (size_t)j + 1];
     qz[i] = qry[3 * (size_t)j + 2];
@@ -191,8 +203,9 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
       bb = lt ? c : bb;
       bi = lt ? ci : bi;
     }
-    const int j = tile * TQ + e;
-    if (j < nq) {
+    int j = tile * TQ + e;
+    if (j < count) {
+      if constexpr (LIST) j = ql[j];
       od[j] = bb;
       oi[j] = bi;
     }
@@ -432,6 +445,23 @@ int zero_outputs(float* dist1, int* idx1, float* dist2, int* idx2, int B, int N,
 }
 
 }  // namespace
+
+// Brute force over listed queries only (see LIST above); used by chamfer_grid.hip.
+namespace pp {
+int nmdist_fwd_c3_list(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
+                       int* idx2, int B, int N, int M, const int* qlist, const int* qcount,
+                       hipStream_t s) {
+  constexpr int Q = 1, TQ = 64;
+  const int tiles1 = (N + TQ - 1) / TQ, tiles2 = (M + TQ - 1) / TQ;
+  const long long total = (long long)B * (tiles1 + tiles2);
+  if (total > 0x7fffff00LL) return PP_EINVAL;
+  const int per_xcd = (int)((total + 7) / 8);
+  nmdist_fwd_c3_kernel<Q, 8, false, false, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
+      xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, tiles1, tiles2, (int)total, per_xcd, qlist, qcount);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+}  // namespace pp
 
 // Tuning override for benchmarking variants in one process (bench.py --variant); 0 = automatic.
 static int g_fwd_variant = 0;

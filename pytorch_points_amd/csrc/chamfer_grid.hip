@@ -1,0 +1,425 @@
+// chamfer_grid.hip -- exact nearest neighbour through a uniform grid (C == 3), with the brute-force
+// scan of chamfer.hip as the fallback.  Same outputs, bit for bit, as the brute force: the
+// candidates' distances are evaluated with the same canonical arithmetic (pp::chamfer_d3), ties
+// are resolved to the lowest original index explicitly, and a query stops expanding only when
+// every unexamined point is PROVABLY farther in computed fp32 distance:
+//
+//   * reference points of one (batch, direction) set are counting-sorted into cubic cells of side
+//     h over their bounding box (<= 32^3 cells, counters in LDS);
+//   * a query is clamped to the box (the projection q' onto a convex set never increases the
+//     distance to points inside it, so bounds derived for q' hold for q) and examines the cells of
+//     the cube of Chebyshev radius rho = 1, then 2, around its own cell; any point in a cell
+//     outside that cube is at true distance >= rho*h from q';
+//   * fp32 evaluation of the canonical formula has relative error <= 6 * 2^-24, and the cell
+//     assignment (one subtraction, one multiplication, one truncation) can misplace a point by
+//     <= 1e-5 h; both are covered by stopping only if  best < (rho*h)^2 * 0.999  (strict).
+//     Then no unexamined point can have a computed distance <= best, i.e. none can win or tie;
+//   * a query that cannot stop at rho = 2 (far from the cloud, or degenerate data) is appended to
+//     a list and resolved by the brute-force kernel (LIST mode), as is every query of a set whose
+//     grid is useless (non-finite coordinates, almost all points in one cell).
+#include "pp_common.h"
+
+namespace pp {
+// implemented in chamfer.hip: brute force over the queries listed in `qlist` (per set: count in
+// qcount[set], indices in qlist[set_offset ...])
+int nmdist_fwd_c3_list(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
+                       int* idx2, int B, int N, int M, const int* qlist, const int* qcount,
+                       hipStream_t s);
+}  // namespace pp
+
+namespace {
+
+constexpr int kGridMax = 32;                                  // cells per axis
+constexpr int kGridCells = kGridMax * kGridMax * kGridMax;    // LDS counters: 128 KiB
+constexpr int kBuildThreads = 1024;
+constexpr float kBoundSlack = 0.999f;
+
+struct GridSet {  // one per (batch, direction); written by the build kernel
+  float minx, miny, minz, h, invh;
+  int gx, gy, gz;
+  int useless;  // 1: send every query of this set to the brute force
+  int pad[7];
+};
+static_assert(sizeof(GridSet) == 64, "");
+
+__device__ __forceinline__ int cell_coord(float p, float mn, float invh, int g) {
+  const float f = (p - mn) * invh;
+  int c = (int)f;  // truncation; negative and NaN inputs end up clamped below
+  c = c < 0 ? 0 : c;
+  return c > g - 1 ? g - 1 : c;
+}
+
+// Workspace layout (bytes), S = 2*B sets, T = B*(N+M) points:
+//   [0, 64*S)                      GridSet[S]
+//   [.., +4*S)  (padded to 256)    int qcount[S]
+//   [.., +4*(kGridCells+1)*S)      unsigned cell_start[S][kGridCells+1]
+//   [.., +16*T)                    float4 sorted[T]   (x, y, z, original index bits)
+//   [.., +4*T)                     int qlist[T]
+struct Layout {
+  size_t sets, qcount, cell_start, sorted, qlist, total;
+};
+__host__ __device__ inline Layout make_layout(int B, int N, int M) {
+  Layout L;
+  const size_t S = (size_t)2 * B, T = (size_t)B * ((size_t)N + M);
+  L.sets = 0;
+  L.qcount = L.sets + 64 * S;
+  L.cell_start = L.qcount + ((4 * S + 255) / 256) * 256;
+  L.sorted = L.cell_start + ((4 * (size_t)(kGridCells + 1) * S + 255) / 256) * 256;
+  L.qlist = L.sorted + 16 * T;
+  L.total = L.qlist + 4 * T;
+  return L;
+}
+// set s = 2*b + dir; dir 0: queries = cloud 1 (N), references = cloud 2 (M)
+__host__ __device__ inline size_t set_point_offset(int b, int dir, int N, int M) {
+  return (size_t)b * ((size_t)N + M) + (dir ? (size_t)M : 0);  // references of (b,0) first (M), then (b,1) (N)
+}
+__host__ __device__ inline size_t set_query_offset(int b, int dir, int N, int M) {
+  return (size_t)b * ((size_t)N + M) + (dir ? (size_t)N : 0);  // queries of (b,0) first (N), then (b,1) (M)
+}
+
+__device__ __forceinline__ float block_reduce(float v, bool take_max, float* s_red) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float o = __shfl_xor(v, off);
+    v = take_max ? fmaxf(v, o) : fminf(v, o);
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[wave] = v;
+  __syncthreads();
+  float r = s_red[0];
+  for (int w = 1; w < kBuildThreads / 64; ++w) r = take_max ? fmaxf(r, s_red[w]) : fminf(r, s_red[w]);
+  return r;
+}
+
+// One workgroup per set: bounding box, cell histogram (LDS), exclusive scan, scatter.
+__global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* __restrict__ xyz1,
+                                                                   const float* __restrict__ xyz2,
+                                                                   unsigned char* __restrict__ ws, int B,
+                                                                   int N, int M) {
+  // counters, skewed by one word per 32 cells so that the per-thread contiguous runs of the scan
+  // (32 cells each) start in different banks
+  extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // [kGridCells + kGridCells / 32]
+  __shared__ float s_red[kBuildThreads / 64];
+  __shared__ unsigned s_part[kBuildThreads];
+  __shared__ int s_bad;
+  __shared__ float s_box[(kBuildThreads / 64) * 6];
+  const int set = blockIdx.x;
+  const int b = set >> 1, dir = set & 1;
+  const int nr = dir ? N : M;
+  const float* __restrict__ ref = (dir ? xyz1 : xyz2) + (size_t)b * nr * 3;
+  const Layout L = make_layout(B, N, M);
+  GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
+  unsigned* cell_start = reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
+  pp::f4* sorted = reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
+  const int t = threadIdx.x;
+
+  // A thread keeps KP points in registers (one chunk = 1024*KP points; a single chunk covers
+  // 16384 points, so the three passes read the cloud from memory once).  Loads are unconditional
+  // (index clamped) so that all KP are in flight together.
+  constexpr int KP = 16;
+  const int nchunks = (nr + kBuildThreads * KP - 1) / (kBuildThreads * KP);
+  float px[KP], py[KP], pz[KP];
+  auto load_chunk = [&](int base) {
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      int k = base + t + kBuildThreads * i;
+      k = k < nr ? k : nr - 1;
+      px[i] = ref[3 * (size_t)k];
+      py[i] = ref[3 * (size_t)k + 1];
+      pz[i] = ref[3 * (size_t)k + 2];
+    }
+  };
+  load_chunk(0);
+  // bounding box + finiteness (the clamped duplicates do not change either)
+  float mnx = __builtin_inff(), mny = mnx, mnz = mnx, mxx = -mnx, mxy = -mnx, mxz = -mnx;
+  bool bad = false;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch > 0) load_chunk(ch * kBuildThreads * KP);
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      const float x = px[i], y = py[i], z = pz[i];
+      bad |= !(__builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z));
+      mnx = fminf(mnx, x); mny = fminf(mny, y); mnz = fminf(mnz, z);
+      mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y); mxz = fmaxf(mxz, z);
+    }
+  }
+  if (t == 0) s_bad = 0;
+  __syncthreads();
+  if (bad) s_bad = 1;
+  {  // six reductions with one barrier pair: max of (-min) and max
+    float v[6] = {-mnx, -mny, -mnz, mxx, mxy, mxz};
+#pragma unroll
+    for (int e = 0; e < 6; ++e)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v[e] = fmaxf(v[e], __shfl_xor(v[e], off));
+    if ((t & 63) == 0)
+#pragma unroll
+      for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 6 + e] = v[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      float r = s_box[e];
+      for (int w = 1; w < kBuildThreads / 64; ++w) r = fmaxf(r, s_box[w * 6 + e]);
+      v[e] = r;
+    }
+    mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
+  }
+  const float ex = mxx - mnx, ey = mxy - mny, ez = mxz - mnz;
+  const float emax = fmaxf(ex, fmaxf(ey, ez));
+  // ~2 points per cell if the cloud filled its box; cubic cells of side h
+  int g0 = (int)ceilf(cbrtf(2.0f * (float)nr));
+  g0 = g0 < 1 ? 1 : (g0 > kGridMax ? kGridMax : g0);
+  const bool degenerate = s_bad || !(emax > 0.0f) || !__builtin_isfinite(emax);
+  float h = emax / (float)g0;
+  if (!(h > 0.0f) || !__builtin_isfinite(h)) h = 1.0f;
+  const float invh = 1.0f / h;
+  auto cells = [&](float e) {
+    int g = (int)(e * invh) + 1;  // g*h > e: the box maximum lies inside the last cell
+    return g < 1 ? 1 : (g > kGridMax ? kGridMax : g);
+  };
+  const int gx = degenerate ? 1 : cells(ex), gy = degenerate ? 1 : cells(ey), gz = degenerate ? 1 : cells(ez);
+  const int ncell = gx * gy * gz;
+
+  auto sk = [](int c) { return c + (c >> 5); };
+  for (int c = t; c < ncell; c += kBuildThreads) s_cnt[sk(c)] = 0;
+  __syncthreads();
+  auto cell_of = [&](float x, float y, float z) {
+    return (cell_coord(z, mnz, invh, gz) * gy + cell_coord(y, mny, invh, gy)) * gx + cell_coord(x, mnx, invh, gx);
+  };
+  if (!degenerate)
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (nchunks > 1) load_chunk(ch * kBuildThreads * KP);
+#pragma unroll
+      for (int i = 0; i < KP; ++i)
+        if (ch * kBuildThreads * KP + t + kBuildThreads * i < nr) atomicAdd(&s_cnt[sk(cell_of(px[i], py[i], pz[i]))], 1u);
+    }
+  __syncthreads();
+  // exclusive scan: each thread owns a contiguous run of cells
+  const int per = (ncell + kBuildThreads - 1) / kBuildThreads;
+  const int c0 = t * per, c1 = min(ncell, c0 + per);
+  unsigned sum = 0, mx = 0;
+  for (int c = c0; c < c1; ++c) {
+    sum += s_cnt[sk(c)];
+    mx = max(mx, s_cnt[sk(c)]);
+  }
+  const float fmx = block_reduce((float)mx, true, s_red);
+  // exclusive scan of the 1024 per-thread sums: inclusive scan inside each wave (shuffles), then
+  // the 16 wave totals
+  unsigned incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = __shfl_up(incl, off);
+    if ((t & 63) >= off) incl += o;
+  }
+  if ((t & 63) == 63) s_part[t >> 6] = incl;
+  __syncthreads();
+  unsigned wave_base = 0;
+  for (int w = 0; w < (t >> 6); ++w) wave_base += s_part[w];
+  unsigned run = wave_base + incl - sum;
+  for (int c = c0; c < c1; ++c) {
+    const unsigned v = s_cnt[sk(c)];
+    s_cnt[sk(c)] = run;  // cell start; becomes the scatter cursor below
+    run += v;
+  }
+  __syncthreads();
+  for (int c = t; c < ncell; c += kBuildThreads) cell_start[c] = s_cnt[sk(c)];  // coalesced copy out
+  if (t == 0) cell_start[ncell] = degenerate ? 0u : (unsigned)nr;
+  __syncthreads();
+  if (!degenerate)
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (nchunks > 1) load_chunk(ch * kBuildThreads * KP);
+#pragma unroll
+      for (int i = 0; i < KP; ++i) {
+        const int k = ch * kBuildThreads * KP + t + kBuildThreads * i;
+        if (k < nr) {
+          const unsigned pos = atomicAdd(&s_cnt[sk(cell_of(px[i], py[i], pz[i]))], 1u);
+          pp::f4 v = {px[i], py[i], pz[i], __int_as_float(k)};
+          sorted[pos] = v;
+        }
+      }
+    }
+  if (t == 0) {
+    GridSet g;
+    g.minx = mnx; g.miny = mny; g.minz = mnz; g.h = h; g.invh = invh;
+    g.gx = gx; g.gy = gy; g.gz = gz;
+    // useless: degenerate, or one cell holds so many points that scanning it approaches a brute force
+    g.useless = (degenerate || fmx > 64.0f + 0.25f * (float)nr) ? 1 : 0;
+    for (int i = 0; i < 7; ++i) g.pad[i] = 0;
+    *gs = g;
+  }
+}
+
+// One lane per query.
+__global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict__ xyz1,
+                                                         const float* __restrict__ xyz2,
+                                                         float* __restrict__ dist1, int* __restrict__ idx1,
+                                                         float* __restrict__ dist2, int* __restrict__ idx2,
+                                                         unsigned char* __restrict__ ws, int B, int N, int M,
+                                                         int tiles1, int tiles2) {
+  const int per_b = tiles1 + tiles2;
+  const int b = blockIdx.x / per_b;
+  const int r = blockIdx.x - b * per_b;
+  const int dir = r >= tiles1 ? 1 : 0;
+  const int tile = dir ? r - tiles1 : r;
+  const int nq = dir ? M : N;
+  const int jj = tile * 256 + threadIdx.x;
+  if (jj >= nq) return;
+  const int set = 2 * b + dir;
+  const Layout L = make_layout(B, N, M);
+  const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[set];
+  // The query cloud is the reference cloud of the partner set (b, 1-dir), already sorted by cell
+  // there: walking the queries in that order makes the lanes of a wave spatial neighbours, so
+  // they read the same cells (coalesced, L1-resident) and run similar trip counts.
+  const GridSet gp = reinterpret_cast<const GridSet*>(ws + L.sets)[set ^ 1];
+  const pp::f4* __restrict__ qsorted =
+      reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir ^ 1, N, M);
+  int* qcount = reinterpret_cast<int*>(ws + L.qcount) + set;
+  int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
+  if (g.useless) {
+    qlist[atomicAdd(qcount, 1)] = jj;  // every query exactly once, any order
+    return;
+  }
+  const unsigned* __restrict__ cell_start =
+      reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
+  const pp::f4* __restrict__ sorted =
+      reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
+  float qx, qy, qz;
+  int j;
+  if (!gp.useless) {
+    const pp::f4 qq = qsorted[jj];
+    qx = qq.x; qy = qq.y; qz = qq.z;
+    j = __float_as_int(qq.w);
+  } else {
+    const float* __restrict__ q = (dir ? xyz2 : xyz1) + ((size_t)b * nq + jj) * 3;
+    qx = q[0]; qy = q[1]; qz = q[2];
+    j = jj;
+  }
+  const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
+  const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
+  const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
+  float best = __builtin_inff();
+  int bidx = 0x7fffffff;
+  auto scan_cells = [&](int z, int y, int x0, int x1) {  // cells (x0..x1, y, z): contiguous points
+    const int c = (z * g.gy + y) * g.gx;
+    const unsigned s = cell_start[c + x0], e = cell_start[c + x1 + 1];
+    for (unsigned i = s; i < e; ++i) {
+      const pp::f4 p = sorted[i];
+      const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
+      const int id = __float_as_int(p.w);
+      const bool take = d < best || (d == best && id < bidx);
+      best = take ? d : best;
+      bidx = take ? id : bidx;
+    }
+  };
+  bool resolved = false;
+  // cube of radius 1: the nine row ranges are fetched first (18 independent loads, cell
+  // coordinates clamped so that none is conditional), then walked four points at a time (the
+  // clamped duplicates of a ragged tail are the same candidate again: harmless)
+  {
+    const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.gz - 1), y0 = max(cy - 1, 0), y1 = min(cy + 1, g.gy - 1);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
+    unsigned rs[9], re[9];
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int z = cz + dz, y = cy + dy;
+        const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
+        const int c = (min(max(z, 0), g.gz - 1) * g.gy + min(max(y, 0), g.gy - 1)) * g.gx;
+        const unsigned s0 = cell_start[c + x0], e0 = cell_start[c + x1 + 1];
+        rs[(dz + 1) * 3 + dy + 1] = ok ? s0 : 0u;
+        re[(dz + 1) * 3 + dy + 1] = ok ? e0 : 0u;
+      }
+#pragma unroll
+    for (int r9 = 0; r9 < 9; ++r9) {
+      for (unsigned i = rs[r9]; i < re[r9]; i += 4) {
+        const unsigned last = re[r9] - 1;
+        pp::f4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = sorted[min(i + u, last)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+          const int id = __float_as_int(p[u].w);
+          const bool take = d < best || (d == best && id < bidx);
+          best = take ? d : best;
+          bidx = take ? id : bidx;
+        }
+      }
+    }
+    const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
+    resolved = all ? (bidx != 0x7fffffff) : (best < g.h * g.h * kBoundSlack);
+  }
+  if (!resolved) {  // shell of radius 2
+    const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.gz - 1), y0 = max(cy - 2, 0), y1 = min(cy + 2, g.gy - 1);
+    const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.gx - 1);
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        const bool inner = z >= cz - 1 && z <= cz + 1 && y >= cy - 1 && y <= cy + 1;
+        if (!inner) {
+          scan_cells(z, y, x0, x1);
+        } else {
+          if (cx - 2 >= 0) scan_cells(z, y, cx - 2, cx - 2);
+          if (cx + 2 <= g.gx - 1) scan_cells(z, y, cx + 2, cx + 2);
+        }
+      }
+    const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
+    const float two_h = 2.0f * g.h;
+    resolved = all ? (bidx != 0x7fffffff) : (best < two_h * two_h * kBoundSlack);
+  }
+  if (resolved) {
+    (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
+    (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
+  } else {
+    qlist[atomicAdd(qcount, 1)] = j;
+  }
+}
+
+}  // namespace
+
+// 0 = automatic (grid when a workspace is given and the clouds are large enough); 1 = brute force
+static int g_grid_mode = 0;
+extern "C" void pp_debug_set_nmdistance_search(int v) { g_grid_mode = v; }
+
+static bool grid_applicable(int B, int N, int M, int C) {
+  return C == 3 && B > 0 && N >= 2048 && M >= 2048 && (long long)B * ((long long)N + M) < (1LL << 31) - 1;
+}
+
+extern "C" size_t pp_nmdistance_forward_workspace_bytes(int B, int N, int M, int C) {
+  if (!grid_applicable(B, N, M, C)) return 0;
+  return make_layout(B, N, M).total;
+}
+
+extern "C" int pp_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2, float* dist1,
+                                            int* idx1, float* dist2, int* idx2, int B, int N, int M,
+                                            int C, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+  const size_t need = pp_nmdistance_forward_workspace_bytes(B, N, M, C);
+  if (g_grid_mode == 1 || need == 0 || !workspace || workspace_bytes < need)
+    return pp_nmdistance_forward_f32(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, stream);
+  if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2) return PP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  const Layout L = make_layout(B, N, M);
+  hipError_t e = hipMemsetAsync(ws + L.qcount, 0, (size_t)2 * B * sizeof(int), s);
+  if (e != hipSuccess) return (int)e;
+  static bool attr_set = false;
+  const size_t lds = (size_t)(kGridCells + kGridCells / 32) * sizeof(unsigned);
+  if (!attr_set) {
+    e = hipFuncSetAttribute((const void*)grid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  grid_build_kernel<<<dim3(2 * B), dim3(kBuildThreads), lds, s>>>(xyz1, xyz2, ws, B, N, M);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
+  const long long blocks = (long long)B * (tiles1 + tiles2);
+  if (blocks > 0x7fffffffLL) return PP_EINVAL;
+  grid_query_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws,
+                                                                   B, N, M, tiles1, tiles2);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
+                                reinterpret_cast<const int*>(ws + L.qlist),
+                                reinterpret_cast<const int*>(ws + L.qcount), s);
+}

@@ -1,0 +1,101 @@
+"""GPU parity of the exact grid search (chamfer_grid.hip) against the CPU oracle on point
+distributions chosen to break a spatial index: the outputs must be bit-identical to the brute
+force's (indices AND distances), whatever path a query takes (grid hit, radius-2 shell, fallback
+list, useless-grid fallback)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pytorch_points_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cuda, x1, x2, mode):
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd.network.model_loss import nndistance
+    setter = _lib.lib().pp_debug_set_nmdistance_search
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(mode)
+    try:
+        d1, d2, i1, i2 = nndistance(torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda))
+        torch.cuda.synchronize()
+    finally:
+        setter(0)
+    return d1.cpu().numpy(), i1.cpu().numpy(), d2.cpu().numpy(), i2.cpu().numpy()
+
+
+def _u(seed, shape):
+    return S.uniform01(seed, shape).reshape(shape).astype(np.float32)
+
+
+def _cases():
+    n = 4096
+    c = {}
+    c["sphere"] = (S.unit_sphere(1, 2, n), S.unit_sphere(2, 2, n))
+    c["sphere_ragged"] = (S.unit_sphere(3, 1, 2048), S.unit_sphere(4, 1, 5003))
+    c["cube_volume"] = (_u(5, (2, n, 3)), _u(6, (2, n, 3)))
+    blobs = (S.normal(7, (1, n, 3)) * 1e-3 + np.repeat(_u(8, (1, 8, 3)), n // 8, 1)).astype(np.float32)
+    c["tight_blobs_vs_uniform"] = (blobs, _u(9, (1, n, 3)))
+    out = _u(10, (1, n, 3)).copy()
+    out[0, :50] += 40.0                                   # far outliers stretch the box
+    c["outliers"] = (out, _u(11, (1, n, 3)))
+    c["all_identical_refs"] = (_u(12, (1, n, 3)), np.full((1, n, 3), 0.25, np.float32))
+    line = np.zeros((1, n, 3), np.float32)
+    line[0, :, 0] = np.linspace(-1, 1, n, dtype=np.float32)
+    c["collinear"] = (line, _u(13, (1, n, 3)))
+    plane = _u(14, (1, n, 3)).copy()
+    plane[..., 2] = 0.5
+    c["planar"] = (plane, (plane[:, ::-1] + np.float32(1e-3)).copy())
+    dup = S.unit_sphere(15, 1, n)
+    dup[0, n // 2:] = dup[0, : n // 2]                    # every point twice: exact ties
+    c["duplicates"] = (S.unit_sphere(16, 1, n), dup)
+    c["self"] = (dup.copy(), dup.copy())                  # zero distances, ties
+    c["huge_offset"] = (S.unit_sphere(17, 1, n) + np.float32(1e6), S.unit_sphere(18, 1, n) + np.float32(1e6))
+    c["tiny_scale"] = (S.unit_sphere(19, 1, n) * np.float32(1e-18), S.unit_sphere(20, 1, n) * np.float32(1e-18))
+    c["disjoint_far_apart"] = (_u(21, (1, n, 3)), _u(22, (1, n, 3)) + np.float32(100.0))
+    lattice = np.stack(np.meshgrid(*[np.arange(16, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(1, -1, 3)
+    c["integer_lattice_ties"] = (lattice + np.float32(0.5), lattice.copy())   # 8-way exact ties
+    mixed = np.concatenate([_u(23, (1, n // 2, 3)) * np.float32(1e-3), _u(24, (1, n // 2, 3)) * np.float32(50)], 1)
+    c["two_scales"] = (mixed, _u(25, (1, n, 3)) * np.float32(50))
+    return c
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_grid_search_equals_oracle(cuda, name):
+    x1, x2 = [np.ascontiguousarray(a) for a in CASES[name]]
+    exp = oracle.chamfer_forward(x1, x2)
+    got = _run(cuda, x1, x2, 0)
+    for g, e, what in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
+        assert np.array_equal(g, e), "%s: %s differs at %d places" % (name, what, int((g != e).sum()))
+    brute = _run(cuda, x1, x2, 1)
+    for g, e in zip(brute, exp):
+        assert np.array_equal(g, e)
+
+
+def test_grid_search_full_size_c2(cuda):
+    """BASELINE config 2 through the default (grid) path == forced brute force, all 32 batch elements."""
+    x1, x2 = S.unit_sphere(0, 32, 16384), S.unit_sphere(1, 32, 16384)
+    a = _run(cuda, x1, x2, 0)
+    b = _run(cuda, x1, x2, 1)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    e = oracle.chamfer_forward(x1[:2], x2[:2])
+    for u, v in zip(a, e):
+        assert np.array_equal(u[:2], v)
+
+
+def test_grid_workspace_reused_across_shapes(cuda):
+    for n, m in [(4096, 2048), (2048, 8192), (3000, 3000)]:
+        x1, x2 = S.unit_sphere(n, 2, n), S.unit_sphere(m + 1, 2, m)
+        got = _run(cuda, x1, x2, 0)
+        exp = oracle.chamfer_forward(x1, x2)
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e)

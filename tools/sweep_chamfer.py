@@ -32,6 +32,24 @@ for rnd in range(6):
         if ref is None: ref = cur
         assert all(torch.equal(a, b) for a, b in zip(ref, cur)), "variant %d differs" % v
 setv(0)
+# the exact grid search (default operator path when a workspace is given)
+L = _lib.lib()
+nb = int(L.pp_nmdistance_forward_workspace_bytes(B, N, N, 3))
+ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+def grid():
+    _lib.check(L.pp_nmdistance_forward_ws_f32(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(d1), _lib.ptr(i1), _lib.ptr(d2), _lib.ptr(i2),
+                                              B, N, N, 3, _lib.ptr(ws), nb, None), "grid")
+torch.cuda.synchronize()
+with torch.cuda.stream(torch.cuda.default_stream()):
+    grid(); torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(ref, (d1, i1, d2, i2))), "grid search differs from brute force"
+    ts = []
+    for _ in range(5):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): grid()
+        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 5)
+    print("grid search      median %.3f ms  %.2f Tpairs/s equivalent" % (np.median(ts), 2 * B * N * N / np.median(ts) / 1e9))
 for v in variants:
     t = np.array(times[v][1:])
     print("variant %5d  median %.3f ms  min %.3f ms   %.2f Tpairs/s" % (v, np.median(t), t.min(), 2 * B * N * N / np.median(t) / 1e9))
