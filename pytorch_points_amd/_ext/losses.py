@@ -10,18 +10,19 @@ import torch
 
 from .. import _lib
 
-# scratch for the exact grid search, one growing buffer per device (reused across calls on the
-# device's streams in launch order, like any torch workspace)
+# scratch for the exact grid search: one growing buffer per (device, stream) -- calls on one
+# stream are ordered, calls on different streams must not share scratch
 _nmd_workspace = {}
 
 
 def _workspace(device, nbytes):
     if nbytes == 0:
         return None
-    buf = _nmd_workspace.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _nmd_workspace.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _nmd_workspace[device] = buf
+        _nmd_workspace[key] = buf
     return buf
 
 

@@ -16,21 +16,24 @@ _fps_workspace = {}
 def _workspace(device, nbytes):
     if nbytes == 0:
         return None
-    buf = _fps_workspace.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)  # never shared between streams
+    buf = _fps_workspace.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _fps_workspace[device] = buf
+        _fps_workspace[key] = buf
     return buf
 
 
 def furthest_sampling_status(device):
     """Test/debug aid: 0 if no inter-workgroup wait of the FPS cluster kernel has timed out on this
     device's workspace since its last call (synchronises the current stream)."""
-    ws = _fps_workspace.get(torch.device(device))
-    if ws is None:
-        return 0
-    with _lib.on_device(ws.device) as stream:
-        return int(_lib.lib().pp_furthest_sampling_status(_lib.ptr(ws), stream))
+    device = torch.device(device)
+    status = 0
+    for (dev, _), ws in list(_fps_workspace.items()):
+        if dev == device:
+            with _lib.on_device(dev) as stream:
+                status |= int(_lib.lib().pp_furthest_sampling_status(_lib.ptr(ws), stream))
+    return status
 
 
 def furthest_sampling(m, seedIdx, input, temp, idx):

@@ -559,13 +559,9 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
   const size_t col_bytes = (size_t)(N > M ? N : M) * sizeof(float);
   if (g_bwd_variant != 1 && col_bytes <= 160 * 1024 && (long long)B * 2 * C <= 0x7fffffffLL &&
       (g_bwd_variant == 2 || ((long long)B * 2 * C >= 64 && N + M >= 4096))) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)nmdist_bwd_lds_kernel,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
+    static bool lds_ok[64] = {};
+    const hipError_t e = pp::allow_big_lds(nmdist_bwd_lds_kernel, 160 * 1024, lds_ok);
+    if (e != hipSuccess) return (int)e;
     nmdist_bwd_lds_kernel<<<dim3((unsigned)(B * 2 * C)), dim3(1024), col_bytes, s>>>(
         xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, C);
     PP_RETURN_IF_LAUNCH_FAILED();

@@ -8,11 +8,11 @@
 //     h over their bounding box (<= 32^3 cells, counters in LDS);
 //   * a query is clamped to the box (the projection q' onto a convex set never increases the
 //     distance to points inside it, so bounds derived for q' hold for q) and examines the cells of
-//     the cube of Chebyshev radius rho = 1, then 2, around its own cell; any point in a cell
-//     outside that cube is at true distance >= rho*h from q';
+//     first the 2x2x2 block of cells nearest to q' (everything else is >= h/2 away), then the
+//     cubes of Chebyshev radius rho = 1 and 2 around its own cell (everything else >= rho*h away);
 //   * fp32 evaluation of the canonical formula has relative error <= 6 * 2^-24, and the cell
 //     assignment (one subtraction, one multiplication, one truncation) can misplace a point by
-//     <= 1e-5 h; both are covered by stopping only if  best < (rho*h)^2 * 0.999  (strict).
+//     <= 1e-5 h; both are covered by stopping only if  best < bound^2 * 0.999  (strict).
 //     Then no unexamined point can have a computed distance <= best, i.e. none can win or tie;
 //   * a query that cannot stop at rho = 2 (far from the cloud, or degenerate data) is appended to
 //     a list and resolved by the brute-force kernel (LIST mode), as is every query of a set whose
@@ -33,6 +33,8 @@ constexpr int kGridMax = 32;                                  // cells per axis
 constexpr int kGridCells = kGridMax * kGridMax * kGridMax;    // LDS counters: 128 KiB
 constexpr int kBuildThreads = 1024;
 constexpr float kBoundSlack = 0.999f;
+constexpr int kWideBlocksPerSet = 4;
+constexpr int kUnresolved = (int)0x80000000;
 
 struct GridSet {  // one per (batch, direction); written by the build kernel
   float minx, miny, minz, h, invh;
@@ -54,19 +56,26 @@ __device__ __forceinline__ int cell_coord(float p, float mn, float invh, int g) 
 //   [.., +4*S)  (padded to 256)    int qcount[S]
 //   [.., +4*(kGridCells+1)*S)      unsigned cell_start[S][kGridCells+1]
 //   [.., +16*T)                    float4 sorted[T]   (x, y, z, original index bits)
-//   [.., +4*T)                     int qlist[T]
+//   [.., +4*T)                     int qlist[T]           queries left to the brute force, per set
+//   [.., +4*T)                     int blist[T]           queries left to stages B/C, per set
+//   [.., +4*T)                     int inv[T]             position of original point k in `sorted`
+//   [.., +8*T)                     {float dist, int idx} res[T]   stage-A results in sorted order
+// qcount has 4*B entries: [0, 2B) count qlist, [2B, 4B) count blist.
 struct Layout {
-  size_t sets, qcount, cell_start, sorted, qlist, total;
+  size_t sets, qcount, cell_start, sorted, qlist, blist, inv, res, total;
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M) {
   Layout L;
   const size_t S = (size_t)2 * B, T = (size_t)B * ((size_t)N + M);
   L.sets = 0;
   L.qcount = L.sets + 64 * S;
-  L.cell_start = L.qcount + ((4 * S + 255) / 256) * 256;
+  L.cell_start = L.qcount + ((4 * 2 * S + 255) / 256) * 256;
   L.sorted = L.cell_start + ((4 * (size_t)(kGridCells + 1) * S + 255) / 256) * 256;
   L.qlist = L.sorted + 16 * T;
-  L.total = L.qlist + 4 * T;
+  L.blist = L.qlist + 4 * T;
+  L.inv = L.blist + 4 * T;
+  L.res = L.inv + 4 * T;
+  L.total = L.res + 8 * T;
   return L;
 }
 // set s = 2*b + dir; dir 0: queries = cloud 1 (N), references = cloud 2 (M)
@@ -112,6 +121,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
   unsigned* cell_start = reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
   pp::f4* sorted = reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
+  int* inv = reinterpret_cast<int*>(ws + L.inv) + set_point_offset(b, dir, N, M);
   const int t = threadIdx.x;
 
   // A thread keeps KP points in registers (one chunk = 1024*KP points; a single chunk covers
@@ -236,6 +246,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
           const unsigned pos = atomicAdd(&s_cnt[sk(cell_of(px[i], py[i], pz[i]))], 1u);
           pp::f4 v = {px[i], py[i], pz[i], __int_as_float(k)};
           sorted[pos] = v;
+          inv[k] = (int)pos;  // coalesced: k is thread-strided
         }
       }
     }
@@ -250,16 +261,32 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   }
 }
 
-// One lane per query.
+// Append `value` to list[counter++] for the lanes with `want`: one atomic per wave.
+__device__ __forceinline__ void wave_append(bool want, int* counter, int* list, int value) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = (int)__builtin_ctzll(mask);
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, (int)__builtin_popcountll(mask));
+  base = __shfl(base, leader);
+  if (want) list[base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+// Stage A for every query, one lane per query (dense launch).  Unresolved queries go to `blist`
+// (compacted, so the rarely needed wider stages run in full waves instead of a few lanes of many).
 __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict__ xyz1,
                                                          const float* __restrict__ xyz2,
                                                          float* __restrict__ dist1, int* __restrict__ idx1,
                                                          float* __restrict__ dist2, int* __restrict__ idx2,
                                                          unsigned char* __restrict__ ws, int B, int N, int M,
-                                                         int tiles1, int tiles2) {
+                                                         int tiles1, int tiles2, int total, int per_xcd) {
+  // workgroups of one set on one XCD: its cells and points (384 KiB) stay in that L2
+  const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
+  if (V >= total) return;
   const int per_b = tiles1 + tiles2;
-  const int b = blockIdx.x / per_b;
-  const int r = blockIdx.x - b * per_b;
+  const int b = V / per_b;
+  const int r = V - b * per_b;
   const int dir = r >= tiles1 ? 1 : 0;
   const int tile = dir ? r - tiles1 : r;
   const int nq = dir ? M : N;
@@ -274,10 +301,10 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
   const GridSet gp = reinterpret_cast<const GridSet*>(ws + L.sets)[set ^ 1];
   const pp::f4* __restrict__ qsorted =
       reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir ^ 1, N, M);
-  int* qcount = reinterpret_cast<int*>(ws + L.qcount) + set;
+  int* counts = reinterpret_cast<int*>(ws + L.qcount);
   int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
-  if (g.useless) {
-    qlist[atomicAdd(qcount, 1)] = jj;  // every query exactly once, any order
+  if (g.useless) {  // uniform over the workgroup (one set per workgroup)
+    wave_append(true, counts + set, qlist, jj);  // every query exactly once, any order
     return;
   }
   const unsigned* __restrict__ cell_start =
@@ -300,41 +327,31 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
   const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
   float best = __builtin_inff();
   int bidx = 0x7fffffff;
-  auto scan_cells = [&](int z, int y, int x0, int x1) {  // cells (x0..x1, y, z): contiguous points
-    const int c = (z * g.gy + y) * g.gx;
-    const unsigned s = cell_start[c + x0], e = cell_start[c + x1 + 1];
-    for (unsigned i = s; i < e; ++i) {
-      const pp::f4 p = sorted[i];
-      const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
-      const int id = __float_as_int(p.w);
-      const bool take = d < best || (d == best && id < bidx);
-      best = take ? d : best;
-      bidx = take ? id : bidx;
-    }
-  };
   bool resolved = false;
-  // cube of radius 1: the nine row ranges are fetched first (18 independent loads, cell
-  // coordinates clamped so that none is conditional), then walked four points at a time (the
-  // clamped duplicates of a ragged tail are the same candidate again: harmless)
+  // Stage A: the 2x2x2 block of cells nearest to q' (own cell + the neighbour on the side of the
+  // cell q' lies in, per axis).  A point outside that block is beyond the far face of q''s cell
+  // along some axis (>= h/2 away) or beyond the neighbour (>= h away): true distance >= h/2.
   {
-    const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.gz - 1), y0 = max(cy - 1, 0), y1 = min(cy + 1, g.gy - 1);
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
-    unsigned rs[9], re[9];
+    const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
+                fz = (qz - g.minz) * g.invh - (float)cz;  // position inside the cell, in cells
+    const int sx = fx < 0.5f ? -1 : 1, sy = fy < 0.5f ? -1 : 1, sz = fz < 0.5f ? -1 : 1;
+    const int x0 = max(min(cx, cx + sx), 0), x1 = min(max(cx, cx + sx), g.gx - 1);
+    unsigned rs[4], re[4];
 #pragma unroll
-    for (int dz = -1; dz <= 1; ++dz)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int z = cz + dz, y = cy + dy;
+      for (int bq = 0; bq < 2; ++bq) {
+        const int z = cz + a * sz, y = cy + bq * sy;
         const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
         const int c = (min(max(z, 0), g.gz - 1) * g.gy + min(max(y, 0), g.gy - 1)) * g.gx;
         const unsigned s0 = cell_start[c + x0], e0 = cell_start[c + x1 + 1];
-        rs[(dz + 1) * 3 + dy + 1] = ok ? s0 : 0u;
-        re[(dz + 1) * 3 + dy + 1] = ok ? e0 : 0u;
+        rs[a * 2 + bq] = ok ? s0 : 0u;
+        re[a * 2 + bq] = ok ? e0 : 0u;
       }
 #pragma unroll
-    for (int r9 = 0; r9 < 9; ++r9) {
-      for (unsigned i = rs[r9]; i < re[r9]; i += 4) {
-        const unsigned last = re[r9] - 1;
+    for (int r4 = 0; r4 < 4; ++r4) {
+      for (unsigned i = rs[r4]; i < re[r4]; i += 4) {
+        const unsigned last = re[r4] - 1;
         pp::f4 p[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) p[u] = sorted[min(i + u, last)];
@@ -348,31 +365,155 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
         }
       }
     }
-    const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
-    resolved = all ? (bidx != 0x7fffffff) : (best < g.h * g.h * kBoundSlack);
+    const float half_h = 0.5f * g.h;
+    resolved = best < half_h * half_h * kBoundSlack;
   }
-  if (!resolved) {  // shell of radius 2
-    const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.gz - 1), y0 = max(cy - 2, 0), y1 = min(cy + 2, g.gy - 1);
-    const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.gx - 1);
-    for (int z = z0; z <= z1; ++z)
-      for (int y = y0; y <= y1; ++y) {
-        const bool inner = z >= cz - 1 && z <= cz + 1 && y >= cy - 1 && y <= cy + 1;
-        if (!inner) {
-          scan_cells(z, y, x0, x1);
-        } else {
-          if (cx - 2 >= 0) scan_cells(z, y, cx - 2, cx - 2);
-          if (cx + 2 <= g.gx - 1) scan_cells(z, y, cx + 2, cx + 2);
-        }
-      }
-    const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
-    const float two_h = 2.0f * g.h;
-    resolved = all ? (bidx != 0x7fffffff) : (best < two_h * two_h * kBoundSlack);
-  }
-  if (resolved) {
+  // Results leave in the order the queries were walked (coalesced 8-byte stores); the unsort pass
+  // gathers them back to the original order.  (Writing dist[j], idx[j] from here would be two
+  // scattered 4-byte stores per query: that alone cost more than the whole search.)
+  if (!gp.useless) {
+    pp::f2 rv = {best, __int_as_float(resolved ? bidx : kUnresolved)};
+    reinterpret_cast<pp::f2*>(ws + L.res)[set_point_offset(b, dir ^ 1, N, M) + jj] = rv;
+  } else if (resolved) {
     (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
     (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
-  } else {
-    qlist[atomicAdd(qcount, 1)] = j;
+  }
+  int* blist = reinterpret_cast<int*>(ws + L.blist) + set_query_offset(b, dir, N, M);
+  wave_append(!resolved, counts + 2 * B + set, blist, j);
+}
+
+// Original order <- walked order: one gather of 8 bytes per query, coalesced stores.
+__global__ __launch_bounds__(256) void grid_unsort_kernel(float* __restrict__ dist1, int* __restrict__ idx1,
+                                                          float* __restrict__ dist2, int* __restrict__ idx2,
+                                                          const unsigned char* __restrict__ ws, int B, int N,
+                                                          int M, int tiles1, int tiles2) {
+  const int per_b = tiles1 + tiles2;
+  const int b = blockIdx.x / per_b;
+  const int r = blockIdx.x - b * per_b;
+  const int dir = r >= tiles1 ? 1 : 0;
+  const int tile = dir ? r - tiles1 : r;
+  const int nq = dir ? M : N;
+  const int j = tile * 256 + threadIdx.x;
+  if (j >= nq) return;
+  const Layout L = make_layout(B, N, M);
+  const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[2 * b + dir];
+  const GridSet gp = reinterpret_cast<const GridSet*>(ws + L.sets)[(2 * b + dir) ^ 1];
+  if (g.useless || gp.useless) return;  // those queries were written (or listed) directly
+  const size_t off = set_point_offset(b, dir ^ 1, N, M);  // the query cloud as the partner's references
+  const int pos = reinterpret_cast<const int*>(ws + L.inv)[off + j];
+  const pp::f2 rv = reinterpret_cast<const pp::f2*>(ws + L.res)[off + pos];
+  const int id = __float_as_int(rv.y);
+  if (id == kUnresolved) return;  // left to the wide / brute-force kernels
+  (dir ? dist2 : dist1)[(size_t)b * nq + j] = rv.x;
+  (dir ? idx2 : idx1)[(size_t)b * nq + j] = id;
+}
+
+// Stages B and C for the queries stage A left over (grid-stride over the compacted list).
+__global__ __launch_bounds__(256) void grid_query_wide_kernel(const float* __restrict__ xyz1,
+                                                              const float* __restrict__ xyz2,
+                                                              float* __restrict__ dist1, int* __restrict__ idx1,
+                                                              float* __restrict__ dist2, int* __restrict__ idx2,
+                                                              unsigned char* __restrict__ ws, int B, int N,
+                                                              int M) {
+  const Layout L = make_layout(B, N, M);
+  int* counts = reinterpret_cast<int*>(ws + L.qcount);
+  const int set = blockIdx.x / kWideBlocksPerSet;  // one set per workgroup
+  const int b = set >> 1, dir = set & 1;
+  const int nq = dir ? M : N;
+  const int nlist = counts[2 * B + set];
+  const int* __restrict__ blist = reinterpret_cast<const int*>(ws + L.blist) + set_query_offset(b, dir, N, M);
+  int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
+  const int first = (blockIdx.x % kWideBlocksPerSet) * 256;
+  for (int base = first; base < nlist; base += kWideBlocksPerSet * 256) {  // uniform trip count per wave
+    const int pos = base + threadIdx.x;
+    const bool active = pos < nlist;
+    const int j = blist[active ? pos : nlist - 1];
+    const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[set];
+    const unsigned* __restrict__ cell_start =
+        reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
+    const pp::f4* __restrict__ sorted =
+        reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
+    const float* __restrict__ q = (dir ? xyz2 : xyz1) + ((size_t)b * nq + j) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
+    const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
+    const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
+    float best = __builtin_inff();
+    int bidx = 0x7fffffff;
+    auto scan_cells = [&](int z, int y, int x0, int x1) {  // cells (x0..x1, y, z): contiguous points
+      const int c = (z * g.gy + y) * g.gx;
+      const unsigned s = cell_start[c + x0], e = cell_start[c + x1 + 1];
+      for (unsigned i = s; i < e; ++i) {
+        const pp::f4 p = sorted[i];
+        const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
+        const int id = __float_as_int(p.w);
+        const bool take = d < best || (d == best && id < bidx);
+        best = take ? d : best;
+        bidx = take ? id : bidx;
+      }
+    };
+    bool resolved = false;
+    // Stage B (only if A could not stop): cube of radius 1 -- re-examining A's cells is harmless.
+    // The nine row ranges are fetched first (18 independent loads, cell
+    // coordinates clamped so that none is conditional), then walked four points at a time (the
+    // clamped duplicates of a ragged tail are the same candidate again: harmless)
+    if (!resolved) {
+      const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.gz - 1), y0 = max(cy - 1, 0), y1 = min(cy + 1, g.gy - 1);
+      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
+      unsigned rs[9], re[9];
+  #pragma unroll
+      for (int dz = -1; dz <= 1; ++dz)
+  #pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int z = cz + dz, y = cy + dy;
+          const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
+          const int c = (min(max(z, 0), g.gz - 1) * g.gy + min(max(y, 0), g.gy - 1)) * g.gx;
+          const unsigned s0 = cell_start[c + x0], e0 = cell_start[c + x1 + 1];
+          rs[(dz + 1) * 3 + dy + 1] = ok ? s0 : 0u;
+          re[(dz + 1) * 3 + dy + 1] = ok ? e0 : 0u;
+        }
+  #pragma unroll
+      for (int r9 = 0; r9 < 9; ++r9) {
+        for (unsigned i = rs[r9]; i < re[r9]; i += 4) {
+          const unsigned last = re[r9] - 1;
+          pp::f4 p[4];
+  #pragma unroll
+          for (int u = 0; u < 4; ++u) p[u] = sorted[min(i + u, last)];
+  #pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+            const int id = __float_as_int(p[u].w);
+            const bool take = d < best || (d == best && id < bidx);
+            best = take ? d : best;
+            bidx = take ? id : bidx;
+          }
+        }
+      }
+      const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
+      resolved = all ? (bidx != 0x7fffffff) : (best < g.h * g.h * kBoundSlack);
+    }
+    if (!resolved) {  // shell of radius 2
+      const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.gz - 1), y0 = max(cy - 2, 0), y1 = min(cy + 2, g.gy - 1);
+      const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.gx - 1);
+      for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y) {
+          const bool inner = z >= cz - 1 && z <= cz + 1 && y >= cy - 1 && y <= cy + 1;
+          if (!inner) {
+            scan_cells(z, y, x0, x1);
+          } else {
+            if (cx - 2 >= 0) scan_cells(z, y, cx - 2, cx - 2);
+            if (cx + 2 <= g.gx - 1) scan_cells(z, y, cx + 2, cx + 2);
+          }
+        }
+      const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
+      const float two_h = 2.0f * g.h;
+      resolved = all ? (bidx != 0x7fffffff) : (best < two_h * two_h * kBoundSlack);
+    }
+    if (active && resolved) {
+      (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
+      (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
+    }
+    wave_append(active && !resolved, counts + set, qlist, j);
   }
 }
 
@@ -402,22 +543,26 @@ extern "C" int pp_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
   const Layout L = make_layout(B, N, M);
-  hipError_t e = hipMemsetAsync(ws + L.qcount, 0, (size_t)2 * B * sizeof(int), s);
+  hipError_t e = hipMemsetAsync(ws + L.qcount, 0, (size_t)4 * B * sizeof(int), s);
   if (e != hipSuccess) return (int)e;
-  static bool attr_set = false;
+  static bool lds_ok[64] = {};
   const size_t lds = (size_t)(kGridCells + kGridCells / 32) * sizeof(unsigned);
-  if (!attr_set) {
-    e = hipFuncSetAttribute((const void*)grid_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  e = pp::allow_big_lds(grid_build_kernel, (int)lds, lds_ok);
+  if (e != hipSuccess) return (int)e;
   grid_build_kernel<<<dim3(2 * B), dim3(kBuildThreads), lds, s>>>(xyz1, xyz2, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
   const long long blocks = (long long)B * (tiles1 + tiles2);
   if (blocks > 0x7fffffffLL) return PP_EINVAL;
-  grid_query_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws,
-                                                                   B, N, M, tiles1, tiles2);
+  const int per_xcd = (int)((blocks + 7) / 8);
+  grid_query_kernel<<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws,
+                                                                          B, N, M, tiles1, tiles2, (int)blocks,
+                                                                          per_xcd);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  grid_unsort_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dist1, idx1, dist2, idx2, ws, B, N, M, tiles1,
+                                                                    tiles2);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  grid_query_wide_kernel<<<dim3((unsigned)(2 * B * kWideBlocksPerSet)), dim3(256), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
                                 reinterpret_cast<const int*>(ws + L.qlist),

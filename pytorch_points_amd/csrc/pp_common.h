@@ -23,6 +23,20 @@
 
 namespace pp {
 
+// Raise a kernel's dynamic-LDS limit (needed above 64 KiB).  Once per device per kernel: `flags`
+// is a zero-initialised static array owned by the call site.
+template <typename K>
+inline hipError_t allow_big_lds(K kernel, int bytes, bool (&flags)[64]) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) dev = 63;
+  if (dev != 63 && flags[dev]) return hipSuccess;
+  e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) flags[dev] = true;
+  return e;
+}
+
 __device__ __forceinline__ float chamfer_d3(float rx, float ry, float rz, float qx, float qy,
                                             float qz) {
   const float t0 = rx - qx, t1 = ry - qy, t2 = rz - qz;

@@ -502,13 +502,8 @@ bool launch_group_dma(const float* points, const int* idx, float* out, int B, in
   const size_t lds = (size_t)2 * buf_floats * sizeof(float);
   if (lds > 160 * 1024 || chunks > 0x7fffffLL || blocks > 0x7fffffffLL) return false;
   if (PACK16 && N > 65536) return false;
-  static bool attr_set = false;  // one flag per instantiation of this function template
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)group_points_dma_kernel<V, PACK16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return false;
-    attr_set = true;
-  }
+  static bool lds_ok[64] = {};  // one set of flags per instantiation of this function template
+  if (pp::allow_big_lds(group_points_dma_kernel<V, PACK16>, 160 * 1024, lds_ok) != hipSuccess) return false;
   group_points_dma_kernel<V, PACK16><<<dim3((unsigned)blocks), dim3(kDmaThreads), lds, s>>>(
       points, idx, out, B, C, N, P, (int)chunks, passes, buf_floats, cgroups, c_per_group);
   return true;
@@ -836,13 +831,9 @@ extern "C" int pp_group_points_grad_f32(const float* grad_out, const int* idx, f
   if (g_group_grad_variant != 1 && (size_t)N * sizeof(float) <= 160 * 1024 &&
       (uintptr_t)grad_out % 16 == 0 && (uintptr_t)idx % 16 == 0 && P % 4 == 0 &&
       8LL * ((B + 7) / 8) * C <= 0x7fffffffLL && (g_group_grad_variant == 2 || P >= 4096)) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)group_points_grad_lds_kernel,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-      attr_set = true;
-    }
+    static bool lds_ok[64] = {};
+    const hipError_t e = pp::allow_big_lds(group_points_grad_lds_kernel, 160 * 1024, lds_ok);
+    if (e != hipSuccess) return (int)e;
     group_points_grad_lds_kernel<<<dim3((unsigned)(8 * ((B + 7) / 8) * C)), dim3(1024),
                                    (size_t)N * sizeof(float), (hipStream_t)stream>>>(
         grad_out, idx, grad_points, B, C, N, P);
