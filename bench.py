@@ -161,8 +161,9 @@ def bench_chamfer(args, dist, world, rank, device):
     g2 = torch.full((B, M), 1.0 / (B * M), device=device)
     gathered = None
     if dist is not None:
-        gathered = [torch.empty(world * B, N, dtype=torch.float32, device=device) for _ in range(2)] + \
-                   [torch.empty(world * B, N, dtype=torch.int32, device=device) for _ in range(2)]
+        # one collective per step: (dist1 | dist2 | idx1 | idx2) of the shard packed as 32-bit words
+        # (8 MiB per rank at B=32, N=M=16384), double-buffered because the gather is asynchronous
+        gathered = [torch.empty(world, B * 2 * (N + M), dtype=torch.float32, device=device) for _ in range(2)]
     fwd_events = []
     pending = []   # (work handles, tensors kept alive) of the previous step's all-gather
 
@@ -183,14 +184,14 @@ def bench_chamfer(args, dist, world, rank, device):
                 for h in w:
                     h.wait()
             pending.clear()
-            srcs = (d1.detach(), d2.detach(), i1, i2)
-            works = []
-            for out, src in zip(gathered, srcs):
-                if dist.get_backend() == "nccl":
-                    works.append(dist.all_gather_into_tensor(out, src, async_op=True))
-                else:  # debug path only
-                    works.append(dist.all_gather(list(out.chunk(world, 0)), src, async_op=True))
-            pending.append((works, srcs))
+            packed = torch.cat([d1.detach().reshape(-1), d2.detach().reshape(-1),
+                                i1.view(torch.float32).reshape(-1), i2.view(torch.float32).reshape(-1)])
+            out = gathered[len(fwd_events) & 1]
+            if dist.get_backend() == "nccl":
+                works = [dist.all_gather_into_tensor(out, packed, async_op=True)]
+            else:  # debug path only
+                works = [dist.all_gather(list(out.unbind(0)), packed, async_op=True)]
+            pending.append((works, packed))
         torch.autograd.backward([d1, d2], [g1, g2])
 
     def drain():

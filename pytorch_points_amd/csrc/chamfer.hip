@@ -451,12 +451,12 @@ namespace pp {
 int nmdist_fwd_c3_list(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
                        int* idx2, int B, int N, int M, const int* qlist, const int* qcount,
                        hipStream_t s) {
-  constexpr int Q = 1, TQ = 64;
+  constexpr int Q = 2, TQ = 128;  // coarse tiles: the launch is mostly workgroups that exit at once
   const int tiles1 = (N + TQ - 1) / TQ, tiles2 = (M + TQ - 1) / TQ;
   const long long total = (long long)B * (tiles1 + tiles2);
   if (total > 0x7fffff00LL) return PP_EINVAL;
   const int per_xcd = (int)((total + 7) / 8);
-  nmdist_fwd_c3_kernel<Q, 8, false, false, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
+  nmdist_fwd_c3_kernel<Q, 8, true, false, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
       xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, tiles1, tiles2, (int)total, per_xcd, qlist, qcount);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;

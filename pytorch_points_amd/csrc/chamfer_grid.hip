@@ -251,6 +251,9 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
       }
     }
   if (t == 0) {
+    int* counts = reinterpret_cast<int*>(ws + L.qcount);
+    counts[set] = 0;          // brute-force list of this set
+    counts[2 * B + set] = 0;  // stage B/C list of this set
     GridSet g;
     g.minx = mnx; g.miny = mny; g.minz = mnz; g.h = h; g.invh = invh;
     g.gx = gx; g.gy = gy; g.gz = gz;
@@ -543,8 +546,7 @@ extern "C" int pp_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
   const Layout L = make_layout(B, N, M);
-  hipError_t e = hipMemsetAsync(ws + L.qcount, 0, (size_t)4 * B * sizeof(int), s);
-  if (e != hipSuccess) return (int)e;
+  hipError_t e;
   static bool lds_ok[64] = {};
   const size_t lds = (size_t)(kGridCells + kGridCells / 32) * sizeof(unsigned);
   e = pp::allow_big_lds(grid_build_kernel, (int)lds, lds_ok);
