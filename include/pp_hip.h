@@ -131,6 +131,9 @@ int pp_three_interpolate_f32(const float* points, const int* idx, const float* w
 int pp_three_interpolate_grad_f32(const float* grad_out, const int* idx, const float* weight,
                                   float* grad_points, int B, int C, int N, int M, void* stream);
 
+/* The library also exports pp_debug_set_* switches that force one kernel variant or another; they
+ * exist for the parity tests and for tuning and are deliberately not declared here. */
+
 /* cuda_utils.h:11-16 opt_n_threads -- the FPS tie-break depends on it, so it is part of the ABI */
 int pp_opt_n_threads(int work_size);
 

@@ -55,6 +55,26 @@ def test_opt_n_threads_matches_reference_helper():
     assert L.pp_opt_n_threads(2048) == 512 and L.pp_opt_n_threads(300) == 256 and L.pp_opt_n_threads(1) == 1
 
 
+def test_workspace_size_queries_are_host_only():
+    """The two *_workspace_bytes entry points are pure host arithmetic (callable without a GPU)."""
+    L = _lib.lib()
+    # grid search: only C == 3 and clouds of >= 2048 points; 0 means "brute force only"
+    assert L.pp_nmdistance_forward_workspace_bytes(32, 16384, 16384, 3) > 20e6
+    assert L.pp_nmdistance_forward_workspace_bytes(2, 1024, 1024, 3) == 0
+    assert L.pp_nmdistance_forward_workspace_bytes(2, 4096, 4096, 5) == 0
+    assert L.pp_nmdistance_forward_workspace_bytes(0, 4096, 4096, 3) == 0
+    # FPS cluster ring: B * CL <= 256 co-resident workgroups, >= 512 points each
+    assert L.pp_furthest_sampling_workspace_bytes(16, 65536, 4096) > 0
+    assert L.pp_furthest_sampling_workspace_bytes(300, 2048, 64) == 0      # more batch elements than CUs
+    assert L.pp_furthest_sampling_workspace_bytes(1, 600, 64) == 0         # too small to split
+    # argument validation happens before anything touches a device
+    assert L.pp_nmdistance_forward_f32(None, None, None, None, None, None, -1, 4, 4, 3, None) != 0
+    assert L.pp_nmdistance_forward_f32(None, None, None, None, None, None, 0, 4, 4, 3, None) == 0
+    assert L.pp_ball_query_f32(None, None, None, 2, 8, 0, 0.1, 4, None) == 0
+    assert L.pp_furthest_sampling_f32(None, None, None, 2, 8, 0, 0, None, 0, None) == 0   # npoint <= 0: no-op
+    assert L.pp_furthest_sampling_f32(None, None, None, 2, 8, 4, 99, None, 0, None) != 0  # null / bad seed
+
+
 def test_no_cpu_fallback():
     from pytorch_points_amd.network.model_loss import nndistance, labeled_nndistance
     from pytorch_points_amd.network.operations import gather_points, ball_query, grouping_operation
