@@ -383,6 +383,25 @@ def bench_ball_group(args, dist, world, rank, device):
     gp_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev[-args.steps:]]))
     gpg_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev[-args.steps:]])) if args.with_backward else None
     ms = dt / args.steps * 1e3
+    # the caller one level up (network/operations.py:162-213): fused (one output tensor) vs the
+    # reference's composition (group, group, subtract, torch.cat)
+    from pytorch_points_amd.network.operations import QueryAndGroup
+    qg = QueryAndGroup(r, ns, use_xyz=True)
+
+    def time_it(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b_.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b_) / n
+
+    with torch.no_grad():
+        qg_fused_ms = time_it(lambda: qg(x, centres, feats))
+        qg_unfused_ms = time_it(lambda: qg.forward_unfused(x, centres, feats))
     gp_bytes = 4.0 * B * C * N + 4.0 * B * npoint * ns + 4.0 * B * C * npoint * ns
     gbs = gp_bytes / (gp_ms * 1e-3) / 1e9
     return {"metric": "group_points_output_bytes_per_s", "value": 4.0 * B * C * npoint * ns * world / (gp_ms * 1e-3),
@@ -391,6 +410,7 @@ def bench_ball_group(args, dist, world, rank, device):
             "config": {"workload": "ball_query r=%.2f nsample=%d + group_points B=%d N=%d npoint=%d C=%d"
                                    % (r, ns, B, N, npoint, C), "parallelism": "batch-shard x%d" % world},
             "ball_query_ms": bq_ms, "group_points_ms": gp_ms, "group_points_grad_ms": gpg_ms,
+            "query_and_group_fused_ms": qg_fused_ms, "query_and_group_composed_ms": qg_unfused_ms,
             "ball_query_pairs_per_s": float(B) * npoint * N / (bq_ms * 1e-3),
             "roofline": {"bound": "hbm", "kernel": "group_points_dma_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,

@@ -105,11 +105,23 @@ int pp_ball_query_f32(const float* new_xyz, const float* xyz, int* idx, int B, i
 int pp_group_points_f32(const float* points, const int* idx, float* out, int B, int C, int N,
                         int npoint, int nsample, void* stream);
 
+/* The same gather into a tensor whose batch stride (in elements) is larger than C*npoint*nsample,
+ * e.g. the channel slice [3, 3+C) of QueryAndGroup's concatenated output
+ * (network/operations.py:196-204): the fused caller writes its result once instead of
+ * grouping and then torch.cat-ing 4 GiB. */
+int pp_group_points_strided_f32(const float* points, const int* idx, float* out, int B, int C, int N,
+                                int npoint, int nsample, long long out_batch_stride, void* stream);
+
 /* Replaces sampling.group_points_grad(grad_out, idx, n)
  *   (_ext/sampling.cpp:140-161 -> _ext/sampling_cuda.cu:482-513).
  * ACCUMULATES into grad_points (B,C,N), which the caller zero-fills. */
 int pp_group_points_grad_f32(const float* grad_out, const int* idx, float* grad_points, int B,
                              int C, int N, int npoint, int nsample, void* stream);
+
+/* grad_out given as a channel slice of a wider tensor (batch stride in elements). */
+int pp_group_points_grad_strided_f32(const float* grad_out, const int* idx, float* grad_points, int B,
+                                     int C, int N, int npoint, int nsample,
+                                     long long grad_out_batch_stride, void* stream);
 
 /* Replaces sampling.three_nn_wrapper(b,n,m,unknown,known,dist2,idx)
  *   (_ext/sampling.cpp:163-172 -> _ext/interpolate_gpu.cu:9-74).

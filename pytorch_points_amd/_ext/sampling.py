@@ -149,6 +149,47 @@ def group_points_grad(grad_out, idx, n):
     return out
 
 
+# --- extensions (not in the reference's module): the gather / its gradient on a channel slice of a
+# --- wider tensor, so that QueryAndGroup can write its concatenated output once -------------------
+def group_points_into(points, idx, out, channel_offset):
+    """out[:, channel_offset : channel_offset + C] = group_points(points, idx), written in place.
+    points (B,C,N), idx (B,npoint,nsample), out (B,Ctot,npoint,nsample) contiguous."""
+    _lib.require_contiguous(("points", points), ("idx", idx), ("out", out))
+    _lib.require_float(("points", points), ("out", out))
+    _lib.require_int(("idx", idx))
+    dev = _lib.require_cuda(("points", points), ("idx", idx), ("out", out))
+    b, c, n = points.shape
+    _, npoint, nsample = idx.shape
+    if out.dim() != 4 or out.size(0) != b or out.size(2) != npoint or out.size(3) != nsample \
+            or channel_offset < 0 or channel_offset + c > out.size(1):
+        raise RuntimeError("out must be (B, Ctot, npoint, nsample) with room for C channels at channel_offset")
+    p = npoint * nsample
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_group_points_strided_f32(
+            _lib.ptr(points), _lib.ptr(idx), _lib._c_void_p(out.data_ptr() + 4 * channel_offset * p),
+            b, c, n, npoint, nsample, out.size(1) * p, stream), "group_points_into")
+    return out
+
+
+def group_points_grad_from(grad_out, idx, n, channel_offset, channels):
+    """group_points_grad of grad_out[:, channel_offset : channel_offset + channels] -> (B,channels,n),
+    without materialising the slice.  grad_out (B,Ctot,npoint,nsample) contiguous."""
+    _lib.require_contiguous(("grad_out", grad_out), ("idx", idx))
+    _lib.require_float(("grad_out", grad_out))
+    _lib.require_int(("idx", idx))
+    dev = _lib.require_cuda(("grad_out", grad_out), ("idx", idx))
+    b, ctot, npoint, nsample = grad_out.shape
+    if channel_offset < 0 or channel_offset + channels > ctot:
+        raise RuntimeError("channel slice out of range")
+    p = npoint * nsample
+    out = torch.zeros(b, channels, int(n), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev) as stream:
+        _lib.check(_lib.lib().pp_group_points_grad_strided_f32(
+            _lib._c_void_p(grad_out.data_ptr() + 4 * channel_offset * p), _lib.ptr(idx), _lib.ptr(out),
+            b, channels, int(n), npoint, nsample, ctot * p, stream), "group_points_grad_from")
+    return out
+
+
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     """three_nn_wrapper_fast (sampling.cpp:163-172): fills dist2 (B,N,3) squared, idx (B,N,3)."""
     floats = (("unknown", unknown), ("known", known), ("dist2", dist2))

@@ -32,6 +32,8 @@ SIGNATURES = {
     "pp_ball_query_f32": [_P, _P, _P, _I, _I, _I, _F, _I, _P],
     "pp_group_points_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pp_group_points_grad_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "pp_group_points_strided_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P],
+    "pp_group_points_grad_strided_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P],
     "pp_three_nn_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
     "pp_three_interpolate_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_three_interpolate_grad_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

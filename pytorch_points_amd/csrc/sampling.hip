@@ -262,7 +262,7 @@ template <bool VEC4>
 __global__ __launch_bounds__(256) void group_points_kernel(const float* __restrict__ points,
                                                            const int* __restrict__ idx,
                                                            float* __restrict__ out, int C, int N,
-                                                           long long P, int c_per_block) {
+                                                           long long P, int c_per_block, long long obs) {
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * c_per_block;
   const int c1 = min(C, c0 + c_per_block);
@@ -278,13 +278,13 @@ __global__ __launch_bounds__(256) void group_points_kernel(const float* __restri
       v.y = row[ii.y];
       v.z = row[ii.z];
       v.w = row[ii.w];
-      *reinterpret_cast<float4*>(out + ((size_t)b * C + c) * P + p) = v;
+      *reinterpret_cast<float4*>(out + (size_t)b * obs + (size_t)c * P + p) = v;
     }
   } else {
     if (t >= P) return;
     const int i = idx[(size_t)b * P + t];
     for (int c = c0; c < c1; ++c)
-      out[((size_t)b * C + c) * P + t] = points[((size_t)b * C + c) * N + i];
+      out[(size_t)b * obs + (size_t)c * P + t] = points[((size_t)b * C + c) * N + i];
   }
 }
 
@@ -366,7 +366,7 @@ template <int V, int KR>
 __global__ __launch_bounds__(512, 4) void group_points_lds_kernel(const float* __restrict__ points,
                                                                   const int* __restrict__ idx,
                                                                   float* __restrict__ out, int B, int C,
-                                                                  int N, long long P, int chunks) {
+                                                                  int N, long long P, int chunks, long long obs) {
   extern __shared__ __attribute__((aligned(16))) float s_row[];
   const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
   const int b = x + 8 * (y / chunks);
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(512, 4) void group_points_lds_kernel(const float* _
     ii[v] = p < P ? *reinterpret_cast<const pp::i4*>(idx + (size_t)b * P + p) : pp::i4{0, 0, 0, 0};
   }
   const pp::f4* __restrict__ row = reinterpret_cast<const pp::f4*>(points + (size_t)b * C * N);
-  float* __restrict__ out_b = out + (size_t)b * C * P;
+  float* __restrict__ out_b = out + (size_t)b * obs;
   if (full)
     group_points_lds_loop<V, KR, true>(row, out_b, s_row, ii, C, N >> 2, P, p0, t);
   else
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kDmaThreads) void group_points_dma_kernel(const flo
                                                                        float* __restrict__ out, int B, int C,
                                                                        int N, long long P, int chunks,
                                                                        int passes, int buf_floats,
-                                                                       int cgroups, int c_per_group) {
+                                                                       int cgroups, int c_per_group, long long obs) {
   extern __shared__ __attribute__((aligned(16))) float s_ring[];  // [2][buf_floats]
   // (batch, position chunk, channel group); workgroups of one batch element share blockIdx % 8
   const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kDmaThreads) void group_points_dma_kernel(const flo
   }
   const int n4 = N >> 2;
   const pp::f4* __restrict__ row0 = reinterpret_cast<const pp::f4*>(points + (size_t)b * C * N);
-  float* __restrict__ out_b = out + (size_t)b * C * P;
+  float* __restrict__ out_b = out + (size_t)b * obs;
 
   // one DMA instruction moves 64 lanes x 16 B to  lds_base(wave-uniform) + lane*16
   auto issue_row = [&](int c, int slot) {
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kDmaThreads) void group_points_dma_kernel(const flo
 
 template <int V, bool PACK16 = false>
 bool launch_group_dma(const float* points, const int* idx, float* out, int B, int C, int N,
-                      long long P, hipStream_t s) {
+                      long long P, long long obs, hipStream_t s) {
   const long long per_block = (long long)kDmaThreads * 4 * V;
   if (P % per_block != 0) return false;  // this form has no ragged-tail path
   const long long chunks = P / per_block;
@@ -505,13 +505,13 @@ bool launch_group_dma(const float* points, const int* idx, float* out, int B, in
   static bool lds_ok[64] = {};  // one set of flags per instantiation of this function template
   if (pp::allow_big_lds(group_points_dma_kernel<V, PACK16>, 160 * 1024, lds_ok) != hipSuccess) return false;
   group_points_dma_kernel<V, PACK16><<<dim3((unsigned)blocks), dim3(kDmaThreads), lds, s>>>(
-      points, idx, out, B, C, N, P, (int)chunks, passes, buf_floats, cgroups, c_per_group);
+      points, idx, out, B, C, N, P, (int)chunks, passes, buf_floats, cgroups, c_per_group, obs);
   return true;
 }
 
 template <int V>
 bool launch_group_lds(const float* points, const int* idx, float* out, int B, int C, int N,
-                      long long P, hipStream_t s) {
+                      long long P, long long obs, hipStream_t s) {
   const long long per_block = 512LL * 4 * V;
   const long long chunks = (P + per_block - 1) / per_block;
   const long long blocks = 8LL * ((B + 7) / 8) * chunks;
@@ -521,13 +521,13 @@ bool launch_group_lds(const float* points, const int* idx, float* out, int B, in
   const size_t lds = (size_t)N * sizeof(float);
   const int n4 = N / 4;
   if (n4 <= 512 * 1)
-    group_points_lds_kernel<V, 1><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks);
+    group_points_lds_kernel<V, 1><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks, obs);
   else if (n4 <= 512 * 2)
-    group_points_lds_kernel<V, 2><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks);
+    group_points_lds_kernel<V, 2><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks, obs);
   else if (n4 <= 512 * 4)
-    group_points_lds_kernel<V, 4><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks);
+    group_points_lds_kernel<V, 4><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks, obs);
   else
-    group_points_lds_kernel<V, 8><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks);
+    group_points_lds_kernel<V, 8><<<grid, block, lds, s>>>(points, idx, out, B, C, N, P, (int)chunks, obs);
   return true;
 }
 
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __r
                                                                 const int* __restrict__ idx,
                                                                 float* __restrict__ grad_points,
                                                                 int C, int N, long long P,
-                                                                int c_per_block) {
+                                                                int c_per_block, long long gbs) {
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * c_per_block;
   const int c1 = min(C, c0 + c_per_block);
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __r
   if (t >= P) return;
   const int i = idx[(size_t)b * P + t];
   for (int c = c0; c < c1; ++c)
-    atomicAdd(grad_points + ((size_t)b * C + c) * N + i, grad_out[((size_t)b * C + c) * P + t]);
+    atomicAdd(grad_points + ((size_t)b * C + c) * N + i, grad_out[(size_t)b * gbs + (size_t)c * P + t]);
 }
 
 // group_points backward without global atomics: one workgroup per (batch, channel) owns the column
@@ -555,7 +555,8 @@ __global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __r
 __global__ __launch_bounds__(1024) void group_points_grad_lds_kernel(const float* __restrict__ grad_out,
                                                                      const int* __restrict__ idx,
                                                                      float* __restrict__ grad_points,
-                                                                     int B, int C, int N, long long P) {
+                                                                     int B, int C, int N, long long P,
+                                                                     long long gbs) {
   extern __shared__ __attribute__((aligned(16))) float s_col[];
   const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
   const int b = x + 8 * (y / C);
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(1024) void group_points_grad_lds_kernel(const float
   const int t = threadIdx.x;
   for (int k = t; k < N; k += 1024) s_col[k] = 0.0f;
   __syncthreads();
-  const float* __restrict__ go = grad_out + ((size_t)b * C + c) * P;
+  const float* __restrict__ go = grad_out + (size_t)b * gbs + (size_t)c * P;
   const int* __restrict__ ib = idx + (size_t)b * P;
   const long long p4 = P >> 2;
   for (long long e = t; e < p4; e += 1024) {
@@ -766,12 +767,21 @@ extern "C" void pp_debug_set_group_points_variant(int v) { g_group_variant = v; 
 
 extern "C" int pp_group_points_f32(const float* points, const int* idx, float* out, int B, int C,
                                    int N, int npoint, int nsample, void* stream) {
+  return pp_group_points_strided_f32(points, idx, out, B, C, N, npoint, nsample,
+                                     (long long)C * npoint * nsample, stream);
+}
+
+extern "C" int pp_group_points_strided_f32(const float* points, const int* idx, float* out, int B, int C,
+                                           int N, int npoint, int nsample, long long out_batch_stride,
+                                           void* stream) {
   if (B < 0 || C < 0 || N < 0 || npoint < 0 || nsample < 0) return PP_EINVAL;
   const long long P = (long long)npoint * nsample;
+  const long long obs = out_batch_stride;
+  if (obs < (long long)C * P) return PP_EINVAL;
   if (B == 0 || C == 0 || P == 0) return PP_OK;
   if (!points || !idx || !out || N == 0) return PP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const bool vec4 = (P % 4 == 0) && ((uintptr_t)idx % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  const bool vec4 = (P % 4 == 0) && (obs % 4 == 0) && ((uintptr_t)idx % 16 == 0) && ((uintptr_t)out % 16 == 0);
   // LDS-staged form: row fits 64 KiB (two workgroups per CU), rows 16-byte aligned, enough channels
   // to amortise keeping the indices in registers, enough positions to fill the chip
   if (g_group_variant != 1 && vec4 && N % 4 == 0 && (uintptr_t)points % 16 == 0 &&
@@ -780,23 +790,23 @@ extern "C" int pp_group_points_f32(const float* points, const int* idx, float* o
     bool ok = false;
     // DMA ring form: full chunks only, one 1024-thread workgroup per CU
     if (g_group_variant == 132)  // 16-bit packed indices, 32 quads per thread: spills at 1024 threads (kept for tuning)
-      ok = launch_group_dma<32, true>(points, idx, out, B, C, N, P, s);
+      ok = launch_group_dma<32, true>(points, idx, out, B, C, N, P, obs, s);
     if (!ok && (g_group_variant == 116 || (g_group_variant == 0 && C >= 8 && (long long)B * P * C >= 256LL * 1024 * 4 * 16 * 8)))
-      ok = launch_group_dma<16>(points, idx, out, B, C, N, P, s);
+      ok = launch_group_dma<16>(points, idx, out, B, C, N, P, obs, s);
     if (!ok && (g_group_variant == 108 || (g_group_variant == 0 && (long long)B * P >= 256LL * 1024 * 4 * 8)))
-      ok = launch_group_dma<8>(points, idx, out, B, C, N, P, s);
+      ok = launch_group_dma<8>(points, idx, out, B, C, N, P, obs, s);
     else if (!ok && g_group_variant == 104)
-      ok = launch_group_dma<4>(points, idx, out, B, C, N, P, s);
+      ok = launch_group_dma<4>(points, idx, out, B, C, N, P, obs, s);
     if (ok) {
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
     }
     if (g_group_variant == 8 || ((g_group_variant == 0 || g_group_variant > 100) && per_cu >= 512LL * 4 * 8))
-      ok = launch_group_lds<8>(points, idx, out, B, C, N, P, s);
+      ok = launch_group_lds<8>(points, idx, out, B, C, N, P, obs, s);
     else if (g_group_variant == 4 || (g_group_variant == 0 && per_cu >= 512LL * 4 * 4))
-      ok = launch_group_lds<4>(points, idx, out, B, C, N, P, s);
+      ok = launch_group_lds<4>(points, idx, out, B, C, N, P, obs, s);
     else
-      ok = launch_group_lds<2>(points, idx, out, B, C, N, P, s);
+      ok = launch_group_lds<2>(points, idx, out, B, C, N, P, obs, s);
     if (ok) {
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
@@ -809,9 +819,9 @@ extern "C" int pp_group_points_f32(const float* points, const int* idx, float* o
   if (!grid_ok(cols, gy, B)) return PP_EINVAL;
   const dim3 grid((unsigned)cols, (unsigned)gy, (unsigned)B);
   if (vec4)
-    group_points_kernel<true><<<grid, dim3(256), 0, s>>>(points, idx, out, C, N, P, cpb);
+    group_points_kernel<true><<<grid, dim3(256), 0, s>>>(points, idx, out, C, N, P, cpb, obs);
   else
-    group_points_kernel<false><<<grid, dim3(256), 0, s>>>(points, idx, out, C, N, P, cpb);
+    group_points_kernel<false><<<grid, dim3(256), 0, s>>>(points, idx, out, C, N, P, cpb, obs);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
 }
@@ -823,20 +833,29 @@ extern "C" void pp_debug_set_group_points_grad_variant(int v) { g_group_grad_var
 extern "C" int pp_group_points_grad_f32(const float* grad_out, const int* idx, float* grad_points,
                                         int B, int C, int N, int npoint, int nsample,
                                         void* stream) {
+  return pp_group_points_grad_strided_f32(grad_out, idx, grad_points, B, C, N, npoint, nsample,
+                                          (long long)C * npoint * nsample, stream);
+}
+
+extern "C" int pp_group_points_grad_strided_f32(const float* grad_out, const int* idx, float* grad_points,
+                                                int B, int C, int N, int npoint, int nsample,
+                                                long long grad_out_batch_stride, void* stream) {
   if (B < 0 || C < 0 || N < 0 || npoint < 0 || nsample < 0) return PP_EINVAL;
   const long long P = (long long)npoint * nsample;
+  const long long gbs = grad_out_batch_stride;
+  if (gbs < (long long)C * P) return PP_EINVAL;
   if (B == 0 || C == 0 || P == 0) return PP_OK;
   if (!grad_out || !idx || !grad_points || N == 0) return PP_EINVAL;
   // LDS-column form: the column fits the LDS, 16-byte aligned streams, enough work per column
   if (g_group_grad_variant != 1 && (size_t)N * sizeof(float) <= 160 * 1024 &&
-      (uintptr_t)grad_out % 16 == 0 && (uintptr_t)idx % 16 == 0 && P % 4 == 0 &&
+      (uintptr_t)grad_out % 16 == 0 && (uintptr_t)idx % 16 == 0 && P % 4 == 0 && gbs % 4 == 0 &&
       8LL * ((B + 7) / 8) * C <= 0x7fffffffLL && (g_group_grad_variant == 2 || P >= 4096)) {
     static bool lds_ok[64] = {};
     const hipError_t e = pp::allow_big_lds(group_points_grad_lds_kernel, 160 * 1024, lds_ok);
     if (e != hipSuccess) return (int)e;
     group_points_grad_lds_kernel<<<dim3((unsigned)(8 * ((B + 7) / 8) * C)), dim3(1024),
                                    (size_t)N * sizeof(float), (hipStream_t)stream>>>(
-        grad_out, idx, grad_points, B, C, N, P);
+        grad_out, idx, grad_points, B, C, N, P, gbs);
     PP_RETURN_IF_LAUNCH_FAILED();
     return PP_OK;
   }
@@ -845,7 +864,7 @@ extern "C" int pp_group_points_grad_f32(const float* grad_out, const int* idx, f
   const long long gy = (C + cpb - 1) / cpb;
   if (!grid_ok(cols, gy, B)) return PP_EINVAL;
   group_points_grad_kernel<<<dim3((unsigned)cols, (unsigned)gy, (unsigned)B), dim3(256), 0,
-                             (hipStream_t)stream>>>(grad_out, idx, grad_points, C, N, P, cpb);
+                             (hipStream_t)stream>>>(grad_out, idx, grad_points, C, N, P, cpb, gbs);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
 }

@@ -104,6 +104,33 @@ def test_fps_config3_full_size(cuda):
         assert len(set(runs[0][b].tolist())) == m
 
 
+def test_fps_cluster_beside_other_work(cuda):
+    """The cluster kernel needs its workgroups co-resident; with another stream keeping the chip
+    busy they may be admitted late -- the bounded waits must ride that out (no timeout, same picks)."""
+    from pytorch_points_amd._ext import sampling
+    from pytorch_points_amd.network.geo_operations import furthest_point_sample
+    B, N, m = 8, 32768, 512
+    x = S.unit_sphere(14, B, N)
+    xt = _t(x, cuda)
+    ref, _ = furthest_point_sample(xt, m, NCHW=False)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=cuda)
+    outs = []
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                a = torch.tanh(a @ a * 1e-3)          # a few ms of chip-filling work per launch
+        idx, _ = furthest_point_sample(xt, m, NCHW=False)
+        outs.append(idx)
+    torch.cuda.synchronize()
+    assert sampling.furthest_sampling_status(cuda) == 0
+    for idx in outs:
+        assert torch.equal(idx, ref)
+    e_idx, _ = oracle.furthest_sampling(x[:1], m, 0)
+    assert np.array_equal(ref[:1].cpu().numpy(), e_idx)
+
+
 def test_gather_matches_torch_and_backward(cuda):
     from pytorch_points_amd.network.operations import gather_points
     b, c, n, m = 3, 37, 500, 123
@@ -252,6 +279,35 @@ def test_query_and_group_composed(cuda):
     assert np.array_equal(out2.cpu().numpy(), gx)
     ga = pointnet2_utils.GroupAll()(_t(x, cuda), None, _t(feats, cuda))
     assert ga.shape == (b, 3 + c, 1, n)
+
+
+@pytest.mark.parametrize("use_xyz,with_features", [(True, True), (True, False), (False, True)])
+def test_query_and_group_fused_equals_composition(cuda, use_xyz, with_features):
+    """The fused caller (one output tensor, no torch.cat) == the reference's op-by-op composition,
+    forward bitwise and backward for xyz, new_xyz and features."""
+    from pytorch_points_amd.network.operations import QueryAndGroup
+    b, n, npoint, c, r, ns = 3, 2048, 256, 9, 0.25, 32
+    x = S.unit_sphere(52, b, n)
+    qg = QueryAndGroup(r, ns, use_xyz=use_xyz)
+
+    def run(fn):
+        xyz = _t(x, cuda).requires_grad_(True)
+        new_xyz = _t(x[:, ::8].copy(), cuda).requires_grad_(True)
+        feats = _t(S.normal(53, (b, c, n)), cuda).requires_grad_(True) if with_features else None
+        out = fn(xyz, new_xyz, feats)
+        w = _t(S.normal(54, tuple(out.shape)), cuda)
+        (out * w).sum().backward()
+        return out.detach(), xyz.grad, new_xyz.grad, (feats.grad if with_features else None)
+
+    fused = run(qg.forward)
+    comp = run(qg.forward_unfused)
+    assert torch.equal(fused[0], comp[0])
+    assert fused[0].shape == (b, (3 if use_xyz else 0) + (c if with_features else 0), npoint, ns)
+    for g, e in zip(fused[1:], comp[1:]):
+        if e is None:
+            assert g is None or float(g.abs().sum()) == 0
+        else:
+            assert torch.allclose(g, e, rtol=1e-4, atol=1e-4)
 
 
 # --------------------------------------------------------------------- three_nn / three_interpolate
