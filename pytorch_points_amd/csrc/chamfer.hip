@@ -396,6 +396,121 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_lds_kernel(
   for (int k = threadIdx.x; k < nt; k += 1024) out[(size_t)k * C + c] = s_acc[k];
 }
 
+// Backward with no floating-point atomics at all (C == 3).  ds_add_f32 runs at 0.36 lanes/clk/CU
+// on gfx950 against 10 for ds_add_u32 (tools/lds_atomic_probe.hip), so the scattered terms are
+// not added atomically but *listed*: a workgroup owns a slice [k0,k1) of one target cloud, counts
+// with integer LDS atomics how many points of the other cloud chose each k as nearest neighbour,
+// scans the counts, fills the lists (integer atomics again), and then one lane per k sums its own
+// term and its list in registers and writes the 12-byte gradient row once.
+constexpr int kCsrSlices = 4;  // workgroups per (batch, target cloud)
+__global__ __launch_bounds__(1024) void nmdist_bwd_csr_kernel(
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, const float* __restrict__ gd1,
+    const float* __restrict__ gd2, const int* __restrict__ idx1, const int* __restrict__ idx2,
+    float* __restrict__ gx1, float* __restrict__ gx2, int N, int M, int slice_len) {
+  extern __shared__ __attribute__((aligned(16))) unsigned s_u[];  // start[slice_len+1] | cursor[slice_len] | list[no]
+  __shared__ unsigned s_wave[16];
+  unsigned* s_start = s_u;
+  unsigned* s_cur = s_u + slice_len + 1;
+  unsigned* s_list = s_cur + slice_len;
+  const int per_b = 2 * kCsrSlices;
+  const int b = blockIdx.x / per_b;
+  const int r = blockIdx.x - b * per_b;
+  const bool second = r >= kCsrSlices;  // target cloud: false -> cloud 1, true -> cloud 2
+  const int slice = second ? r - kCsrSlices : r;
+  const int nt = second ? M : N, no = second ? N : M;
+  const int k0 = slice * slice_len;
+  const int len = max(0, min(slice_len, nt - k0));
+  if (len == 0) return;
+  const float* __restrict__ xt = (second ? xyz2 : xyz1) + (size_t)b * nt * 3;
+  const float* __restrict__ xo = (second ? xyz1 : xyz2) + (size_t)b * no * 3;
+  const float* __restrict__ gt = (second ? gd2 : gd1) + (size_t)b * nt;
+  const float* __restrict__ go = (second ? gd1 : gd2) + (size_t)b * no;
+  const int* __restrict__ it = (second ? idx2 : idx1) + (size_t)b * nt;
+  const int* __restrict__ io = (second ? idx1 : idx2) + (size_t)b * no;
+  float* __restrict__ out = (second ? gx2 : gx1) + (size_t)b * nt * 3;
+  const int t = threadIdx.x;
+  for (int k = t; k <= len; k += 1024) s_start[k] = 0;
+  // the other cloud's neighbour indices are needed twice (count, fill): keep up to KJ per thread in
+  // registers (16384 points per pass), loads unconditional so that they are all in flight together
+  constexpr int KJ = 16;
+  const bool cached = no <= 1024 * KJ;
+  int kj[KJ];
+#pragma unroll
+  for (int u = 0; u < KJ; ++u) {
+    const int j = t + 1024 * u;
+    kj[u] = (cached && j < no) ? io[j] - k0 : -1;
+  }
+  __syncthreads();
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < KJ; ++u)
+      if (kj[u] >= 0 && kj[u] < len) atomicAdd(&s_start[kj[u]], 1u);
+  } else {
+    for (int j = t; j < no; j += 1024) {
+      const int k = io[j] - k0;
+      if (k >= 0 && k < len) atomicAdd(&s_start[k], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of s_start[0..len): thread t owns a contiguous run
+  const int per = (len + 1023) / 1024;
+  const int c0 = min(t * per, len), c1 = min(c0 + per, len);
+  unsigned sum = 0;
+  for (int c = c0; c < c1; ++c) sum += s_start[c];
+  unsigned incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = __shfl_up(incl, off);
+    if ((t & 63) >= off) incl += o;
+  }
+  if ((t & 63) == 63) s_wave[t >> 6] = incl;
+  __syncthreads();
+  unsigned run = incl - sum;
+  for (int w = 0; w < (t >> 6); ++w) run += s_wave[w];
+  for (int c = c0; c < c1; ++c) {
+    const unsigned v = s_start[c];
+    s_start[c] = run;
+    s_cur[c] = run;
+    run += v;
+  }
+  if (t == 1023) s_start[len] = run;  // total (the last thread's run ends at the grand total)
+  __syncthreads();
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < KJ; ++u)
+      if (kj[u] >= 0 && kj[u] < len) s_list[atomicAdd(&s_cur[kj[u]], 1u)] = (unsigned)(t + 1024 * u);
+  } else {
+    for (int j = t; j < no; j += 1024) {
+      const int k = io[j] - k0;
+      if (k >= 0 && k < len) s_list[atomicAdd(&s_cur[k], 1u)] = (unsigned)j;
+    }
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int kk = t; kk < len; kk += 1024) {
+    const int k = k0 + kk;
+    const float tx = xt[3 * (size_t)k], ty = xt[3 * (size_t)k + 1], tz = xt[3 * (size_t)k + 2];
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    const int j2 = it[k];
+    if (j2 >= 0) {  // own term: +g*(x_T[k] - x_O[idx_T[k]])          (ref nmdistance_cuda.cu:176-180)
+      const float g = gt[k] * 2;
+      ax = g * (tx - xo[3 * (size_t)j2]);
+      ay = g * (ty - xo[3 * (size_t)j2 + 1]);
+      az = g * (tz - xo[3 * (size_t)j2 + 2]);
+    }
+    for (unsigned e = s_start[kk]; e < s_start[kk + 1]; ++e) {  // scattered terms (:181)
+      const unsigned j = s_list[e];
+      const float g = go[j] * 2;
+      ax += -(g * (xo[3 * (size_t)j] - tx));
+      ay += -(g * (xo[3 * (size_t)j + 1] - ty));
+      az += -(g * (xo[3 * (size_t)j + 2] - tz));
+    }
+    out[3 * (size_t)k] = ax;
+    out[3 * (size_t)k + 1] = ay;
+    out[3 * (size_t)k + 2] = az;
+  }
+}
+
 __global__ void fill_zero_kernel(float* __restrict__ a, int* __restrict__ b, long long n) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t < n) {
@@ -531,7 +646,8 @@ extern "C" int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float*
   return PP_OK;
 }
 
-// 0 = automatic; 1 = force the global-atomic form; 2 = force the LDS-column form (tests and tuning)
+// 0 = automatic (CSR form where it applies); 1 = force the global-atomic form; 2 = force the
+// LDS-column form; 3 = automatic (same as 0)   (tests and tuning)
 static int g_bwd_variant = 0;
 extern "C" void pp_debug_set_nmdistance_backward_variant(int v) { g_bwd_variant = v; }
 
@@ -554,6 +670,22 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
   }
   if (!xyz1 || !xyz2 || !graddist1 || !graddist2 || !idx1 || !idx2 || !gradxyz1 || !gradxyz2)
     return PP_EINVAL;
+  // CSR form (no fp atomics): C == 3, slice bookkeeping + the other cloud's list fit the LDS
+  if (g_bwd_variant != 1 && g_bwd_variant != 2 && C == 3 && N + M >= 4096) {
+    const int big = N > M ? N : M;
+    const int slice_len = (big + kCsrSlices - 1) / kCsrSlices;
+    const size_t lds = ((size_t)2 * slice_len + 1 + big) * sizeof(unsigned);
+    if (lds <= 150 * 1024 && (long long)B * 2 * kCsrSlices <= 0x7fffffffLL) {
+      static bool lds_ok[64] = {};
+      // (the kernel also has 64 bytes of static LDS: the dynamic limit must leave room for them)
+      const hipError_t e = pp::allow_big_lds(nmdist_bwd_csr_kernel, 152 * 1024, lds_ok);
+      if (e != hipSuccess) return (int)e;
+      nmdist_bwd_csr_kernel<<<dim3((unsigned)(B * 2 * kCsrSlices)), dim3(1024), lds, s>>>(
+          xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, slice_len);
+      PP_RETURN_IF_LAUNCH_FAILED();
+      return PP_OK;
+    }
+  }
   // LDS-column form: the larger cloud's column must fit the LDS; enough (b, cloud, c) columns to
   // occupy the chip, and clouds large enough that scattered global atomics would hurt
   const size_t col_bytes = (size_t)(N > M ? N : M) * sizeof(float);

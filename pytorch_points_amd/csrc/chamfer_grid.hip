@@ -386,13 +386,13 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
 }
 
 // Original order <- walked order: one gather of 8 bytes per query, coalesced stores.
-__global__ __launch_bounds__(256) void grid_unsort_kernel(float* __restrict__ dist1, int* __restrict__ idx1,
-                                                          float* __restrict__ dist2, int* __restrict__ idx2,
-                                                          const unsigned char* __restrict__ ws, int B, int N,
-                                                          int M, int tiles1, int tiles2) {
+__device__ __forceinline__ void grid_unsort_block(int block, float* __restrict__ dist1, int* __restrict__ idx1,
+                                                  float* __restrict__ dist2, int* __restrict__ idx2,
+                                                  const unsigned char* __restrict__ ws, int B, int N, int M,
+                                                  int tiles1, int tiles2) {
   const int per_b = tiles1 + tiles2;
-  const int b = blockIdx.x / per_b;
-  const int r = blockIdx.x - b * per_b;
+  const int b = block / per_b;
+  const int r = block - b * per_b;
   const int dir = r >= tiles1 ? 1 : 0;
   const int tile = dir ? r - tiles1 : r;
   const int nq = dir ? M : N;
@@ -412,21 +412,20 @@ __global__ __launch_bounds__(256) void grid_unsort_kernel(float* __restrict__ di
 }
 
 // Stages B and C for the queries stage A left over (grid-stride over the compacted list).
-__global__ __launch_bounds__(256) void grid_query_wide_kernel(const float* __restrict__ xyz1,
-                                                              const float* __restrict__ xyz2,
-                                                              float* __restrict__ dist1, int* __restrict__ idx1,
-                                                              float* __restrict__ dist2, int* __restrict__ idx2,
-                                                              unsigned char* __restrict__ ws, int B, int N,
-                                                              int M) {
+__device__ __forceinline__ void grid_query_wide_block(int block, const float* __restrict__ xyz1,
+                                                      const float* __restrict__ xyz2,
+                                                      float* __restrict__ dist1, int* __restrict__ idx1,
+                                                      float* __restrict__ dist2, int* __restrict__ idx2,
+                                                      unsigned char* __restrict__ ws, int B, int N, int M) {
   const Layout L = make_layout(B, N, M);
   int* counts = reinterpret_cast<int*>(ws + L.qcount);
-  const int set = blockIdx.x / kWideBlocksPerSet;  // one set per workgroup
+  const int set = block / kWideBlocksPerSet;  // one set per workgroup
   const int b = set >> 1, dir = set & 1;
   const int nq = dir ? M : N;
   const int nlist = counts[2 * B + set];
   const int* __restrict__ blist = reinterpret_cast<const int*>(ws + L.blist) + set_query_offset(b, dir, N, M);
   int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
-  const int first = (blockIdx.x % kWideBlocksPerSet) * 256;
+  const int first = (block % kWideBlocksPerSet) * 256;
   for (int base = first; base < nlist; base += kWideBlocksPerSet * 256) {  // uniform trip count per wave
     const int pos = base + threadIdx.x;
     const bool active = pos < nlist;
@@ -520,6 +519,22 @@ __global__ __launch_bounds__(256) void grid_query_wide_kernel(const float* __res
   }
 }
 
+// After stage A two independent things remain: putting the resolved results back in the original
+// order, and the wide stages for the unresolved queries (disjoint outputs).  One launch runs both:
+// the first `wide_blocks` workgroups take the wide stages (the longer, latency-bound job), the
+// rest unsort.
+__global__ __launch_bounds__(256) void grid_finish_kernel(const float* __restrict__ xyz1,
+                                                          const float* __restrict__ xyz2,
+                                                          float* __restrict__ dist1, int* __restrict__ idx1,
+                                                          float* __restrict__ dist2, int* __restrict__ idx2,
+                                                          unsigned char* __restrict__ ws, int B, int N, int M,
+                                                          int tiles1, int tiles2, int wide_blocks) {
+  if ((int)blockIdx.x < wide_blocks)
+    grid_query_wide_block(blockIdx.x, xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M);
+  else
+    grid_unsort_block(blockIdx.x - wide_blocks, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2);
+}
+
 }  // namespace
 
 // 0 = automatic (grid when a workspace is given and the clouds are large enough); 1 = brute force
@@ -561,10 +576,9 @@ extern "C" int pp_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2
                                                                           B, N, M, tiles1, tiles2, (int)blocks,
                                                                           per_xcd);
   PP_RETURN_IF_LAUNCH_FAILED();
-  grid_unsort_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(dist1, idx1, dist2, idx2, ws, B, N, M, tiles1,
-                                                                    tiles2);
-  PP_RETURN_IF_LAUNCH_FAILED();
-  grid_query_wide_kernel<<<dim3((unsigned)(2 * B * kWideBlocksPerSet)), dim3(256), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M);
+  const int wide_blocks = 2 * B * kWideBlocksPerSet;
+  grid_finish_kernel<<<dim3((unsigned)(wide_blocks + blocks)), dim3(256), 0, s>>>(
+      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, wide_blocks);
   PP_RETURN_IF_LAUNCH_FAILED();
   return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
                                 reinterpret_cast<const int*>(ws + L.qlist),

@@ -31,13 +31,15 @@ class NmDistanceFunction(torch.autograd.Function):
         losses.nmdistance_forward(xyz1, xyz2, dist1, dist2, idx1, idx2)
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
+        # do not let autograd zero-fill gradient tensors for the two index outputs on every backward
+        ctx.set_materialize_grads(False)
         return dist1, dist2, idx1, idx2
 
     @staticmethod
     def backward(ctx, graddist1, graddist2, gradNone1, gradNone2):
         xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
-        graddist1 = graddist1.contiguous()
-        graddist2 = graddist2.contiguous()
+        graddist1 = torch.zeros_like(idx1, dtype=xyz1.dtype) if graddist1 is None else graddist1.contiguous()
+        graddist2 = torch.zeros_like(idx2, dtype=xyz2.dtype) if graddist2 is None else graddist2.contiguous()
         gradxyz1 = torch.empty_like(xyz1)  # fully overwritten by the kernel
         gradxyz2 = torch.empty_like(xyz2)
         losses.nmdistance_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
@@ -68,13 +70,14 @@ class LabeledNmdistanceFunction(torch.autograd.Function):
         losses.labeled_nmdistance_forward(xyz1, xyz2, label1, label2, dist1, dist2, idx1, idx2)
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
         ctx.mark_non_differentiable(idx1, idx2)
+        ctx.set_materialize_grads(False)
         return dist1, dist2, idx1, idx2
 
     @staticmethod
     def backward(ctx, graddist1, graddist2, gradNone1, gradNone2):
         xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
-        graddist1 = graddist1.contiguous()
-        graddist2 = graddist2.contiguous()
+        graddist1 = torch.zeros_like(idx1, dtype=xyz1.dtype) if graddist1 is None else graddist1.contiguous()
+        graddist2 = torch.zeros_like(idx2, dtype=xyz2.dtype) if graddist2 is None else graddist2.contiguous()
         gradxyz1 = torch.empty_like(xyz1)
         gradxyz2 = torch.empty_like(xyz2)
         losses.nmdistance_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)

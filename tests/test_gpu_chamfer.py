@@ -98,7 +98,7 @@ def test_forward_empty(cuda):
     assert np.array_equal(e[2], d2.cpu().numpy())
 
 
-@pytest.fixture(params=["auto", "global_atomics", "lds_columns"])
+@pytest.fixture(params=["auto", "global_atomics", "lds_columns"])  # auto = CSR lists for C == 3
 def bwd_path(request, cuda):
     from pytorch_points_amd import _lib
     setter = _lib.lib().pp_debug_set_nmdistance_backward_variant
@@ -110,7 +110,7 @@ def bwd_path(request, cuda):
 
 
 @pytest.mark.parametrize("shape", [(2, 1024, 1024, 3), (1, 1000, 777, 3), (1, 64, 64, 2), (1, 513, 511, 5),
-                                   (12, 2048, 3000, 3)])
+                                   (12, 2048, 3000, 3), (2, 5000, 1200, 3), (1, 4097, 4099, 3)])
 def test_backward_matches_oracle_and_fp64(cuda, bwd_path, shape):
     from pytorch_points_amd.network.model_loss import nndistance
     b, n, m, c = shape
@@ -146,6 +146,20 @@ def test_backward_equals_torch_autograd(cuda):
     (r1.mean() + r2.mean()).backward()
     assert torch.allclose(t1.grad.double(), a1.grad, rtol=1e-5, atol=1e-9)
     assert torch.allclose(t2.grad.double(), a2.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_backward_with_one_output_unused(cuda):
+    """Only dist1 enters the loss: the gradient of dist2 is undefined (None) and counts as zero."""
+    from pytorch_points_amd.network.model_loss import nndistance
+    x1, x2 = _clouds(2, 700, 600, 3)
+    t1 = torch.from_numpy(x1).to(cuda).requires_grad_(True)
+    t2 = torch.from_numpy(x2).to(cuda).requires_grad_(True)
+    d1, d2, i1, i2 = nndistance(t1, t2)
+    d1.sum().backward()
+    e1, e2 = oracle.chamfer_backward(x1, x2, np.ones((2, 700), np.float32), np.zeros((2, 600), np.float32),
+                                     i1.cpu().numpy(), i2.cpu().numpy())
+    assert np.allclose(t1.grad.cpu().numpy(), e1, rtol=1e-5, atol=1e-6)
+    assert np.allclose(t2.grad.cpu().numpy(), e2, rtol=1e-5, atol=1e-6)
 
 
 def test_labeled_matches_oracle(cuda, bwd_path):
