@@ -36,12 +36,18 @@ constexpr int kBlock = 64 * kWavesPerBlock;
 // LIST: the queries of a set are not 0..nq-1 but the `qcount[set]` indices stored in
 // qlist[set's query offset ...] (the grid search's unresolved queries, chamfer_grid.hip); tiles
 // beyond the list exit at once.
-template <int Q, int G, bool PK, bool PF, bool LIST = false>
+// LAB: labeled Chamfer (ref LabeledNmDistanceKernel, nmdistance_cuda.cu:55-115): a reference point
+// is a candidate only if its label equals the query's (compared as floats, :89) -- its distance
+// is replaced by +inf otherwise (one v_cmp_eq + one v_cndmask per pair); a query whose minimum is
+// still +inf has no candidate: idx -1, dist 0 (:110-113).
+template <int Q, int G, bool PK, bool PF, bool LIST = false, bool LAB = false>
 __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
     int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M,
     int tiles1, int tiles2, int total, int per_xcd, const int* __restrict__ qlist = nullptr,
-    const int* __restrict__ qcount = nullptr) {
+    const int* __restrict__ qcount = nullptr, const float* __restrict__ label1 = nullptr,
+    const float* __restrict__ label2 = nullptr) {
+  static_assert(!(LAB && (PF || LIST)), "labels are not combined with prefetch or list mode");
   static_assert(G % 2 == 0, "groups are consumed two reference points per v_min3");
   constexpr int TQ = 64 * Q;  // queries per workgroup
   __shared__ float s_best[kWavesPerBlock][TQ];
@@ -69,13 +75,16 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     ql = qlist + (size_t)b * ((size_t)N + M) + (second ? (size_t)N : 0);
   }
 
-  float qx[Q], qy[Q], qz[Q], best[Q];
+  const float* __restrict__ qlab = LAB ? (second ? label2 : label1) + (size_t)b * nq : nullptr;
+  const float* __restrict__ rlab = LAB ? (second ? label1 : label2) + (size_t)b * nr : nullptr;
+  float qx[Q], qy[Q], qz[Q], best[Q], lq[Q];
   int gid[Q];
 #pragma unroll
   for (int i = 0; i < Q; ++i) {
     int j = tile * TQ + i * 64 + lane;
     j = j < count ? j : count - 1;  // clamp: out-of-range lanes compute a valid query, never stored
     if constexpr (LIST) j = ql[j];
+    lq[i] = LAB ? qlab[j] : 0.0f;
     qx[i] = qry[3 * (size_t)j + 0];
     qy[i] = qry[3 * (size_t)j + 1];
     qz[i] = qry[3 * (size_t)j + 2];
@@ -96,6 +105,12 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     float nb[Q];
 #pragma unroll
     for (int i = 0; i < Q; ++i) nb[i] = best[i];
+    float rl[G];
+    if constexpr (LAB) {
+      const float* __restrict__ lp = rlab + (size_t)g * G;  // wave-uniform -> s_load
+#pragma unroll
+      for (int e = 0; e < G; ++e) rl[e] = lp[e];
+    }
     if constexpr (PK) {
       static_assert(!PK || Q % 2 == 0, "packed form pairs the queries of a lane");
 #pragma unroll
@@ -103,8 +118,15 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
 #pragma unroll
         for (int i = 0; i < Q; i += 2) {
           const pp::f2 x2 = {qx[i], qx[i + 1]}, y2 = {qy[i], qy[i + 1]}, z2 = {qz[i], qz[i + 1]};
-          const pp::f2 da = pp::chamfer_d3_pk(rr[3 * p + 0], rr[3 * p + 1], rr[3 * p + 2], x2, y2, z2);
-          const pp::f2 db = pp::chamfer_d3_pk(rr[3 * p + 3], rr[3 * p + 4], rr[3 * p + 5], x2, y2, z2);
+          pp::f2 da = pp::chamfer_d3_pk(rr[3 * p + 0], rr[3 * p + 1], rr[3 * p + 2], x2, y2, z2);
+          pp::f2 db = pp::chamfer_d3_pk(rr[3 * p + 3], rr[3 * p + 4], rr[3 * p + 5], x2, y2, z2);
+          if constexpr (LAB) {
+            const float inf = __builtin_inff();
+            da.x = lq[i] == rl[p] ? da.x : inf;
+            da.y = lq[i + 1] == rl[p] ? da.y : inf;
+            db.x = lq[i] == rl[p + 1] ? db.x : inf;
+            db.y = lq[i + 1] == rl[p + 1] ? db.y : inf;
+          }
           nb[i] = pp::min3(da.x, db.x, nb[i]);
           nb[i + 1] = pp::min3(da.y, db.y, nb[i + 1]);
         }
@@ -114,8 +136,12 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
       for (int p = 0; p < G; p += 2) {
 #pragma unroll
         for (int i = 0; i < Q; ++i) {
-          const float da = chamfer_d3(rr[3 * p + 0], rr[3 * p + 1], rr[3 * p + 2], qx[i], qy[i], qz[i]);
-          const float db = chamfer_d3(rr[3 * p + 3], rr[3 * p + 4], rr[3 * p + 5], qx[i], qy[i], qz[i]);
+          float da = chamfer_d3(rr[3 * p + 0], rr[3 * p + 1], rr[3 * p + 2], qx[i], qy[i], qz[i]);
+          float db = chamfer_d3(rr[3 * p + 3], rr[3 * p + 4], rr[3 * p + 5], qx[i], qy[i], qz[i]);
+          if constexpr (LAB) {
+            da = lq[i] == rl[p] ? da : __builtin_inff();
+            db = lq[i] == rl[p + 1] ? db : __builtin_inff();
+          }
           nb[i] = pp::min3(da, db, nb[i]);
         }
       }
@@ -162,7 +188,8 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
       const float* rp = ref + 3 * (size_t)k0;
 #pragma unroll
       for (int p = G - 1; p >= 0; --p) {  // descending: the last hit kept is the lowest index
-        const float d = chamfer_d3(rp[3 * p + 0], rp[3 * p + 1], rp[3 * p + 2], qx[i], qy[i], qz[i]);
+        float d = chamfer_d3(rp[3 * p + 0], rp[3 * p + 1], rp[3 * p + 2], qx[i], qy[i], qz[i]);
+        if constexpr (LAB) d = lq[i] == rlab[k0 + p] ? d : __builtin_inff();
         k = d == best[i] ? k0 + p : k;
       }
     }
@@ -173,9 +200,11 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
   if (wave == kWavesPerBlock - 1) {
     for (int k = ngroups * G; k < nr; ++k) {
       const float rx = ref[3 * (size_t)k + 0], ry = ref[3 * (size_t)k + 1], rz = ref[3 * (size_t)k + 2];
+      const float rlk = LAB ? rlab[k] : 0.0f;
 #pragma unroll
       for (int i = 0; i < Q; ++i) {
-        const float d = chamfer_d3(rx, ry, rz, qx[i], qy[i], qz[i]);
+        float d = chamfer_d3(rx, ry, rz, qx[i], qy[i], qz[i]);
+        if constexpr (LAB) d = lq[i] == rlk ? d : __builtin_inff();
         const bool lt = d < best[i];
         best[i] = lt ? d : best[i];
         bidx[i] = lt ? k : bidx[i];
@@ -206,6 +235,11 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     int j = tile * TQ + e;
     if (j < count) {
       if constexpr (LIST) j = ql[j];
+      if constexpr (LAB) {
+        const bool none = !(bb < __builtin_inff());  // no reference point with this query's label
+        bb = none ? 0.0f : bb;
+        bi = none ? -1 : bi;
+      }
       od[j] = bb;
       oi[j] = bi;
     }
@@ -625,6 +659,10 @@ extern "C" int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, f
   }
 }
 
+// 0 = automatic; 1 = force the one-lane-per-query kernel (tests and tuning)
+static int g_labeled_variant = 0;
+extern "C" void pp_debug_set_labeled_variant(int v) { g_labeled_variant = v; }
+
 extern "C" int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float* xyz2,
                                                  const float* label1, const float* label2,
                                                  float* dist1, int* idx1, float* dist2, int* idx2,
@@ -637,6 +675,17 @@ extern "C" int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float*
   // post-pass (:110-113) sees idx 0 (not < 0) -- so zeros, like the unlabeled case.
   if (N == 0 || M == 0) return zero_outputs(dist1, idx1, dist2, idx2, B, N, M, s);
   if (!xyz1 || !xyz2 || !label1 || !label2) return PP_EINVAL;
+  if (C == 3 && g_labeled_variant != 1) {  // the tiled scan with the label filter
+    constexpr int Q = 4, G = 8, TQ = 64 * Q;
+    const int t1 = (N + TQ - 1) / TQ, t2 = (M + TQ - 1) / TQ;
+    const long long tot = (long long)B * (t1 + t2);
+    if (tot > 0x7fffff00LL) return PP_EINVAL;
+    const int per_xcd = (int)((tot + 7) / 8);
+    nmdist_fwd_c3_kernel<Q, G, true, false, false, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
+        xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, t1, t2, (int)tot, per_xcd, nullptr, nullptr, label1, label2);
+    PP_RETURN_IF_LAUNCH_FAILED();
+    return PP_OK;
+  }
   const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
   const long long total = (long long)B * (tiles1 + tiles2);
   if (total > 0x7fffff00LL) return PP_EINVAL;

@@ -182,6 +182,30 @@ def test_labeled_matches_oracle(cuda, bwd_path):
     assert np.allclose(t2.grad.cpu().numpy(), e2, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("b,n,m,nl1,nl2", [(2, 1000, 777, 4, 3), (1, 300, 2500, 2, 2), (1, 64, 64, 70, 70), (3, 9, 7, 1, 2)])
+def test_labeled_both_kernels(cuda, variant, b, n, m, nl1, nl2):
+    """tiled scan with the label filter and the one-lane-per-query kernel == oracle (idx -1 / dist 0
+    for queries whose label does not occur on the other side; lowest index on ties)."""
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd.network.model_loss import labeled_nndistance
+    x1, x2 = _clouds(b, n, m, 3, dup=True)
+    l1 = (S.uniform01(70, (b, n)).reshape(b, n) * nl1).astype(np.int64)
+    l2 = (S.uniform01(71, (b, m)).reshape(b, m) * nl2).astype(np.int64)
+    setter = _lib.lib().pp_debug_set_labeled_variant
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(variant)
+    try:
+        d1, d2, i1, i2 = labeled_nndistance(torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda),
+                                            torch.from_numpy(l1).to(cuda), torch.from_numpy(l2).to(cuda))
+    finally:
+        setter(0)
+    e = oracle.labeled_chamfer_forward(x1, x2, l1, l2)
+    for g, x in zip([d1, i1, d2, i2], e):
+        assert np.array_equal(g.cpu().numpy(), x)
+
+
 def test_rejects_bad_inputs(cuda):
     from pytorch_points_amd._ext import losses
     x = torch.zeros(1, 4, 3, device=cuda)
