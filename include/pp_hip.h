@@ -143,6 +143,27 @@ int pp_three_interpolate_f32(const float* points, const int* idx, const float* w
 int pp_three_interpolate_grad_f32(const float* grad_out, const int* idx, const float* weight,
                                   float* grad_points, int B, int C, int N, int M, void* stream);
 
+/* ---- the three scatter-add backwards with a caller-provided workspace -----------------------
+ * Same contracts as pp_group_points_grad_strided_f32 / pp_gather_backward_f32 /
+ * pp_three_interpolate_grad_f32 (they ACCUMULATE into caller-zeroed outputs).  With a workspace of
+ * pp_scatter_workspace_bytes(B, triples per batch element, destinations per batch element,
+ * triples per source element, weighted) bytes the (source, destination) pairs are sorted once per
+ * call and no atomics are issued; without one (or when the size does not qualify: the function
+ * returns 0 bytes) they are the atomic forms.
+ *   group_points_grad:      triples = npoint*nsample, destinations = N, per_source = 1, weighted = 0
+ *   gather_backward:        triples = M,              destinations = N, per_source = 1, weighted = 0
+ *   three_interpolate_grad: triples = 3*N,            destinations = M, per_source = 3, weighted = 1 */
+size_t pp_scatter_workspace_bytes(int B, long long triples_per_batch, int destinations, int per_source,
+                                  int weighted);
+int pp_group_points_grad_ws_f32(const float* grad_out, const int* idx, float* grad_points, int B, int C,
+                                int N, int npoint, int nsample, long long grad_out_batch_stride,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int pp_gather_backward_ws_f32(const float* grad_out, const int* idx, float* grad_points, int B, int C,
+                              int N, int M, void* workspace, size_t workspace_bytes, void* stream);
+int pp_three_interpolate_grad_ws_f32(const float* grad_out, const int* idx, const float* weight,
+                                     float* grad_points, int B, int C, int N, int M, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+
 /* The library also exports pp_debug_set_* switches that force one kernel variant or another; they
  * exist for the parity tests and for tuning and are deliberately not declared here. */
 

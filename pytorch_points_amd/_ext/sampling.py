@@ -24,6 +24,23 @@ def _workspace(device, nbytes):
     return buf
 
 
+_scatter_workspace = {}
+
+
+def _scatter_ws(device, b, triples, destinations, per_source, weighted):
+    """(pointer, bytes) of the per-(device, stream) scratch for the sorted scatter-add; (None, 0) when
+    the problem does not qualify."""
+    nbytes = int(_lib.lib().pp_scatter_workspace_bytes(b, triples, destinations, per_source, weighted))
+    if nbytes == 0:
+        return None, 0
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _scatter_workspace.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _scatter_workspace[key] = buf
+    return _lib.ptr(buf), nbytes
+
+
 def furthest_sampling_status(device):
     """Test/debug aid: 0 if no inter-workgroup wait of the FPS cluster kernel has timed out on this
     device's workspace since its last call (synchronises the current stream)."""
@@ -83,8 +100,9 @@ def gather_backward(b, c, n, npoints, grad_out, idx, grad_points):
             or grad_points.numel() != b * c * n):
         raise RuntimeError("gather_backward: tensor sizes do not match (b, c, n, npoints)")
     with _lib.on_device(dev) as stream:
-        _lib.check(_lib.lib().pp_gather_backward_f32(
-            _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_points), b, c, n, npoints, stream),
+        ws, nbytes = _scatter_ws(dev, b, npoints, n, 1, 0)
+        _lib.check(_lib.lib().pp_gather_backward_ws_f32(
+            _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_points), b, c, n, npoints, ws, nbytes, stream),
             "gather_backward")
     return 1
 
@@ -143,9 +161,10 @@ def group_points_grad(grad_out, idx, n):
     b, c, npoint, nsample = grad_out.shape
     out = torch.zeros(b, c, int(n), dtype=torch.float32, device=dev)
     with _lib.on_device(dev) as stream:
-        _lib.check(_lib.lib().pp_group_points_grad_f32(
+        ws, nbytes = _scatter_ws(dev, b, npoint * nsample, int(n), 1, 0)
+        _lib.check(_lib.lib().pp_group_points_grad_ws_f32(
             _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(out), b, c, int(n), npoint, nsample,
-            stream), "group_points_grad")
+            c * npoint * nsample, ws, nbytes, stream), "group_points_grad")
     return out
 
 
@@ -184,9 +203,10 @@ def group_points_grad_from(grad_out, idx, n, channel_offset, channels):
     p = npoint * nsample
     out = torch.zeros(b, channels, int(n), dtype=torch.float32, device=dev)
     with _lib.on_device(dev) as stream:
-        _lib.check(_lib.lib().pp_group_points_grad_strided_f32(
+        ws, nbytes = _scatter_ws(dev, b, p, int(n), 1, 0)
+        _lib.check(_lib.lib().pp_group_points_grad_ws_f32(
             _lib._c_void_p(grad_out.data_ptr() + 4 * channel_offset * p), _lib.ptr(idx), _lib.ptr(out),
-            b, channels, int(n), npoint, nsample, ctot * p, stream), "group_points_grad_from")
+            b, channels, int(n), npoint, nsample, ctot * p, ws, nbytes, stream), "group_points_grad_from")
     return out
 
 
@@ -235,6 +255,7 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
             or grad_points.numel() != b * c * m:
         raise RuntimeError("three_interpolate_grad_wrapper: tensor sizes do not match (b, c, n, m)")
     with _lib.on_device(dev) as stream:
-        _lib.check(_lib.lib().pp_three_interpolate_grad_f32(
+        ws, nbytes = _scatter_ws(dev, b, 3 * n, m, 3, 1)
+        _lib.check(_lib.lib().pp_three_interpolate_grad_ws_f32(
             _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(grad_points), b, c, n, m,
-            stream), "three_interpolate_grad_wrapper")
+            ws, nbytes, stream), "three_interpolate_grad_wrapper")

@@ -34,12 +34,17 @@ SIGNATURES = {
     "pp_group_points_grad_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pp_group_points_strided_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P],
     "pp_group_points_grad_strided_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P],
+    "pp_scatter_workspace_bytes": [_I, ctypes.c_longlong, _I, _I, _I],
+    "pp_group_points_grad_ws_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P, _c_size_t, _P],
+    "pp_gather_backward_ws_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
+    "pp_three_interpolate_grad_ws_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_three_nn_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
     "pp_three_interpolate_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_three_interpolate_grad_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
 }
 _RESTYPES = {"pp_version": ctypes.c_char_p, "pp_furthest_sampling_workspace_bytes": _c_size_t,
-             "pp_nmdistance_forward_workspace_bytes": _c_size_t}
+             "pp_nmdistance_forward_workspace_bytes": _c_size_t,
+             "pp_scatter_workspace_bytes": _c_size_t}
 
 _lib = None
 

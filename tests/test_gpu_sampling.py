@@ -192,18 +192,63 @@ def test_ball_query_edges(cuda, bq_path, b, n, m, r, ns):
 # --------------------------------------------------------------------------------- group points
 @pytest.fixture(params=["auto", "global_atomics", "lds_columns"])
 def group_grad_path(request, cuda):
+    """auto = sorted-triples scatter-add where it qualifies (scatter.hip); the other two switch it
+    off and force one of the atomic kernels."""
     import ctypes
     from pytorch_points_amd import _lib
     setter = _lib.lib().pp_debug_set_group_points_grad_variant
     setter.argtypes = [ctypes.c_int]
     setter.restype = None
+    smode = _lib.lib().pp_debug_set_scatter_mode
+    smode.argtypes = [ctypes.c_int]
+    smode.restype = None
     setter({"auto": 0, "global_atomics": 1, "lds_columns": 2}[request.param])
+    smode(0 if request.param == "auto" else 1)
     yield request.param
     setter(0)
+    smode(0)
+
+
+@pytest.fixture(params=["sorted", "atomics"])
+def scatter_path(request, cuda):
+    import ctypes
+    from pytorch_points_amd import _lib
+    smode = _lib.lib().pp_debug_set_scatter_mode
+    smode.argtypes = [ctypes.c_int]
+    smode.restype = None
+    smode(0 if request.param == "sorted" else 1)
+    yield request.param
+    smode(0)
+
+
+@pytest.mark.parametrize("b,c,n,m", [(3, 40, 5000, 20001), (9, 16, 16384, 8192), (1, 130, 777, 40000)])
+def test_gather_backward_large(cuda, scatter_path, b, c, n, m):
+    from pytorch_points_amd._ext import sampling
+    go = _t(S.normal(23, (b, c, m)), cuda)
+    idx = _t((S.uniform01(24, (b, m)).reshape(b, m) * n).astype(np.int32), cuda)
+    gp = torch.zeros(b, c, n, device=cuda)
+    sampling.gather_backward(b, c, n, m, go, idx, gp)
+    ref = torch.zeros(b, c, n, device=cuda, dtype=torch.float64)
+    ref.scatter_add_(2, idx.long()[:, None, :].expand(-1, c, -1), go.double())
+    assert torch.allclose(gp.double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,c,n,m", [(2, 33, 16384, 4096), (9, 8, 5001, 700), (1, 64, 40000, 20480)])
+def test_three_interpolate_grad_large(cuda, scatter_path, b, c, n, m):
+    from pytorch_points_amd._ext import sampling
+    go = _t(S.normal(25, (b, c, n)), cuda)
+    idx = _t((S.uniform01(26, (b, n, 3)).reshape(b, n, 3) * m).astype(np.int32), cuda)
+    w = _t(S.uniform01(27, (b, n, 3)).reshape(b, n, 3).astype(np.float32), cuda)
+    gp = torch.zeros(b, c, m, device=cuda)
+    sampling.three_interpolate_grad_wrapper(b, c, n, m, go, idx, w, gp)
+    ref = torch.zeros(b, c, m, device=cuda, dtype=torch.float64)
+    contrib = go.double()[:, :, :, None] * w.double()[:, None]                       # (b,c,n,3)
+    ref.scatter_add_(2, idx.long()[:, None].expand(-1, c, -1, -1).reshape(b, c, -1), contrib.reshape(b, c, -1))
+    assert torch.allclose(gp.double(), ref, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("b,c,n,npoint,ns", [(2, 8, 2048, 256, 16), (1, 3, 100, 7, 5), (2, 67, 500, 33, 12), (1, 1, 10, 1, 1),
-                                             (9, 4, 4096, 512, 32)])
+                                             (9, 4, 4096, 512, 32), (4, 16, 4096, 1024, 32), (3, 10, 5000, 700, 48)])
 def test_group_points_matches_torch_and_backward(cuda, group_grad_path, b, c, n, npoint, ns):
     from pytorch_points_amd.network.operations import grouping_operation
     f = _t(S.normal(40, (b, c, n)), cuda).requires_grad_(True)
