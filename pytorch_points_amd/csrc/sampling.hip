@@ -652,6 +652,68 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(const float* __r
   }
 }
 
+// three_interpolate, LDS-staged form: like group_points v2 -- the channel row points[b,c,:]
+// (M floats) is staged in LDS once per 512-thread workgroup (next row prefetched through
+// registers), a thread keeps (idx, weight) of four consecutive n for all C channels and streams
+// 16-byte stores.  Same canonical fma order as the gather form.
+template <int KR>
+__global__ __launch_bounds__(512, 4) void three_interpolate_lds_kernel(const float* __restrict__ points,
+                                                                       const int* __restrict__ idx,
+                                                                       const float* __restrict__ weight,
+                                                                       float* __restrict__ out, int B, int C,
+                                                                       int M, int N, int chunks) {
+  extern __shared__ __attribute__((aligned(16))) float s_row[];
+  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+  const int b = x + 8 * (y / chunks);
+  const int chunk = y % chunks;
+  if (b >= B) return;
+  const int t = threadIdx.x;
+  const int n0 = chunk * 2048 + t * 4;  // four consecutive outputs per thread (N % 4 == 0)
+  const bool active = n0 < N;
+  const int nc = active ? n0 : 0;
+  int ii[12];
+  float ww[12];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const pp::i4 q = reinterpret_cast<const pp::i4*>(idx + ((size_t)b * N + nc) * 3)[e];
+    const pp::f4 w = reinterpret_cast<const pp::f4*>(weight + ((size_t)b * N + nc) * 3)[e];
+    ii[4 * e] = q.x; ii[4 * e + 1] = q.y; ii[4 * e + 2] = q.z; ii[4 * e + 3] = q.w;
+    ww[4 * e] = w.x; ww[4 * e + 1] = w.y; ww[4 * e + 2] = w.z; ww[4 * e + 3] = w.w;
+  }
+  const int m4 = M >> 2;
+  const pp::f4* __restrict__ row = reinterpret_cast<const pp::f4*>(points + (size_t)b * C * M);
+  int ee[KR];
+  pp::f4 pre[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    ee[k] = min(t + 512 * k, m4 - 1);
+    pre[k] = row[ee[k]];
+  }
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KR; ++k) reinterpret_cast<pp::f4*>(s_row)[ee[k]] = pre[k];
+    __syncthreads();
+    const pp::f4* __restrict__ nrow = row + (size_t)(c + 1 < C ? c + 1 : c) * m4;
+#pragma unroll
+    for (int k = 0; k < KR; ++k) pre[k] = nrow[ee[k]];
+    pp::f4 r;
+    r.x = __builtin_fmaf(ww[2], s_row[ii[2]], __builtin_fmaf(ww[0], s_row[ii[0]], ww[1] * s_row[ii[1]]));
+    r.y = __builtin_fmaf(ww[5], s_row[ii[5]], __builtin_fmaf(ww[3], s_row[ii[3]], ww[4] * s_row[ii[4]]));
+    r.z = __builtin_fmaf(ww[8], s_row[ii[8]], __builtin_fmaf(ww[6], s_row[ii[6]], ww[7] * s_row[ii[7]]));
+    r.w = __builtin_fmaf(ww[11], s_row[ii[11]], __builtin_fmaf(ww[9], s_row[ii[9]], ww[10] * s_row[ii[10]]));
+    if (active) *reinterpret_cast<pp::f4*>(out + ((size_t)b * C + c) * N + n0) = r;
+  }
+}
+
+template <int KR>
+void launch_three_interpolate_lds(const float* points, const int* idx, const float* weight, float* out,
+                                  int B, int C, int M, int N, hipStream_t s) {
+  const int chunks = (N + 2047) / 2048;
+  three_interpolate_lds_kernel<KR><<<dim3((unsigned)(8 * ((B + 7) / 8) * chunks)), dim3(512),
+                                     (size_t)M * sizeof(float), s>>>(points, idx, weight, out, B, C, M, N, chunks);
+}
+
 // three_interpolate backward (ref interpolate_gpu.cu:120-142)
 __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
     const float* __restrict__ grad_out, const int* __restrict__ idx,
@@ -889,11 +951,28 @@ extern "C" int pp_three_nn_f32(const float* unknown, const float* known, float* 
   return PP_OK;
 }
 
+// 0 = automatic; 1 = force the global-gather kernel (tests and tuning)
+static int g_interp_variant = 0;
+extern "C" void pp_debug_set_three_interpolate_variant(int v) { g_interp_variant = v; }
+
 extern "C" int pp_three_interpolate_f32(const float* points, const int* idx, const float* weight,
                                         float* out, int B, int C, int M, int N, void* stream) {
   if (B < 0 || C < 0 || N < 0 || M < 0) return PP_EINVAL;
   if (B == 0 || C == 0 || N == 0) return PP_OK;
   if (!points || !idx || !weight || !out || M == 0) return PP_EINVAL;
+  // LDS-staged form: 16-byte aligned rows and quads, row within 64 KiB, enough channels to amortise
+  if (g_interp_variant != 1 && M % 4 == 0 && N % 4 == 0 && M <= 16384 && C >= 4 &&
+      (uintptr_t)points % 16 == 0 && (uintptr_t)idx % 16 == 0 && (uintptr_t)weight % 16 == 0 &&
+      (uintptr_t)out % 16 == 0 && (long long)B * N >= 64 * 2048) {
+    hipStream_t s = (hipStream_t)stream;
+    const int m4 = M / 4;
+    if (m4 <= 512) launch_three_interpolate_lds<1>(points, idx, weight, out, B, C, M, N, s);
+    else if (m4 <= 1024) launch_three_interpolate_lds<2>(points, idx, weight, out, B, C, M, N, s);
+    else if (m4 <= 2048) launch_three_interpolate_lds<4>(points, idx, weight, out, B, C, M, N, s);
+    else launch_three_interpolate_lds<8>(points, idx, weight, out, B, C, M, N, s);
+    PP_RETURN_IF_LAUNCH_FAILED();
+    return PP_OK;
+  }
   const long long cols = (N + 255) / 256;
   const int cpb = pick_c_per_block(cols, B, C);
   const long long gy = (C + cpb - 1) / cpb;

@@ -396,6 +396,32 @@ def test_three_interpolate_forward_backward(cuda):
     assert np.allclose(gr.cpu().numpy(), eg, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("b,c,m,n", [(9, 16, 4096, 16384), (2, 7, 1000, 70000), (3, 5, 16384, 40000), (1, 64, 512, 131072)])
+def test_three_interpolate_both_kernels(cuda, variant, b, c, m, n):
+    """LDS-staged and global-gather forms == oracle bitwise (canonical fma order)."""
+    import ctypes
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd._ext import sampling
+    feats = _t(S.normal(74, (b, c, m)), cuda)
+    idx = _t((S.uniform01(75, (b, n, 3)).reshape(b, n, 3) * m).astype(np.int32), cuda)
+    idx[:, 0, 0] = m - 1
+    w = _t(S.uniform01(76, (b, n, 3)).reshape(b, n, 3).astype(np.float32), cuda)
+    out = torch.empty(b, c, n, device=cuda)
+    setter = _lib.lib().pp_debug_set_three_interpolate_variant
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(variant)
+    try:
+        sampling.three_interpolate_wrapper(b, c, m, n, feats, idx, w, out)
+    finally:
+        setter(0)
+    e = oracle.three_interpolate(feats[:2].cpu().numpy(), idx[:2].cpu().numpy(), w[:2].cpu().numpy())
+    assert np.array_equal(out[:2].cpu().numpy(), e)
+    g = torch.gather(feats.unsqueeze(2).expand(-1, -1, n, -1), 3, idx.long()[:, None].expand(-1, c, -1, -1))
+    assert torch.allclose(out, (g * w[:, None]).sum(-1), rtol=1e-5, atol=1e-5)
+
+
 def test_fp_module_style_pipeline(cuda):
     """three_nn -> inverse-distance weights -> three_interpolate, as PointnetFPModule does
     (reference network/pointnet2_modules.py:136-141)."""
