@@ -99,6 +99,14 @@ int pp_gather_backward_f32(const float* grad_out, const int* idx, float* grad_po
 int pp_ball_query_f32(const float* new_xyz, const float* xyz, int* idx, int B, int N, int M,
                       float radius, int nsample, void* stream);
 
+/* The same operation through a uniform grid over xyz (exact, same output), with the scan as the
+ * fallback for batch elements whose radius spans too many cells.  workspace:
+ * pp_ball_query_workspace_bytes(...) bytes (0 = not applicable); NULL = the scan. */
+size_t pp_ball_query_workspace_bytes(int B, int N, int M, int nsample);
+int pp_ball_query_ws_f32(const float* new_xyz, const float* xyz, int* idx, int B, int N, int M,
+                         float radius, int nsample, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
 /* Replaces sampling.group_points(points, idx)
  *   (_ext/sampling.cpp:113-138 -> _ext/sampling_cuda.cu:447-478).
  * points (B,C,N), idx (B,npoint,nsample) -> out (B,C,npoint,nsample), fully written. */

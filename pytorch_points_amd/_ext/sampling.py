@@ -121,9 +121,17 @@ def ball_query(new_xyz, xyz, radius, nsample):
     nsample = int(nsample)
     idx = torch.empty(b, m, nsample, dtype=torch.int32, device=dev)  # kernel writes every slot
     with _lib.on_device(dev) as stream:
-        _lib.check(_lib.lib().pp_ball_query_f32(
+        nbytes = int(_lib.lib().pp_ball_query_workspace_bytes(b, n, m, nsample))
+        ws = None
+        if nbytes:
+            key = (dev, torch.cuda.current_stream(dev).cuda_stream, "ball_query")
+            ws = _scatter_workspace.get(key)
+            if ws is None or ws.numel() < nbytes:
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _scatter_workspace[key] = ws
+        _lib.check(_lib.lib().pp_ball_query_ws_f32(
             _lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), b, n, m, float(radius), nsample,
-            stream), "ball_query")
+            _lib.ptr(ws) if ws is not None else None, nbytes, stream), "ball_query")
     return idx
 
 

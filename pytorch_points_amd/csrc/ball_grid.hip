@@ -1,0 +1,386 @@
+// ball_grid.hip -- ball_query through the uniform grid of grid_common.h, with the scan kernels of
+// sampling.hip as the fallback.  Same output as the scan (ref _ext/sampling_cuda.cu:340-376): per
+// centre the first `nsample` in-radius indices in ASCENDING INDEX order, padded with the first one,
+// zeros when the ball is empty.
+//
+// A hit needs dist3 < r^2 in fp32, hence |p_a - q_a| <= r(1 + 1e-6) on every axis; the cell
+// coordinate is a monotone function of the coordinate, so every hit of a centre lies in its cell
+// box [cell(q - r'), cell(q + r')] with r' = r(1 + 1e-5) + tiny.
+//
+// The reference's order (ascending index, cut at nsample) is what makes this more than a range
+// query.  A wave takes 64 centres that are close in space (the build kernel also sorts the centres,
+// along a Morton curve), and
+//   1. marks the cells of the 64 boxes in an LDS bitmap (one bit per cell: the union),
+//   2. marks the points of those cells in an LDS bitmap indexed by ORIGINAL point index,
+//   3. walks that bitmap in order -- the candidates come out sorted by index for free -- and stages
+//      them (coordinates from the cloud itself) in LDS, kBqCap at a time,
+//   4. lets every lane scan the staged candidates in order with the scan kernel's test
+//      (pp::dist3 < r^2) and append its hits to its row, exactly like the brute-force scan but over
+//      a few hundred candidates instead of the whole cloud,
+//   5. writes the 64 rows, padded, to the centres' original positions.
+// Sets whose box would exceed 7x7x7 cells (large radius), or whose grid is useless, are left to the
+// scan kernel, launched afterwards for those sets only.
+#include "grid_common.h"
+
+namespace pp {
+// sampling.hip: the scan kernel over the batch elements whose grid set says "not usable"
+int ball_query_scan_unusable(const float* new_xyz, const float* xyz, int* idx, int B, int N, int M,
+                             float radius, int nsample, const GridSet* sets, hipStream_t s);
+}  // namespace pp
+
+namespace {
+
+using pp::GridSet;
+using pp::cell_coord;
+using pp::kGridCells;
+using pp::kBuildThreads;
+
+constexpr int kBqMaxCells = 3;   // cell-box half-extent the grid path accepts
+constexpr int kBqCap = 512;      // candidates staged per pass (8 KiB)
+constexpr int kBqMaxN = 131072;  // point bitmap <= 16 KiB
+
+struct BqLayout {
+  size_t sets, cell_start, sorted, csorted, total;
+};
+__host__ __device__ inline BqLayout bq_layout(int B, int N, int M) {
+  BqLayout L;
+  L.sets = 0;  // [2B]: cloud sets, then the (unused) sets of the centre sort
+  L.cell_start = ((size_t)64 * 2 * B + 255) / 256 * 256;
+  L.sorted = L.cell_start + ((size_t)4 * (kGridCells + 1) * B + 255) / 256 * 256;
+  L.csorted = L.sorted + ((size_t)16 * B * N + 255) / 256 * 256;
+  L.total = L.csorted + (size_t)16 * B * M;
+  return L;
+}
+
+// blocks [0, B): the cloud of batch element b into its grid; blocks [B, 2B): the centres of batch
+// element b into Morton order
+__global__ __launch_bounds__(kBuildThreads) void bq_build_kernel(const float* __restrict__ xyz,
+                                                                 const float* __restrict__ new_xyz,
+                                                                 unsigned char* __restrict__ ws, int B, int N,
+                                                                 int M, float rpad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];
+  const BqLayout L = bq_layout(B, N, M);
+  GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + blockIdx.x;
+  if ((int)blockIdx.x >= B) {
+    const int b = blockIdx.x - B;
+    pp::grid_build_set<true>(new_xyz + (size_t)b * M * 3, M, gs, nullptr,
+                             reinterpret_cast<pp::f4*>(ws + L.csorted) + (size_t)b * M, nullptr, s_cnt);
+    return;
+  }
+  const int b = blockIdx.x;
+  pp::grid_build_set<false>(xyz + (size_t)b * N * 3, N, gs,
+                            reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
+                            reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * N, nullptr, s_cnt);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // pad[0] = 1: the grid path handles this batch element; 0: the scan kernel does
+    const float cells = rpad * gs->invh;
+    gs->pad[0] = (!gs->useless && cells <= (float)kBqMaxCells) ? 1 : 0;
+  }
+}
+
+// One wave per workgroup; see the file header for the five steps.  LPC lanes share a centre: the
+// wave serves G = 64 / LPC centres (a smaller union, more waves), and in step 4 the LPC lanes of a
+// centre scan consecutive segments of the staged candidates, so their hits concatenate in order.
+template <typename IT, int LPC>
+__global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ xyz, int* __restrict__ idx,
+                                                      const unsigned char* __restrict__ ws, int B, int N, int M,
+                                                      float radius2, float rpad, int nsample, int tiles_per_b,
+                                                      int per_xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  const int vb = pp::xcd_virtual_block(blockIdx.x, per_xcd);  // a batch element stays on one XCD's L2
+  if (vb >= B * tiles_per_b) return;
+  const int b = vb / tiles_per_b;
+  const int tile = vb - b * tiles_per_b;
+  const BqLayout L = bq_layout(B, N, M);
+  const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[b];
+  if (!g.pad[0]) return;  // this batch element goes to the scan kernel
+  const int ncell = g.gx * g.gy * g.gz;
+  const int ncw = (ncell + 31) >> 5;  // words of the cell bitmap
+  const int npw = (N + 31) >> 5;      // words of the point bitmap
+  unsigned* s_cell = reinterpret_cast<unsigned*>(s_raw);                 // [kGridCells / 32]
+  unsigned* s_pt = s_cell + kGridCells / 32;                             // [npw]
+  float* s_cx = reinterpret_cast<float*>(s_pt + ((npw + 3) & ~3));       // [kBqCap] each, 16-byte aligned
+  float* s_cy = s_cx + kBqCap;
+  float* s_cz = s_cy + kBqCap;
+  int* s_cid = reinterpret_cast<int*>(s_cz + kBqCap);
+  IT* s_rows = reinterpret_cast<IT*>(s_cid + kBqCap);                    // [G][nsample + 1]
+  unsigned short* s_words = reinterpret_cast<unsigned short*>(s_cx);     // step 2 only: non-empty bitmap words
+  __shared__ int s_rng[2];
+  const int stride = nsample + 1;
+
+  const unsigned* __restrict__ cell_start =
+      reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1);
+  const pp::f4* __restrict__ sorted = reinterpret_cast<const pp::f4*>(ws + L.sorted) + (size_t)b * N;
+  const pp::f4* __restrict__ csorted = reinterpret_cast<const pp::f4*>(ws + L.csorted) + (size_t)b * M;
+  const float* __restrict__ cloud = xyz + (size_t)b * N * 3;
+  constexpr int G = 64 / LPC;
+  const int lane = threadIdx.x;
+  const int ci = lane & (G - 1), sub = lane / G;  // centre of the tile; which of its LPC lanes
+  const int m0 = tile * G;
+  const bool valid = m0 + ci < M;
+  const pp::f4 q = csorted[valid ? m0 + ci : M - 1];
+  const int qorig = __float_as_int(q.w);  // the centre's row in the output
+
+  for (int w = lane; w < ncw; w += 64) s_cell[w] = 0;
+  for (int w = lane; w < npw; w += 64) s_pt[w] = 0;
+  if (lane == 0) {
+    s_rng[0] = ncw;
+    s_rng[1] = -1;
+  }
+  __syncthreads();
+  // 1. cells of the 64 boxes: a row of cells along x is a run of consecutive bits
+  if (valid) {
+    const int x0 = cell_coord(q.x - rpad, g.minx, g.invh, g.gx), x1 = cell_coord(q.x + rpad, g.minx, g.invh, g.gx);
+    const int y0 = cell_coord(q.y - rpad, g.miny, g.invh, g.gy), y1 = cell_coord(q.y + rpad, g.miny, g.invh, g.gy);
+    const int z0 = cell_coord(q.z - rpad, g.minz, g.invh, g.gz), z1 = cell_coord(q.z + rpad, g.minz, g.invh, g.gz);
+    const unsigned long long run = (2ull << (x1 - x0)) - 1ull;  // x1 - x0 + 1 <= 8 ones
+    const int ny = y1 - y0 + 1, nzy = (z1 - z0 + 1) * ny;
+    for (int t = sub; t < nzy; t += LPC) {  // the centre's rows, dealt to its LPC lanes
+      const int zz = t / ny;
+      const int c = ((z0 + zz) * g.gy + y0 + (t - zz * ny)) * g.gx + x0;
+      const unsigned long long bits = run << (c & 31);
+      atomicOr(&s_cell[c >> 5], (unsigned)bits);
+      if (bits >> 32) atomicOr(&s_cell[(c >> 5) + 1], (unsigned)(bits >> 32));
+    }
+    atomicMin(&s_rng[0], ((z0 * g.gy + y0) * g.gx + x0) >> 5);
+    atomicMax(&s_rng[1], ((z1 * g.gy + y1) * g.gx + x1) >> 5);
+  }
+  __syncthreads();
+  // 2. points of the marked cells.  The non-empty bitmap words are first compacted into a list so
+  // that the lanes share them evenly; a run of marked cells is contiguous in `sorted`.
+  int nwords = 0;
+  for (int wb = s_rng[0]; wb <= s_rng[1]; wb += 64) {
+    const int w = wb + lane;
+    const bool nz = w <= s_rng[1] && s_cell[w] != 0;
+    const unsigned long long bal = __ballot(nz);
+    if (nz) s_words[nwords + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0))] =
+        (unsigned short)w;
+    nwords += __builtin_popcountll(bal);
+  }
+  __syncthreads();
+  for (int k = lane; k < nwords; k += 64) {
+    const int w = s_words[k];
+    unsigned bits = s_cell[w];
+    while (bits) {
+      const int lo = __builtin_ctz(bits);
+      const unsigned inv = ~(bits >> lo);  // bits >> lo starts with a one; its high `lo` bits are zero
+      const int len = inv ? __builtin_ctz(inv) : 32;
+      const int c = w * 32 + lo;
+      const unsigned e = cell_start[c + len];
+      for (unsigned i = cell_start[c]; i < e; i += 4) {
+        int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) id[u] = __float_as_int(sorted[min(i + u, e - 1)].w);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i + u < e) atomicOr(&s_pt[id[u] >> 5], 1u << (id[u] & 31));
+      }
+      bits = (lo + len >= 32) ? 0u : (bits >> (lo + len)) << (lo + len);
+    }
+  }
+  __syncthreads();
+  // 3. ranks: a lane owns a contiguous chunk of bitmap words
+  const int per = (npw + 63) >> 6;
+  const int w0 = min(npw, lane * per), w1 = min(npw, w0 + per);
+  int mine = 0;
+  for (int w = w0; w < w1; ++w) mine += __builtin_popcount(s_pt[w]);
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  const int total = __shfl(incl, 63);
+  const int mybase = incl - mine;
+
+  IT* myrow = s_rows + (size_t)ci * stride;
+  int cnt = valid ? 0 : nsample;  // hits of the centre so far (same in its LPC lanes); idle lanes count as full
+  const float r2v = radius2;
+  constexpr int NB = kBqCap / 32 / LPC;  // 32-candidate blocks a lane scans per pass, at most
+  for (int base = 0; base < total; base += kBqCap) {
+    const int ncand = min(kBqCap, total - base);
+    // 3a. indices of the candidates of this pass, ascending
+    int r = mybase;
+    for (int w = w0; w < w1 && r < base + kBqCap; ++w) {
+      unsigned bits = s_pt[w];
+      const int pc = __builtin_popcount(bits);
+      if (r + pc <= base) {
+        r += pc;
+        continue;
+      }
+      while (bits) {
+        const int bit = __builtin_ctz(bits);
+        bits &= bits - 1;
+        if (r >= base && r < base + kBqCap) s_cid[r - base] = w * 32 + bit;
+        ++r;
+      }
+    }
+    __syncthreads();
+    // 3b. coordinates; the tail up to a multiple of 32 gets +inf (never in radius)
+    const int padded = (ncand + 31) & ~31;
+    for (int c = lane; c < padded; c += 256) {
+      int id[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) id[u] = s_cid[min(c + 64 * u, ncand - 1)];
+      float v[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) v[u][a] = cloud[3 * (size_t)id[u] + a];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = c + 64 * u;
+        if (cc < padded) {
+          const bool real = cc < ncand;
+          s_cx[cc] = real ? v[u][0] : __builtin_inff();
+          s_cy[cc] = real ? v[u][1] : __builtin_inff();
+          s_cz[cc] = real ? v[u][2] : __builtin_inff();
+        }
+      }
+    }
+    __syncthreads();
+    // 4. ordered scan.  Lane `sub` of a centre takes the sub-th segment of the staged candidates, 32
+    // at a time: the in-radius flags are shifted into a mask (first candidate of the block ends up
+    // in bit 31).  The hit counts of the LPC lanes give each its offset in the row; then the set
+    // bits are appended in order.
+    const int seg = ((padded / 32 + LPC - 1) / LPC) * 32;
+    const int cbeg = sub * seg;
+    unsigned hits[NB];
+    int mine_hits = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      hits[j] = 0;
+      const int c0 = cbeg + 32 * j;
+      if (32 * j < seg && c0 < padded) {  // wave-uniform for LPC = 1; per-sub otherwise
+#pragma unroll
+        for (int u = 0; u < 32; u += 4) {
+          const pp::f4 X = *reinterpret_cast<const pp::f4*>(s_cx + c0 + u);
+          const pp::f4 Y = *reinterpret_cast<const pp::f4*>(s_cy + c0 + u);
+          const pp::f4 Z = *reinterpret_cast<const pp::f4*>(s_cz + c0 + u);
+          const float d0 = pp::dist3(q.x, q.y, q.z, X.x, Y.x, Z.x), d1 = pp::dist3(q.x, q.y, q.z, X.y, Y.y, Z.y);
+          const float d2 = pp::dist3(q.x, q.y, q.z, X.z, Y.z, Z.z), d3 = pp::dist3(q.x, q.y, q.z, X.w, Y.w, Z.w);
+          // hits = 2 * hits + (d < r^2), four times
+          asm volatile(
+              "v_cmp_lt_f32 vcc, %1, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+              "v_cmp_lt_f32 vcc, %2, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+              "v_cmp_lt_f32 vcc, %3, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+              "v_cmp_lt_f32 vcc, %4, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+              : "+v"(hits[j])
+              : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(r2v)
+              : "vcc");
+        }
+        mine_hits += __builtin_popcount(hits[j]);
+      }
+    }
+    int off = cnt, all_hits = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < LPC; ++s2) {
+      const int v = __shfl(mine_hits, ci + G * s2);
+      if (s2 < sub) off += v;
+      all_hits += v;
+    }
+    if (off < nsample) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        unsigned h = hits[j];
+        while (h && off < nsample) {
+          const int p = __builtin_clz(h);
+          h &= ~(0x80000000u >> p);
+          myrow[off++] = (IT)s_cid[cbeg + 32 * j + p];
+        }
+      }
+    }
+    cnt = min(nsample, cnt + all_hits);
+    if (__all(cnt >= nsample)) break;
+    __syncthreads();
+  }
+  __syncthreads();
+  // 5. rows to the centres' original positions; slot >= count: the pad (first hit, 0 if none)
+  if (!valid) cnt = 0;
+  const int first = cnt > 0 ? (int)myrow[0] : 0;
+  const int nrows = min(G, M - m0);
+  const int total_out = nrows * nsample;
+  int* __restrict__ gout = idx + (size_t)b * M * nsample;
+  for (int f0 = 0; f0 < total_out; f0 += 64) {  // uniform trip count: a shuffle needs its source lane active
+    const int f = min(f0 + lane, total_out - 1);
+    const int row = f / nsample;
+    const int slot = f - row * nsample;
+    const int rc = __shfl(cnt, row);
+    const int rf = __shfl(first, row);
+    const int ro = __shfl(qorig, row);
+    const int v = slot < rc ? (int)s_rows[(size_t)row * stride + slot] : rf;
+    if (f0 + lane < total_out) gout[(size_t)ro * nsample + slot] = v;
+  }
+}
+
+}  // namespace
+
+// 0 = automatic (grid when a workspace is given); 1 = scan kernels only
+static int g_bq_grid_mode = 0;
+static int g_bq_lpc = 0;
+extern "C" void pp_debug_set_ball_query_lpc(int v) { g_bq_lpc = v; }
+extern "C" void pp_debug_set_ball_query_search(int v) { g_bq_grid_mode = v; }
+
+static size_t bq_query_lds(int N, int nsample, int G) {
+  const size_t npw = ((size_t)N + 31) / 32;
+  return (size_t)kGridCells / 8 + ((npw + 3) & ~(size_t)3) * 4 + (size_t)kBqCap * 16 +
+         (size_t)G * (nsample + 1) * (N <= 65536 ? 2 : 4);
+}
+
+extern "C" size_t pp_ball_query_workspace_bytes(int B, int N, int M, int nsample) {
+  if (B <= 0 || M <= 0 || N < 2048 || N > kBqMaxN || nsample < 1) return 0;
+  if ((long long)B * N >= (1LL << 31) || (long long)B * M >= (1LL << 31)) return 0;
+  if (bq_query_lds(N, nsample, 16) > 64 * 1024) return 0;  // at least two waves per CU
+  return bq_layout(B, N, M).total;
+}
+
+template <typename IT, int LPC>
+static int bq_launch_query(const float* xyz, int* idx, const unsigned char* ws, int B, int N, int M, float radius2,
+                           float rpad, int nsample, hipStream_t s) {
+  constexpr int G = 64 / LPC;
+  const int tiles = (M + G - 1) / G;
+  const long long per_xcd = ((long long)B * tiles + 7) / 8;
+  if (per_xcd * 8 > 0x7fffffffLL) return PP_EINVAL;
+  static bool ok[64] = {};
+  hipError_t e = pp::allow_big_lds(bq_query_kernel<IT, LPC>, 64 * 1024, ok);
+  if (e != hipSuccess) return (int)e;
+  bq_query_kernel<IT, LPC><<<dim3((unsigned)(per_xcd * 8)), dim3(64), bq_query_lds(N, nsample, G), s>>>(
+      xyz, idx, ws, B, N, M, radius2, rpad, nsample, tiles, (int)per_xcd);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+
+extern "C" int pp_ball_query_ws_f32(const float* new_xyz, const float* xyz, int* idx, int B, int N, int M,
+                                    float radius, int nsample, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  const size_t need = pp_ball_query_workspace_bytes(B, N, M, nsample);
+  if (g_bq_grid_mode == 1 || need == 0 || !workspace || workspace_bytes < need || !(radius > 0.0f))
+    return pp_ball_query_f32(new_xyz, xyz, idx, B, N, M, radius, nsample, stream);
+  if (!new_xyz || !xyz || !idx) return PP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  const float radius2 = radius * radius;  // fp32, as the reference (sampling_cuda.cu:354)
+  const float rpad = radius * 1.00001f + 1e-30f;
+  static bool lds_ok[64] = {};
+  const size_t lds = (size_t)(kGridCells + kGridCells / 32) * sizeof(unsigned);
+  hipError_t e = pp::allow_big_lds(bq_build_kernel, (int)lds, lds_ok);
+  if (e != hipSuccess) return (int)e;
+  bq_build_kernel<<<dim3(2 * B), dim3(kBuildThreads), lds, s>>>(xyz, new_xyz, ws, B, N, M, rpad);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  // lanes per centre: 2 unless forced (tuning knob; 2 and 4 measure alike at config 4, 1 is 30 % slower)
+  const int lpc = g_bq_lpc ? g_bq_lpc : 2;
+  int rc;
+  if (N <= 65536)
+    rc = lpc == 1 ? bq_launch_query<unsigned short, 1>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)
+       : lpc == 2 ? bq_launch_query<unsigned short, 2>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)
+                  : bq_launch_query<unsigned short, 4>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s);
+  else
+    rc = lpc == 1 ? bq_launch_query<unsigned, 1>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)
+       : lpc == 2 ? bq_launch_query<unsigned, 2>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)
+                  : bq_launch_query<unsigned, 4>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s);
+  if (rc != PP_OK) return rc;
+  const BqLayout L = bq_layout(B, N, M);
+  return pp::ball_query_scan_unusable(new_xyz, xyz, idx, B, N, M, radius, nsample,
+                                      reinterpret_cast<const GridSet*>(ws + L.sets), s);
+}

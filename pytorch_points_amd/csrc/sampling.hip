@@ -1,7 +1,7 @@
 // sampling.hip -- gather_points, ball_query, group_points, three_nn, three_interpolate for gfx950.
 // Replaces the reference's _ext/sampling_cuda.cu (gather :9-84, ball_query :340-397,
 // group_points :447-513) and _ext/interpolate_gpu.cu (three_nn :9-74, three_interpolate :77-160).
-#include "pp_common.h"
+#include "grid_common.h"
 
 namespace pp {  // scatter.hip
 size_t ssa_workspace_bytes(int B, long long P, int R, int Nd, bool weighted);
@@ -63,10 +63,11 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
                                                          const float* __restrict__ xyz,
                                                          int* __restrict__ idx, int N, int M,
                                                          float radius2, int nsample,
-                                                         int tiles_per_b) {
+                                                         int tiles_per_b, const pp::GridSet* __restrict__ skip) {
   extern __shared__ __attribute__((aligned(16))) int s_rows[];  // [4 waves][64][nsample]
   const int b = blockIdx.x / tiles_per_b;
   const int tile = blockIdx.x - b * tiles_per_b;
+  if (skip && skip[b].pad[0]) return;  // this batch element was handled by the grid search
   const int wave = pp::wave_id_uniform();
   const int lane = threadIdx.x & 63;
   const int m0 = tile * 256 + wave * 64;  // first centre of this wave
@@ -124,13 +125,15 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
     int* __restrict__ gout = idx + ((size_t)b * M + m0) * nsample;
     const int nrows = min(64, M - m0);
     const int total = nrows * nsample;
-    for (int f = lane; f < total; f += 64) {
+    for (int f0 = 0; f0 < total; f0 += 64) {  // uniform trip count: a shuffle needs its source lane active
+      const int f = min(f0 + lane, total - 1);
       const int row = f / nsample;
       const int slot = f - row * nsample;
       const int rc = __shfl(cnt, row);
       const int rf = __shfl(first, row);
       // slot < rc: a recorded hit; otherwise the pad (first hit, or 0 when the ball is empty)
-      gout[f] = slot < rc ? wrows[f] : rf;
+      const int v = slot < rc ? wrows[f] : rf;
+      if (f0 + lane < total) gout[f] = v;
     }
   } else if (valid) {
     for (int s = cnt; s < nsample; ++s) grow[s] = first;
@@ -152,8 +155,10 @@ __global__ __launch_bounds__(256) void ball_query_split_kernel(const float* __re
                                                                const float* __restrict__ xyz,
                                                                int* __restrict__ idx, int N, int M,
                                                                float radius2, int nsample,
-                                                               int tiles_per_b) {
+                                                               int tiles_per_b,
+                                                               const pp::GridSet* __restrict__ skip) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  if (skip && skip[blockIdx.x / tiles_per_b].pad[0]) return;  // handled by the grid search
   IT* s_list = reinterpret_cast<IT*>(s_raw);                               // [4][64][nsample]
   int* s_cnt = reinterpret_cast<int*>(s_raw + (size_t)4 * 64 * nsample * sizeof(IT));  // [4][64]
   const int b = blockIdx.x / tiles_per_b;
@@ -788,8 +793,8 @@ extern "C" int pp_gather_backward_f32(const float* grad_out, const int* idx, flo
 static int g_ball_variant = 0;
 extern "C" void pp_debug_set_ball_query_variant(int v) { g_ball_variant = v; }
 
-extern "C" int pp_ball_query_f32(const float* new_xyz, const float* xyz, int* idx, int B, int N,
-                                 int M, float radius, int nsample, void* stream) {
+static int ball_query_launch(const float* new_xyz, const float* xyz, int* idx, int B, int N, int M,
+                             float radius, int nsample, const pp::GridSet* skip, void* stream) {
   if (B < 0 || N < 0 || M < 0 || nsample < 0) return PP_EINVAL;
   if (B == 0 || M == 0 || nsample == 0) return PP_OK;
   if (!new_xyz || !idx || (N > 0 && !xyz)) return PP_EINVAL;
@@ -805,10 +810,10 @@ extern "C" int pp_ball_query_f32(const float* new_xyz, const float* xyz, int* id
     if (blocks64 <= 0x7fffffffLL && lds64 <= 64 * 1024) {
       if (esz == 2)
         ball_query_split_kernel<unsigned short><<<dim3((unsigned)blocks64), dim3(256), lds64, s>>>(
-            new_xyz, xyz, idx, N, M, radius2, nsample, tiles64);
+            new_xyz, xyz, idx, N, M, radius2, nsample, tiles64, skip);
       else
         ball_query_split_kernel<unsigned><<<dim3((unsigned)blocks64), dim3(256), lds64, s>>>(
-            new_xyz, xyz, idx, N, M, radius2, nsample, tiles64);
+            new_xyz, xyz, idx, N, M, radius2, nsample, tiles64, skip);
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
     }
@@ -819,14 +824,26 @@ extern "C" int pp_ball_query_f32(const float* new_xyz, const float* xyz, int* id
   const size_t lds = (size_t)4 * 64 * nsample * sizeof(int);
   if (lds <= 64 * 1024) {
     ball_query_kernel<true><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(
-        new_xyz, xyz, idx, N, M, radius2, nsample, tiles);
+        new_xyz, xyz, idx, N, M, radius2, nsample, tiles, skip);
   } else {
     ball_query_kernel<false><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(
-        new_xyz, xyz, idx, N, M, radius2, nsample, tiles);
+        new_xyz, xyz, idx, N, M, radius2, nsample, tiles, skip);
   }
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
 }
+
+extern "C" int pp_ball_query_f32(const float* new_xyz, const float* xyz, int* idx, int B, int N,
+                                 int M, float radius, int nsample, void* stream) {
+  return ball_query_launch(new_xyz, xyz, idx, B, N, M, radius, nsample, nullptr, stream);
+}
+
+namespace pp {
+int ball_query_scan_unusable(const float* new_xyz, const float* xyz, int* idx, int B, int N, int M,
+                             float radius, int nsample, const GridSet* sets, hipStream_t s) {
+  return ball_query_launch(new_xyz, xyz, idx, B, N, M, radius, nsample, sets, (void*)s);
+}
+}  // namespace pp
 
 // 0 = automatic; 1 = force the global-gather kernel; 2/4/8 = force the LDS-staged kernel with that
 // many index quads per thread (tests and tuning)

@@ -151,17 +151,28 @@ def test_gather_matches_torch_and_backward(cuda):
 
 
 # ----------------------------------------------------------------------------------- ball query
-@pytest.fixture(params=["split", "single_wave"], autouse=False)
+@pytest.fixture(params=["grid", "grid_lpc4", "grid_lpc1", "split", "single_wave"], autouse=False)
 def bq_path(request, cuda):
-    """both ball_query decompositions: 4 waves x cloud quarters (default) and one wave per centre tile"""
+    """the ball_query paths: uniform grid (default for N >= 2048, scan fallback) with 2 (default), 4
+    or 1 lanes per centre; scan with 4 waves x cloud quarters; scan with one wave per centre tile"""
     import ctypes
     from pytorch_points_amd import _lib
     setter = _lib.lib().pp_debug_set_ball_query_variant
     setter.argtypes = [ctypes.c_int]
     setter.restype = None
+    search = _lib.lib().pp_debug_set_ball_query_search
+    search.argtypes = [ctypes.c_int]
+    search.restype = None
+    lpc = _lib.lib().pp_debug_set_ball_query_lpc
+    lpc.argtypes = [ctypes.c_int]
+    lpc.restype = None
     setter(1 if request.param == "single_wave" else 0)
+    search(0 if request.param.startswith("grid") else 1)
+    lpc({"grid_lpc4": 4, "grid_lpc1": 1}.get(request.param, 0))
     yield request.param
     setter(0)
+    search(0)
+    lpc(0)
 
 
 @pytest.mark.parametrize("r", [0.05, 0.2, 0.5])
@@ -176,9 +187,40 @@ def test_ball_query_matches_oracle(cuda, bq_path, r, ns):
     assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(centres, x, r, ns))
 
 
+def test_ball_query_grid_adversarial(cuda, bq_path):
+    """grid path on data built to break it: duplicates, planar / collinear clouds, centres far outside
+    the cloud, tight clusters, mixed batch (one element falls back to the scan: big radius in cells)."""
+    from pytorch_points_amd._ext import sampling
+    n, m = 4096, 300
+    cases = []
+    x = S.unit_sphere(33, 1, n)
+    x[0, n // 2:] = x[0, : n // 2]
+    cases.append((x, x[:, ::13].copy()[:, :m], 0.12, 24))                       # duplicates
+    pl = S.uniform01(34, (1, n, 3)).reshape(1, n, 3).astype(np.float32); pl[..., 2] = 0.25
+    cases.append((pl, pl[:, :m].copy() + np.float32(0.01), 0.08, 16))           # planar
+    ln = np.zeros((1, n, 3), np.float32); ln[0, :, 1] = np.linspace(0, 1, n, dtype=np.float32)
+    cases.append((ln, ln[:, ::11].copy()[:, :m], 0.01, 32))                     # collinear
+    far = S.unit_sphere(35, 1, m) * np.float32(30)
+    cases.append((S.unit_sphere(36, 1, n), far, 0.5, 8))                        # empty balls far away
+    cl = (S.normal(37, (1, n, 3)) * 1e-3).astype(np.float32)
+    cases.append((cl, cl[:, :m].copy(), 2e-3, 64))                              # one tight cluster: dense balls
+    mixed = np.concatenate([S.unit_sphere(38, 1, n), S.unit_sphere(39, 1, n) * np.float32(1e-2)], 0)
+    cases.append((mixed, mixed[:, ::9].copy()[:, :m], 0.05, 20))                # element 1: radius >> cell
+    for k, (x, c, r, ns) in enumerate(cases):
+        x = np.ascontiguousarray(x); c = np.ascontiguousarray(c)
+        got = sampling.ball_query(_t(c, cuda), _t(x, cuda), r, ns).cpu().numpy()
+        want = oracle.ball_query(c, x, r, ns)
+        bad = np.argwhere((got != want).any(-1))
+        assert bad.size == 0, "case %d: %d rows differ, first %s got %s want %s" % (
+            k, len(bad), bad[0], got[tuple(bad[0])], want[tuple(bad[0])])
+
+
 @pytest.mark.parametrize("b,n,m,r,ns", [(1, 100, 70, 0.3, 5), (2, 1000, 300, 1e-4, 8), (1, 37, 3, 10.0, 200),
                                         (1, 2000, 515, 0.25, 33), (1, 9, 1, 0.5, 1), (1, 64, 64, 0.4, 300),
-                                        (1, 70000, 130, 0.05, 40), (2, 4099, 777, 0.3, 128), (1, 33, 65, 2.0, 7)])
+                                        (1, 70000, 130, 0.05, 40), (2, 4099, 777, 0.3, 128), (1, 33, 65, 2.0, 7),
+                                        (3, 16384, 1000, 0.1, 64), (2, 5000, 600, 0.02, 16), (1, 8192, 300, 0.6, 32),
+                                        (2, 3000, 200, 0.15, 3), (1, 3000, 300, 0.1, 24), (1, 140000, 100, 0.05, 8),
+                                        (2, 2048, 4096, 0.2, 12)])
 def test_ball_query_edges(cuda, bq_path, b, n, m, r, ns):
     """odd sizes; empty balls (all-zero rows); full balls (early exit); nsample beyond the LDS
     staging limit (direct-store path)."""
