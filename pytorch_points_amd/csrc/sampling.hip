@@ -593,6 +593,69 @@ __global__ __launch_bounds__(1024) void group_points_grad_lds_kernel(const float
   for (int k = t; k < N; k += 1024) gp[k] += s_col[k];  // accumulate: the ABI's contract
 }
 
+// The same with a DOUBLE column: on gfx950 ds_add_f64 runs at 3.3 lanes/clk/CU against 0.36 for
+// ds_add_f32 (tools/lds_atomic_probe.hip), so widening the accumulator is 9x faster -- and the sum
+// is rounded to fp32 once, at the end, instead of at every addend.  A workgroup owns W <= 19456
+// destinations (8 W bytes of LDS) of one (batch, channel): the whole column when N fits, otherwise
+// one of `nsplit` ranges, each workgroup streaming the column's grad_out and skipping the entries
+// of the other ranges.  U 16-byte load pairs are in flight per thread before the first atomic.
+template <int U>
+__global__ __launch_bounds__(1024) void group_points_grad_lds64_kernel(const float* __restrict__ grad_out,
+                                                                       const int* __restrict__ idx,
+                                                                       float* __restrict__ grad_points,
+                                                                       int B, int C, int N, long long P,
+                                                                       long long gbs, int nsplit, int W) {
+  extern __shared__ __attribute__((aligned(16))) double s_col64[];
+  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+  const int per_b = C * nsplit;
+  const int b = x + 8 * (y / per_b);
+  const int r = y % per_b;
+  const int c = r / nsplit;
+  const int lo = (r - c * nsplit) * W;     // this workgroup's destinations: [lo, lo + w)
+  const int w = min(W, N - lo);
+  if (b >= B) return;
+  const int t = threadIdx.x;
+  for (int k = t; k < w; k += 1024) s_col64[k] = 0.0;
+  __syncthreads();
+  const float* __restrict__ go = grad_out + (size_t)b * gbs + (size_t)c * P;
+  const int* __restrict__ ib = idx + (size_t)b * P;
+  const long long p4 = P >> 2;
+  auto add1 = [&](int i, double v) {
+    if ((unsigned)(i - lo) < (unsigned)w) atomicAdd(&s_col64[i - lo], v);
+  };
+  // Runs of equal consecutive indices (the pad of a ball_query row repeats its first index) are
+  // summed in registers and added once, by the run's first element: same-address LDS atomics
+  // serialise, and at config 4 a third of all entries are pads.
+  auto add4 = [&](const pp::f4& g, const pp::i4& i) {
+    const bool e1 = i.y == i.x, e2 = i.z == i.y, e3 = i.w == i.z;
+    const double sw = (double)g.w;
+    const double sz = (double)g.z + (e3 ? sw : 0.0);
+    const double sy = (double)g.y + (e2 ? sz : 0.0);
+    const double sx = (double)g.x + (e1 ? sy : 0.0);
+    add1(i.x, sx);
+    if (!e1) add1(i.y, sy);
+    if (!e2) add1(i.z, sz);
+    if (!e3) add1(i.w, sw);
+  };
+  long long e = t;
+  for (; e + 1024 * (U - 1) < p4; e += 1024 * U) {
+    pp::f4 g[U];
+    pp::i4 i[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      g[u] = reinterpret_cast<const pp::f4*>(go)[e + 1024 * u];
+      i[u] = reinterpret_cast<const pp::i4*>(ib)[e + 1024 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) add4(g[u], i[u]);
+  }
+  for (; e < p4; e += 1024) add4(reinterpret_cast<const pp::f4*>(go)[e], reinterpret_cast<const pp::i4*>(ib)[e]);
+  for (long long q = (p4 << 2) + t; q < P; q += 1024) add1(ib[q], (double)go[q]);
+  __syncthreads();
+  float* __restrict__ gp = grad_points + ((size_t)b * C + c) * N + lo;
+  for (int k = t; k < w; k += 1024) gp[k] += (float)s_col64[k];  // accumulate: the ABI's contract
+}
+
 // ------------------------------------------------------------------------------------------------
 // three_nn (ref interpolate_gpu.cu:9-52): the three smallest dist3 and their indices, ascending,
 // strict < at every rank (earlier index wins ties).  The reference keeps the bests as double
@@ -911,7 +974,8 @@ extern "C" int pp_group_points_strided_f32(const float* points, const int* idx, 
   return PP_OK;
 }
 
-// 0 = automatic; 1 = force global atomics; 2 = force the LDS-column form (tests and tuning)
+// 0 = automatic; 1 = force global atomics; 2 = force the LDS-column form (double column when it
+// fits); 3 = force the LDS-column form with the fp32 column (tests and tuning)
 static int g_group_grad_variant = 0;
 extern "C" void pp_debug_set_group_points_grad_variant(int v) { g_group_grad_variant = v; }
 
@@ -931,18 +995,34 @@ extern "C" int pp_group_points_grad_strided_f32(const float* grad_out, const int
   if (gbs < (long long)C * P) return PP_EINVAL;
   if (B == 0 || C == 0 || P == 0) return PP_OK;
   if (!grad_out || !idx || !grad_points || N == 0) return PP_EINVAL;
-  // LDS-column form: the column fits the LDS, 16-byte aligned streams, enough work per column
-  if (g_group_grad_variant != 1 && (size_t)N * sizeof(float) <= 160 * 1024 &&
+  // LDS-column forms: 16-byte aligned streams, enough work per column
+  if (g_group_grad_variant != 1 &&
       (uintptr_t)grad_out % 16 == 0 && (uintptr_t)idx % 16 == 0 && P % 4 == 0 && gbs % 4 == 0 &&
-      8LL * ((B + 7) / 8) * C <= 0x7fffffffLL && (g_group_grad_variant == 2 || P >= 4096)) {
-    static bool lds_ok[64] = {};
-    const hipError_t e = pp::allow_big_lds(group_points_grad_lds_kernel, 160 * 1024, lds_ok);
-    if (e != hipSuccess) return (int)e;
-    group_points_grad_lds_kernel<<<dim3((unsigned)(8 * ((B + 7) / 8) * C)), dim3(1024),
-                                   (size_t)N * sizeof(float), (hipStream_t)stream>>>(
-        grad_out, idx, grad_points, B, C, N, P, gbs);
-    PP_RETURN_IF_LAUNCH_FAILED();
-    return PP_OK;
+      8LL * ((B + 7) / 8) * C <= 0x7fffffffLL && (g_group_grad_variant >= 2 || P >= 4096)) {
+    constexpr int kW64 = 152 * 1024 / 8;  // destinations per workgroup with a double column
+    const int nsplit = (N + kW64 - 1) / kW64;
+    const long long wgs = 8LL * ((B + 7) / 8) * C * nsplit;
+    if (g_group_grad_variant != 3 && nsplit <= 16 && wgs <= 0x7fffffffLL) {
+      const int W = nsplit == 1 ? N : kW64;
+      static bool lds64_ok[64] = {};
+      const hipError_t e = pp::allow_big_lds(group_points_grad_lds64_kernel<8>, 152 * 1024, lds64_ok);
+      if (e != hipSuccess) return (int)e;
+      group_points_grad_lds64_kernel<8><<<dim3((unsigned)wgs), dim3(1024), (size_t)W * sizeof(double),
+                                          (hipStream_t)stream>>>(grad_out, idx, grad_points, B, C, N, P, gbs,
+                                                                 nsplit, W);
+      PP_RETURN_IF_LAUNCH_FAILED();
+      return PP_OK;
+    }
+    if ((size_t)N * sizeof(float) <= 160 * 1024) {  // fp32 column (kept for comparison: ds_add_f32 is slow)
+      static bool lds_ok[64] = {};
+      const hipError_t e = pp::allow_big_lds(group_points_grad_lds_kernel, 160 * 1024, lds_ok);
+      if (e != hipSuccess) return (int)e;
+      group_points_grad_lds_kernel<<<dim3((unsigned)(8 * ((B + 7) / 8) * C)), dim3(1024),
+                                     (size_t)N * sizeof(float), (hipStream_t)stream>>>(
+          grad_out, idx, grad_points, B, C, N, P, gbs);
+      PP_RETURN_IF_LAUNCH_FAILED();
+      return PP_OK;
+    }
   }
   const long long cols = (P + 255) / 256;
   const int cpb = pick_c_per_block(cols, B, C);

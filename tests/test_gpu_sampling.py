@@ -232,10 +232,10 @@ def test_ball_query_edges(cuda, bq_path, b, n, m, r, ns):
 
 
 # --------------------------------------------------------------------------------- group points
-@pytest.fixture(params=["auto", "global_atomics", "lds_columns"])
+@pytest.fixture(params=["auto", "global_atomics", "lds_columns", "lds_columns_f32"])
 def group_grad_path(request, cuda):
-    """auto = sorted-triples scatter-add where it qualifies (scatter.hip); the other two switch it
-    off and force one of the atomic kernels."""
+    """auto = sorted-triples scatter-add where it qualifies (scatter.hip); the others switch it off and
+    force global atomics, the LDS column in double (ds_add_f64) or the LDS column in fp32."""
     import ctypes
     from pytorch_points_amd import _lib
     setter = _lib.lib().pp_debug_set_group_points_grad_variant
@@ -244,7 +244,7 @@ def group_grad_path(request, cuda):
     smode = _lib.lib().pp_debug_set_scatter_mode
     smode.argtypes = [ctypes.c_int]
     smode.restype = None
-    setter({"auto": 0, "global_atomics": 1, "lds_columns": 2}[request.param])
+    setter({"auto": 0, "global_atomics": 1, "lds_columns": 2, "lds_columns_f32": 3}[request.param])
     smode(0 if request.param == "auto" else 1)
     yield request.param
     setter(0)
@@ -307,6 +307,26 @@ def test_group_points_matches_torch_and_backward(cuda, group_grad_path, b, c, n,
     assert torch.allclose(g, f.grad, rtol=1e-5, atol=1e-5)
     e = oracle.group_points_grad(w.cpu().numpy(), idx.cpu().numpy(), n)
     assert np.allclose(g.cpu().numpy(), e, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,c,n,npoint,ns,r", [(2, 6, 4096, 512, 64, 0.08), (1, 5, 50000, 1024, 32, 0.02),
+                                               (9, 3, 20001, 256, 16, 0.05), (2, 4, 2048, 300, 24, 0.6)])
+def test_group_points_grad_ball_rows_and_split_columns(cuda, group_grad_path, b, c, n, npoint, ns, r):
+    """index rows as ball_query writes them (ascending hits, then the first one repeated: runs of equal
+    consecutive indices, merged in registers by the double-column kernel), and clouds too large for
+    one LDS column (n > 19456: the column is split into destination ranges)."""
+    from pytorch_points_amd._ext import sampling
+    x = S.unit_sphere(45, b, n)
+    idx = sampling.ball_query(_t(np.ascontiguousarray(x[:, :npoint]), cuda), _t(x, cuda), r, ns)
+    idx[:, 0, :] = n - 1                 # a whole row on the last destination
+    idx[:, -1, 1::2] = idx[:, -1, 0:1]   # alternating: no runs longer than one
+    go = _t(S.normal(46, (b, c, npoint, ns)), cuda)
+    got = sampling.group_points_grad(go, idx, n)
+    ref = torch.zeros(b, c, n, device=cuda, dtype=torch.float64)
+    ref.scatter_add_(2, idx.long().reshape(b, 1, -1).expand(-1, c, -1), go.double().reshape(b, c, -1))
+    assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-5)
+    e = oracle.group_points_grad(go.cpu().numpy(), idx.cpu().numpy(), n)
+    assert np.allclose(got.cpu().numpy(), e, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("variant", [1, 2, 4, 8, 104, 108, 116, 132])
