@@ -138,6 +138,14 @@ int pp_group_points_grad_strided_f32(const float* grad_out, const int* idx, floa
 int pp_three_nn_f32(const float* unknown, const float* known, float* dist2, int* idx, int B, int N,
                     int M, void* stream);
 
+/* The same three_nn through an exact uniform-grid search (three_nn_grid.hip): identical outputs,
+ * a few dozen candidates per unknown point instead of M.  pp_three_nn_workspace_bytes returns 0
+ * when the grid path does not apply (small N or M); with a null / too small workspace the call is
+ * pp_three_nn_f32.  The workspace is scratch: no state is kept between calls. */
+size_t pp_three_nn_workspace_bytes(int B, int N, int M);
+int pp_three_nn_ws_f32(const float* unknown, const float* known, float* dist2, int* idx, int B, int N,
+                       int M, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Replaces sampling.three_interpolate_wrapper(b,c,m,n,points,idx,weight,out)
  *   (_ext/sampling.cpp:175-188 -> _ext/interpolate_gpu.cu:77-117).
  * points (B,C,M), idx (B,N,3), weight (B,N,3) -> out (B,C,N) */

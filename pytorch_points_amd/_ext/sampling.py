@@ -107,6 +107,18 @@ def gather_backward(b, c, n, npoints, grad_out, idx, grad_points):
     return 1
 
 
+def _named_workspace(dev, name, nbytes):
+    """scratch for the grid searches, one per (device, stream, op); None when nbytes == 0"""
+    if not nbytes:
+        return None
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, name)
+    ws = _scatter_workspace.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _scatter_workspace[key] = ws
+    return ws
+
+
 def ball_query(new_xyz, xyz, radius, nsample):
     """ball_query_wrapper_fast (sampling.cpp:85-104): new_xyz (B,M,3) centres, xyz (B,N,3) ->
     int32 idx (B,M,nsample)."""
@@ -122,13 +134,7 @@ def ball_query(new_xyz, xyz, radius, nsample):
     idx = torch.empty(b, m, nsample, dtype=torch.int32, device=dev)  # kernel writes every slot
     with _lib.on_device(dev) as stream:
         nbytes = int(_lib.lib().pp_ball_query_workspace_bytes(b, n, m, nsample))
-        ws = None
-        if nbytes:
-            key = (dev, torch.cuda.current_stream(dev).cuda_stream, "ball_query")
-            ws = _scatter_workspace.get(key)
-            if ws is None or ws.numel() < nbytes:
-                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                _scatter_workspace[key] = ws
+        ws = _named_workspace(dev, "ball_query", nbytes)
         _lib.check(_lib.lib().pp_ball_query_ws_f32(
             _lib.ptr(new_xyz), _lib.ptr(xyz), _lib.ptr(idx), b, n, m, float(radius), nsample,
             _lib.ptr(ws) if ws is not None else None, nbytes, stream), "ball_query")
@@ -229,9 +235,11 @@ def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
             or idx.numel() != b * n * 3:
         raise RuntimeError("three_nn_wrapper: tensor sizes do not match (b, n, m)")
     with _lib.on_device(dev) as stream:
-        _lib.check(_lib.lib().pp_three_nn_f32(
-            _lib.ptr(unknown), _lib.ptr(known), _lib.ptr(dist2), _lib.ptr(idx), b, n, m, stream),
-            "three_nn_wrapper")
+        nbytes = int(_lib.lib().pp_three_nn_workspace_bytes(b, n, m))
+        ws = _named_workspace(dev, "three_nn", nbytes)
+        _lib.check(_lib.lib().pp_three_nn_ws_f32(
+            _lib.ptr(unknown), _lib.ptr(known), _lib.ptr(dist2), _lib.ptr(idx), b, n, m,
+            _lib.ptr(ws) if ws is not None else None, nbytes, stream), "three_nn_wrapper")
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):

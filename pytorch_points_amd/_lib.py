@@ -32,6 +32,8 @@ SIGNATURES = {
     "pp_ball_query_f32": [_P, _P, _P, _I, _I, _I, _F, _I, _P],
     "pp_ball_query_workspace_bytes": [_I, _I, _I, _I],
     "pp_ball_query_ws_f32": [_P, _P, _P, _I, _I, _I, _F, _I, _P, _c_size_t, _P],
+    "pp_three_nn_workspace_bytes": [_I, _I, _I],
+    "pp_three_nn_ws_f32": [_P, _P, _P, _P, _I, _I, _I, _P, _c_size_t, _P],
     "pp_group_points_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pp_group_points_grad_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pp_group_points_strided_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P],
@@ -46,7 +48,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"pp_version": ctypes.c_char_p, "pp_furthest_sampling_workspace_bytes": _c_size_t,
              "pp_nmdistance_forward_workspace_bytes": _c_size_t,
-             "pp_scatter_workspace_bytes": _c_size_t, "pp_ball_query_workspace_bytes": _c_size_t}
+             "pp_scatter_workspace_bytes": _c_size_t, "pp_ball_query_workspace_bytes": _c_size_t,
+             "pp_three_nn_workspace_bytes": _c_size_t}
 
 _lib = None
 

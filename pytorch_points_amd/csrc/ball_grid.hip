@@ -5,7 +5,9 @@
 //
 // A hit needs dist3 < r^2 in fp32, hence |p_a - q_a| <= r(1 + 1e-6) on every axis; the cell
 // coordinate is a monotone function of the coordinate, so every hit of a centre lies in its cell
-// box [cell(q - r'), cell(q + r')] with r' = r(1 + 1e-5) + tiny.
+// box [cell(lo), cell(hi)] with lo <= q - r' and hi >= q + r' in exact arithmetic, r' = r(1 + 1e-5)
+// (the fp32 sums q -+ r' are pushed outwards by more than their rounding error: coordinates may be
+// large against r).
 //
 // The reference's order (ascending index, cut at nsample) is what makes this more than a range
 // query.  A wave takes 64 centres that are close in space (the build kernel also sorts the centres,
@@ -131,9 +133,12 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
   __syncthreads();
   // 1. cells of the 64 boxes: a row of cells along x is a run of consecutive bits
   if (valid) {
-    const int x0 = cell_coord(q.x - rpad, g.minx, g.invh, g.gx), x1 = cell_coord(q.x + rpad, g.minx, g.invh, g.gx);
-    const int y0 = cell_coord(q.y - rpad, g.miny, g.invh, g.gy), y1 = cell_coord(q.y + rpad, g.miny, g.invh, g.gy);
-    const int z0 = cell_coord(q.z - rpad, g.minz, g.invh, g.gz), z1 = cell_coord(q.z + rpad, g.minz, g.invh, g.gz);
+    // bounds rounded OUTWARDS by more than an ulp: q -+ r' is rounded to fp32, and |q| may dwarf r
+    auto above = [](float v) { return v + (fabsf(v) * 1.2e-7f + 1e-37f); };
+    auto below = [](float v) { return v - (fabsf(v) * 1.2e-7f + 1e-37f); };
+    const int x0 = cell_coord(below(q.x - rpad), g.minx, g.invh, g.gx), x1 = cell_coord(above(q.x + rpad), g.minx, g.invh, g.gx);
+    const int y0 = cell_coord(below(q.y - rpad), g.miny, g.invh, g.gy), y1 = cell_coord(above(q.y + rpad), g.miny, g.invh, g.gy);
+    const int z0 = cell_coord(below(q.z - rpad), g.minz, g.invh, g.gz), z1 = cell_coord(above(q.z + rpad), g.minz, g.invh, g.gz);
     const unsigned long long run = (2ull << (x1 - x0)) - 1ull;  // x1 - x0 + 1 <= 8 ones
     const int ny = y1 - y0 + 1, nzy = (z1 - z0 + 1) * ny;
     for (int t = sub; t < nzy; t += LPC) {  // the centre's rows, dealt to its LPC lanes

@@ -1,0 +1,174 @@
+// three_nn_grid.hip -- three_nn through the uniform grid of grid_common.h, with the scan kernel of
+// sampling.hip as the fallback.  Same output as the scan (ref _ext/interpolate_gpu.cu:9-52): per
+// unknown point the three smallest dist3 over the known points and their indices, ascending,
+// earlier index first among equal distances (the reference's strict `<` in index order) -- i.e. the
+// three smallest pairs (dist3, index) in lexicographic order.
+//
+// The known points of a batch element are counting-sorted into the grid (cell side h); the unknown
+// points are sorted along a Morton curve so that the lanes of a wave walk neighbouring cells.  A
+// lane searches the cell box [cell(q - R), cell(q + R)], R = h first, keeping the three smallest
+// (dist3, index) pairs of the box (same arithmetic as the scan: pp::dist3).  A known point outside
+// that box lies beyond one of the (rounded) bounds q -+ R along some axis (the cell coordinate is
+// monotone in the coordinate), so it differs from q by more than reach = min over the axes of
+// fl(q + R) - q and q - fl(q - R), and its fp32 dist3 is >= reach^2 (1 - 1e-6): once the third
+// best is < 0.9999 reach^2 no outside point can enter the result or tie with it, and the lane is
+// done.  (reach, not R: coordinates may be large against the cell size.)  Otherwise R doubles
+// and the lane searches again; a box that covers the whole grid ends the search unconditionally
+// (that is the scan).  Batch elements whose grid is useless go to the scan kernel.
+#include "grid_common.h"
+
+namespace pp {
+// sampling.hip: the scan kernel over the batch elements whose grid set says "not usable"
+int three_nn_scan_unusable(const float* unknown, const float* known, float* dist2, int* idx, int B, int N,
+                           int M, const GridSet* sets, hipStream_t s);
+}  // namespace pp
+
+namespace {
+
+using pp::GridSet;
+using pp::cell_coord;
+using pp::kGridCells;
+using pp::kBuildThreads;
+
+struct TnLayout {
+  size_t sets, cell_start, sorted, qsorted, total;
+};
+__host__ __device__ inline TnLayout tn_layout(int B, int N, int M) {
+  TnLayout L;
+  L.sets = 0;  // [2B]: sets of the known clouds, then the (unused) sets of the query sort
+  L.cell_start = ((size_t)64 * 2 * B + 255) / 256 * 256;
+  L.sorted = L.cell_start + ((size_t)4 * (kGridCells + 1) * B + 255) / 256 * 256;
+  L.qsorted = L.sorted + ((size_t)16 * B * M + 255) / 256 * 256;
+  L.total = L.qsorted + (size_t)16 * B * N;
+  return L;
+}
+
+// blocks [0, B): known points of batch element b into their grid; blocks [B, 2B): the unknown
+// points of batch element b into Morton order
+__global__ __launch_bounds__(kBuildThreads) void tn_build_kernel(const float* __restrict__ known,
+                                                                 const float* __restrict__ unknown,
+                                                                 unsigned char* __restrict__ ws, int B, int N,
+                                                                 int M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];
+  const TnLayout L = tn_layout(B, N, M);
+  GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + blockIdx.x;
+  if ((int)blockIdx.x >= B) {
+    const int b = blockIdx.x - B;
+    pp::grid_build_set<true>(unknown + (size_t)b * N * 3, N, gs, nullptr,
+                             reinterpret_cast<pp::f4*>(ws + L.qsorted) + (size_t)b * N, nullptr, s_cnt);
+    return;
+  }
+  const int b = blockIdx.x;
+  pp::grid_build_set<false>(known + (size_t)b * M * 3, M, gs,
+                            reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
+                            reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * M, nullptr, s_cnt);
+  __syncthreads();
+  if (threadIdx.x == 0) gs->pad[0] = gs->useless ? 0 : 1;  // 1: the grid kernel serves this batch element
+}
+
+// (d, k) enters the ascending triple if it is lexicographically smaller than an entry
+__device__ __forceinline__ void insert3(float d, int k, float& b1, float& b2, float& b3, int& i1, int& i2,
+                                        int& i3) {
+  const bool l1 = d < b1 || (d == b1 && k < i1);
+  const bool l2 = d < b2 || (d == b2 && k < i2);
+  const bool l3 = d < b3 || (d == b3 && k < i3);
+  b3 = l2 ? b2 : (l3 ? d : b3);
+  i3 = l2 ? i2 : (l3 ? k : i3);
+  b2 = l1 ? b1 : (l2 ? d : b2);
+  i2 = l1 ? i1 : (l2 ? k : i2);
+  b1 = l1 ? d : b1;
+  i1 = l1 ? k : i1;
+}
+
+__global__ __launch_bounds__(256) void tn_query_kernel(float* __restrict__ dist2, int* __restrict__ idx,
+                                                       const unsigned char* __restrict__ ws, int B, int N, int M,
+                                                       int tiles_per_b, int per_xcd) {
+  const int vb = pp::xcd_virtual_block(blockIdx.x, per_xcd);  // a batch element stays on one XCD's L2
+  if (vb >= B * tiles_per_b) return;
+  const int b = vb / tiles_per_b;
+  const int tile = vb - b * tiles_per_b;
+  const TnLayout L = tn_layout(B, N, M);
+  const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[b];
+  if (!g.pad[0]) return;  // this batch element goes to the scan kernel
+  const int n = tile * 256 + threadIdx.x;
+  if (n >= N) return;
+  const unsigned* __restrict__ cell_start =
+      reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1);
+  const pp::f4* __restrict__ sorted = reinterpret_cast<const pp::f4*>(ws + L.sorted) + (size_t)b * M;
+  const pp::f4 q = (reinterpret_cast<const pp::f4*>(ws + L.qsorted) + (size_t)b * N)[n];
+  const int qorig = __float_as_int(q.w);
+
+  float b1, b2, b3;
+  int i1, i2, i3;
+  const bool finite_q = __builtin_isfinite(q.x) && __builtin_isfinite(q.y) && __builtin_isfinite(q.z);
+  float R = finite_q ? g.h : 2.0e38f;
+  while (true) {
+    b1 = b2 = b3 = __builtin_inff();
+    i1 = i2 = i3 = 0;
+    const float lx = q.x - R, hx = q.x + R, ly = q.y - R, hy = q.y + R, lz = q.z - R, hz = q.z + R;
+    const bool everything = !(R < 1.0e38f);  // last round (also: non-finite q): the whole grid, no questions
+    const int x0 = everything ? 0 : cell_coord(lx, g.minx, g.invh, g.gx);
+    const int x1 = everything ? g.gx - 1 : cell_coord(hx, g.minx, g.invh, g.gx);
+    const int y0 = everything ? 0 : cell_coord(ly, g.miny, g.invh, g.gy);
+    const int y1 = everything ? g.gy - 1 : cell_coord(hy, g.miny, g.invh, g.gy);
+    const int z0 = everything ? 0 : cell_coord(lz, g.minz, g.invh, g.gz);
+    const int z1 = everything ? g.gz - 1 : cell_coord(hz, g.minz, g.invh, g.gz);
+    // what the box really guarantees, from the rounded bounds themselves (|q| may dwarf R)
+    const float reach = fminf(fminf(fminf(hx - q.x, q.x - lx), fminf(hy - q.y, q.y - ly)), fminf(hz - q.z, q.z - lz));
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        const int c = (z * g.gy + y) * g.gx;
+        const unsigned e = cell_start[c + x1 + 1];
+        for (unsigned i = cell_start[c + x0]; i < e; i += 2) {
+          const pp::f4 p0 = sorted[i];
+          const pp::f4 p1 = sorted[min(i + 1, e - 1)];
+          insert3(pp::dist3(q.x, q.y, q.z, p0.x, p0.y, p0.z), __float_as_int(p0.w), b1, b2, b3, i1, i2, i3);
+          if (i + 1 < e)
+            insert3(pp::dist3(q.x, q.y, q.z, p1.x, p1.y, p1.z), __float_as_int(p1.w), b1, b2, b3, i1, i2, i3);
+        }
+      }
+    const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.gx - 1 && y1 == g.gy - 1 && z1 == g.gz - 1;
+    if (whole || b3 < 0.9999f * (reach * reach)) break;
+    R *= 2.0f;
+  }
+  float* od = dist2 + ((size_t)b * N + qorig) * 3;
+  int* oi = idx + ((size_t)b * N + qorig) * 3;
+  od[0] = b1; od[1] = b2; od[2] = b3;
+  oi[0] = i1; oi[1] = i2; oi[2] = i3;
+}
+
+}  // namespace
+
+// 0 = automatic (grid when a workspace is given); 1 = scan kernel only (tests and tuning)
+static int g_tn_grid_mode = 0;
+extern "C" void pp_debug_set_three_nn_search(int v) { g_tn_grid_mode = v; }
+
+extern "C" size_t pp_three_nn_workspace_bytes(int B, int N, int M) {
+  if (B <= 0 || N < 1024 || M < 1024) return 0;
+  if ((long long)B * N >= (1LL << 31) || (long long)B * M >= (1LL << 31)) return 0;
+  return tn_layout(B, N, M).total;
+}
+
+extern "C" int pp_three_nn_ws_f32(const float* unknown, const float* known, float* dist2, int* idx, int B, int N,
+                                  int M, void* workspace, size_t workspace_bytes, void* stream) {
+  const size_t need = pp_three_nn_workspace_bytes(B, N, M);
+  if (g_tn_grid_mode == 1 || need == 0 || !workspace || workspace_bytes < need)
+    return pp_three_nn_f32(unknown, known, dist2, idx, B, N, M, stream);
+  if (!unknown || !known || !dist2 || !idx) return PP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  static bool lds_ok[64] = {};
+  const size_t lds = (size_t)(kGridCells + kGridCells / 32) * sizeof(unsigned);
+  hipError_t e = pp::allow_big_lds(tn_build_kernel, (int)lds, lds_ok);
+  if (e != hipSuccess) return (int)e;
+  tn_build_kernel<<<dim3(2 * B), dim3(kBuildThreads), lds, s>>>(known, unknown, ws, B, N, M);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  const int tiles = (N + 255) / 256;
+  const long long per_xcd = ((long long)B * tiles + 7) / 8;
+  if (per_xcd * 8 > 0x7fffffffLL) return PP_EINVAL;
+  tn_query_kernel<<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(dist2, idx, ws, B, N, M, tiles, (int)per_xcd);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  const TnLayout L = tn_layout(B, N, M);
+  return pp::three_nn_scan_unusable(unknown, known, dist2, idx, B, N, M,
+                                    reinterpret_cast<const GridSet*>(ws + L.sets), s);
+}

@@ -206,6 +206,8 @@ def test_ball_query_grid_adversarial(cuda, bq_path):
     cases.append((cl, cl[:, :m].copy(), 2e-3, 64))                              # one tight cluster: dense balls
     mixed = np.concatenate([S.unit_sphere(38, 1, n), S.unit_sphere(39, 1, n) * np.float32(1e-2)], 0)
     cases.append((mixed, mixed[:, ::9].copy()[:, :m], 0.05, 20))                # element 1: radius >> cell
+    off = S.unit_sphere(40, 1, n) + np.float32(2000.0)
+    cases.append((off, off[:, ::5].copy()[:, :m], 0.07, 32))                    # coordinates >> radius and cell size
     for k, (x, c, r, ns) in enumerate(cases):
         x = np.ascontiguousarray(x); c = np.ascontiguousarray(c)
         got = sampling.ball_query(_t(c, cuda), _t(x, cuda), r, ns).cpu().numpy()
@@ -275,8 +277,28 @@ def test_gather_backward_large(cuda, scatter_path, b, c, n, m):
     assert torch.allclose(gp.double(), ref, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("b,c,n,m", [(2, 33, 16384, 4096), (9, 8, 5001, 700), (1, 64, 40000, 20480)])
-def test_three_interpolate_grad_large(cuda, scatter_path, b, c, n, m):
+@pytest.fixture(params=["auto", "global_atomics", "lds_columns", "sorted"])
+def interp_grad_path(request, cuda):
+    """three_interpolate_grad forms: global atomics (the reference's), LDS columns in double
+    (ds_add_f64), sorted triples (scatter.hip)"""
+    import ctypes
+    from pytorch_points_amd import _lib
+    setter = _lib.lib().pp_debug_set_three_interpolate_grad_variant
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    smode = _lib.lib().pp_debug_set_scatter_mode
+    smode.argtypes = [ctypes.c_int]
+    smode.restype = None
+    setter({"auto": 0, "global_atomics": 1, "lds_columns": 2, "sorted": 3}[request.param])
+    smode(1 if request.param == "global_atomics" else 0)
+    yield request.param
+    setter(0)
+    smode(0)
+
+
+@pytest.mark.parametrize("b,c,n,m", [(2, 33, 16384, 4096), (9, 8, 5001, 700), (1, 64, 40000, 20480), (3, 6, 3000, 9000),
+                                     (2, 3, 2500, 19456)])
+def test_three_interpolate_grad_large(cuda, interp_grad_path, b, c, n, m):
     from pytorch_points_amd._ext import sampling
     go = _t(S.normal(25, (b, c, n)), cuda)
     idx = _t((S.uniform01(26, (b, n, 3)).reshape(b, n, 3) * m).astype(np.int32), cuda)
@@ -432,6 +454,64 @@ def test_three_nn_matches_oracle(cuda, b, n, m):
         assert np.array_equal(dist.cpu().numpy(), np.sqrt(e_d2))     # wrapper returns sqrt (ref :33)
     if m < 3:
         assert np.isinf(dist.cpu().numpy()[..., m:]).all() and (e_idx[..., m:] == 0).all()
+
+
+@pytest.fixture(params=["grid", "scan"])
+def tn_path(request, cuda):
+    import ctypes
+    from pytorch_points_amd import _lib
+    search = _lib.lib().pp_debug_set_three_nn_search
+    search.argtypes = [ctypes.c_int]
+    search.restype = None
+    search(0 if request.param == "grid" else 1)
+    yield request.param
+    search(0)
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 4096, 1024), (3, 5000, 3001), (1, 16384, 4096), (2, 1024, 8192), (1, 70000, 1500)])
+def test_three_nn_grid_matches_oracle(cuda, tn_path, b, n, m):
+    from pytorch_points_amd._ext import sampling
+    u = S.unit_sphere(62, b, n)
+    k = S.unit_sphere(63, b, m)
+    k[:, m // 2:m // 2 + 5] = k[:, :5]                # exact ties at every rank
+    u[:, :7] = k[:, 10:17]                            # zero distances
+    d2 = torch.empty(b, n, 3, device=cuda)
+    idx = torch.empty(b, n, 3, dtype=torch.int32, device=cuda)
+    sampling.three_nn_wrapper(b, n, m, _t(u, cuda), _t(k, cuda), d2, idx)
+    e_d2, e_idx = oracle.three_nn(u, k)
+    assert np.array_equal(idx.cpu().numpy(), e_idx) and np.array_equal(d2.cpu().numpy(), e_d2)
+
+
+def test_three_nn_grid_adversarial(cuda, tn_path):
+    """data built to break the grid search: cloud far from the origin (coordinates >> cell size),
+    planar / collinear / clustered known points, unknown points far outside the known cloud, all
+    known points identical (useless grid -> scan fallback for that batch element only), duplicates"""
+    from pytorch_points_amd._ext import sampling
+    n, m = 3000, 2048
+    cases = []
+    cases.append((S.unit_sphere(64, 1, n) + np.float32(1000.0), S.unit_sphere(65, 1, m) + np.float32(1000.0)))
+    pl = S.uniform01(66, (1, m, 3)).reshape(1, m, 3).astype(np.float32); pl[..., 1] = -3.0
+    cases.append((S.unit_sphere(67, 1, n), pl))
+    ln = np.zeros((1, m, 3), np.float32); ln[0, :, 2] = np.linspace(-1, 1, m, dtype=np.float32)
+    cases.append((S.unit_sphere(68, 1, n), ln))
+    cases.append((S.unit_sphere(69, 1, n) * np.float32(50), S.unit_sphere(70, 1, m)))
+    cl = (S.normal(71, (1, m, 3)) * 1e-3).astype(np.float32); cl[0, ::3] += np.float32(0.7)
+    cases.append((S.unit_sphere(72, 1, n), cl))
+    same = np.concatenate([np.full((1, m, 3), 0.25, np.float32), S.unit_sphere(73, 1, m)], 0)
+    cases.append((S.unit_sphere(74, 2, n), same))
+    dup = S.unit_sphere(75, 1, m); dup[0, m // 4:] = dup[0, : m - m // 4]
+    cases.append((dup[:, ::-1][:, :n // 2].repeat(2, 1).copy(), dup))
+    for i, (u, k) in enumerate(cases):
+        u = np.ascontiguousarray(u, np.float32); k = np.ascontiguousarray(k, np.float32)
+        b = u.shape[0]
+        d2 = torch.empty(b, u.shape[1], 3, device=cuda)
+        idx = torch.empty(b, u.shape[1], 3, dtype=torch.int32, device=cuda)
+        sampling.three_nn_wrapper(b, u.shape[1], k.shape[1], _t(u, cuda), _t(k, cuda), d2, idx)
+        e_d2, e_idx = oracle.three_nn(u, k)
+        bad = np.argwhere((idx.cpu().numpy() != e_idx).any(-1))
+        assert bad.size == 0, "case %d: %d rows differ, first %s got %s want %s" % (
+            i, len(bad), bad[0], idx.cpu().numpy()[tuple(bad[0])], e_idx[tuple(bad[0])])
+        assert np.array_equal(d2.cpu().numpy(), e_d2), "case %d distances" % i
 
 
 def test_three_interpolate_forward_backward(cuda):

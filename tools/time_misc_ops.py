@@ -27,8 +27,15 @@ ms = t(lambda: sampling.three_interpolate_wrapper(B, C, M, N, feats, idx, w, out
 byt = 4.0 * B * C * (M + N) + 24.0 * B * N
 print("three_interpolate C=%d: %.3f ms  (%.2f TB/s algorithmic)" % (C, ms, byt / ms / 1e9))
 gp = torch.zeros(B, C, M, device=dev)
-ms = t(lambda: sampling.three_interpolate_grad_wrapper(B, C, N, M, out, idx, w, gp))
-print("three_interpolate_grad: %.3f ms  (%.2f G atomics/s)" % (ms, 3.0 * B * C * N / ms / 1e6))
+import ctypes
+from pytorch_points_amd import _lib
+_v = _lib.lib().pp_debug_set_three_interpolate_grad_variant
+_v.argtypes = [ctypes.c_int]; _v.restype = None
+for name, v in (("auto", 0), ("lds columns f64", 2), ("sorted triples", 3)):
+    _v(v)
+    ms = t(lambda: sampling.three_interpolate_grad_wrapper(B, C, N, M, out, idx, w, gp))
+    print("three_interpolate_grad [%s]: %.3f ms  (%.2f G adds/s)" % (name, ms, 3.0 * B * C * N / ms / 1e6))
+_v(0)
 gi = torch.randint(0, N, (B, M), dtype=torch.int32, device=dev)
 f2 = torch.randn(B, C, N, device=dev); go = torch.empty(B, C, M, device=dev)
 ms = t(lambda: sampling.gather_forward(B, C, N, M, f2, gi, go)); print("gather_forward C=%d N=%d->%d: %.3f ms" % (C, N, M, ms))
