@@ -159,13 +159,14 @@ def bench_chamfer(args, dist, world, rank, device):
     x2.requires_grad_(True)
     g1 = torch.full((B, N), 1.0 / (B * N), device=device)   # gradient of dist.mean()
     g2 = torch.full((B, M), 1.0 / (B * M), device=device)
-    gathered = None
+    exchange = None
     if dist is not None:
-        # one collective per step: (dist1 | dist2 | idx1 | idx2) of the shard packed as 32-bit words
-        # (8 MiB per rank at B=32, N=M=16384), double-buffered because the gather is asynchronous
-        gathered = [torch.empty(world, B * 2 * (N + M), dtype=torch.float32, device=device) for _ in range(2)]
+        # one asynchronous collective per step: (dist1 | dist2 | idx1 | idx2) of the shard, packed (idx as
+        # 16-bit words: 6 MiB per rank at B=32, N=M=16384), double-buffered (pytorch_points_amd/sharded.py)
+        from pytorch_points_amd.sharded import PackedShardGather
+        exchange = PackedShardGather(B, N, M, device)
     fwd_events = []
-    pending = []   # (work handles, tensors kept alive) of the previous step's all-gather
+    pending = []   # slot of the previous step's all-gather
 
     def step():
         x1.grad = None
@@ -176,29 +177,20 @@ def bench_chamfer(args, dist, world, rank, device):
         d1, d2, i1, i2 = nndistance(x1, x2)
         e1.record()
         fwd_events.append((e0, e1))
-        if dist is not None:
+        if exchange is not None:
             # all-gather of the per-shard (dist, idx) over xGMI (RCCL), asynchronous: it runs on the
-            # collective stream beside this step's backward and the next step's forward, and is
-            # waited for before its buffers are reused (and before the timed region ends)
-            for w, _ in pending:
-                for h in w:
-                    h.wait()
-            pending.clear()
-            packed = torch.cat([d1.detach().reshape(-1), d2.detach().reshape(-1),
-                                i1.view(torch.float32).reshape(-1), i2.view(torch.float32).reshape(-1)])
-            out = gathered[len(fwd_events) & 1]
-            if dist.get_backend() == "nccl":
-                works = [dist.all_gather_into_tensor(out, packed, async_op=True)]
-            else:  # debug path only
-                works = [dist.all_gather(list(out.unbind(0)), packed, async_op=True)]
-            pending.append((works, packed))
+            # collective stream beside this step's backward and the next step's forward; the previous
+            # step's gathered result is consumed (unpacked to the global-batch tensors) first
+            if pending:
+                exchange.wait(pending.pop())
+            pending.append(exchange.launch(d1, d2, i1, i2))
         torch.autograd.backward([d1, d2], [g1, g2])
 
     def drain():
-        for w, _ in pending:
-            for h in w:
-                h.wait()
-        pending.clear()
+        if exchange is not None:
+            while pending:
+                exchange.wait(pending.pop())
+            exchange.drain()
 
     for _ in range(args.warmup):
         step()

@@ -83,3 +83,44 @@ def test_shard_bounds_partition_the_batch():
 def test_single_process_is_identity():
     x = torch.randn(2, 3)
     assert sharded.all_gather_batch(x) is x
+
+
+def _packed_worker(rank, world, port, n, m, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B = 3
+        ex = sharded.PackedShardGather(B, n, m, torch.device("cpu"))
+        ok = True
+        for step in range(3):   # more steps than buffers: slots are reused
+            g = torch.Generator().manual_seed(100 + step)
+            D1 = torch.rand(world * B, n, generator=g)
+            D2 = torch.rand(world * B, m, generator=g)
+            I1 = torch.randint(0, m, (world * B, n), generator=g, dtype=torch.int32)
+            I2 = torch.randint(0, n, (world * B, m), generator=g, dtype=torch.int32)
+            I1[:, 0] = m - 1        # the largest index (65535 in the compact case: above int16's range)
+            I2[:, -1] = n - 1
+            lo, hi = rank * B, (rank + 1) * B
+            h = ex.launch(D1[lo:hi], D2[lo:hi], I1[lo:hi], I2[lo:hi])
+            d1, d2, i1, i2 = ex.wait(h)
+            ok = ok and torch.equal(d1, D1) and torch.equal(d2, D2) and torch.equal(i1, I1) and torch.equal(i2, I2)
+            ok = ok and i1.dtype == torch.int32
+        ex.drain()
+        q.put((rank, bool(ok), ex.compact))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,m,compact", [(50, 65536, True), (70000, 33, False)])
+def test_packed_shard_gather_world2(n, m, compact):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_packed_worker, args=(r, 2, port, n, m, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True, compact), (1, True, compact)]
