@@ -51,6 +51,8 @@ def parse():
                     help="chamfer: auto = the operator's default (exact grid search, brute-force "
                          "fallback); bruteforce = evaluate every pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
+                    help="chamfer: replay the step as a hipGraph (default) or issue it eagerly")
     ap.add_argument("--with-backward", action="store_true", help="ball_group: also time group_points_grad")
     return ap.parse_args()
 
@@ -192,33 +194,71 @@ def bench_chamfer(args, dist, world, rank, device):
                 exchange.wait(pending.pop())
             exchange.drain()
 
-    for _ in range(args.warmup):
-        step()
-    drain()
-    fwd_events.clear()
+    def run_timed(fn, warmup, steps):
+        """W untimed steps, then exactly K steps between barrier+synchronize; MAX over ranks (seconds).
+        The last step's gather is part of the timed work: drained before the closing synchronize."""
+        for _ in range(warmup):
+            fn()
+        drain()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        drain()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([t], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        return t
 
-    def timed_steps():
-        step()
+    # hipGraph replay of the same step (pytorch_points_amd/graphs.py): the kernels of one step take
+    # less time than the Python/autograd work that launches them, so the eager loop is host-bound
+    gstep = None
+    graph_note = None
+    if args.launch == "graph":
+        try:
+            from pytorch_points_amd.graphs import GraphedChamferStep
+            gstep = GraphedChamferStep(B, N, M, device)
+            with torch.no_grad():
+                gstep.xyz1.copy_(x1)
+                gstep.xyz2.copy_(x2)
+                gstep.grad_dist1.copy_(g1)
+                gstep.grad_dist2.copy_(g2)
+            gstep.capture()
+        except Exception as exc:  # capture not available: report the eager loop and say so
+            gstep = None
+            graph_note = "graph capture failed (%s: %s); eager launches timed instead" % (type(exc).__name__, exc)
+    if dist is not None:  # every rank must take the same path
+        flag = torch.tensor([1 if gstep is not None else 0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            gstep = None
 
-    # the last step's gather is part of the timed work: drained before the closing synchronize
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events[-args.steps:]]))
+    def graph_step():
+        d1, d2, i1, i2, _, _ = gstep.replay()
+        if exchange is not None:
+            if pending:
+                exchange.wait(pending.pop())
+            pending.append(exchange.launch(d1, d2, i1, i2))   # packs on this stream, before the next replay
+
+    if gstep is not None:
+        dt = run_timed(graph_step, args.warmup, args.steps)
+        n_eager = max(5, min(args.steps, 20))
+        fwd_events.clear()
+        eager_dt = run_timed(step, 3, n_eager) / n_eager
+        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events[-n_eager:]]))
+    else:
+        dt = run_timed(step, args.warmup, args.steps)
+        eager_dt = dt / args.steps
+        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events[-args.steps:]]))
 
     # the same step with the search forced to the brute-force kernel (every pair evaluated)
     brute = None
@@ -277,6 +317,12 @@ def bench_chamfer(args, dist, world, rank, device):
                    "parallelism": "batch-shard x%d%s" % (world, " + RCCL all-gather(dist,idx), async" if world > 1 else "")},
         "fwd_ms": fwd_ms,
     }
+    out["config"]["launch"] = ("hipGraph replay of the step's launches (same kernels as the eager operator)"
+                               if gstep is not None else "eager (one Python call per operator)")
+    out["eager"] = {"ms_per_step": eager_dt * 1e3, "pairs_per_s": pairs_per_step / eager_dt,
+                    "note": "same step issued through torch.autograd.Function calls; fwd_ms is measured here"}
+    if graph_note:
+        out["config"]["launch_note"] = graph_note
     if grid:
         # forward = grid_build_kernel + grid_query_kernel (the dominant one, ~2/3 of the forward) +
         # the brute-force kernel over the unresolved list; timed together by the HIP events

@@ -545,6 +545,77 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_csr_kernel(
   }
 }
 
+// Backward with DOUBLE accumulators in LDS (C == 3).  ds_add_f64 runs at 3.3 lanes/clk/CU on gfx950
+// (ds_add_f32: 0.36, tools/lds_atomic_probe.hip), which makes the direct form -- seed the slice
+// with the own-point terms, add the scattered terms atomically, round once at the end -- cheaper
+// than listing them (the CSR kernel above needs a count pass, a scan and a fill pass before it can
+// sum).  A workgroup owns a slice [k0,k1) of one target cloud: 3 doubles per point.  Every term is
+// computed in fp32 exactly as the reference does; only the running sum is wider.
+__global__ __launch_bounds__(1024) void nmdist_bwd_lds64_kernel(
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, const float* __restrict__ gd1,
+    const float* __restrict__ gd2, const int* __restrict__ idx1, const int* __restrict__ idx2,
+    float* __restrict__ gx1, float* __restrict__ gx2, int N, int M, int slice_len, int slices) {
+  extern __shared__ __attribute__((aligned(16))) double s_acc64[];  // [slice_len][3]
+  const int per_b = 2 * slices;
+  const int b = blockIdx.x / per_b;
+  const int r = blockIdx.x - b * per_b;
+  const bool second = r >= slices;  // target cloud: false -> cloud 1, true -> cloud 2
+  const int slice = second ? r - slices : r;
+  const int nt = second ? M : N, no = second ? N : M;
+  const int k0 = slice * slice_len;
+  const int len = max(0, min(slice_len, nt - k0));
+  if (len == 0) return;
+  const float* __restrict__ xt = (second ? xyz2 : xyz1) + (size_t)b * nt * 3;
+  const float* __restrict__ xo = (second ? xyz1 : xyz2) + (size_t)b * no * 3;
+  const float* __restrict__ gt = (second ? gd2 : gd1) + (size_t)b * nt;
+  const float* __restrict__ go = (second ? gd1 : gd2) + (size_t)b * no;
+  const int* __restrict__ it = (second ? idx2 : idx1) + (size_t)b * nt;
+  const int* __restrict__ io = (second ? idx1 : idx2) + (size_t)b * no;
+  float* __restrict__ out = (second ? gx2 : gx1) + (size_t)b * nt * 3;
+  const int t = threadIdx.x;
+  // own terms: +g*(x_T[k] - x_O[idx_T[k]])                              (ref nmdistance_cuda.cu:176-180)
+  // (seeding the slice with plain stores and a barrier measured faster -- 30 vs 36 us at config 2 --
+  // than zero-filling and adding the own terms atomically in the same pass as the scattered ones)
+  for (int kk = t; kk < len; kk += 1024) {
+    const int k = k0 + kk;
+    const int j2 = it[k];
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    if (j2 >= 0) {
+      const float g = gt[k] * 2;
+      ax = g * (xt[3 * (size_t)k] - xo[3 * (size_t)j2]);
+      ay = g * (xt[3 * (size_t)k + 1] - xo[3 * (size_t)j2 + 1]);
+      az = g * (xt[3 * (size_t)k + 2] - xo[3 * (size_t)j2 + 2]);
+    }
+    s_acc64[3 * kk] = (double)ax;
+    s_acc64[3 * kk + 1] = (double)ay;
+    s_acc64[3 * kk + 2] = (double)az;
+  }
+  __syncthreads();
+  // scattered terms of the other direction: -g*(x_O[j] - x_T[idx_O[j]]) onto row idx_O[j]        (:181)
+  constexpr int KJ = 4;
+  for (int j0 = t; j0 < no; j0 += 1024 * KJ) {
+    int kj[KJ];
+#pragma unroll
+    for (int u = 0; u < KJ; ++u) {
+      const int j = j0 + 1024 * u;
+      kj[u] = j < no ? io[j] - k0 : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < KJ; ++u) {
+      const int j = j0 + 1024 * u;
+      if (kj[u] >= 0 && kj[u] < len) {
+        const int k = k0 + kj[u];
+        const float g = go[j] * 2;
+        atomicAdd(&s_acc64[3 * kj[u]], (double)(-(g * (xo[3 * (size_t)j] - xt[3 * (size_t)k]))));
+        atomicAdd(&s_acc64[3 * kj[u] + 1], (double)(-(g * (xo[3 * (size_t)j + 1] - xt[3 * (size_t)k + 1]))));
+        atomicAdd(&s_acc64[3 * kj[u] + 2], (double)(-(g * (xo[3 * (size_t)j + 2] - xt[3 * (size_t)k + 2]))));
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < 3 * len; e += 1024) out[3 * (size_t)k0 + e] = (float)s_acc64[e];  // coalesced
+}
+
 __global__ void fill_zero_kernel(float* __restrict__ a, int* __restrict__ b, long long n) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t < n) {
@@ -695,8 +766,8 @@ extern "C" int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float*
   return PP_OK;
 }
 
-// 0 = automatic (CSR form where it applies); 1 = force the global-atomic form; 2 = force the
-// LDS-column form; 3 = automatic (same as 0)   (tests and tuning)
+// 0 = automatic (double LDS accumulators for C == 3); 1 = force the global-atomic form; 2 = force
+// the fp32 LDS-column form; 3 = the CSR form; 4 = same as 0   (tests and tuning)
 static int g_bwd_variant = 0;
 extern "C" void pp_debug_set_nmdistance_backward_variant(int v) { g_bwd_variant = v; }
 
@@ -719,6 +790,22 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
   }
   if (!xyz1 || !xyz2 || !graddist1 || !graddist2 || !idx1 || !idx2 || !gradxyz1 || !gradxyz2)
     return PP_EINVAL;
+  // double LDS accumulators: C == 3; slices of at most 4096 points (96 KiB), at least 4 per cloud
+  if ((g_bwd_variant == 0 || g_bwd_variant == 4) && C == 3 && N + M >= 4096) {
+    const int big = N > M ? N : M;
+    int slices = (big + 4095) / 4096;
+    if (slices < 4) slices = 4;  // 4 measured best at config 2 (8: 38 us, 16: 40 us)
+    const int slice_len = (big + slices - 1) / slices;
+    if ((long long)B * 2 * slices <= 0x7fffffffLL) {
+      static bool lds_ok[64] = {};
+      const hipError_t e = pp::allow_big_lds(nmdist_bwd_lds64_kernel, 152 * 1024, lds_ok);
+      if (e != hipSuccess) return (int)e;
+      nmdist_bwd_lds64_kernel<<<dim3((unsigned)(B * 2 * slices)), dim3(1024), (size_t)slice_len * 24, s>>>(
+          xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, slice_len, slices);
+      PP_RETURN_IF_LAUNCH_FAILED();
+      return PP_OK;
+    }
+  }
   // CSR form (no fp atomics): C == 3, slice bookkeeping + the other cloud's list fit the LDS
   if (g_bwd_variant != 1 && g_bwd_variant != 2 && C == 3 && N + M >= 4096) {
     const int big = N > M ? N : M;

@@ -8,7 +8,8 @@
 //     h over their bounding box (<= 32^3 cells, counters in LDS);
 //   * a query is clamped to the box (the projection q' onto a convex set never increases the
 //     distance to points inside it, so bounds derived for q' hold for q) and examines the cells of
-//     first the 2x2x2 block of cells nearest to q' (everything else is >= h/2 away), then the
+//     first the 2x2x2 block of cells nearest to q' (everything else is at least `reach` away: the
+//     distance from q to the nearest face of that block with grid beyond it, >= h/2), then the
 //     cubes of Chebyshev radius rho = 1 and 2 around its own cell (everything else >= rho*h away);
 //   * fp32 evaluation of the canonical formula has relative error <= 6 * 2^-24, and the cell
 //     assignment (one subtraction, one multiplication, one truncation) can misplace a point by
@@ -200,8 +201,17 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
         }
       }
     }
-    const float half_h = 0.5f * g.h;
-    resolved = best < half_h * half_h * kBoundSlack;
+    // What the block guarantees for THIS query: along each axis the nearer face of the block that has
+    // grid beyond it (beyond the grid there are no points).  Lower face: 1 + f cells away when the
+    // block includes cell c-1, f when it starts at c; upper face: 1 - f or 2 - f.  Never below h/2.
+    auto reach1 = [](float f, int s, int c, int gdim) {
+      const float lo = s < 0 ? (c >= 1 ? f + 1.0f : __builtin_inff()) : (c >= 1 ? f : __builtin_inff());
+      const float hi = s < 0 ? (c + 1 <= gdim - 1 ? 1.0f - f : __builtin_inff())
+                             : (c + 1 <= gdim - 1 ? 2.0f - f : __builtin_inff());
+      return fminf(lo, hi);
+    };
+    const float reach = g.h * fminf(reach1(fx, sx, cx, g.gx), fminf(reach1(fy, sy, cy, g.gy), reach1(fz, sz, cz, g.gz)));
+    resolved = best < reach * reach * kBoundSlack;
   }
   // Results leave in the order the queries were walked (coalesced 8-byte stores); the unsort pass
   // gathers them back to the original order.  (Writing dist[j], idx[j] from here would be two
@@ -286,6 +296,18 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
         bidx = take ? id : bidx;
       }
     };
+    // distance (in cells) from q to the nearest face of the cube of Chebyshev radius rho around its
+    // cell that has grid beyond it: rho + f below, rho + 1 - f above (>= rho)
+    const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
+                fz = (qz - g.minz) * g.invh - (float)cz;
+    auto reach_cube = [&](int rho) {
+      auto axis = [&](float f, int c, int gdim) {
+        const float lo = c - rho >= 1 ? (float)rho + f : __builtin_inff();
+        const float hi = c + rho <= gdim - 2 ? (float)(rho + 1) - f : __builtin_inff();
+        return fminf(lo, hi);
+      };
+      return fminf(axis(fx, cx, g.gx), fminf(axis(fy, cy, g.gy), axis(fz, cz, g.gz)));
+    };
     bool resolved = false;
     // Stage B (only if A could not stop): cube of radius 1 -- re-examining A's cells is harmless.
     // The nine row ranges are fetched first (18 independent loads, cell
@@ -324,7 +346,8 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
         }
       }
       const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
-      resolved = all ? (bidx != 0x7fffffff) : (best < g.h * g.h * kBoundSlack);
+      const float reach = g.h * reach_cube(1);
+      resolved = all ? (bidx != 0x7fffffff) : (best < reach * reach * kBoundSlack);
     }
     if (!resolved) {  // shell of radius 2
       const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.gz - 1), y0 = max(cy - 2, 0), y1 = min(cy + 2, g.gy - 1);
@@ -340,8 +363,8 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
           }
         }
       const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
-      const float two_h = 2.0f * g.h;
-      resolved = all ? (bidx != 0x7fffffff) : (best < two_h * two_h * kBoundSlack);
+      const float reach = g.h * reach_cube(2);
+      resolved = all ? (bidx != 0x7fffffff) : (best < reach * reach * kBoundSlack);
     }
     if (active && resolved) {
       (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
@@ -360,11 +383,16 @@ __global__ __launch_bounds__(256) void grid_finish_kernel(const float* __restric
                                                           float* __restrict__ dist1, int* __restrict__ idx1,
                                                           float* __restrict__ dist2, int* __restrict__ idx2,
                                                           unsigned char* __restrict__ ws, int B, int N, int M,
-                                                          int tiles1, int tiles2, int wide_blocks) {
-  if ((int)blockIdx.x < wide_blocks)
-    grid_query_wide_block(blockIdx.x, xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M);
-  else
-    grid_unsort_block(blockIdx.x - wide_blocks, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2);
+                                                          int tiles1, int tiles2, int wide_blocks, int per_xcd) {
+  // both parts keep a set on the XCD whose L2 holds it from grid_query_kernel (same blockIdx % 8
+  // -> set mapping; wide_blocks is a multiple of 8)
+  if ((int)blockIdx.x < wide_blocks) {
+    grid_query_wide_block(pp::xcd_virtual_block(blockIdx.x, wide_blocks / 8), xyz1, xyz2, dist1, idx1, dist2, idx2,
+                          ws, B, N, M);
+  } else {
+    const int V = pp::xcd_virtual_block(blockIdx.x - wide_blocks, per_xcd);
+    if (V < B * (tiles1 + tiles2)) grid_unsort_block(V, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2);
+  }
 }
 
 }  // namespace
@@ -408,9 +436,9 @@ extern "C" int pp_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2
                                                                           B, N, M, tiles1, tiles2, (int)blocks,
                                                                           per_xcd);
   PP_RETURN_IF_LAUNCH_FAILED();
-  const int wide_blocks = 2 * B * kWideBlocksPerSet;
-  grid_finish_kernel<<<dim3((unsigned)(wide_blocks + blocks)), dim3(256), 0, s>>>(
-      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, wide_blocks);
+  const int wide_blocks = 2 * B * kWideBlocksPerSet;  // 8 B: a multiple of 8 (finish kernel XCD mapping)
+  grid_finish_kernel<<<dim3((unsigned)(wide_blocks + per_xcd * 8)), dim3(256), 0, s>>>(
+      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, wide_blocks, per_xcd);
   PP_RETURN_IF_LAUNCH_FAILED();
   return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
                                 reinterpret_cast<const int*>(ws + L.qlist),

@@ -98,13 +98,13 @@ def test_forward_empty(cuda):
     assert np.array_equal(e[2], d2.cpu().numpy())
 
 
-@pytest.fixture(params=["auto", "global_atomics", "lds_columns"])  # auto = CSR lists for C == 3
+@pytest.fixture(params=["auto", "global_atomics", "lds_columns", "csr_lists"])  # auto = double LDS accumulators for C == 3
 def bwd_path(request, cuda):
     from pytorch_points_amd import _lib
     setter = _lib.lib().pp_debug_set_nmdistance_backward_variant
     setter.argtypes = [ctypes.c_int]
     setter.restype = None
-    setter({"auto": 0, "global_atomics": 1, "lds_columns": 2}[request.param])
+    setter({"auto": 0, "global_atomics": 1, "lds_columns": 2, "csr_lists": 3}[request.param])
     yield request.param
     setter(0)
 
@@ -252,3 +252,26 @@ def test_full_size_c2_properties(cuda):
     # (5) deterministic
     u1, u2, v1, v2 = nndistance(t1, t2)
     assert torch.equal(u1, d1) and torch.equal(v1, i1) and torch.equal(u2, d2) and torch.equal(v2, i2)
+
+
+def test_graph_replay_equals_eager(cuda):
+    """hipGraph replay of a fixed-shape step (graphs.py): same outputs as the eager operator, and
+    inputs rewritten in place between replays are honoured."""
+    from pytorch_points_amd.graphs import GraphedChamferStep
+    from pytorch_points_amd.network.model_loss import nndistance
+    b, n, m = 2, 4096, 3000
+    gs = GraphedChamferStep(b, n, m, cuda)
+    for seed in (0, 5):
+        x1 = torch.from_numpy(S.unit_sphere(seed, b, n)).to(cuda)
+        x2 = torch.from_numpy(S.unit_sphere(seed + 1, b, m)).to(cuda)
+        g1 = torch.from_numpy(S.normal(seed + 2, (b, n))).to(cuda)
+        g2 = torch.from_numpy(S.normal(seed + 3, (b, m))).to(cuda)
+        with torch.no_grad():
+            gs.xyz1.copy_(x1); gs.xyz2.copy_(x2); gs.grad_dist1.copy_(g1); gs.grad_dist2.copy_(g2)
+        d1, d2, i1, i2, gx1, gx2 = gs.replay()
+        t1 = x1.clone().requires_grad_(True)
+        t2 = x2.clone().requires_grad_(True)
+        e1, e2, j1, j2 = nndistance(t1, t2)
+        torch.autograd.backward([e1, e2], [g1, g2])
+        assert torch.equal(d1, e1) and torch.equal(d2, e2) and torch.equal(i1, j1) and torch.equal(i2, j2)
+        assert torch.allclose(gx1, t1.grad, rtol=1e-6, atol=1e-7) and torch.allclose(gx2, t2.grad, rtol=1e-6, atol=1e-7)
