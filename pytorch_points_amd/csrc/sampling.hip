@@ -31,6 +31,47 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(const float* __restrict
     out[((size_t)b * C + c) * M + m] = points[((size_t)b * C + c) * N + i];
 }
 
+// gather_points through the LDS: a workgroup stages the row points[b,c,:] (coalesced 16-byte loads)
+// and gathers from LDS, CPB channels in turn, the next row's loads in flight while this one is
+// gathered.  Reads 4 N bytes per row instead of one 64-byte sector per gathered element: the better
+// deal when N <= 16 M.  XCD mapping as group_points: idx of one batch element is read by one L2.
+template <int KR>
+__global__ __launch_bounds__(1024) void gather_fwd_lds_kernel(const float* __restrict__ points,
+                                                              const int* __restrict__ idx,
+                                                              float* __restrict__ out, int B, int C, int N,
+                                                              int M, int cpb, int groups) {
+  extern __shared__ __attribute__((aligned(16))) float s_grow[];
+  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+  const int b = x + 8 * (y / groups);
+  if (b >= B) return;
+  const int c0 = (y % groups) * cpb;
+  const int c1 = min(C, c0 + cpb);
+  const int t = threadIdx.x;
+  const int n4 = N >> 2;
+  const int* __restrict__ ib = idx + (size_t)b * M;
+  pp::f4 pre[KR];
+  auto load_row = [&](int c) {
+    const pp::f4* __restrict__ row = reinterpret_cast<const pp::f4*>(points + ((size_t)b * C + c) * N);
+#pragma unroll
+    for (int k = 0; k < KR; ++k) pre[k] = row[min(t + 1024 * k, n4 - 1)];
+  };
+  load_row(c0);
+  for (int c = c0; c < c1; ++c) {
+    __syncthreads();  // the previous row has been gathered
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+      if (t + 1024 * k < n4) reinterpret_cast<pp::f4*>(s_grow)[t + 1024 * k] = pre[k];
+    __syncthreads();
+    if (c + 1 < c1) load_row(c + 1);
+    float* __restrict__ o = out + ((size_t)b * C + c) * M;
+    for (int m = t * 4; m < M; m += 4096) {
+      const pp::i4 i = *reinterpret_cast<const pp::i4*>(ib + m);
+      pp::f4 r = {s_grow[i.x], s_grow[i.y], s_grow[i.z], s_grow[i.w]};
+      *reinterpret_cast<pp::f4*>(o + m) = r;
+    }
+  }
+}
+
 // gather backward: grad_points[b,c,idx[b,m]] += grad_out[b,c,m]   (ref sampling_cuda.cu:47-64)
 __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict__ grad_out,
                                                          const int* __restrict__ idx,
@@ -880,11 +921,43 @@ bool grid_ok(long long x, long long y, long long z) {
 
 }  // namespace
 
+// 0 = automatic; 1 = force the global-gather kernel (tests and tuning)
+static int g_gather_variant = 0;
+extern "C" void pp_debug_set_gather_variant(int v) { g_gather_variant = v; }
+
 extern "C" int pp_gather_forward_f32(const float* points, const int* idx, float* out, int B, int C,
                                      int N, int M, void* stream) {
   if (B < 0 || C < 0 || N < 0 || M < 0) return PP_EINVAL;
   if (B == 0 || C == 0 || M == 0) return PP_OK;
   if (!points || !idx || !out || N == 0) return PP_EINVAL;
+  // LDS-staged rows: 16-byte aligned rows and index quads, the row fits, reading whole rows pays
+  if (g_gather_variant != 1 && N % 4 == 0 && M % 4 == 0 && (size_t)N * sizeof(float) <= 64 * 1024 &&
+      (uintptr_t)points % 16 == 0 && (uintptr_t)idx % 16 == 0 && (uintptr_t)out % 16 == 0 &&
+      (long long)N <= 16LL * M && (long long)B * C >= 512 && M >= 1024) {
+    int cpb = 4;
+    while (cpb > 1 && 8LL * ((B + 7) / 8) * ((C + cpb - 1) / cpb) < 1024) cpb /= 2;
+    const int groups = (C + cpb - 1) / cpb;
+    const long long wgs = 8LL * ((B + 7) / 8) * groups;
+    if (wgs <= 0x7fffffffLL) {
+      const dim3 grid((unsigned)wgs), block(1024);
+      const size_t lds = (size_t)N * sizeof(float);
+      hipStream_t s = (hipStream_t)stream;
+      const int n4 = N / 4;
+      static bool ok1[64] = {}, ok2[64] = {}, ok4[64] = {};
+      if (n4 <= 1024) {
+        if (pp::allow_big_lds(gather_fwd_lds_kernel<1>, 64 * 1024, ok1) != hipSuccess) return PP_EINVAL;
+        gather_fwd_lds_kernel<1><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
+      } else if (n4 <= 2048) {
+        if (pp::allow_big_lds(gather_fwd_lds_kernel<2>, 64 * 1024, ok2) != hipSuccess) return PP_EINVAL;
+        gather_fwd_lds_kernel<2><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
+      } else {
+        if (pp::allow_big_lds(gather_fwd_lds_kernel<4>, 64 * 1024, ok4) != hipSuccess) return PP_EINVAL;
+        gather_fwd_lds_kernel<4><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
+      }
+      PP_RETURN_IF_LAUNCH_FAILED();
+      return PP_OK;
+    }
+  }
   const long long cols = (M + 255) / 256;
   const int cpb = pick_c_per_block(cols, B, C);
   const long long gy = (C + cpb - 1) / cpb;

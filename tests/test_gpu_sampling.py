@@ -265,6 +265,30 @@ def scatter_path(request, cuda):
     smode(0)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("b,c,n,m", [(9, 64, 16384, 4096), (4, 130, 4096, 1024), (17, 33, 8200, 8192), (2, 300, 1024, 2052),
+                                     (2, 256, 16380, 1028)])
+def test_gather_forward_large(cuda, variant, b, c, n, m):
+    """shapes the LDS-staged gather takes (variant 0) and the same through the global-gather kernel"""
+    import ctypes
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd._ext import sampling
+    f = _t(S.normal(28, (b, c, n)), cuda)
+    idx = _t((S.uniform01(29, (b, m)).reshape(b, m) * n).astype(np.int32), cuda)
+    idx[:, 0] = n - 1
+    idx[:, -1] = 0
+    out = torch.empty(b, c, m, device=cuda)
+    setter = _lib.lib().pp_debug_set_gather_variant
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(variant)
+    try:
+        sampling.gather_forward(b, c, n, m, f, idx, out)
+    finally:
+        setter(0)
+    assert torch.equal(out, torch.gather(f, 2, idx.long()[:, None, :].expand(-1, c, -1)))
+
+
 @pytest.mark.parametrize("b,c,n,m", [(3, 40, 5000, 20001), (9, 16, 16384, 8192), (1, 130, 777, 40000)])
 def test_gather_backward_large(cuda, scatter_path, b, c, n, m):
     from pytorch_points_amd._ext import sampling
