@@ -59,6 +59,15 @@ int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float* xyz2, cons
                                       const float* label2, float* dist1, int* idx1, float* dist2,
                                       int* idx2, int B, int N, int M, int C, void* stream);
 
+/* The labeled forward through the exact uniform-grid search (same outputs; see
+ * pp_nmdistance_forward_ws_f32).  The workspace is larger than the unlabeled one (the labels are
+ * carried in sorted order); 0 bytes = not applicable, null / too small workspace = the call above. */
+size_t pp_labeled_nmdistance_forward_workspace_bytes(int B, int N, int M, int C);
+int pp_labeled_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2, const float* label1,
+                                         const float* label2, float* dist1, int* idx1, float* dist2,
+                                         int* idx2, int B, int N, int M, int C, void* workspace,
+                                         size_t workspace_bytes, void* stream);
+
 /* Replaces losses.nmdistance_backward(xyz1,xyz2,gradxyz1,gradxyz2,graddist1,graddist2,idx1,idx2)
  *   (_ext/nmdistance.cpp:23-27 -> chamfer_cuda_backward, _ext/nmdistance_cuda.cu:195-221).
  * gradxyz1 (B,N,C), gradxyz2 (B,M,C) are fully overwritten (the reference zeroes them first). */

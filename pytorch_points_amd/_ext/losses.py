@@ -75,11 +75,15 @@ def labeled_nmdistance_forward(xyz1, xyz2, label1, label2, dist1, dist2, idx1, i
     _lib.require_int(*ints)
     if label1.numel() != b * n or label2.numel() != b * m:
         raise RuntimeError("labels must be (B, N) and (B, M)")
+    L = _lib.lib()
+    nbytes = 0 if os.environ.get("PP_NMDISTANCE_SEARCH") == "bruteforce" else \
+        int(L.pp_labeled_nmdistance_forward_workspace_bytes(b, n, m, c))
+    ws = _workspace(dev, nbytes)
     with _lib.on_device(dev) as stream:
-        _lib.check(_lib.lib().pp_labeled_nmdistance_forward_f32(
+        _lib.check(L.pp_labeled_nmdistance_forward_ws_f32(
             _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(label1), _lib.ptr(label2), _lib.ptr(dist1),
-            _lib.ptr(idx1), _lib.ptr(dist2), _lib.ptr(idx2), b, n, m, c, stream),
-            "labeled_nmdistance_forward")
+            _lib.ptr(idx1), _lib.ptr(dist2), _lib.ptr(idx2), b, n, m, c,
+            _lib.ptr(ws) if ws is not None else None, nbytes, stream), "labeled_nmdistance_forward")
     return 1
 
 

@@ -23,6 +23,8 @@ SIGNATURES = {
     "pp_nmdistance_forward_workspace_bytes": [_I, _I, _I, _I],
     "pp_nmdistance_forward_ws_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_labeled_nmdistance_forward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_labeled_nmdistance_forward_workspace_bytes": [_I, _I, _I, _I],
+    "pp_labeled_nmdistance_forward_ws_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_nmdistance_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_furthest_sampling_workspace_bytes": [_I, _I, _I],
     "pp_furthest_sampling_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
@@ -48,6 +50,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"pp_version": ctypes.c_char_p, "pp_furthest_sampling_workspace_bytes": _c_size_t,
              "pp_nmdistance_forward_workspace_bytes": _c_size_t,
+             "pp_labeled_nmdistance_forward_workspace_bytes": _c_size_t,
              "pp_scatter_workspace_bytes": _c_size_t, "pp_ball_query_workspace_bytes": _c_size_t,
              "pp_three_nn_workspace_bytes": _c_size_t}
 

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     int tiles1, int tiles2, int total, int per_xcd, const int* __restrict__ qlist = nullptr,
     const int* __restrict__ qcount = nullptr, const float* __restrict__ label1 = nullptr,
     const float* __restrict__ label2 = nullptr) {
-  static_assert(!(LAB && (PF || LIST)), "labels are not combined with prefetch or list mode");
+  static_assert(!(LAB && PF), "labels are not combined with the prefetch form");
   static_assert(G % 2 == 0, "groups are consumed two reference points per v_min3");
   constexpr int TQ = 64 * Q;  // queries per workgroup
   __shared__ float s_best[kWavesPerBlock][TQ];
@@ -670,14 +670,19 @@ int zero_outputs(float* dist1, int* idx1, float* dist2, int* idx2, int B, int N,
 namespace pp {
 int nmdist_fwd_c3_list(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
                        int* idx2, int B, int N, int M, const int* qlist, const int* qcount,
-                       hipStream_t s) {
+                       hipStream_t s, const float* label1, const float* label2) {
   constexpr int Q = 2, TQ = 128;  // coarse tiles: the launch is mostly workgroups that exit at once
   const int tiles1 = (N + TQ - 1) / TQ, tiles2 = (M + TQ - 1) / TQ;
   const long long total = (long long)B * (tiles1 + tiles2);
   if (total > 0x7fffff00LL) return PP_EINVAL;
   const int per_xcd = (int)((total + 7) / 8);
-  nmdist_fwd_c3_kernel<Q, 8, true, false, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
-      xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, tiles1, tiles2, (int)total, per_xcd, qlist, qcount);
+  if (label1)
+    nmdist_fwd_c3_kernel<Q, 8, true, false, true, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
+        xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, tiles1, tiles2, (int)total, per_xcd, qlist, qcount, label1,
+        label2);
+  else
+    nmdist_fwd_c3_kernel<Q, 8, true, false, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
+        xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, tiles1, tiles2, (int)total, per_xcd, qlist, qcount);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
 }

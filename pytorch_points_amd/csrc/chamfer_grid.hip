@@ -25,7 +25,7 @@ namespace pp {
 // qcount[set], indices in qlist[set_offset ...])
 int nmdist_fwd_c3_list(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
                        int* idx2, int B, int N, int M, const int* qlist, const int* qcount,
-                       hipStream_t s);
+                       hipStream_t s, const float* label1 = nullptr, const float* label2 = nullptr);
 }  // namespace pp
 
 namespace {
@@ -49,11 +49,12 @@ constexpr int kUnresolved = (int)0x80000000;
 //   [.., +4*T)                     int blist[T]           queries left to stages B/C, per set
 //   [.., +4*T)                     int inv[T]             position of original point k in `sorted`
 //   [.., +8*T)                     {float dist, int idx} res[T]   stage-A results in sorted order
+//   [.., +4*T)                     float slab[T]          labels in sorted order (labeled Chamfer only)
 // qcount has 4*B entries: [0, 2B) count qlist, [2B, 4B) count blist.
 struct Layout {
-  size_t sets, qcount, cell_start, sorted, qlist, blist, inv, res, total;
+  size_t sets, qcount, cell_start, sorted, qlist, blist, inv, res, slab, total;
 };
-__host__ __device__ inline Layout make_layout(int B, int N, int M) {
+__host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
   Layout L;
   const size_t S = (size_t)2 * B, T = (size_t)B * ((size_t)N + M);
   L.sets = 0;
@@ -64,7 +65,8 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M) {
   L.blist = L.qlist + 4 * T;
   L.inv = L.blist + 4 * T;
   L.res = L.inv + 4 * T;
-  L.total = L.res + 8 * T;
+  L.slab = L.res + 8 * T;
+  L.total = L.slab + (labeled ? 4 * T : 0);
   return L;
 }
 // set s = 2*b + dir; dir 0: queries = cloud 1 (N), references = cloud 2 (M)
@@ -79,13 +81,17 @@ __host__ __device__ inline size_t set_query_offset(int b, int dir, int N, int M)
 __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* __restrict__ xyz1,
                                                                    const float* __restrict__ xyz2,
                                                                    unsigned char* __restrict__ ws, int B,
-                                                                   int N, int M) {
+                                                                   int N, int M,
+                                                                   const float* __restrict__ label1,
+                                                                   const float* __restrict__ label2) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // [kGridCells + kGridCells / 32]
   const int set = blockIdx.x;
   const int b = set >> 1, dir = set & 1;
   const int nr = dir ? N : M;
   const float* __restrict__ ref = (dir ? xyz1 : xyz2) + (size_t)b * nr * 3;
-  const Layout L = make_layout(B, N, M);
+  const bool labeled = label1 != nullptr;
+  const Layout L = make_layout(B, N, M, labeled);
+  const float* __restrict__ lab = labeled ? (dir ? label1 : label2) + (size_t)b * nr : nullptr;
   if (threadIdx.x == 0) {  // the lists this set's queries may be appended to start empty
     int* counts = reinterpret_cast<int*>(ws + L.qcount);
     counts[set] = 0;          // brute-force list of this set
@@ -94,7 +100,8 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   pp::grid_build_set(ref, nr, reinterpret_cast<GridSet*>(ws + L.sets) + set,
                      reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1),
                      reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M),
-                     reinterpret_cast<int*>(ws + L.inv) + set_point_offset(b, dir, N, M), s_cnt);
+                     reinterpret_cast<int*>(ws + L.inv) + set_point_offset(b, dir, N, M), s_cnt, lab,
+                     labeled ? reinterpret_cast<float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr);
 }
 
 // Append `value` to list[counter++] for the lanes with `want`: one atomic per wave.
@@ -111,12 +118,17 @@ __device__ __forceinline__ void wave_append(bool want, int* counter, int* list, 
 
 // Stage A for every query, one lane per query (dense launch).  Unresolved queries go to `blist`
 // (compacted, so the rarely needed wider stages run in full waves instead of a few lanes of many).
+// LAB (labeled Chamfer): a reference point is a candidate only if its label equals the query's; the
+// stopping rule is unchanged (it bounds EVERY unexamined point, whatever its label).
+template <bool LAB>
 __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict__ xyz1,
                                                          const float* __restrict__ xyz2,
                                                          float* __restrict__ dist1, int* __restrict__ idx1,
                                                          float* __restrict__ dist2, int* __restrict__ idx2,
                                                          unsigned char* __restrict__ ws, int B, int N, int M,
-                                                         int tiles1, int tiles2, int total, int per_xcd) {
+                                                         int tiles1, int tiles2, int total, int per_xcd,
+                                                         const float* __restrict__ label1,
+                                                         const float* __restrict__ label2) {
   // workgroups of one set on one XCD: its cells and points (384 KiB) stay in that L2
   const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
   if (V >= total) return;
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
   const int jj = tile * 256 + threadIdx.x;
   if (jj >= nq) return;
   const int set = 2 * b + dir;
-  const Layout L = make_layout(B, N, M);
+  const Layout L = make_layout(B, N, M, LAB);
   const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[set];
   // The query cloud is the reference cloud of the partner set (b, 1-dir), already sorted by cell
   // there: walking the queries in that order makes the lanes of a wave spatial neighbours, so
@@ -147,17 +159,21 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
       reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
   const pp::f4* __restrict__ sorted =
       reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
-  float qx, qy, qz;
+  float qx, qy, qz, ql = 0.0f;
   int j;
   if (!gp.useless) {
     const pp::f4 qq = qsorted[jj];
     qx = qq.x; qy = qq.y; qz = qq.z;
     j = __float_as_int(qq.w);
+    if (LAB) ql = (reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir ^ 1, N, M))[jj];
   } else {
     const float* __restrict__ q = (dir ? xyz2 : xyz1) + ((size_t)b * nq + jj) * 3;
     qx = q[0]; qy = q[1]; qz = q[2];
     j = jj;
+    if (LAB) ql = (dir ? label2 : label1)[(size_t)b * nq + jj];
   }
+  const float* __restrict__ slab =
+      LAB ? reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr;
   const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
   const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
   const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
@@ -189,13 +205,17 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
       for (unsigned i = rs[r4]; i < re[r4]; i += 4) {
         const unsigned last = re[r4] - 1;
         pp::f4 p[4];
+        float pl[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = sorted[min(i + u, last)];
+        for (int u = 0; u < 4; ++u) {
+          p[u] = sorted[min(i + u, last)];
+          if (LAB) pl[u] = slab[min(i + u, last)];
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
           const int id = __float_as_int(p[u].w);
-          const bool take = d < best || (d == best && id < bidx);
+          const bool take = (!LAB || pl[u] == ql) && (d < best || (d == best && id < bidx));
           best = take ? d : best;
           bidx = take ? id : bidx;
         }
@@ -254,21 +274,26 @@ __device__ __forceinline__ void grid_unsort_block(int block, float* __restrict__
 }
 
 // Stages B and C for the queries stage A left over (grid-stride over the compacted list).
+template <bool LAB>
 __device__ __forceinline__ void grid_query_wide_block(int block, const float* __restrict__ xyz1,
                                                       const float* __restrict__ xyz2,
                                                       float* __restrict__ dist1, int* __restrict__ idx1,
                                                       float* __restrict__ dist2, int* __restrict__ idx2,
-                                                      unsigned char* __restrict__ ws, int B, int N, int M) {
-  const Layout L = make_layout(B, N, M);
+                                                      unsigned char* __restrict__ ws, int B, int N, int M,
+                                                      int wide_per_set, const float* __restrict__ label1,
+                                                      const float* __restrict__ label2) {
+  const Layout L = make_layout(B, N, M, LAB);
   int* counts = reinterpret_cast<int*>(ws + L.qcount);
-  const int set = block / kWideBlocksPerSet;  // one set per workgroup
+  const int set = block / wide_per_set;  // one set per workgroup
   const int b = set >> 1, dir = set & 1;
   const int nq = dir ? M : N;
   const int nlist = counts[2 * B + set];
   const int* __restrict__ blist = reinterpret_cast<const int*>(ws + L.blist) + set_query_offset(b, dir, N, M);
   int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
-  const int first = (block % kWideBlocksPerSet) * 256;
-  for (int base = first; base < nlist; base += kWideBlocksPerSet * 256) {  // uniform trip count per wave
+  const int first = (block % wide_per_set) * 256;
+  const float* __restrict__ slab =
+      LAB ? reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr;
+  for (int base = first; base < nlist; base += wide_per_set * 256) {  // uniform trip count per wave
     const int pos = base + threadIdx.x;
     const bool active = pos < nlist;
     const int j = blist[active ? pos : nlist - 1];
@@ -279,6 +304,7 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
         reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
     const float* __restrict__ q = (dir ? xyz2 : xyz1) + ((size_t)b * nq + j) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
+    const float ql = LAB ? (dir ? label2 : label1)[(size_t)b * nq + j] : 0.0f;
     const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
     const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
     const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
@@ -291,7 +317,7 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
         const pp::f4 p = sorted[i];
         const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
         const int id = __float_as_int(p.w);
-        const bool take = d < best || (d == best && id < bidx);
+        const bool take = (!LAB || slab[i] == ql) && (d < best || (d == best && id < bidx));
         best = take ? d : best;
         bidx = take ? id : bidx;
       }
@@ -333,13 +359,17 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
         for (unsigned i = rs[r9]; i < re[r9]; i += 4) {
           const unsigned last = re[r9] - 1;
           pp::f4 p[4];
+          float pl[4];
   #pragma unroll
-          for (int u = 0; u < 4; ++u) p[u] = sorted[min(i + u, last)];
+          for (int u = 0; u < 4; ++u) {
+            p[u] = sorted[min(i + u, last)];
+            if (LAB) pl[u] = slab[min(i + u, last)];
+          }
   #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
             const int id = __float_as_int(p[u].w);
-            const bool take = d < best || (d == best && id < bidx);
+            const bool take = (!LAB || pl[u] == ql) && (d < best || (d == best && id < bidx));
             best = take ? d : best;
             bidx = take ? id : bidx;
           }
@@ -347,7 +377,7 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
       }
       const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
       const float reach = g.h * reach_cube(1);
-      resolved = all ? (bidx != 0x7fffffff) : (best < reach * reach * kBoundSlack);
+      resolved = all ? (LAB || bidx != 0x7fffffff) : (best < reach * reach * kBoundSlack);
     }
     if (!resolved) {  // shell of radius 2
       const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.gz - 1), y0 = max(cy - 2, 0), y1 = min(cy + 2, g.gy - 1);
@@ -364,7 +394,11 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
         }
       const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
       const float reach = g.h * reach_cube(2);
-      resolved = all ? (bidx != 0x7fffffff) : (best < reach * reach * kBoundSlack);
+      resolved = all ? (LAB || bidx != 0x7fffffff) : (best < reach * reach * kBoundSlack);
+    }
+    if (LAB && resolved && bidx == 0x7fffffff) {  // whole grid examined, nobody carries this label
+      best = 0.0f;                                  // (ref nmdistance_cuda.cu:110-113)
+      bidx = -1;
     }
     if (active && resolved) {
       (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
@@ -378,20 +412,24 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
 // order, and the wide stages for the unresolved queries (disjoint outputs).  One launch runs both:
 // the first `wide_blocks` workgroups take the wide stages (the longer, latency-bound job), the
 // rest unsort.
+template <bool LAB>
 __global__ __launch_bounds__(256) void grid_finish_kernel(const float* __restrict__ xyz1,
                                                           const float* __restrict__ xyz2,
                                                           float* __restrict__ dist1, int* __restrict__ idx1,
                                                           float* __restrict__ dist2, int* __restrict__ idx2,
                                                           unsigned char* __restrict__ ws, int B, int N, int M,
-                                                          int tiles1, int tiles2, int wide_blocks, int per_xcd) {
+                                                          int tiles1, int tiles2, int wide_blocks, int per_xcd,
+                                                          int wide_per_set, const float* __restrict__ label1,
+                                                          const float* __restrict__ label2) {
   // both parts keep a set on the XCD whose L2 holds it from grid_query_kernel (same blockIdx % 8
   // -> set mapping; wide_blocks is a multiple of 8)
   if ((int)blockIdx.x < wide_blocks) {
-    grid_query_wide_block(pp::xcd_virtual_block(blockIdx.x, wide_blocks / 8), xyz1, xyz2, dist1, idx1, dist2, idx2,
-                          ws, B, N, M);
+    grid_query_wide_block<LAB>(pp::xcd_virtual_block(blockIdx.x, wide_blocks / 8), xyz1, xyz2, dist1, idx1, dist2,
+                               idx2, ws, B, N, M, wide_per_set, label1, label2);
   } else {
     const int V = pp::xcd_virtual_block(blockIdx.x - wide_blocks, per_xcd);
-    if (V < B * (tiles1 + tiles2)) grid_unsort_block(V, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2);
+    if (V < B * (tiles1 + tiles2))
+      grid_unsort_block(V, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2);
   }
 }
 
@@ -410,6 +448,45 @@ extern "C" size_t pp_nmdistance_forward_workspace_bytes(int B, int N, int M, int
   return make_layout(B, N, M).total;
 }
 
+extern "C" size_t pp_labeled_nmdistance_forward_workspace_bytes(int B, int N, int M, int C) {
+  if (!grid_applicable(B, N, M, C)) return 0;
+  return make_layout(B, N, M, true).total;
+}
+
+// build -> stage A for every query -> wide stages + unsort -> brute force over what is left
+template <bool LAB>
+static int grid_forward(const float* xyz1, const float* xyz2, const float* label1, const float* label2,
+                        float* dist1, int* idx1, float* dist2, int* idx2, int B, int N, int M,
+                        unsigned char* ws, hipStream_t s) {
+  const Layout L = make_layout(B, N, M, LAB);
+  hipError_t e;
+  static bool lds_ok[64] = {};
+  const size_t lds = (size_t)(kGridCells + kGridCells / 32) * sizeof(unsigned);
+  e = pp::allow_big_lds(grid_build_kernel, (int)lds, lds_ok);
+  if (e != hipSuccess) return (int)e;
+  grid_build_kernel<<<dim3(2 * B), dim3(kBuildThreads), lds, s>>>(xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr,
+                                                                  LAB ? label2 : nullptr);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
+  const long long blocks = (long long)B * (tiles1 + tiles2);
+  if (blocks > 0x7fffffffLL) return PP_EINVAL;
+  const int per_xcd = (int)((blocks + 7) / 8);
+  grid_query_kernel<LAB><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(
+      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  // labeled: a candidate must also carry the query's label, so more queries outlive stage A
+  const int wide_per_set = LAB ? 4 * kWideBlocksPerSet : kWideBlocksPerSet;
+  const int wide_blocks = 2 * B * wide_per_set;  // a multiple of 8 (finish kernel XCD mapping)
+  grid_finish_kernel<LAB><<<dim3((unsigned)(wide_blocks + per_xcd * 8)), dim3(256), 0, s>>>(
+      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, wide_blocks, per_xcd, wide_per_set, label1,
+      label2);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
+                                reinterpret_cast<const int*>(ws + L.qlist),
+                                reinterpret_cast<const int*>(ws + L.qcount), s, LAB ? label1 : nullptr,
+                                LAB ? label2 : nullptr);
+}
+
 extern "C" int pp_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2, float* dist1,
                                             int* idx1, float* dist2, int* idx2, int B, int N, int M,
                                             int C, void* workspace, size_t workspace_bytes,
@@ -418,29 +495,19 @@ extern "C" int pp_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2
   if (g_grid_mode == 1 || need == 0 || !workspace || workspace_bytes < need)
     return pp_nmdistance_forward_f32(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, stream);
   if (!xyz1 || !xyz2 || !dist1 || !idx1 || !dist2 || !idx2) return PP_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  unsigned char* ws = (unsigned char*)workspace;
-  const Layout L = make_layout(B, N, M);
-  hipError_t e;
-  static bool lds_ok[64] = {};
-  const size_t lds = (size_t)(kGridCells + kGridCells / 32) * sizeof(unsigned);
-  e = pp::allow_big_lds(grid_build_kernel, (int)lds, lds_ok);
-  if (e != hipSuccess) return (int)e;
-  grid_build_kernel<<<dim3(2 * B), dim3(kBuildThreads), lds, s>>>(xyz1, xyz2, ws, B, N, M);
-  PP_RETURN_IF_LAUNCH_FAILED();
-  const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
-  const long long blocks = (long long)B * (tiles1 + tiles2);
-  if (blocks > 0x7fffffffLL) return PP_EINVAL;
-  const int per_xcd = (int)((blocks + 7) / 8);
-  grid_query_kernel<<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws,
-                                                                          B, N, M, tiles1, tiles2, (int)blocks,
-                                                                          per_xcd);
-  PP_RETURN_IF_LAUNCH_FAILED();
-  const int wide_blocks = 2 * B * kWideBlocksPerSet;  // 8 B: a multiple of 8 (finish kernel XCD mapping)
-  grid_finish_kernel<<<dim3((unsigned)(wide_blocks + per_xcd * 8)), dim3(256), 0, s>>>(
-      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, wide_blocks, per_xcd);
-  PP_RETURN_IF_LAUNCH_FAILED();
-  return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
-                                reinterpret_cast<const int*>(ws + L.qlist),
-                                reinterpret_cast<const int*>(ws + L.qcount), s);
+  return grid_forward<false>(xyz1, xyz2, nullptr, nullptr, dist1, idx1, dist2, idx2, B, N, M,
+                             (unsigned char*)workspace, (hipStream_t)stream);
+}
+
+extern "C" int pp_labeled_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2, const float* label1,
+                                                    const float* label2, float* dist1, int* idx1, float* dist2,
+                                                    int* idx2, int B, int N, int M, int C, void* workspace,
+                                                    size_t workspace_bytes, void* stream) {
+  const size_t need = pp_labeled_nmdistance_forward_workspace_bytes(B, N, M, C);
+  if (g_grid_mode == 1 || need == 0 || !workspace || workspace_bytes < need)
+    return pp_labeled_nmdistance_forward_f32(xyz1, xyz2, label1, label2, dist1, idx1, dist2, idx2, B, N, M, C,
+                                             stream);
+  if (!xyz1 || !xyz2 || !label1 || !label2 || !dist1 || !idx1 || !dist2 || !idx2) return PP_EINVAL;
+  return grid_forward<true>(xyz1, xyz2, label1, label2, dist1, idx1, dist2, idx2, B, N, M,
+                            (unsigned char*)workspace, (hipStream_t)stream);
 }

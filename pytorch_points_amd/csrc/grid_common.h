@@ -55,7 +55,8 @@ __device__ __forceinline__ int morton3(int x, int y, int z) {
 // Body of a build kernel: one 1024-thread workgroup sorts the `nr` points at `ref` into the grid.
 // Dynamic LDS: (kGridCells + kGridCells / 32) unsigned counters, bank-skewed.
 // Writes *gs, cell_start[0..ncell] (if non-null), sorted[0..nr) = (x, y, z, original index) and, if
-// non-null, inv[k] = position of original point k in `sorted`.
+// non-null, inv[k] = position of original point k in `sorted`; if `sorted_payload` is non-null,
+// sorted_payload[pos] = payload[k] (a per-point float, e.g. a label, in the sorted order).
 // MORTON = false: cells in z-major linear order (a row of cells along x is contiguous in `sorted`);
 // a degenerate set (non-finite or zero extent) is marked useless and `sorted` is left unwritten.
 // MORTON = true: cells in Morton order -- `sorted` is then just a spatially coherent permutation of
@@ -63,7 +64,9 @@ __device__ __forceinline__ int morton3(int x, int y, int z) {
 template <bool MORTON = false>
 __device__ __forceinline__ void grid_build_set(const float* __restrict__ ref, int nr, GridSet* gs,
                                                unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
-                                               int* __restrict__ inv, unsigned* s_cnt) {
+                                               int* __restrict__ inv, unsigned* s_cnt,
+                                               const float* __restrict__ payload = nullptr,
+                                               float* __restrict__ sorted_payload = nullptr) {
   __shared__ float s_red[kBuildThreads / 64];
   __shared__ unsigned s_part[kBuildThreads];
   __shared__ int s_bad;
@@ -197,6 +200,7 @@ __device__ __forceinline__ void grid_build_set(const float* __restrict__ ref, in
           f4 v = {px[i], py[i], pz[i], __int_as_float(k)};
           sorted[pos] = v;
           if (inv) inv[k] = (int)pos;  // coalesced: k is thread-strided
+          if (sorted_payload) sorted_payload[pos] = payload[k];  // one float per point, carried along
         }
       }
     }

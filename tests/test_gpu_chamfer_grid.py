@@ -99,3 +99,47 @@ def test_grid_workspace_reused_across_shapes(cuda):
         exp = oracle.chamfer_forward(x1, x2)
         for g, e in zip(got, exp):
             assert np.array_equal(g, e)
+
+
+def _run_labeled(cuda, x1, x2, l1, l2, mode):
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd.network.model_loss import labeled_nndistance
+    setter = _lib.lib().pp_debug_set_nmdistance_search
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(mode)
+    try:
+        d1, d2, i1, i2 = labeled_nndistance(torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda),
+                                            torch.from_numpy(l1).to(cuda), torch.from_numpy(l2).to(cuda))
+        torch.cuda.synchronize()
+    finally:
+        setter(0)
+    return d1.cpu().numpy(), i1.cpu().numpy(), d2.cpu().numpy(), i2.cpu().numpy()
+
+
+def _labels(seed, shape, nlabels):
+    return np.floor(S.uniform01(seed, shape).reshape(shape) * nlabels).astype(np.float32)
+
+
+@pytest.mark.parametrize("labels", ["four", "one_missing", "all_same", "mostly_unique", "disjoint"])
+@pytest.mark.parametrize("name", ["sphere", "sphere_ragged", "cube_volume", "tight_blobs_vs_uniform", "duplicates",
+                                  "all_identical_refs", "huge_offset", "integer_lattice_ties", "outliers"])
+def test_labeled_grid_search_equals_oracle(cuda, name, labels):
+    """labeled Chamfer through the grid (the label filter inside the staged search, the labeled list
+    fallback, idx -1 / dist 0 for queries without a partner) == oracle, bit for bit"""
+    x1, x2 = [np.ascontiguousarray(a) for a in CASES[name]]
+    s1, s2 = x1.shape[:2], x2.shape[:2]
+    if labels == "four":
+        l1, l2 = _labels(50, s1, 4), _labels(51, s2, 4)
+    elif labels == "one_missing":
+        l1, l2 = _labels(52, s1, 4), _labels(53, s2, 3)          # label 3 has no partner in cloud 2
+    elif labels == "all_same":
+        l1, l2 = np.full(s1, 7.0, np.float32), np.full(s2, 7.0, np.float32)
+    elif labels == "mostly_unique":
+        l1, l2 = _labels(54, s1, 3000), _labels(55, s2, 3000)    # most queries have no or one partner
+    else:
+        l1, l2 = _labels(56, s1, 2), _labels(57, s2, 2) + np.float32(10)   # nobody matches
+    exp = oracle.labeled_chamfer_forward(x1, x2, l1, l2)
+    got = _run_labeled(cuda, x1, x2, l1, l2, 0)
+    for g, e, what in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
+        assert np.array_equal(g, e), "%s/%s: %s differs at %d places" % (name, labels, what, int((g != e).sum()))
