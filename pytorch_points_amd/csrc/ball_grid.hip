@@ -54,31 +54,34 @@ __host__ __device__ inline BqLayout bq_layout(int B, int N, int M) {
   return L;
 }
 
-// blocks [0, B): the cloud of batch element b into its grid; blocks [B, 2B): the centres of batch
-// element b into Morton order
+// workgroups [0, S*B): slab s of the cloud of batch element b into its grid; [S*B, 2*S*B): slab s of
+// the centres of batch element b into Morton order (S = kBuildSlabs)
 __global__ __launch_bounds__(kBuildThreads) void bq_build_kernel(const float* __restrict__ xyz,
                                                                  const float* __restrict__ new_xyz,
                                                                  unsigned char* __restrict__ ws, int B, int N,
-                                                                 int M, float rpad) {
+                                                                 int M) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];
   const BqLayout L = bq_layout(B, N, M);
-  GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + blockIdx.x;
-  if ((int)blockIdx.x >= B) {
-    const int b = blockIdx.x - B;
+  const int set = blockIdx.x / pp::kBuildSlabs, slab = blockIdx.x % pp::kBuildSlabs;
+  GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
+  if (set >= B) {
+    const int b = set - B;
     pp::grid_build_set<true>(new_xyz + (size_t)b * M * 3, M, gs, nullptr,
-                             reinterpret_cast<pp::f4*>(ws + L.csorted) + (size_t)b * M, nullptr, s_cnt);
+                             reinterpret_cast<pp::f4*>(ws + L.csorted) + (size_t)b * M, nullptr, s_cnt, nullptr,
+                             nullptr, slab, pp::kBuildSlabs);
     return;
   }
-  const int b = blockIdx.x;
+  const int b = set;
   pp::grid_build_set<false>(xyz + (size_t)b * N * 3, N, gs,
                             reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
-                            reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * N, nullptr, s_cnt);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // pad[0] = 1: the grid path handles this batch element; 0: the scan kernel does
-    const float cells = rpad * gs->invh;
-    gs->pad[0] = (!gs->useless && cells <= (float)kBqMaxCells) ? 1 : 0;
-  }
+                            reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * N, nullptr, s_cnt, nullptr,
+                            nullptr, slab, pp::kBuildSlabs);
+}
+
+// the grid path serves this batch element (otherwise the scan kernel does): the grid exists and the
+// cell box of a centre stays within 7 cells per axis
+__device__ __forceinline__ bool bq_usable(const GridSet& g, float rpad) {
+  return !pp::grid_useless(g) && rpad * g.invh <= (float)kBqMaxCells;
 }
 
 // One wave per workgroup; see the file header for the five steps.  LPC lanes share a centre: the
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(kBuildThreads) void bq_build_kernel(const float* __
 // centre scan consecutive segments of the staged candidates, so their hits concatenate in order.
 template <typename IT, int LPC>
 __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ xyz, int* __restrict__ idx,
-                                                      const unsigned char* __restrict__ ws, int B, int N, int M,
+                                                      unsigned char* __restrict__ ws, int B, int N, int M,
                                                       float radius2, float rpad, int nsample, int tiles_per_b,
                                                       int per_xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -96,7 +99,10 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
   const int tile = vb - b * tiles_per_b;
   const BqLayout L = bq_layout(B, N, M);
   const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[b];
-  if (!g.pad[0]) return;  // this batch element goes to the scan kernel
+  const bool usable = bq_usable(g, rpad);
+  if (tile == 0 && threadIdx.x == 0)  // the scan kernel, launched next, skips the sets served here
+    reinterpret_cast<GridSet*>(ws + L.sets)[b].pad[0] = usable ? 1 : 0;
+  if (!usable) return;
   const int ncell = g.gx * g.gy * g.gz;
   const int ncw = (ncell + 31) >> 5;  // words of the cell bitmap
   const int npw = (N + 31) >> 5;      // words of the point bitmap
@@ -341,7 +347,7 @@ extern "C" size_t pp_ball_query_workspace_bytes(int B, int N, int M, int nsample
 }
 
 template <typename IT, int LPC>
-static int bq_launch_query(const float* xyz, int* idx, const unsigned char* ws, int B, int N, int M, float radius2,
+static int bq_launch_query(const float* xyz, int* idx, unsigned char* ws, int B, int N, int M, float radius2,
                            float rpad, int nsample, hipStream_t s) {
   constexpr int G = 64 / LPC;
   const int tiles = (M + G - 1) / G;
@@ -368,10 +374,10 @@ extern "C" int pp_ball_query_ws_f32(const float* new_xyz, const float* xyz, int*
   const float radius2 = radius * radius;  // fp32, as the reference (sampling_cuda.cu:354)
   const float rpad = radius * 1.00001f + 1e-30f;
   static bool lds_ok[64] = {};
-  const size_t lds = (size_t)(kGridCells + kGridCells / 32) * sizeof(unsigned);
+  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
   hipError_t e = pp::allow_big_lds(bq_build_kernel, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  bq_build_kernel<<<dim3(2 * B), dim3(kBuildThreads), lds, s>>>(xyz, new_xyz, ws, B, N, M, rpad);
+  bq_build_kernel<<<dim3(2 * B * pp::kBuildSlabs), dim3(kBuildThreads), lds, s>>>(xyz, new_xyz, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   // lanes per centre: 2 unless forced (tuning knob; 2 and 4 measure alike at config 4, 1 is 30 % slower)
   const int lpc = g_bq_lpc ? g_bq_lpc : 2;

@@ -77,22 +77,23 @@ __host__ __device__ inline size_t set_query_offset(int b, int dir, int N, int M)
   return (size_t)b * ((size_t)N + M) + (dir ? (size_t)N : 0);  // queries of (b,0) first (N), then (b,1) (M)
 }
 
-// One workgroup per set: bounding box, cell histogram (LDS), exclusive scan, scatter (grid_common.h).
+// kBuildSlabs workgroups per set: bounding box, cell histogram (LDS), exclusive scan, scatter
+// (grid_common.h).
 __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* __restrict__ xyz1,
                                                                    const float* __restrict__ xyz2,
                                                                    unsigned char* __restrict__ ws, int B,
                                                                    int N, int M,
                                                                    const float* __restrict__ label1,
                                                                    const float* __restrict__ label2) {
-  extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // [kGridCells + kGridCells / 32]
-  const int set = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // pp::grid_build_lds_bytes(kBuildSlabs)
+  const int set = blockIdx.x / pp::kBuildSlabs, slab = blockIdx.x % pp::kBuildSlabs;
   const int b = set >> 1, dir = set & 1;
   const int nr = dir ? N : M;
   const float* __restrict__ ref = (dir ? xyz1 : xyz2) + (size_t)b * nr * 3;
   const bool labeled = label1 != nullptr;
   const Layout L = make_layout(B, N, M, labeled);
   const float* __restrict__ lab = labeled ? (dir ? label1 : label2) + (size_t)b * nr : nullptr;
-  if (threadIdx.x == 0) {  // the lists this set's queries may be appended to start empty
+  if (threadIdx.x == 0 && slab == 0) {  // the lists this set's queries may be appended to start empty
     int* counts = reinterpret_cast<int*>(ws + L.qcount);
     counts[set] = 0;          // brute-force list of this set
     counts[2 * B + set] = 0;  // stage B/C list of this set
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
                      reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1),
                      reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M),
                      reinterpret_cast<int*>(ws + L.inv) + set_point_offset(b, dir, N, M), s_cnt, lab,
-                     labeled ? reinterpret_cast<float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr);
+                     labeled ? reinterpret_cast<float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr,
+                     slab, pp::kBuildSlabs);
 }
 
 // Append `value` to list[counter++] for the lanes with `want`: one atomic per wave.
@@ -151,7 +153,8 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
       reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir ^ 1, N, M);
   int* counts = reinterpret_cast<int*>(ws + L.qcount);
   int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
-  if (g.useless) {  // uniform over the workgroup (one set per workgroup)
+  const bool g_useless = pp::grid_useless(g), gp_useless = pp::grid_useless(gp);
+  if (g_useless) {  // uniform over the workgroup (one set per workgroup)
     wave_append(true, counts + set, qlist, jj);  // every query exactly once, any order
     return;
   }
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
       reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
   float qx, qy, qz, ql = 0.0f;
   int j;
-  if (!gp.useless) {
+  if (!gp_useless) {
     const pp::f4 qq = qsorted[jj];
     qx = qq.x; qy = qq.y; qz = qq.z;
     j = __float_as_int(qq.w);
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
   // Results leave in the order the queries were walked (coalesced 8-byte stores); the unsort pass
   // gathers them back to the original order.  (Writing dist[j], idx[j] from here would be two
   // scattered 4-byte stores per query: that alone cost more than the whole search.)
-  if (!gp.useless) {
+  if (!gp_useless) {
     pp::f2 rv = {best, __int_as_float(resolved ? bidx : kUnresolved)};
     reinterpret_cast<pp::f2*>(ws + L.res)[set_point_offset(b, dir ^ 1, N, M) + jj] = rv;
   } else if (resolved) {
@@ -263,7 +266,7 @@ __device__ __forceinline__ void grid_unsort_block(int block, float* __restrict__
   const Layout L = make_layout(B, N, M);
   const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[2 * b + dir];
   const GridSet gp = reinterpret_cast<const GridSet*>(ws + L.sets)[(2 * b + dir) ^ 1];
-  if (g.useless || gp.useless) return;  // those queries were written (or listed) directly
+  if (pp::grid_useless(g) || pp::grid_useless(gp)) return;  // those queries were written (or listed) directly
   const size_t off = set_point_offset(b, dir ^ 1, N, M);  // the query cloud as the partner's references
   const int pos = reinterpret_cast<const int*>(ws + L.inv)[off + j];
   const pp::f2 rv = reinterpret_cast<const pp::f2*>(ws + L.res)[off + pos];
@@ -461,10 +464,10 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   const Layout L = make_layout(B, N, M, LAB);
   hipError_t e;
   static bool lds_ok[64] = {};
-  const size_t lds = (size_t)(kGridCells + kGridCells / 32) * sizeof(unsigned);
+  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
   e = pp::allow_big_lds(grid_build_kernel, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  grid_build_kernel<<<dim3(2 * B), dim3(kBuildThreads), lds, s>>>(xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr,
+  grid_build_kernel<<<dim3(2 * B * pp::kBuildSlabs), dim3(kBuildThreads), lds, s>>>(xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr,
                                                                   LAB ? label2 : nullptr);
   PP_RETURN_IF_LAUNCH_FAILED();
   const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;

@@ -43,27 +43,28 @@ __host__ __device__ inline TnLayout tn_layout(int B, int N, int M) {
   return L;
 }
 
-// blocks [0, B): known points of batch element b into their grid; blocks [B, 2B): the unknown
-// points of batch element b into Morton order
+// workgroups [0, S*B): slab s of the known points of batch element b into their grid; [S*B, 2*S*B):
+// slab s of the unknown points of batch element b into Morton order (S = kBuildSlabs)
 __global__ __launch_bounds__(kBuildThreads) void tn_build_kernel(const float* __restrict__ known,
                                                                  const float* __restrict__ unknown,
                                                                  unsigned char* __restrict__ ws, int B, int N,
                                                                  int M) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];
   const TnLayout L = tn_layout(B, N, M);
-  GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + blockIdx.x;
-  if ((int)blockIdx.x >= B) {
-    const int b = blockIdx.x - B;
+  const int set = blockIdx.x / pp::kBuildSlabs, slab = blockIdx.x % pp::kBuildSlabs;
+  GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
+  if (set >= B) {
+    const int b = set - B;
     pp::grid_build_set<true>(unknown + (size_t)b * N * 3, N, gs, nullptr,
-                             reinterpret_cast<pp::f4*>(ws + L.qsorted) + (size_t)b * N, nullptr, s_cnt);
+                             reinterpret_cast<pp::f4*>(ws + L.qsorted) + (size_t)b * N, nullptr, s_cnt, nullptr,
+                             nullptr, slab, pp::kBuildSlabs);
     return;
   }
-  const int b = blockIdx.x;
+  const int b = set;
   pp::grid_build_set<false>(known + (size_t)b * M * 3, M, gs,
                             reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
-                            reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * M, nullptr, s_cnt);
-  __syncthreads();
-  if (threadIdx.x == 0) gs->pad[0] = gs->useless ? 0 : 1;  // 1: the grid kernel serves this batch element
+                            reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * M, nullptr, s_cnt, nullptr,
+                            nullptr, slab, pp::kBuildSlabs);
 }
 
 // (d, k) enters the ascending triple if it is lexicographically smaller than an entry
@@ -81,7 +82,7 @@ __device__ __forceinline__ void insert3(float d, int k, float& b1, float& b2, fl
 }
 
 __global__ __launch_bounds__(256) void tn_query_kernel(float* __restrict__ dist2, int* __restrict__ idx,
-                                                       const unsigned char* __restrict__ ws, int B, int N, int M,
+                                                       unsigned char* __restrict__ ws, int B, int N, int M,
                                                        int tiles_per_b, int per_xcd) {
   const int vb = pp::xcd_virtual_block(blockIdx.x, per_xcd);  // a batch element stays on one XCD's L2
   if (vb >= B * tiles_per_b) return;
@@ -89,7 +90,10 @@ __global__ __launch_bounds__(256) void tn_query_kernel(float* __restrict__ dist2
   const int tile = vb - b * tiles_per_b;
   const TnLayout L = tn_layout(B, N, M);
   const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[b];
-  if (!g.pad[0]) return;  // this batch element goes to the scan kernel
+  const bool usable = !pp::grid_useless(g);
+  if (tile == 0 && threadIdx.x == 0)  // the scan kernel, launched next, skips the sets served here
+    reinterpret_cast<GridSet*>(ws + L.sets)[b].pad[0] = usable ? 1 : 0;
+  if (!usable) return;  // this batch element goes to the scan kernel
   const int n = tile * 256 + threadIdx.x;
   if (n >= N) return;
   const unsigned* __restrict__ cell_start =
@@ -158,10 +162,10 @@ extern "C" int pp_three_nn_ws_f32(const float* unknown, const float* known, floa
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
   static bool lds_ok[64] = {};
-  const size_t lds = (size_t)(kGridCells + kGridCells / 32) * sizeof(unsigned);
+  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
   hipError_t e = pp::allow_big_lds(tn_build_kernel, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  tn_build_kernel<<<dim3(2 * B), dim3(kBuildThreads), lds, s>>>(known, unknown, ws, B, N, M);
+  tn_build_kernel<<<dim3(2 * B * pp::kBuildSlabs), dim3(kBuildThreads), lds, s>>>(known, unknown, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   const int tiles = (N + 255) / 256;
   const long long per_xcd = ((long long)B * tiles + 7) / 8;

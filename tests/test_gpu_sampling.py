@@ -370,9 +370,12 @@ def test_group_points_grad_ball_rows_and_split_columns(cuda, group_grad_path, b,
     got = sampling.group_points_grad(go, idx, n)
     ref = torch.zeros(b, c, n, device=cuda, dtype=torch.float64)
     ref.scatter_add_(2, idx.long().reshape(b, 1, -1).expand(-1, c, -1), go.double().reshape(b, c, -1))
-    assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-5)
+    # destinations here collect up to a few hundred addends: the forms that accumulate in fp32 in
+    # arbitrary order (the reference's global atomics, the fp32 LDS column) carry that many roundings
+    atol = 1e-4 if group_grad_path in ("global_atomics", "lds_columns_f32") else 1e-5
+    assert torch.allclose(got.double(), ref, rtol=1e-5, atol=atol)
     e = oracle.group_points_grad(go.cpu().numpy(), idx.cpu().numpy(), n)
-    assert np.allclose(got.cpu().numpy(), e, rtol=1e-5, atol=1e-5)
+    assert np.allclose(got.cpu().numpy(), e, rtol=1e-5, atol=1e-4)   # the oracle sums in fp32 too
 
 
 @pytest.mark.parametrize("variant", [1, 2, 4, 8, 104, 108, 116, 132])
