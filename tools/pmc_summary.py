@@ -25,6 +25,6 @@ for d in sorted(glob.glob(os.path.join(root, "*_*"))):
         v = list(disp.values())
         mean = sum(v) / len(v)
         du = dur.get(k, [0])
-        short = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+        short = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:60]
         print("   %-60s %s launches=%d mean=%.0f KB = %.1f MB   mean duration %.1f us"
               % (short, cname, len(v), mean, mean / 1024, sum(du) / len(du) / 1e3))

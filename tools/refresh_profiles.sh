@@ -18,5 +18,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   (timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/bg_$c -- python3 bench.py --workload ball_group --with-backward --steps 3 --warmup 1 > $O/pmc_bg_$c.log 2>&1)
 done
 python3 tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1
-rm -rf $O/pmc $O/prof_chamfer $O/prof_fps $O/prof_ball_group
+rm -rf $O/prof_chamfer $O/prof_fps $O/prof_ball_group
+find $O/pmc -name '*agent_info.csv' -delete
 ls -la $O
