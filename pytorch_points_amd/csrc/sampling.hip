@@ -824,6 +824,69 @@ void launch_three_interpolate_lds(const float* points, const int* idx, const flo
                                      (size_t)M * sizeof(float), s>>>(points, idx, weight, out, B, C, M, N, chunks);
 }
 
+// three_interpolate, channel-group form: a workgroup stages CG whole rows points[b, c0..c0+CG, :]
+// in LDS once (one barrier) and then walks ALL n, four per thread and step: (idx, weight) of the
+// four points are read once for the CG channels, 12 LDS gathers per channel, one 16-byte store per
+// channel.  The row-at-a-time form above pays two barriers per channel row for 12 gathers; here
+// the only serial part is the staging.  Same canonical fma order.
+template <int CG>
+__global__ __launch_bounds__(1024) void three_interpolate_rows_kernel(const float* __restrict__ points,
+                                                                      const int* __restrict__ idx,
+                                                                      const float* __restrict__ weight,
+                                                                      float* __restrict__ out, int B, int C,
+                                                                      int M, int N) {
+  extern __shared__ __attribute__((aligned(16))) float s_irows[];  // [CG][M]
+  const int groups = (C + CG - 1) / CG;
+  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+  const int b = x + 8 * (y / groups);
+  if (b >= B) return;
+  const int c0 = (y % groups) * CG;
+  const int nc = min(CG, C - c0);
+  const int t = threadIdx.x;
+  const int m4 = M >> 2;
+  for (int k = 0; k < nc; ++k) {
+    const pp::f4* __restrict__ row = reinterpret_cast<const pp::f4*>(points + ((size_t)b * C + c0 + k) * M);
+    for (int e = t; e < m4; e += 1024) reinterpret_cast<pp::f4*>(s_irows + (size_t)k * M)[e] = row[e];
+  }
+  __syncthreads();
+  for (int n0 = 4 * t; n0 < N; n0 += 4096) {
+    int ii[12];
+    float ww[12];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const pp::i4 q = reinterpret_cast<const pp::i4*>(idx + ((size_t)b * N + n0) * 3)[e];
+      const pp::f4 w = reinterpret_cast<const pp::f4*>(weight + ((size_t)b * N + n0) * 3)[e];
+      ii[4 * e] = q.x; ii[4 * e + 1] = q.y; ii[4 * e + 2] = q.z; ii[4 * e + 3] = q.w;
+      ww[4 * e] = w.x; ww[4 * e + 1] = w.y; ww[4 * e + 2] = w.z; ww[4 * e + 3] = w.w;
+    }
+#pragma unroll
+    for (int k = 0; k < CG; ++k)
+      if (k < nc) {
+        const float* __restrict__ sr = s_irows + (size_t)k * M;
+        pp::f4 r;
+        r.x = __builtin_fmaf(ww[2], sr[ii[2]], __builtin_fmaf(ww[0], sr[ii[0]], ww[1] * sr[ii[1]]));
+        r.y = __builtin_fmaf(ww[5], sr[ii[5]], __builtin_fmaf(ww[3], sr[ii[3]], ww[4] * sr[ii[4]]));
+        r.z = __builtin_fmaf(ww[8], sr[ii[8]], __builtin_fmaf(ww[6], sr[ii[6]], ww[7] * sr[ii[7]]));
+        r.w = __builtin_fmaf(ww[11], sr[ii[11]], __builtin_fmaf(ww[9], sr[ii[9]], ww[10] * sr[ii[10]]));
+        *reinterpret_cast<pp::f4*>(out + ((size_t)b * C + c0 + k) * N + n0) = r;
+      }
+  }
+}
+
+template <int CG>
+static int launch_three_interpolate_rows(const float* points, const int* idx, const float* weight, float* out,
+                                         int B, int C, int M, int N, hipStream_t s) {
+  static bool ok[64] = {};
+  const hipError_t e = pp::allow_big_lds(three_interpolate_rows_kernel<CG>, 152 * 1024, ok);
+  if (e != hipSuccess) return (int)e;
+  const long long wgs = 8LL * ((B + 7) / 8) * ((C + CG - 1) / CG);
+  if (wgs > 0x7fffffffLL) return PP_EINVAL;
+  three_interpolate_rows_kernel<CG><<<dim3((unsigned)wgs), dim3(1024), (size_t)CG * M * sizeof(float), s>>>(
+      points, idx, weight, out, B, C, M, N);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+
 // three_interpolate backward (ref interpolate_gpu.cu:120-142)
 __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
     const float* __restrict__ grad_out, const int* __restrict__ idx,
@@ -1191,7 +1254,8 @@ int three_nn_scan_unusable(const float* unknown, const float* known, float* dist
 }
 }  // namespace pp
 
-// 0 = automatic; 1 = force the global-gather kernel (tests and tuning)
+// 0 = automatic; 1 = force the global-gather kernel; 2 = no channel-group form (row-at-a-time LDS
+// form where it applies)   (tests and tuning)
 static int g_interp_variant = 0;
 extern "C" void pp_debug_set_three_interpolate_variant(int v) { g_interp_variant = v; }
 
@@ -1205,6 +1269,11 @@ extern "C" int pp_three_interpolate_f32(const float* points, const int* idx, con
       (uintptr_t)points % 16 == 0 && (uintptr_t)idx % 16 == 0 && (uintptr_t)weight % 16 == 0 &&
       (uintptr_t)out % 16 == 0 && (long long)B * N >= 64 * 2048) {
     hipStream_t s = (hipStream_t)stream;
+    // channel-group form: four whole rows fit 64 KiB (two workgroups per CU) and there are enough
+    // (batch, group) workgroups to fill the chip
+    if (g_interp_variant != 2 && (size_t)4 * M * sizeof(float) <= 64 * 1024 && N >= 4096 &&
+        8LL * ((B + 7) / 8) * ((C + 3) / 4) >= 512)
+      return launch_three_interpolate_rows<4>(points, idx, weight, out, B, C, M, N, s);
     const int m4 = M / 4;
     if (m4 <= 512) launch_three_interpolate_lds<1>(points, idx, weight, out, B, C, M, N, s);
     else if (m4 <= 1024) launch_three_interpolate_lds<2>(points, idx, weight, out, B, C, M, N, s);

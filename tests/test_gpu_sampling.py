@@ -565,10 +565,12 @@ def test_three_interpolate_forward_backward(cuda):
     assert np.allclose(gr.cpu().numpy(), eg, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("b,c,m,n", [(9, 16, 4096, 16384), (2, 7, 1000, 70000), (3, 5, 16384, 40000), (1, 64, 512, 131072)])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("b,c,m,n", [(9, 16, 4096, 16384), (2, 7, 1000, 70000), (3, 5, 16384, 40000), (1, 64, 512, 131072),
+                                     (17, 130, 2048, 4096), (32, 67, 4096, 8192)])
 def test_three_interpolate_both_kernels(cuda, variant, b, c, m, n):
-    """LDS-staged and global-gather forms == oracle bitwise (canonical fma order)."""
+    """channel-group (0, where it applies), global-gather (1) and row-at-a-time LDS (2) forms == oracle
+    bitwise (canonical fma order)."""
     import ctypes
     from pytorch_points_amd import _lib
     from pytorch_points_amd._ext import sampling
