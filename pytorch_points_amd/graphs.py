@@ -44,7 +44,9 @@ class GraphedChamferStep:
         torch.cuda.current_stream(self.xyz1.device).wait_stream(side)
         torch.cuda.synchronize(self.xyz1.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads of the process (e.g. the RCCL watchdog of torch.distributed) may
+        # keep querying their own events while this thread captures
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             (self.dist1, self.dist2, self.idx1, self.idx2, self.grad_xyz1, self.grad_xyz2) = self._step()
         return self
 
