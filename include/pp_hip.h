@@ -155,6 +155,21 @@ size_t pp_three_nn_workspace_bytes(int B, int N, int M);
 int pp_three_nn_ws_f32(const float* unknown, const float* known, float* dist2, int* idx, int B, int N,
                        int M, void* workspace, size_t workspace_bytes, void* stream);
 
+/* K nearest neighbours: replaces pytorch3d.ops.knn_points, which the reference calls at
+ *   network/model_loss.py:120,147,378, geo_operations.py:112,139, layers.py:52,99,115
+ *   (pytorch3d is an un-vendored dependency, environment.yml:11).
+ * p1 (B,N,3), p2 (B,M,3) -> dist2 (B,N,K) squared distances ascending, idx (B,N,K); 1 <= K <= 32.
+ * Ties go to the lower index.  lengths1 / lengths2 (B ints, may be null): valid points per cloud;
+ * slots beyond the valid points of p2 and rows beyond lengths1 hold (0, 0).
+ * pp_knn_ws_f32: the same through the exact uniform-grid search (identical outputs); ragged batches
+ * and small clouds take the scan. */
+int pp_knn_f32(const float* p1, const float* p2, const int* lengths1, const int* lengths2, float* dist2,
+               int* idx, int B, int N, int M, int K, void* stream);
+size_t pp_knn_workspace_bytes(int B, int N, int M, int K);
+int pp_knn_ws_f32(const float* p1, const float* p2, const int* lengths1, const int* lengths2, float* dist2,
+                  int* idx, int B, int N, int M, int K, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
 /* Replaces sampling.three_interpolate_wrapper(b,c,m,n,points,idx,weight,out)
  *   (_ext/sampling.cpp:175-188 -> _ext/interpolate_gpu.cu:77-117).
  * points (B,C,M), idx (B,N,3), weight (B,N,3) -> out (B,C,N) */

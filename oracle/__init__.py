@@ -197,6 +197,27 @@ def three_nn(unknown, known):
     return d2, idx
 
 
+def knn(p1, p2, K, lengths1=None, lengths2=None):
+    """K nearest neighbours of p1 (B,N,3) in p2 (B,M,3) -> dist2 (B,N,K) f32 ascending, idx (B,N,K) i32;
+    ties to the lower index; padding (0, 0)"""
+    p1, q1 = _f(p1)
+    p2, q2 = _f(p2)
+    b, n, _ = p1.shape
+    m = p2.shape[1]
+    d2 = np.zeros((b, n, K), np.float32)
+    idx = np.zeros((b, n, K), np.int32)
+    l1 = l2 = None
+    a1 = a2 = None
+    if lengths1 is not None:
+        a1 = np.ascontiguousarray(lengths1, np.int32)
+        l1 = a1.ctypes.data_as(ctypes.c_void_p)
+    if lengths2 is not None:
+        a2 = np.ascontiguousarray(lengths2, np.int32)
+        l2 = a2.ctypes.data_as(ctypes.c_void_p)
+    lib().oracle_knn(q1, q2, l1, l2, _p(d2), _p(idx), b, n, m, int(K))
+    return d2, idx
+
+
 def three_interpolate(points, idx, weight):
     points, pp = _f(points)
     idx, pi = _i(idx)

@@ -436,6 +436,45 @@ void oracle_three_nn(const float* unknown, const float* known, float* dist2, int
     }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * K nearest neighbours: what the reference gets from pytorch3d.ops.knn_points
+ * (not vendored: no source to follow; version unpinned in environment.yml:11).  Restated from its
+ * published contract: per point of p1 the K nearest points of p2, squared distances ascending,
+ * computed sequentially over the coordinates (d = dx*dx; d += dy*dy; d += dz*dz with FMA
+ * contraction = distc above); ties resolved to the lower index (pytorch3d leaves them unspecified);
+ * slots beyond the valid points, and rows beyond lengths1, hold (0, 0).
+ * ------------------------------------------------------------------------------------------- */
+void oracle_knn(const float* p1, const float* p2, const int* len1, const int* len2, float* dist, int* idx,
+                int b, int n, int m, int K) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int i = 0; i < b; ++i)
+    for (int j = 0; j < n; ++j) {
+      float* od = dist + ((size_t)i * n + j) * K;
+      int* oi = idx + ((size_t)i * n + j) * K;
+      const int n1 = len1 ? (len1[i] < 0 ? 0 : (len1[i] > n ? n : len1[i])) : n;
+      const int m2 = len2 ? (len2[i] < 0 ? 0 : (len2[i] > m ? m : len2[i])) : m;
+      for (int k = 0; k < K; ++k) { od[k] = 0.0f; oi[k] = 0; }
+      if (j >= n1) continue;
+      const float* q = p1 + ((size_t)i * n + j) * 3;
+      int have = 0;
+      for (int k = 0; k < m2; ++k) {
+        const float d = distc(p2 + ((size_t)i * m + k) * 3, q, 3);
+        if (d != d) continue; /* NaN never enters */
+        /* insertion into the ascending list; strict <: the earlier index stays ahead among equals */
+        int pos = have < K ? have : K;
+        while (pos > 0 && d < od[pos - 1]) --pos;
+        if (pos >= K) continue;
+        const int last = have < K ? have : K - 1;
+        for (int t = last; t > pos; --t) { od[t] = od[t - 1]; oi[t] = oi[t - 1]; }
+        od[pos] = d; oi[pos] = k;
+        if (have < K) ++have;
+      }
+      /* valid points that never entered (NaN distances): distance +inf, index 0 */
+      const int valid = m2 < K ? m2 : K;
+      for (int k = have; k < valid; ++k) { od[k] = INFINITY; oi[k] = 0; }
+    }
+}
+
 /* K11  three_interpolate_kernel_fast, interpolate_gpu.cu:77-97 */
 void oracle_three_interpolate(const float* points, const int* idx, const float* weight, float* out,
                               int b, int c, int m, int n) {

@@ -27,3 +27,24 @@ def install_as_pytorch_points():
     for suffix in names:
         mod = importlib.import_module(__name__ + suffix)
         sys.modules["pytorch_points" + suffix] = mod
+
+
+def install_knn_as_pytorch3d_ops():
+    """Opt-in: make ``import pytorch3d.ops as ops; ops.knn_points(...)`` -- the only use the reference
+    makes of pytorch3d -- resolve to pytorch_points_amd.ops when pytorch3d itself is not installed.
+    Does nothing if a real pytorch3d is importable."""
+    import importlib
+    import sys
+    import types
+    try:
+        importlib.import_module("pytorch3d.ops")
+        return False
+    except ImportError:
+        pass
+    from . import ops
+    pkg = types.ModuleType("pytorch3d")
+    pkg.__path__ = []
+    pkg.ops = ops
+    sys.modules["pytorch3d"] = pkg
+    sys.modules["pytorch3d.ops"] = ops
+    return True

@@ -1,0 +1,274 @@
+// knn.hip -- K nearest neighbours of every point of p1 (B,N,3) among p2 (B,M,3): the operator the
+// reference obtains from pytorch3d.ops.knn_points at eight call sites (network/model_loss.py:120,147,378,
+// geo_operations.py:112,139, layers.py:52,99,115; pytorch3d itself is not vendored -- SURVEY.md §8f N4).
+//
+// Result per query: the K smallest pairs (d, index) in lexicographic order, d = squared distance in
+// the sequential form pytorch3d's kernels use (dx*dx, then fma(dy,dy,.), fma(dz,dz,.) = pp::chamfer_d3),
+// ascending; ties go to the lower index.  Slots beyond the number of valid reference points hold
+// (0, 0), as do the rows of queries beyond lengths1 (pytorch3d pads with zeros).
+//   * knn_scan_kernel<KT>: one lane per query, reference point wave-uniform, sorted K-list in registers.
+//   * knn_grid_kernel<KT>: the exact grid search of three_nn_grid.hip with a K-list: reference points
+//     counting-sorted into the grid, queries Morton-sorted, a lane scans the cell box
+//     [cell(q - R), cell(q + R)] and stops when its K-th best is below 0.9999 reach^2 (reach = what the
+//     rounded box bounds guarantee on every axis); otherwise R doubles.  Same bits as the scan.
+#include "grid_common.h"
+
+namespace {
+
+using pp::GridSet;
+using pp::cell_coord;
+using pp::kGridCells;
+using pp::kBuildThreads;
+
+// ascending K-list in registers; (d, k) enters if it is lexicographically smaller than an entry
+template <int KT>
+struct KList {
+  float d[KT];
+  int i[KT];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      d[j] = __builtin_inff();
+      i[j] = 0x7fffffff;
+    }
+  }
+  __device__ __forceinline__ bool beats_last(float nd, int ni) const {
+    return nd < d[KT - 1] || (nd == d[KT - 1] && ni < i[KT - 1]);
+  }
+  __device__ __forceinline__ void insert(float nd, int ni) {
+    bool lt[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) lt[j] = nd < d[j] || (nd == d[j] && ni < i[j]);
+#pragma unroll
+    for (int j = KT - 1; j >= 1; --j) {
+      d[j] = lt[j - 1] ? d[j - 1] : (lt[j] ? nd : d[j]);
+      i[j] = lt[j - 1] ? i[j - 1] : (lt[j] ? ni : i[j]);
+    }
+    d[0] = lt[0] ? nd : d[0];
+    i[0] = lt[0] ? ni : i[0];
+  }
+};
+
+template <int KT>
+__device__ __forceinline__ void knn_store(const KList<KT>& L, float* __restrict__ od, int* __restrict__ oi, int K,
+                                          int nvalid) {
+  // slots beyond the valid reference points: (0, 0)
+#pragma unroll
+  for (int j = 0; j < KT; ++j)
+    if (j < K) {
+      const bool real = j < nvalid;
+      od[j] = real ? L.d[j] : 0.0f;
+      oi[j] = (real && L.i[j] != 0x7fffffff) ? L.i[j] : 0;  // a slot no point entered (NaN distances): (inf, 0)
+    }
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                       const int* __restrict__ len1, const int* __restrict__ len2,
+                                                       float* __restrict__ dist, int* __restrict__ idx, int N, int M,
+                                                       int K, int tiles_per_b, const GridSet* __restrict__ skip) {
+  const int b = blockIdx.x / tiles_per_b;
+  if (skip && skip[b].pad[0]) return;  // this batch element was handled by the grid search
+  const int tile = blockIdx.x - b * tiles_per_b;
+  const int n = tile * 256 + threadIdx.x;
+  const int n1 = len1 ? min(max(len1[b], 0), N) : N;
+  const int m2 = len2 ? min(max(len2[b], 0), M) : M;
+  if (n >= N) return;
+  float* od = dist + ((size_t)b * N + n) * K;
+  int* oi = idx + ((size_t)b * N + n) * K;
+  if (n >= n1) {  // a padded query row
+    for (int j = 0; j < K; ++j) {
+      od[j] = 0.0f;
+      oi[j] = 0;
+    }
+    return;
+  }
+  const float* __restrict__ q = p1 + ((size_t)b * N + n) * 3;
+  const float* __restrict__ r = p2 + (size_t)b * M * 3;
+  const float qx = q[0], qy = q[1], qz = q[2];
+  KList<KT> L;
+  L.clear();
+  for (int k = 0; k < m2; ++k) {  // r[...] is wave-uniform: scalar loads
+    const float d = pp::chamfer_d3(r[3 * (size_t)k], r[3 * (size_t)k + 1], r[3 * (size_t)k + 2], qx, qy, qz);
+    if (__any(L.beats_last(d, k))) L.insert(d, k);
+  }
+  knn_store<KT>(L, od, oi, K, m2);
+}
+
+struct KnLayout {
+  size_t sets, cell_start, sorted, qsorted, total;
+};
+__host__ __device__ inline KnLayout kn_layout(int B, int N, int M) {
+  KnLayout L;
+  L.sets = 0;  // [2B]: sets of the reference clouds, then the (unused) sets of the query sort
+  L.cell_start = ((size_t)64 * 2 * B + 255) / 256 * 256;
+  L.sorted = L.cell_start + ((size_t)4 * (kGridCells + 1) * B + 255) / 256 * 256;
+  L.qsorted = L.sorted + ((size_t)16 * B * M + 255) / 256 * 256;
+  L.total = L.qsorted + (size_t)16 * B * N;
+  return L;
+}
+
+__global__ __launch_bounds__(kBuildThreads) void kn_build_kernel(const float* __restrict__ p2,
+                                                                 const float* __restrict__ p1,
+                                                                 unsigned char* __restrict__ ws, int B, int N,
+                                                                 int M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];
+  const KnLayout L = kn_layout(B, N, M);
+  const int set = blockIdx.x / pp::kBuildSlabs, slab = blockIdx.x % pp::kBuildSlabs;
+  GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
+  if (set >= B) {
+    const int b = set - B;
+    pp::grid_build_set<true>(p1 + (size_t)b * N * 3, N, gs, nullptr,
+                             reinterpret_cast<pp::f4*>(ws + L.qsorted) + (size_t)b * N, nullptr, s_cnt, nullptr,
+                             nullptr, slab, pp::kBuildSlabs);
+    return;
+  }
+  const int b = set;
+  pp::grid_build_set<false>(p2 + (size_t)b * M * 3, M, gs,
+                            reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
+                            reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * M, nullptr, s_cnt, nullptr,
+                            nullptr, slab, pp::kBuildSlabs);
+}
+
+template <int KT>
+__global__ __launch_bounds__(256) void knn_grid_kernel(float* __restrict__ dist, int* __restrict__ idx,
+                                                       unsigned char* __restrict__ ws, int B, int N, int M, int K,
+                                                       int tiles_per_b, int per_xcd) {
+  const int vb = pp::xcd_virtual_block(blockIdx.x, per_xcd);  // a batch element stays on one XCD's L2
+  if (vb >= B * tiles_per_b) return;
+  const int b = vb / tiles_per_b;
+  const int tile = vb - b * tiles_per_b;
+  const KnLayout L = kn_layout(B, N, M);
+  const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[b];
+  const bool usable = !pp::grid_useless(g);
+  if (tile == 0 && threadIdx.x == 0)  // the scan kernel, launched next, skips the sets served here
+    reinterpret_cast<GridSet*>(ws + L.sets)[b].pad[0] = usable ? 1 : 0;
+  if (!usable) return;
+  const int n = tile * 256 + threadIdx.x;
+  if (n >= N) return;
+  const unsigned* __restrict__ cell_start =
+      reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1);
+  const pp::f4* __restrict__ sorted = reinterpret_cast<const pp::f4*>(ws + L.sorted) + (size_t)b * M;
+  const pp::f4 q = (reinterpret_cast<const pp::f4*>(ws + L.qsorted) + (size_t)b * N)[n];
+  const int qorig = __float_as_int(q.w);
+  const bool finite_q = __builtin_isfinite(q.x) && __builtin_isfinite(q.y) && __builtin_isfinite(q.z);
+  // first box: about 2K points expected if the cloud filled its cells evenly (2 per cell), at least one cell
+  float R = finite_q ? g.h * fmaxf(1.0f, 0.5f * cbrtf((float)K)) : 2.0e38f;
+  KList<KT> Lk;
+  const int kth = min(K, M) - 1;  // the entry that decides when to stop
+  while (true) {
+    Lk.clear();
+    const float lx = q.x - R, hx = q.x + R, ly = q.y - R, hy = q.y + R, lz = q.z - R, hz = q.z + R;
+    const bool everything = !(R < 1.0e38f);  // last round (also: non-finite q): the whole grid, no questions
+    const int x0 = everything ? 0 : cell_coord(lx, g.minx, g.invh, g.gx);
+    const int x1 = everything ? g.gx - 1 : cell_coord(hx, g.minx, g.invh, g.gx);
+    const int y0 = everything ? 0 : cell_coord(ly, g.miny, g.invh, g.gy);
+    const int y1 = everything ? g.gy - 1 : cell_coord(hy, g.miny, g.invh, g.gy);
+    const int z0 = everything ? 0 : cell_coord(lz, g.minz, g.invh, g.gz);
+    const int z1 = everything ? g.gz - 1 : cell_coord(hz, g.minz, g.invh, g.gz);
+    // what the box really guarantees, from the rounded bounds themselves (|q| may dwarf R)
+    const float reach = fminf(fminf(fminf(hx - q.x, q.x - lx), fminf(hy - q.y, q.y - ly)), fminf(hz - q.z, q.z - lz));
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        const int c = (z * g.gy + y) * g.gx;
+        const unsigned e = cell_start[c + x1 + 1];
+        for (unsigned i = cell_start[c + x0]; i < e; ++i) {
+          const pp::f4 p = sorted[i];
+          const float d = pp::chamfer_d3(p.x, p.y, p.z, q.x, q.y, q.z);
+          const int id = __float_as_int(p.w);
+          if (Lk.beats_last(d, id)) Lk.insert(d, id);
+        }
+      }
+    const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.gx - 1 && y1 == g.gy - 1 && z1 == g.gz - 1;
+    float dk = Lk.d[0];
+#pragma unroll
+    for (int j = 1; j < KT; ++j) dk = j <= kth ? Lk.d[j] : dk;
+    if (whole || dk < 0.9999f * (reach * reach)) break;
+    R *= 2.0f;
+  }
+  knn_store<KT>(Lk, dist + ((size_t)b * N + qorig) * K, idx + ((size_t)b * N + qorig) * K, K, M);
+}
+
+template <int KT>
+int knn_scan_launch(const float* p1, const float* p2, const int* len1, const int* len2, float* dist, int* idx,
+                    int B, int N, int M, int K, const GridSet* skip, hipStream_t s) {
+  const int tiles = (N + 255) / 256;
+  const long long blocks = (long long)B * tiles;
+  if (blocks > 0x7fffffffLL) return PP_EINVAL;
+  knn_scan_kernel<KT><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(p1, p2, len1, len2, dist, idx, N, M, K, tiles,
+                                                                    skip);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+
+int knn_scan_dispatch(const float* p1, const float* p2, const int* len1, const int* len2, float* dist, int* idx,
+                      int B, int N, int M, int K, const GridSet* skip, hipStream_t s) {
+  if (K <= 1) return knn_scan_launch<1>(p1, p2, len1, len2, dist, idx, B, N, M, K, skip, s);
+  if (K <= 4) return knn_scan_launch<4>(p1, p2, len1, len2, dist, idx, B, N, M, K, skip, s);
+  if (K <= 8) return knn_scan_launch<8>(p1, p2, len1, len2, dist, idx, B, N, M, K, skip, s);
+  if (K <= 16) return knn_scan_launch<16>(p1, p2, len1, len2, dist, idx, B, N, M, K, skip, s);
+  return knn_scan_launch<32>(p1, p2, len1, len2, dist, idx, B, N, M, K, skip, s);
+}
+
+template <int KT>
+int knn_grid_launch(float* dist, int* idx, unsigned char* ws, int B, int N, int M, int K, hipStream_t s) {
+  const int tiles = (N + 255) / 256;
+  const long long per_xcd = ((long long)B * tiles + 7) / 8;
+  if (per_xcd * 8 > 0x7fffffffLL) return PP_EINVAL;
+  knn_grid_kernel<KT><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(dist, idx, ws, B, N, M, K, tiles,
+                                                                          (int)per_xcd);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+
+}  // namespace
+
+// 0 = automatic (grid when a workspace is given); 1 = scan kernel only (tests and tuning)
+static int g_knn_grid_mode = 0;
+extern "C" void pp_debug_set_knn_search(int v) { g_knn_grid_mode = v; }
+
+static bool knn_args_ok(const float* p1, const float* p2, const float* dist, const int* idx, int B, int N, int M,
+                        int K) {
+  return B >= 0 && N >= 0 && M >= 0 && K >= 1 && K <= 32 && (B == 0 || N == 0 || (p1 && dist && idx && (M == 0 || p2)));
+}
+
+extern "C" int pp_knn_f32(const float* p1, const float* p2, const int* lengths1, const int* lengths2, float* dist2,
+                          int* idx, int B, int N, int M, int K, void* stream) {
+  if (!knn_args_ok(p1, p2, dist2, idx, B, N, M, K)) return PP_EINVAL;
+  if (B == 0 || N == 0) return PP_OK;
+  return knn_scan_dispatch(p1, p2, lengths1, lengths2, dist2, idx, B, N, M, K, nullptr, (hipStream_t)stream);
+}
+
+extern "C" size_t pp_knn_workspace_bytes(int B, int N, int M, int K) {
+  if (B <= 0 || N < 1024 || M < 1024 || K < 1 || K > 32 || M < 4 * K) return 0;
+  if ((long long)B * N >= (1LL << 31) || (long long)B * M >= (1LL << 31)) return 0;
+  return kn_layout(B, N, M).total;
+}
+
+extern "C" int pp_knn_ws_f32(const float* p1, const float* p2, const int* lengths1, const int* lengths2,
+                             float* dist2, int* idx, int B, int N, int M, int K, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  const size_t need = pp_knn_workspace_bytes(B, N, M, K);
+  // ragged batches (lengths given) take the scan: the grid is built over all M points of a cloud
+  if (g_knn_grid_mode == 1 || need == 0 || !workspace || workspace_bytes < need || lengths1 || lengths2)
+    return pp_knn_f32(p1, p2, lengths1, lengths2, dist2, idx, B, N, M, K, stream);
+  if (!knn_args_ok(p1, p2, dist2, idx, B, N, M, K)) return PP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  static bool lds_ok[64] = {};
+  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
+  hipError_t e = pp::allow_big_lds(kn_build_kernel, (int)lds, lds_ok);
+  if (e != hipSuccess) return (int)e;
+  kn_build_kernel<<<dim3(2 * B * pp::kBuildSlabs), dim3(kBuildThreads), lds, s>>>(p2, p1, ws, B, N, M);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  int rc;
+  if (K <= 1) rc = knn_grid_launch<1>(dist2, idx, ws, B, N, M, K, s);
+  else if (K <= 4) rc = knn_grid_launch<4>(dist2, idx, ws, B, N, M, K, s);
+  else if (K <= 8) rc = knn_grid_launch<8>(dist2, idx, ws, B, N, M, K, s);
+  else if (K <= 16) rc = knn_grid_launch<16>(dist2, idx, ws, B, N, M, K, s);
+  else rc = knn_grid_launch<32>(dist2, idx, ws, B, N, M, K, s);
+  if (rc != PP_OK) return rc;
+  const KnLayout L = kn_layout(B, N, M);
+  return knn_scan_dispatch(p1, p2, nullptr, nullptr, dist2, idx, B, N, M, K,
+                           reinterpret_cast<const GridSet*>(ws + L.sets), s);
+}

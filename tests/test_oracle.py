@@ -196,3 +196,26 @@ def test_synthetic_generator_is_counter_based():
     assert abs(a.mean()) < 0.1 and S.polar_sphere(0, 1, 10).shape == (1, 10, 3)
     # a pinned value: inputs must not drift with numpy versions
     assert S.unit_sphere(0, 1, 4).dtype == np.float32
+
+
+def test_knn_oracle_vs_fp64_bruteforce():
+    """oracle.knn against an fp64 evaluation: same neighbours except across fp32
+    near-ties, distances within fp32 rounding; padding conventions."""
+    p1 = S.unit_sphere(200, 2, 300)
+    p2 = S.unit_sphere(201, 2, 257)
+    K = 7
+    d, i = oracle.knn(p1, p2, K)
+    D = ((p1[:, :, None].astype(np.float64) - p2[:, None].astype(np.float64)) ** 2).sum(-1)
+    ref = np.argsort(D, axis=-1, kind="stable")[..., :K]
+    dref = np.take_along_axis(D, ref, -1)
+    assert np.allclose(d, dref, rtol=1e-5, atol=1e-6)
+    assert (i == ref).mean() > 0.999          # the rest are fp32 near-ties
+    assert (np.diff(d, axis=-1) >= 0).all()
+    d, i = oracle.knn(p1, p2, K, lengths1=[300, 5], lengths2=[257, 3])
+    assert (d[1, 5:] == 0).all() and (i[1, 5:] == 0).all()        # rows beyond lengths1
+    assert (d[1, :5, 3:] == 0).all() and (i[1, :5, 3:] == 0).all() and (i[1, :5, :3] < 3).all()
+    # exact ties: the lower index first
+    q = np.zeros((1, 1, 3), np.float32)
+    r = np.array([[[1, 0, 0], [0, 1, 0], [0, 0, 1], [0.5, 0, 0], [-1, 0, 0]]], np.float32)
+    d, i = oracle.knn(q, r, 5)
+    assert i[0, 0].tolist() == [3, 0, 1, 2, 4]

@@ -47,3 +47,12 @@ dd1 = torch.empty(B, N, device=dev); dd2 = torch.empty(B, N, device=dev)
 ii1 = torch.empty(B, N, dtype=torch.int32, device=dev); ii2 = torch.empty(B, N, dtype=torch.int32, device=dev)
 ms = t(lambda: losses.labeled_nmdistance_forward(x1, x2, l1, l2, dd1, dd2, ii1, ii2), 3)
 print("labeled_nmdistance_forward B=%d N=M=%d: %.3f ms  (%.2f Tpairs/s)" % (B, N, ms, 2.0 * B * N * N / ms / 1e9))
+from pytorch_points_amd.ops import knn_points
+_ks = _lib.lib().pp_debug_set_knn_search
+_ks.argtypes = [ctypes.c_int]; _ks.restype = None
+for K in (1, 8, 16):
+    for name, v in (("grid", 0), ("scan", 1)):
+        _ks(v)
+        ms = t(lambda: knn_points(x1, x2, K=K), 3)
+        print("knn_points K=%d B=%d N=M=%d [%s]: %.3f ms" % (K, B, N, name, ms))
+_ks(0)
