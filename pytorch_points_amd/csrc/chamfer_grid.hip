@@ -38,7 +38,6 @@ using pp::kBuildThreads;
 
 constexpr float kBoundSlack = 0.999f;
 constexpr int kWideBlocksPerSet = 4;
-constexpr int kUnresolved = (int)0x80000000;
 
 // Workspace layout (bytes), S = 2*B sets, T = B*(N+M) points:
 //   [0, 64*S)                      GridSet[S]
@@ -47,12 +46,10 @@ constexpr int kUnresolved = (int)0x80000000;
 //   [.., +16*T)                    float4 sorted[T]   (x, y, z, original index bits)
 //   [.., +4*T)                     int qlist[T]           queries left to the brute force, per set
 //   [.., +4*T)                     int blist[T]           queries left to stages B/C, per set
-//   [.., +4*T)                     int inv[T]             position of original point k in `sorted`
-//   [.., +8*T)                     {float dist, int idx} res[T]   stage-A results in sorted order
 //   [.., +4*T)                     float slab[T]          labels in sorted order (labeled Chamfer only)
 // qcount has 4*B entries: [0, 2B) count qlist, [2B, 4B) count blist.
 struct Layout {
-  size_t sets, qcount, cell_start, sorted, qlist, blist, inv, res, slab, total;
+  size_t sets, qcount, cell_start, sorted, qlist, blist, slab, total;
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
   Layout L;
@@ -63,9 +60,7 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   L.sorted = L.cell_start + ((4 * (size_t)(kGridCells + 1) * S + 255) / 256) * 256;
   L.qlist = L.sorted + 16 * T;
   L.blist = L.qlist + 4 * T;
-  L.inv = L.blist + 4 * T;
-  L.res = L.inv + 4 * T;
-  L.slab = L.res + 8 * T;
+  L.slab = L.blist + 4 * T;
   L.total = L.slab + (labeled ? 4 * T : 0);
   return L;
 }
@@ -101,7 +96,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   pp::grid_build_set(ref, nr, reinterpret_cast<GridSet*>(ws + L.sets) + set,
                      reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1),
                      reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M),
-                     reinterpret_cast<int*>(ws + L.inv) + set_point_offset(b, dir, N, M), s_cnt, lab,
+                     nullptr, s_cnt, lab,
                      labeled ? reinterpret_cast<float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr,
                      slab, pp::kBuildSlabs);
 }
@@ -236,44 +231,16 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
     const float reach = g.h * fminf(reach1(fx, sx, cx, g.gx), fminf(reach1(fy, sy, cy, g.gy), reach1(fz, sz, cz, g.gz)));
     resolved = best < reach * reach * kBoundSlack;
   }
-  // Results leave in the order the queries were walked (coalesced 8-byte stores); the unsort pass
-  // gathers them back to the original order.  (Writing dist[j], idx[j] from here would be two
-  // scattered 4-byte stores per query: that alone cost more than the whole search.)
-  if (!gp_useless) {
-    pp::f2 rv = {best, __int_as_float(resolved ? bidx : kUnresolved)};
-    reinterpret_cast<pp::f2*>(ws + L.res)[set_point_offset(b, dir ^ 1, N, M) + jj] = rv;
-  } else if (resolved) {
+  // Results go straight to the query's original position: two scattered 4-byte stores per query.
+  // (Measured against leaving them in walked order, coalesced, plus an inverse permutation written by
+  // the build and an unsort pass: the direct form is 4 us faster per forward at config 2 and needs
+  // 12 bytes less workspace per point.)
+  if (resolved) {
     (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
     (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
   }
   int* blist = reinterpret_cast<int*>(ws + L.blist) + set_query_offset(b, dir, N, M);
   wave_append(!resolved, counts + 2 * B + set, blist, j);
-}
-
-// Original order <- walked order: one gather of 8 bytes per query, coalesced stores.
-__device__ __forceinline__ void grid_unsort_block(int block, float* __restrict__ dist1, int* __restrict__ idx1,
-                                                  float* __restrict__ dist2, int* __restrict__ idx2,
-                                                  const unsigned char* __restrict__ ws, int B, int N, int M,
-                                                  int tiles1, int tiles2) {
-  const int per_b = tiles1 + tiles2;
-  const int b = block / per_b;
-  const int r = block - b * per_b;
-  const int dir = r >= tiles1 ? 1 : 0;
-  const int tile = dir ? r - tiles1 : r;
-  const int nq = dir ? M : N;
-  const int j = tile * 256 + threadIdx.x;
-  if (j >= nq) return;
-  const Layout L = make_layout(B, N, M);
-  const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[2 * b + dir];
-  const GridSet gp = reinterpret_cast<const GridSet*>(ws + L.sets)[(2 * b + dir) ^ 1];
-  if (pp::grid_useless(g) || pp::grid_useless(gp)) return;  // those queries were written (or listed) directly
-  const size_t off = set_point_offset(b, dir ^ 1, N, M);  // the query cloud as the partner's references
-  const int pos = reinterpret_cast<const int*>(ws + L.inv)[off + j];
-  const pp::f2 rv = reinterpret_cast<const pp::f2*>(ws + L.res)[off + pos];
-  const int id = __float_as_int(rv.y);
-  if (id == kUnresolved) return;  // left to the wide / brute-force kernels
-  (dir ? dist2 : dist1)[(size_t)b * nq + j] = rv.x;
-  (dir ? idx2 : idx1)[(size_t)b * nq + j] = id;
 }
 
 // Stages B and C for the queries stage A left over (grid-stride over the compacted list).
@@ -411,29 +378,19 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
   }
 }
 
-// After stage A two independent things remain: putting the resolved results back in the original
-// order, and the wide stages for the unresolved queries (disjoint outputs).  One launch runs both:
-// the first `wide_blocks` workgroups take the wide stages (the longer, latency-bound job), the
-// rest unsort.
+// After stage A: the wide stages for the queries it left over, one set per workgroup, on the XCD whose
+// L2 holds the set from grid_query_kernel (same blockIdx % 8 -> set mapping; the grid is a multiple of 8).
 template <bool LAB>
 __global__ __launch_bounds__(256) void grid_finish_kernel(const float* __restrict__ xyz1,
                                                           const float* __restrict__ xyz2,
                                                           float* __restrict__ dist1, int* __restrict__ idx1,
                                                           float* __restrict__ dist2, int* __restrict__ idx2,
                                                           unsigned char* __restrict__ ws, int B, int N, int M,
-                                                          int tiles1, int tiles2, int wide_blocks, int per_xcd,
-                                                          int wide_per_set, const float* __restrict__ label1,
+                                                          int wide_blocks, int wide_per_set,
+                                                          const float* __restrict__ label1,
                                                           const float* __restrict__ label2) {
-  // both parts keep a set on the XCD whose L2 holds it from grid_query_kernel (same blockIdx % 8
-  // -> set mapping; wide_blocks is a multiple of 8)
-  if ((int)blockIdx.x < wide_blocks) {
-    grid_query_wide_block<LAB>(pp::xcd_virtual_block(blockIdx.x, wide_blocks / 8), xyz1, xyz2, dist1, idx1, dist2,
-                               idx2, ws, B, N, M, wide_per_set, label1, label2);
-  } else {
-    const int V = pp::xcd_virtual_block(blockIdx.x - wide_blocks, per_xcd);
-    if (V < B * (tiles1 + tiles2))
-      grid_unsort_block(V, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2);
-  }
+  grid_query_wide_block<LAB>(pp::xcd_virtual_block(blockIdx.x, wide_blocks / 8), xyz1, xyz2, dist1, idx1, dist2,
+                             idx2, ws, B, N, M, wide_per_set, label1, label2);
 }
 
 }  // namespace
@@ -456,7 +413,7 @@ extern "C" size_t pp_labeled_nmdistance_forward_workspace_bytes(int B, int N, in
   return make_layout(B, N, M, true).total;
 }
 
-// build -> stage A for every query -> wide stages + unsort -> brute force over what is left
+// build -> stage A for every query -> wide stages -> brute force over what is left
 template <bool LAB>
 static int grid_forward(const float* xyz1, const float* xyz2, const float* label1, const float* label2,
                         float* dist1, int* idx1, float* dist2, int* idx2, int B, int N, int M,
@@ -479,10 +436,9 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   PP_RETURN_IF_LAUNCH_FAILED();
   // labeled: a candidate must also carry the query's label, so more queries outlive stage A
   const int wide_per_set = LAB ? 4 * kWideBlocksPerSet : kWideBlocksPerSet;
-  const int wide_blocks = 2 * B * wide_per_set;  // a multiple of 8 (finish kernel XCD mapping)
-  grid_finish_kernel<LAB><<<dim3((unsigned)(wide_blocks + per_xcd * 8)), dim3(256), 0, s>>>(
-      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, wide_blocks, per_xcd, wide_per_set, label1,
-      label2);
+  const int wide_blocks = 2 * B * wide_per_set;  // a multiple of 8 (XCD mapping of the finish kernel)
+  grid_finish_kernel<LAB><<<dim3((unsigned)wide_blocks), dim3(256), 0, s>>>(
+      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, wide_blocks, wide_per_set, label1, label2);
   PP_RETURN_IF_LAUNCH_FAILED();
   return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
                                 reinterpret_cast<const int*>(ws + L.qlist),
