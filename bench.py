@@ -329,7 +329,7 @@ def bench_chamfer(args, dist, world, rank, device):
         out["roofline"] = {"bound": "hbm", "kernel": "grid_build_kernel + grid_query_kernel + list fallback",
                            "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None,
-                           "note": "latency/L2-gather-bound search over a 29 MB workspace; 'bruteforce' "
+                           "note": "latency/L2-gather-bound search over a 17 MB workspace; 'bruteforce' "
                                    "carries the every-pair kernel and its VALU roofline"}
         if brute is not None:
             bg = alg_bytes_fwd / (brute["fwd_ms"] * 1e-3) / 1e9
