@@ -1,0 +1,97 @@
+"""Randomised shapes and point distributions for every search operator (Chamfer, labeled Chamfer,
+ball_query, three_nn, knn) against the CPU oracle, bit for bit.  Seeds are fixed: a failure names the
+case.  Sizes straddle the thresholds at which the operators switch between scan and grid kernels."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pytorch_points_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, b, n, kind):
+    """a (b, n, 3) fp32 cloud of a random family"""
+    if kind == 0:
+        x = S.unit_sphere(int(rng.integers(1 << 30)), b, n)
+    elif kind == 1:
+        x = rng.random((b, n, 3), dtype=np.float32)
+    elif kind == 2:   # clusters of very different scales
+        c = rng.random((b, 7, 3), dtype=np.float32) * 4
+        x = c[:, rng.integers(0, 7, n)] + (rng.standard_normal((b, n, 3)) * rng.choice([1e-3, 1e-2, 0.3])).astype(np.float32)
+    elif kind == 3:   # quantised coordinates: many exact ties and duplicates
+        x = (rng.integers(0, 12, (b, n, 3)) / 4).astype(np.float32)
+    elif kind == 4:   # thin slab far from the origin
+        x = rng.random((b, n, 3), dtype=np.float32) * np.array([3, 3, 1e-3], np.float32) + np.float32(300.0)
+    else:             # one far outlier stretches the bounding box
+        x = rng.random((b, n, 3), dtype=np.float32)
+        x[:, 0] = 1e3
+    return np.ascontiguousarray(x, np.float32)
+
+
+def _sizes(rng):
+    b = int(rng.integers(1, 5))
+    n = int(rng.choice([1, 7, 64, 300, 1023, 1024, 2047, 2048, 2500, 4096, 5003, 8192, 16384]))
+    m = int(rng.choice([1, 5, 64, 333, 1024, 2047, 2048, 3000, 4096, 6001, 9000, 16384]))
+    return b, n, m
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_chamfer_and_labeled(cuda, seed):
+    from pytorch_points_amd.network.model_loss import nndistance, labeled_nndistance
+    rng = np.random.default_rng(1000 + seed)
+    b, n, m = _sizes(rng)
+    k1, k2 = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+    x1, x2 = _cloud(rng, b, n, k1), _cloud(rng, b, m, k2)
+    if seed % 3 == 0:
+        x2 = x2 + x1.mean(1, keepdims=True) - x2.mean(1, keepdims=True)   # overlapping clouds
+    got = nndistance(torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda))
+    exp = oracle.chamfer_forward(x1, x2)
+    for g, e, what in zip((got[0], got[2], got[1], got[3]), exp, ("dist1", "idx1", "dist2", "idx2")):
+        assert np.array_equal(g.cpu().numpy(), e), "seed %d (b=%d n=%d m=%d kinds %d/%d): %s" % (seed, b, n, m, k1, k2, what)
+    nl = int(rng.choice([1, 2, 5, 400]))
+    l1 = rng.integers(0, nl, (b, n)).astype(np.float32)
+    l2 = rng.integers(0, max(1, nl - (seed % 2)), (b, m)).astype(np.float32)
+    got = labeled_nndistance(torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda),
+                             torch.from_numpy(l1).to(cuda), torch.from_numpy(l2).to(cuda))
+    exp = oracle.labeled_chamfer_forward(x1, x2, l1, l2)
+    for g, e, what in zip((got[0], got[2], got[1], got[3]), exp, ("dist1", "idx1", "dist2", "idx2")):
+        assert np.array_equal(g.cpu().numpy(), e), "labeled seed %d (b=%d n=%d m=%d nl=%d): %s" % (seed, b, n, m, nl, what)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_ball_query(cuda, seed):
+    from pytorch_points_amd._ext import sampling
+    rng = np.random.default_rng(2000 + seed)
+    b, m, n = _sizes(rng)                      # m centres, n points
+    kind = int(rng.integers(0, 6))
+    x = _cloud(rng, b, n, kind)
+    c = x[:, rng.integers(0, n, m)] if seed % 2 else _cloud(rng, b, m, int(rng.integers(0, 6)))
+    c = np.ascontiguousarray(c + (rng.standard_normal(c.shape) * 1e-3).astype(np.float32))
+    ext = float(np.ptp(x.reshape(-1, 3), 0).max()) or 1.0
+    r = float(rng.choice([1e-4, 0.01, 0.05, 0.2, 1.5])) * min(ext, 3.0)
+    ns = int(rng.choice([1, 3, 16, 33, 64, 128]))
+    got = sampling.ball_query(torch.from_numpy(c).to(cuda), torch.from_numpy(x).to(cuda), r, ns)
+    exp = oracle.ball_query(c, x, r, ns)
+    assert np.array_equal(got.cpu().numpy(), exp), "seed %d: b=%d n=%d m=%d kind %d r=%g ns=%d" % (seed, b, n, m, kind, r, ns)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fuzz_three_nn_and_knn(cuda, seed):
+    from pytorch_points_amd._ext import sampling
+    from pytorch_points_amd.ops import knn_points
+    rng = np.random.default_rng(3000 + seed)
+    b, n, m = _sizes(rng)
+    u, k = _cloud(rng, b, n, int(rng.integers(0, 6))), _cloud(rng, b, m, int(rng.integers(0, 6)))
+    d2 = torch.empty(b, n, 3, device=cuda)
+    idx = torch.empty(b, n, 3, dtype=torch.int32, device=cuda)
+    sampling.three_nn_wrapper(b, n, m, torch.from_numpy(u).to(cuda), torch.from_numpy(k).to(cuda), d2, idx)
+    e_d, e_i = oracle.three_nn(u, k)
+    assert np.array_equal(idx.cpu().numpy(), e_i) and np.array_equal(d2.cpu().numpy(), e_d), \
+        "three_nn seed %d b=%d n=%d m=%d" % (seed, b, n, m)
+    K = int(rng.choice([1, 2, 5, 8, 13, 16, 32]))
+    out = knn_points(torch.from_numpy(u).to(cuda), torch.from_numpy(k).to(cuda), K=K)
+    e_d, e_i = oracle.knn(u, k, K)
+    assert np.array_equal(out.idx.cpu().numpy(), e_i) and np.array_equal(out.dists.cpu().numpy(), e_d), \
+        "knn seed %d b=%d n=%d m=%d K=%d" % (seed, b, n, m, K)
