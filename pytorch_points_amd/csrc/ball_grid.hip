@@ -39,7 +39,7 @@ using pp::kBuildThreads;
 
 constexpr int kBqMaxCells = 3;   // cell-box half-extent the grid path accepts
 constexpr int kBqCap = 512;      // candidates staged per pass (8 KiB)
-constexpr int kBqMaxN = 131072;  // point bitmap <= 16 KiB
+constexpr int kBqMaxN = 524288;  // point bitmap <= 64 KiB
 
 struct BqLayout {
   size_t sets, cell_start, sorted, csorted, total;
@@ -342,7 +342,7 @@ static size_t bq_query_lds(int N, int nsample, int G) {
 extern "C" size_t pp_ball_query_workspace_bytes(int B, int N, int M, int nsample) {
   if (B <= 0 || M <= 0 || N < 2048 || N > kBqMaxN || nsample < 1) return 0;
   if ((long long)B * N >= (1LL << 31) || (long long)B * M >= (1LL << 31)) return 0;
-  if (bq_query_lds(N, nsample, 16) > 64 * 1024) return 0;  // at least two waves per CU
+  if (bq_query_lds(N, nsample, 16) > 128 * 1024) return 0;  // it has to fit (with the static LDS)
   return bq_layout(B, N, M).total;
 }
 
@@ -354,7 +354,7 @@ static int bq_launch_query(const float* xyz, int* idx, unsigned char* ws, int B,
   const long long per_xcd = ((long long)B * tiles + 7) / 8;
   if (per_xcd * 8 > 0x7fffffffLL) return PP_EINVAL;
   static bool ok[64] = {};
-  hipError_t e = pp::allow_big_lds(bq_query_kernel<IT, LPC>, 64 * 1024, ok);
+  hipError_t e = pp::allow_big_lds(bq_query_kernel<IT, LPC>, 152 * 1024, ok);
   if (e != hipSuccess) return (int)e;
   bq_query_kernel<IT, LPC><<<dim3((unsigned)(per_xcd * 8)), dim3(64), bq_query_lds(N, nsample, G), s>>>(
       xyz, idx, ws, B, N, M, radius2, rpad, nsample, tiles, (int)per_xcd);
@@ -380,7 +380,8 @@ extern "C" int pp_ball_query_ws_f32(const float* new_xyz, const float* xyz, int*
   bq_build_kernel<<<dim3(2 * B * pp::kBuildSlabs), dim3(kBuildThreads), lds, s>>>(xyz, new_xyz, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   // lanes per centre: 2 unless forced (tuning knob; 2 and 4 measure alike at config 4, 1 is 30 % slower)
-  const int lpc = g_bq_lpc ? g_bq_lpc : 2;
+  int lpc = g_bq_lpc ? g_bq_lpc : 2;
+  while (lpc < 4 && bq_query_lds(N, nsample, 64 / lpc) > 128 * 1024) lpc *= 2;  // fewer rows per wave if the LDS is short
   int rc;
   if (N <= 65536)
     rc = lpc == 1 ? bq_launch_query<unsigned short, 1>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)

@@ -221,7 +221,7 @@ def test_ball_query_grid_adversarial(cuda, bq_path):
                                         (1, 2000, 515, 0.25, 33), (1, 9, 1, 0.5, 1), (1, 64, 64, 0.4, 300),
                                         (1, 70000, 130, 0.05, 40), (2, 4099, 777, 0.3, 128), (1, 33, 65, 2.0, 7),
                                         (3, 16384, 1000, 0.1, 64), (2, 5000, 600, 0.02, 16), (1, 8192, 300, 0.6, 32),
-                                        (2, 3000, 200, 0.15, 3), (1, 3000, 300, 0.1, 24), (1, 140000, 100, 0.05, 8),
+                                        (2, 3000, 200, 0.15, 3), (1, 3000, 300, 0.1, 24), (1, 140000, 100, 0.05, 8), (1, 300000, 500, 0.02, 16), (1, 600000, 64, 0.02, 8),
                                         (2, 2048, 4096, 0.2, 12)])
 def test_ball_query_edges(cuda, bq_path, b, n, m, r, ns):
     """odd sizes; empty balls (all-zero rows); full balls (early exit); nsample beyond the LDS
