@@ -155,8 +155,8 @@ def bench_chamfer(args, dist, world, rank, device):
         fn.restype = None
         fn(args.variant)
     # rank r owns batch elements [r*B, (r+1)*B) of the global batch; seeds 0 / 1 as SURVEY.md §8d
-    x1 = torch.from_numpy(S.unit_sphere(0, world * B, N, C)[rank * B:(rank + 1) * B].copy()).to(device)
-    x2 = torch.from_numpy(S.unit_sphere(1, world * B, M, C)[rank * B:(rank + 1) * B].copy()).to(device)
+    x1 = torch.from_numpy(S.unit_sphere(0, B, N, C, batch_offset=rank * B)).to(device)
+    x2 = torch.from_numpy(S.unit_sphere(1, B, M, C, batch_offset=rank * B)).to(device)
     x1.requires_grad_(True)
     x2.requires_grad_(True)
     g1 = torch.full((B, N), 1.0 / (B * N), device=device)   # gradient of dist.mean()
