@@ -61,7 +61,9 @@ def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("PP_BENCH_FORCE_DIST") == "1":
+        # PP_BENCH_FORCE_DIST=1: run the distributed code path (RCCL process group, packed all-gather,
+        # graph capture beside the RCCL watchdog) with a single rank -- a logic check on a 1-GPU box
         import torch.distributed as dist
         if os.environ.get("PP_BENCH_DEBUG_GLOO") == "1":
             # logic check on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL (not a measurement)

@@ -210,6 +210,17 @@ int pp_three_interpolate_grad_ws_f32(const float* grad_out, const int* idx, cons
 /* cuda_utils.h:11-16 opt_n_threads -- the FPS tie-break depends on it, so it is part of the ABI */
 int pp_opt_n_threads(int work_size);
 
+/* ---- batch-sharded execution (no counterpart in the reference, which has no multi-GPU code):
+ * packing of a rank's Chamfer outputs for ONE collective per step, and unpacking of the gathered
+ * buffer (pytorch_points_amd/sharded.py PackedShardGather).  n1 = B_local*N, n2 = B_local*M.
+ * Packed layout: dist1 | dist2 | idx1 | idx2, indices as uint16 when compact != 0 (all < 65536).
+ * pp_shard_packed_bytes: bytes of one rank's packed buffer (multiple of 16 = the row stride). */
+size_t pp_shard_packed_bytes(long long n1, long long n2, int compact);
+int pp_shard_pack_f32(const float* dist1, const float* dist2, const int* idx1, const int* idx2, void* packed,
+                      long long n1, long long n2, int compact, void* stream);
+int pp_shard_unpack_f32(const void* gathered, int world, long long stride_bytes, long long n1, long long n2,
+                        int compact, float* dist1, float* dist2, int* idx1, int* idx2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

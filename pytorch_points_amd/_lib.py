@@ -34,6 +34,9 @@ SIGNATURES = {
     "pp_ball_query_f32": [_P, _P, _P, _I, _I, _I, _F, _I, _P],
     "pp_ball_query_workspace_bytes": [_I, _I, _I, _I],
     "pp_ball_query_ws_f32": [_P, _P, _P, _I, _I, _I, _F, _I, _P, _c_size_t, _P],
+    "pp_shard_packed_bytes": [ctypes.c_longlong, ctypes.c_longlong, _I],
+    "pp_shard_pack_f32": [_P, _P, _P, _P, _P, ctypes.c_longlong, ctypes.c_longlong, _I, _P],
+    "pp_shard_unpack_f32": [_P, _I, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _P, _P, _P, _P],
     "pp_knn_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_knn_workspace_bytes": [_I, _I, _I, _I],
     "pp_knn_ws_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
@@ -55,7 +58,8 @@ _RESTYPES = {"pp_version": ctypes.c_char_p, "pp_furthest_sampling_workspace_byte
              "pp_nmdistance_forward_workspace_bytes": _c_size_t,
              "pp_labeled_nmdistance_forward_workspace_bytes": _c_size_t,
              "pp_scatter_workspace_bytes": _c_size_t, "pp_ball_query_workspace_bytes": _c_size_t,
-             "pp_three_nn_workspace_bytes": _c_size_t, "pp_knn_workspace_bytes": _c_size_t}
+             "pp_three_nn_workspace_bytes": _c_size_t, "pp_knn_workspace_bytes": _c_size_t,
+             "pp_shard_packed_bytes": _c_size_t}
 
 _lib = None
 

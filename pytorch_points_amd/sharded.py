@@ -115,17 +115,31 @@ class PackedShardGather:
         return (buf[o[0]:o[1]].view(torch.float32), buf[o[1]:o[2]].view(torch.float32),
                 buf[o[2]:o[3]].view(idt), buf[o[3]:self.nbytes].view(idt))
 
+    def _hip(self, t):
+        """GPU tensors go through the library's pack / unpack kernels (one launch each); CPU tensors
+        (the gloo tests) through the equivalent tensor operations."""
+        return t.is_cuda
+
     def launch(self, d1, d2, i1, i2):
         slot = self.turn
         self.turn = (self.turn + 1) % len(self.send)
         if self.inflight[slot] is not None:   # the buffers of this slot are about to be overwritten
             self.inflight[slot].wait()
             self.inflight[slot] = None
-        v = self._views(self.send[slot])
-        v[0].copy_(d1.detach().reshape(-1))
-        v[1].copy_(d2.detach().reshape(-1))
-        v[2].copy_(i1.reshape(-1))            # int32 -> int16 keeps the low 16 bits
-        v[3].copy_(i2.reshape(-1))
+        if self._hip(self.send[slot]):
+            from . import _lib
+            d1 = d1.detach().contiguous(); d2 = d2.detach().contiguous()
+            i1 = i1.contiguous(); i2 = i2.contiguous()
+            with _lib.on_device(self.send[slot].device) as stream:
+                _lib.check(_lib.lib().pp_shard_pack_f32(
+                    _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(self.send[slot]),
+                    self.b * self.n, self.b * self.m, 1 if self.compact else 0, stream), "shard_pack")
+        else:
+            v = self._views(self.send[slot])
+            v[0].copy_(d1.detach().reshape(-1))
+            v[1].copy_(d2.detach().reshape(-1))
+            v[2].copy_(i1.reshape(-1))            # int32 -> int16 keeps the low 16 bits
+            v[3].copy_(i2.reshape(-1))
         if dist.get_backend(self.group) == "nccl":
             work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
         else:                                 # gloo (CPU tests)
@@ -143,6 +157,18 @@ class PackedShardGather:
         r = self.recv[slot]
         o = self.off
         w, b = self.world, self.b
+        if self._hip(r):
+            from . import _lib
+            dev = r.device
+            d1 = torch.empty(w * b, self.n, dtype=torch.float32, device=dev)
+            d2 = torch.empty(w * b, self.m, dtype=torch.float32, device=dev)
+            i1 = torch.empty(w * b, self.n, dtype=torch.int32, device=dev)
+            i2 = torch.empty(w * b, self.m, dtype=torch.int32, device=dev)
+            with _lib.on_device(dev) as stream:
+                _lib.check(_lib.lib().pp_shard_unpack_f32(
+                    _lib.ptr(r), w, self.nbytes_padded, b * self.n, b * self.m, 1 if self.compact else 0,
+                    _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2), stream), "shard_unpack")
+            return d1, d2, i1, i2
         d1 = r[:, o[0]:o[1]].view(torch.float32).reshape(w * b, self.n)
         d2 = r[:, o[1]:o[2]].view(torch.float32).reshape(w * b, self.m)
         if self.compact:

@@ -1,0 +1,45 @@
+"""pack / unpack kernels of the batch-sharded exchange (csrc/shard.hip) against the tensor-op form of
+pytorch_points_amd/sharded.py, for a fabricated world of three ranks (single process, no collective)."""
+import numpy as np
+import pytest
+import torch
+
+from pytorch_points_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("b,n,m", [(3, 1000, 777), (2, 65536, 40), (1, 5, 70000), (4, 16384, 16384)])
+def test_shard_pack_unpack_roundtrip(cuda, b, n, m):
+    world = 3
+    compact = max(n, m) <= 65536
+    g = torch.Generator(device="cpu").manual_seed(b * 131 + n)
+    D1 = torch.rand(world * b, n, generator=g).to(cuda)
+    D2 = torch.rand(world * b, m, generator=g).to(cuda)
+    I1 = torch.randint(0, m, (world * b, n), generator=g, dtype=torch.int32).to(cuda)
+    I2 = torch.randint(0, n, (world * b, m), generator=g, dtype=torch.int32).to(cuda)
+    I1[:, 0] = m - 1
+    I2[:, -1] = n - 1
+    L = _lib.lib()
+    stride = int(L.pp_shard_packed_bytes(b * n, b * m, 1 if compact else 0))
+    assert stride % 16 == 0 and stride >= (b * n + b * m) * (6 if compact else 8)
+    recv = torch.zeros(world, stride, dtype=torch.uint8, device=cuda)
+    with _lib.on_device(cuda) as stream:
+        for r in range(world):
+            sl = slice(r * b, (r + 1) * b)
+            _lib.check(L.pp_shard_pack_f32(_lib.ptr(D1[sl].contiguous()), _lib.ptr(D2[sl].contiguous()),
+                                           _lib.ptr(I1[sl].contiguous()), _lib.ptr(I2[sl].contiguous()),
+                                           _lib.ptr(recv[r]), b * n, b * m, 1 if compact else 0, stream), "pack")
+        o1 = torch.empty_like(D1); o2 = torch.empty_like(D2); j1 = torch.empty_like(I1); j2 = torch.empty_like(I2)
+        _lib.check(L.pp_shard_unpack_f32(_lib.ptr(recv), world, stride, b * n, b * m, 1 if compact else 0,
+                                         _lib.ptr(o1), _lib.ptr(o2), _lib.ptr(j1), _lib.ptr(j2), stream), "unpack")
+    assert torch.equal(o1, D1) and torch.equal(o2, D2) and torch.equal(j1, I1) and torch.equal(j2, I2)
+    # the packed bytes are what the tensor-op form (CPU / gloo path) produces
+    row = recv[1].cpu()
+    f = row[: 4 * b * (n + m)].view(torch.float32)
+    assert torch.equal(f[: b * n], D1[b:2 * b].reshape(-1).cpu()) and torch.equal(f[b * n:], D2[b:2 * b].reshape(-1).cpu())
+    if compact:
+        i = row[4 * b * (n + m): 6 * b * (n + m)].view(torch.int16).to(torch.int32) & 0xFFFF
+    else:
+        i = row[4 * b * (n + m): 8 * b * (n + m)].view(torch.int32)
+    assert torch.equal(i[: b * n], I1[b:2 * b].reshape(-1).cpu()) and torch.equal(i[b * n:], I2[b:2 * b].reshape(-1).cpu())
