@@ -18,7 +18,7 @@ _nmd_workspace = {}
 def _workspace(device, nbytes):
     if nbytes == 0:
         return None
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _lib.raw_stream(device))
     buf = _nmd_workspace.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)

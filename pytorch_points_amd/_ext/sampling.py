@@ -16,7 +16,7 @@ _fps_workspace = {}
 def _workspace(device, nbytes):
     if nbytes == 0:
         return None
-    key = (device, torch.cuda.current_stream(device).cuda_stream)  # never shared between streams
+    key = (device, _lib.raw_stream(device))  # never shared between streams
     buf = _fps_workspace.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -33,7 +33,7 @@ def _scatter_ws(device, b, triples, destinations, per_source, weighted):
     nbytes = int(_lib.lib().pp_scatter_workspace_bytes(b, triples, destinations, per_source, weighted))
     if nbytes == 0:
         return None, 0
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _lib.raw_stream(device))
     buf = _scatter_workspace.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -111,7 +111,7 @@ def _named_workspace(dev, name, nbytes):
     """scratch for the grid searches, one per (device, stream, op); None when nbytes == 0"""
     if not nbytes:
         return None
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream, name)
+    key = (dev, _lib.raw_stream(dev), name)
     ws = _scatter_workspace.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)

@@ -133,16 +133,32 @@ def ptr(t):
     return _c_void_p(t.data_ptr())
 
 
+def raw_stream(device):
+    """handle (int) of the current HIP stream of ``device`` -- the cheap form of
+    torch.cuda.current_stream(device).cuda_stream"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    try:
+        return torch._C._cuda_getCurrentRawStream(idx)
+    except AttributeError:  # private API moved: the public one is slower, not different
+        return torch.cuda.current_stream(device).cuda_stream
+
+
 class on_device(object):
-    """Device guard + current stream handle for a launch."""
+    """Device guard + current stream handle for a launch.  The guard is skipped when the tensors'
+    device is already current (the common case; entering a guard costs several microseconds)."""
 
     def __init__(self, device):
-        self._guard = torch.cuda.device(device)
         self.device = device
+        self._guard = None
 
     def __enter__(self):
-        self._guard.__enter__()
-        return _c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        idx = self.device.index
+        if idx is not None and idx != torch.cuda.current_device():
+            self._guard = torch.cuda.device(self.device)
+            self._guard.__enter__()
+        return _c_void_p(raw_stream(self.device))
 
     def __exit__(self, *exc):
-        return self._guard.__exit__(*exc)
+        if self._guard is not None:
+            return self._guard.__exit__(*exc)
+        return False
