@@ -574,43 +574,71 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_lds64_kernel(
   float* __restrict__ out = (second ? gx2 : gx1) + (size_t)b * nt * 3;
   const int t = threadIdx.x;
   // own terms: +g*(x_T[k] - x_O[idx_T[k]])                              (ref nmdistance_cuda.cu:176-180)
-  // (seeding the slice with plain stores and a barrier measured faster -- 30 vs 36 us at config 2 --
-  // than zero-filling and adding the own terms atomically in the same pass as the scattered ones)
-  for (int kk = t; kk < len; kk += 1024) {
-    const int k = k0 + kk;
-    const int j2 = it[k];
-    float ax = 0.0f, ay = 0.0f, az = 0.0f;
-    if (j2 >= 0) {
-      const float g = gt[k] * 2;
-      ax = g * (xt[3 * (size_t)k] - xo[3 * (size_t)j2]);
-      ay = g * (xt[3 * (size_t)k + 1] - xo[3 * (size_t)j2 + 1]);
-      az = g * (xt[3 * (size_t)k + 2] - xo[3 * (size_t)j2 + 2]);
+  // (seeding the slice with plain stores and a barrier measured faster than zero-filling and adding
+  // the own terms atomically in the same pass as the scattered ones)
+  // Both passes issue the loads of several elements before using any of them (indices clamped, so no
+  // load is conditional): a pass costs two memory round trips per batch instead of two per element.
+  constexpr int KO = 4;
+  for (int kk0 = t; kk0 < len; kk0 += 1024 * KO) {
+    int j2[KO];
+    float g[KO], tx[KO], ty[KO], tz[KO], ox[KO], oy[KO], oz[KO];
+#pragma unroll
+    for (int u = 0; u < KO; ++u) {
+      const int k = k0 + min(kk0 + 1024 * u, len - 1);
+      j2[u] = it[k];
+      g[u] = gt[k];
+      tx[u] = xt[3 * (size_t)k]; ty[u] = xt[3 * (size_t)k + 1]; tz[u] = xt[3 * (size_t)k + 2];
     }
-    s_acc64[3 * kk] = (double)ax;
-    s_acc64[3 * kk + 1] = (double)ay;
-    s_acc64[3 * kk + 2] = (double)az;
+#pragma unroll
+    for (int u = 0; u < KO; ++u) {
+      const int jc = j2[u] >= 0 ? j2[u] : 0;
+      ox[u] = xo[3 * (size_t)jc]; oy[u] = xo[3 * (size_t)jc + 1]; oz[u] = xo[3 * (size_t)jc + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < KO; ++u) {
+      const int kk = kk0 + 1024 * u;
+      if (kk < len) {
+        float ax = 0.0f, ay = 0.0f, az = 0.0f;
+        if (j2[u] >= 0) {
+          const float gg = g[u] * 2;
+          ax = gg * (tx[u] - ox[u]);
+          ay = gg * (ty[u] - oy[u]);
+          az = gg * (tz[u] - oz[u]);
+        }
+        s_acc64[3 * kk] = (double)ax;
+        s_acc64[3 * kk + 1] = (double)ay;
+        s_acc64[3 * kk + 2] = (double)az;
+      }
+    }
   }
   __syncthreads();
   // scattered terms of the other direction: -g*(x_O[j] - x_T[idx_O[j]]) onto row idx_O[j]        (:181)
-  constexpr int KJ = 4;
+  constexpr int KJ = 8;
   for (int j0 = t; j0 < no; j0 += 1024 * KJ) {
     int kj[KJ];
+    float g[KJ], ox[KJ], oy[KJ], oz[KJ], tx[KJ], ty[KJ], tz[KJ];
 #pragma unroll
     for (int u = 0; u < KJ; ++u) {
       const int j = j0 + 1024 * u;
-      kj[u] = j < no ? io[j] - k0 : -1;
+      const int jc = min(j, no - 1);
+      const int kr = io[jc] - k0;
+      kj[u] = (j < no && kr >= 0 && kr < len) ? kr : -1;
+      g[u] = go[jc];
+      ox[u] = xo[3 * (size_t)jc]; oy[u] = xo[3 * (size_t)jc + 1]; oz[u] = xo[3 * (size_t)jc + 2];
     }
 #pragma unroll
     for (int u = 0; u < KJ; ++u) {
-      const int j = j0 + 1024 * u;
-      if (kj[u] >= 0 && kj[u] < len) {
-        const int k = k0 + kj[u];
-        const float g = go[j] * 2;
-        atomicAdd(&s_acc64[3 * kj[u]], (double)(-(g * (xo[3 * (size_t)j] - xt[3 * (size_t)k]))));
-        atomicAdd(&s_acc64[3 * kj[u] + 1], (double)(-(g * (xo[3 * (size_t)j + 1] - xt[3 * (size_t)k + 1]))));
-        atomicAdd(&s_acc64[3 * kj[u] + 2], (double)(-(g * (xo[3 * (size_t)j + 2] - xt[3 * (size_t)k + 2]))));
+      const int k = k0 + (kj[u] >= 0 ? kj[u] : 0);
+      tx[u] = xt[3 * (size_t)k]; ty[u] = xt[3 * (size_t)k + 1]; tz[u] = xt[3 * (size_t)k + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < KJ; ++u)
+      if (kj[u] >= 0) {
+        const float gg = g[u] * 2;
+        atomicAdd(&s_acc64[3 * kj[u]], (double)(-(gg * (ox[u] - tx[u]))));
+        atomicAdd(&s_acc64[3 * kj[u] + 1], (double)(-(gg * (oy[u] - ty[u]))));
+        atomicAdd(&s_acc64[3 * kj[u] + 2], (double)(-(gg * (oz[u] - tz[u]))));
       }
-    }
   }
   __syncthreads();
   for (int e = t; e < 3 * len; e += 1024) out[3 * (size_t)k0 + e] = (float)s_acc64[e];  // coalesced
