@@ -62,7 +62,12 @@ __global__ __launch_bounds__(kBuildThreads) void bq_build_kernel(const float* __
                                                                  int M) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];
   const BqLayout L = bq_layout(B, N, M);
-  const int set = blockIdx.x / pp::kBuildSlabs, slab = blockIdx.x % pp::kBuildSlabs;
+  // both sets of a batch element are built on the XCD that will search it (the query kernel's batch ->
+  // XCD mapping): virtual order (batch, cloud | queries, slab)
+  const int V = pp::xcd_virtual_block(blockIdx.x, (2 * B * pp::kBuildSlabs + 7) / 8);
+  if (V >= 2 * B * pp::kBuildSlabs) return;
+  const int slab = V % pp::kBuildSlabs;
+  const int set = ((V / pp::kBuildSlabs) & 1) * B + V / (2 * pp::kBuildSlabs);
   GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
   if (set >= B) {
     const int b = set - B;
@@ -377,7 +382,7 @@ extern "C" int pp_ball_query_ws_f32(const float* new_xyz, const float* xyz, int*
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
   hipError_t e = pp::allow_big_lds(bq_build_kernel, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  bq_build_kernel<<<dim3(2 * B * pp::kBuildSlabs), dim3(kBuildThreads), lds, s>>>(xyz, new_xyz, ws, B, N, M);
+  bq_build_kernel<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(xyz, new_xyz, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   // lanes per centre: 2 unless forced (tuning knob; 2 and 4 measure alike at config 4, 1 is 30 % slower)
   int lpc = g_bq_lpc ? g_bq_lpc : 2;

@@ -554,11 +554,16 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_csr_kernel(
 __global__ __launch_bounds__(1024) void nmdist_bwd_lds64_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, const float* __restrict__ gd1,
     const float* __restrict__ gd2, const int* __restrict__ idx1, const int* __restrict__ idx2,
-    float* __restrict__ gx1, float* __restrict__ gx2, int N, int M, int slice_len, int slices) {
+    float* __restrict__ gx1, float* __restrict__ gx2, int N, int M, int slice_len, int slices, int total,
+    int per_xcd) {
   extern __shared__ __attribute__((aligned(16))) double s_acc64[];  // [slice_len][3]
+  // the workgroups of a batch element share an XCD -- the one whose L2 holds its clouds and the
+  // indices the forward pass has just written (same batch -> XCD mapping as chamfer_grid.hip)
+  const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
   const int per_b = 2 * slices;
-  const int b = blockIdx.x / per_b;
-  const int r = blockIdx.x - b * per_b;
+  if (V >= total) return;
+  const int b = V / per_b;
+  const int r = V - b * per_b;
   const bool second = r >= slices;  // target cloud: false -> cloud 1, true -> cloud 2
   const int slice = second ? r - slices : r;
   const int nt = second ? M : N, no = second ? N : M;
@@ -833,8 +838,9 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
       static bool lds_ok[64] = {};
       const hipError_t e = pp::allow_big_lds(nmdist_bwd_lds64_kernel, 152 * 1024, lds_ok);
       if (e != hipSuccess) return (int)e;
-      nmdist_bwd_lds64_kernel<<<dim3((unsigned)(B * 2 * slices)), dim3(1024), (size_t)slice_len * 24, s>>>(
-          xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, slice_len, slices);
+      const int total = B * 2 * slices, per_xcd = (total + 7) / 8;
+      nmdist_bwd_lds64_kernel<<<dim3((unsigned)(per_xcd * 8)), dim3(1024), (size_t)slice_len * 24, s>>>(
+          xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, slice_len, slices, total, per_xcd);
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
     }

@@ -81,7 +81,11 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
                                                                    const float* __restrict__ label1,
                                                                    const float* __restrict__ label2) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // pp::grid_build_lds_bytes(kBuildSlabs)
-  const int set = blockIdx.x / pp::kBuildSlabs, slab = blockIdx.x % pp::kBuildSlabs;
+  // a set is built on the XCD that will search it (grid_query_kernel's set -> XCD mapping): its sorted
+  // points and cell table are then already in that L2
+  const int V = pp::xcd_virtual_block(blockIdx.x, (2 * B * pp::kBuildSlabs + 7) / 8);
+  if (V >= 2 * B * pp::kBuildSlabs) return;
+  const int set = V / pp::kBuildSlabs, slab = V % pp::kBuildSlabs;
   const int b = set >> 1, dir = set & 1;
   const int nr = dir ? N : M;
   const float* __restrict__ ref = (dir ? xyz1 : xyz2) + (size_t)b * nr * 3;
@@ -424,7 +428,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
   e = pp::allow_big_lds(grid_build_kernel, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  grid_build_kernel<<<dim3(2 * B * pp::kBuildSlabs), dim3(kBuildThreads), lds, s>>>(xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr,
+  grid_build_kernel<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr,
                                                                   LAB ? label2 : nullptr);
   PP_RETURN_IF_LAUNCH_FAILED();
   const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;

@@ -114,7 +114,12 @@ __global__ __launch_bounds__(kBuildThreads) void kn_build_kernel(const float* __
                                                                  int M) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];
   const KnLayout L = kn_layout(B, N, M);
-  const int set = blockIdx.x / pp::kBuildSlabs, slab = blockIdx.x % pp::kBuildSlabs;
+  // both sets of a batch element are built on the XCD that will search it (the query kernel's batch ->
+  // XCD mapping): virtual order (batch, cloud | queries, slab)
+  const int V = pp::xcd_virtual_block(blockIdx.x, (2 * B * pp::kBuildSlabs + 7) / 8);
+  if (V >= 2 * B * pp::kBuildSlabs) return;
+  const int slab = V % pp::kBuildSlabs;
+  const int set = ((V / pp::kBuildSlabs) & 1) * B + V / (2 * pp::kBuildSlabs);
   GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
   if (set >= B) {
     const int b = set - B;
@@ -259,7 +264,7 @@ extern "C" int pp_knn_ws_f32(const float* p1, const float* p2, const int* length
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
   hipError_t e = pp::allow_big_lds(kn_build_kernel, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  kn_build_kernel<<<dim3(2 * B * pp::kBuildSlabs), dim3(kBuildThreads), lds, s>>>(p2, p1, ws, B, N, M);
+  kn_build_kernel<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(p2, p1, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   int rc;
   if (K <= 1) rc = knn_grid_launch<1>(dist2, idx, ws, B, N, M, K, s);

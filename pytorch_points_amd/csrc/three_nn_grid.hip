@@ -51,7 +51,12 @@ __global__ __launch_bounds__(kBuildThreads) void tn_build_kernel(const float* __
                                                                  int M) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];
   const TnLayout L = tn_layout(B, N, M);
-  const int set = blockIdx.x / pp::kBuildSlabs, slab = blockIdx.x % pp::kBuildSlabs;
+  // both sets of a batch element are built on the XCD that will search it (the query kernel's batch ->
+  // XCD mapping): virtual order (batch, cloud | queries, slab)
+  const int V = pp::xcd_virtual_block(blockIdx.x, (2 * B * pp::kBuildSlabs + 7) / 8);
+  if (V >= 2 * B * pp::kBuildSlabs) return;
+  const int slab = V % pp::kBuildSlabs;
+  const int set = ((V / pp::kBuildSlabs) & 1) * B + V / (2 * pp::kBuildSlabs);
   GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
   if (set >= B) {
     const int b = set - B;
@@ -165,7 +170,7 @@ extern "C" int pp_three_nn_ws_f32(const float* unknown, const float* known, floa
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
   hipError_t e = pp::allow_big_lds(tn_build_kernel, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  tn_build_kernel<<<dim3(2 * B * pp::kBuildSlabs), dim3(kBuildThreads), lds, s>>>(known, unknown, ws, B, N, M);
+  tn_build_kernel<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(known, unknown, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   const int tiles = (N + 255) / 256;
   const long long per_xcd = ((long long)B * tiles + 7) / 8;
