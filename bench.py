@@ -172,15 +172,19 @@ def bench_chamfer(args, dist, world, rank, device):
     fwd_events = []
     pending = []   # slot of the previous step's all-gather
 
+    instrument = [True]   # HIP events around the forward (they cost host time: off for the eager timing)
+
     def step():
         x1.grad = None
         x2.grad = None
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        if instrument[0]:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         d1, d2, i1, i2 = nndistance(x1, x2)
-        e1.record()
-        fwd_events.append((e0, e1))
+        if instrument[0]:
+            e1.record()
+            fwd_events.append((e0, e1))
         if exchange is not None:
             # all-gather of the per-shard (dist, idx) over xGMI (RCCL), asynchronous: it runs on the
             # collective stream beside this step's backward and the next step's forward; the previous
@@ -253,10 +257,30 @@ def bench_chamfer(args, dist, world, rank, device):
 
     if gstep is not None:
         dt = run_timed(graph_step, args.warmup, args.steps)
-        n_eager = max(5, min(args.steps, 20))
-        fwd_events.clear()
+        n_eager = 200   # enough steps that the closing synchronize does not weigh on the per-step time
+        instrument[0] = False
         eager_dt = run_timed(step, 3, n_eager) / n_eager
-        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events[-n_eager:]]))
+        # forward duration: the forward's launches alone, replayed as a graph between two HIP events on
+        # the launch stream (no host gaps between the kernels)
+        with torch.no_grad():
+            fx1, fx2 = x1.detach(), x2.detach()
+            for _ in range(2):
+                nndistance(fx1, fx2)
+            torch.cuda.synchronize()
+            fgraph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fgraph, capture_error_mode="thread_local"):
+                fout = nndistance(fx1, fx2)
+        fgraph.replay()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_eager):
+            fgraph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        fwd_ms = e0.elapsed_time(e1) / n_eager
+        del fout
     else:
         dt = run_timed(step, args.warmup, args.steps)
         eager_dt = dt / args.steps
@@ -322,7 +346,7 @@ def bench_chamfer(args, dist, world, rank, device):
     out["config"]["launch"] = ("hipGraph replay of the step's launches (same kernels as the eager operator)"
                                if gstep is not None else "eager (one Python call per operator)")
     out["eager"] = {"ms_per_step": eager_dt * 1e3, "pairs_per_s": pairs_per_step / eager_dt,
-                    "note": "same step issued through torch.autograd.Function calls; fwd_ms is measured here"}
+                    "note": "same step issued through torch.autograd.Function calls, one Python call per operator"}
     if graph_note:
         out["config"]["launch_note"] = graph_note
     if grid:
