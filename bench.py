@@ -41,8 +41,8 @@ VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz fp32 lane-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="chamfer", choices=["chamfer", "fps", "ball_group"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
     ap.add_argument("--points", type=int, default=None)
