@@ -519,17 +519,28 @@ __global__ __launch_bounds__(kDmaThreads) void group_points_dma_kernel(const flo
     for (int v = 0; v < V; ++v) {
       pp::f4 r;
       if constexpr (PACK16) {
-        r.x = cur[ii[v][0] & 0xFFFFu];
-        r.y = cur[ii[v][0] >> 16];
-        r.z = cur[ii[v][1] & 0xFFFFu];
-        r.w = cur[ii[v][1] >> 16];
+        // the unpacked LDS addresses are loop-invariant; left alone the compiler keeps all 4 V of them
+        // in registers across the channel loop (and spills) -- the empty asm makes them per-row values
+        unsigned w0 = ii[v][0], w1 = ii[v][1];
+        asm volatile("" : "+v"(w0), "+v"(w1));
+        r.x = cur[w0 & 0xFFFFu];
+        r.y = cur[w0 >> 16];
+        r.z = cur[w1 & 0xFFFFu];
+        r.w = cur[w1 >> 16];
       } else {
         r.x = cur[ii[v][0]];
         r.y = cur[ii[v][1]];
         r.z = cur[ii[v][2]];
         r.w = cur[ii[v][3]];
       }
-      *reinterpret_cast<pp::f4*>(o + p0 + (long long)v * (kDmaThreads * 4)) = r;
+      if constexpr (V >= 32) {
+        // wave-uniform base in SGPRs + one 32-bit lane offset for all V stores: with V separate 64-bit
+        // store addresses in VGPRs this instantiation spills
+        const float* base = o + (long long)chunk * (kDmaThreads * 4 * V) + (long long)v * (kDmaThreads * 4);
+        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(t * 16), "v"(r), "s"(base) : "memory");
+      } else {
+        *reinterpret_cast<pp::f4*>(o + p0 + (long long)v * (kDmaThreads * 4)) = r;
+      }
     }
   }
 }
