@@ -332,7 +332,8 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
 
 }  // namespace
 
-// 0 = automatic (grid when a workspace is given); 1 = scan kernels only
+// 0 = automatic (grid when a workspace is given and N >= 4096: below, the scan's ~27 us are less than
+// the grid's two launches); 1 = scan kernels only; 2 = grid from N = 2048 (tests)
 static int g_bq_grid_mode = 0;
 static int g_bq_lpc = 0;
 extern "C" void pp_debug_set_ball_query_lpc(int v) { g_bq_lpc = v; }
@@ -345,7 +346,7 @@ static size_t bq_query_lds(int N, int nsample, int G) {
 }
 
 extern "C" size_t pp_ball_query_workspace_bytes(int B, int N, int M, int nsample) {
-  if (B <= 0 || M <= 0 || N < 2048 || N > kBqMaxN || nsample < 1) return 0;
+  if (B <= 0 || M <= 0 || N < (g_bq_grid_mode == 2 ? 2048 : 4096) || N > kBqMaxN || nsample < 1) return 0;
   if ((long long)B * N >= (1LL << 31) || (long long)B * M >= (1LL << 31)) return 0;
   if (bq_query_lds(N, nsample, 16) > 128 * 1024) return 0;  // it has to fit (with the static LDS)
   return bq_layout(B, N, M).total;

@@ -399,12 +399,16 @@ __global__ __launch_bounds__(256) void grid_finish_kernel(const float* __restric
 
 }  // namespace
 
-// 0 = automatic (grid when a workspace is given and the clouds are large enough); 1 = brute force
+// 0 = automatic (grid when a workspace is given and the problem is large enough to pay for its four
+// launches); 1 = brute force; 2 = grid wherever it is structurally possible (tests)
 static int g_grid_mode = 0;
 extern "C" void pp_debug_set_nmdistance_search(int v) { g_grid_mode = v; }
 
 static bool grid_applicable(int B, int N, int M, int C) {
-  return C == 3 && B > 0 && N >= 2048 && M >= 2048 && (long long)B * ((long long)N + M) < (1LL << 31) - 1;
+  if (!(C == 3 && B > 0 && N >= 2048 && M >= 2048 && (long long)B * ((long long)N + M) < (1LL << 31) - 1)) return false;
+  // the search costs ~45 us before the first query is answered; the brute force evaluates ~9e6 pairs per
+  // microsecond (tools/threshold_probe.py): below ~5e8 pairs it is the faster one
+  return g_grid_mode == 2 || (long long)B * N * M >= 250000000LL;
 }
 
 extern "C" size_t pp_nmdistance_forward_workspace_bytes(int B, int N, int M, int C) {

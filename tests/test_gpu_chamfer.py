@@ -259,7 +259,7 @@ def test_graph_replay_equals_eager(cuda):
     inputs rewritten in place between replays are honoured."""
     from pytorch_points_amd.graphs import GraphedChamferStep
     from pytorch_points_amd.network.model_loss import nndistance
-    b, n, m = 2, 4096, 3000
+    b, n, m = 8, 8192, 4096          # large enough for the grid search to be the automatic choice
     gs = GraphedChamferStep(b, n, m, cuda)
     for seed in (0, 5):
         x1 = torch.from_numpy(S.unit_sphere(seed, b, n)).to(cuda)

@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(cuda, x1, x2, mode):
+    """mode 2: the grid search wherever it is structurally possible (automatic mode leaves small problems
+    to the brute force); 1: brute force"""
     from pytorch_points_amd import _lib
     from pytorch_points_amd.network.model_loss import nndistance
     setter = _lib.lib().pp_debug_set_nmdistance_search
@@ -72,7 +74,7 @@ CASES = _cases()
 def test_grid_search_equals_oracle(cuda, name):
     x1, x2 = [np.ascontiguousarray(a) for a in CASES[name]]
     exp = oracle.chamfer_forward(x1, x2)
-    got = _run(cuda, x1, x2, 0)
+    got = _run(cuda, x1, x2, 2)
     for g, e, what in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
         assert np.array_equal(g, e), "%s: %s differs at %d places" % (name, what, int((g != e).sum()))
     brute = _run(cuda, x1, x2, 1)
@@ -83,7 +85,7 @@ def test_grid_search_equals_oracle(cuda, name):
 def test_grid_search_full_size_c2(cuda):
     """BASELINE config 2 through the default (grid) path == forced brute force, all 32 batch elements."""
     x1, x2 = S.unit_sphere(0, 32, 16384), S.unit_sphere(1, 32, 16384)
-    a = _run(cuda, x1, x2, 0)
+    a = _run(cuda, x1, x2, 2)
     b = _run(cuda, x1, x2, 1)
     for u, v in zip(a, b):
         assert np.array_equal(u, v)
@@ -95,7 +97,7 @@ def test_grid_search_full_size_c2(cuda):
 def test_grid_workspace_reused_across_shapes(cuda):
     for n, m in [(4096, 2048), (2048, 8192), (3000, 3000)]:
         x1, x2 = S.unit_sphere(n, 2, n), S.unit_sphere(m + 1, 2, m)
-        got = _run(cuda, x1, x2, 0)
+        got = _run(cuda, x1, x2, 2)
         exp = oracle.chamfer_forward(x1, x2)
         for g, e in zip(got, exp):
             assert np.array_equal(g, e)
@@ -140,6 +142,6 @@ def test_labeled_grid_search_equals_oracle(cuda, name, labels):
     else:
         l1, l2 = _labels(56, s1, 2), _labels(57, s2, 2) + np.float32(10)   # nobody matches
     exp = oracle.labeled_chamfer_forward(x1, x2, l1, l2)
-    got = _run_labeled(cuda, x1, x2, l1, l2, 0)
+    got = _run_labeled(cuda, x1, x2, l1, l2, 2)
     for g, e, what in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
         assert np.array_equal(g, e), "%s/%s: %s differs at %d places" % (name, labels, what, int((g != e).sum()))

@@ -11,6 +11,24 @@ from pytorch_points_amd import synthetic as S
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "grid"])
+def search_mode(request, cuda):
+    """auto: the operators' own choice between scan and grid kernels; grid: the grid kernels wherever
+    they are structurally possible (the automatic choice leaves small problems to the scans)"""
+    import ctypes
+    from pytorch_points_amd import _lib
+    knobs = []
+    for name in ("pp_debug_set_nmdistance_search", "pp_debug_set_ball_query_search"):
+        f = getattr(_lib.lib(), name)
+        f.argtypes = [ctypes.c_int]
+        f.restype = None
+        f(2 if request.param == "grid" else 0)
+        knobs.append(f)
+    yield request.param
+    for f in knobs:
+        f(0)
+
+
 def _cloud(rng, b, n, kind):
     """a (b, n, 3) fp32 cloud of a random family"""
     if kind == 0:
@@ -38,7 +56,7 @@ def _sizes(rng):
 
 
 @pytest.mark.parametrize("seed", range(60))
-def test_fuzz_chamfer_and_labeled(cuda, seed):
+def test_fuzz_chamfer_and_labeled(cuda, search_mode, seed):
     from pytorch_points_amd.network.model_loss import nndistance, labeled_nndistance
     rng = np.random.default_rng(1000 + seed)
     b, n, m = _sizes(rng)
@@ -61,7 +79,7 @@ def test_fuzz_chamfer_and_labeled(cuda, seed):
 
 
 @pytest.mark.parametrize("seed", range(60))
-def test_fuzz_ball_query(cuda, seed):
+def test_fuzz_ball_query(cuda, search_mode, seed):
     from pytorch_points_amd._ext import sampling
     rng = np.random.default_rng(2000 + seed)
     b, m, n = _sizes(rng)                      # m centres, n points

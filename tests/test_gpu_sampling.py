@@ -167,7 +167,7 @@ def bq_path(request, cuda):
     lpc.argtypes = [ctypes.c_int]
     lpc.restype = None
     setter(1 if request.param == "single_wave" else 0)
-    search(0 if request.param.startswith("grid") else 1)
+    search(2 if request.param.startswith("grid") else 1)   # 2: grid from N = 2048 (automatic: from 4096)
     lpc({"grid_lpc4": 4, "grid_lpc1": 1}.get(request.param, 0))
     yield request.param
     setter(0)
