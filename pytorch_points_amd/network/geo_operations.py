@@ -1,27 +1,29 @@
-"""``pytorch_points.network.geo_operations`` -- the part on the hot path: FurthestPointSampling /
-furthest_point_sample (reference: network/geo_operations.py:11-64).  The mesh-geometry functions of
-that file are out of scope."""
+"""Drop-in for the hot-path names of ``pytorch_points.network.geo_operations``: FurthestPointSampling /
+furthest_point_sample (reference network/geo_operations.py:11-64).  The mesh-geometry functions of that
+file are out of scope."""
 import torch
 
 from .._ext import sampling
 from .operations import gather_points
 
+_FAR = 1e10   # initial running minimum of every point (reference :29)
+
 
 class FurthestPointSampling(torch.autograd.Function):
-    """xyz (B,N,3), npoint, seedIdx -> int32 idx (B,npoint)   (reference geo_operations.py:11-38)"""
+    """``(xyz (B,N,3), npoint, seedIdx)`` -> int32 ``(B,npoint)``: iterative farthest point sampling started
+    at point ``seedIdx``.  Not differentiable."""
 
     @staticmethod
     def forward(ctx, xyz, npoint, seedIdx):
-        B, N, _ = xyz.size()
-
-        idx = torch.empty([B, npoint], dtype=torch.int32, device=xyz.device)
-        temp = torch.full([B, N], 1e10, dtype=torch.float32, device=xyz.device)
-        sampling.furthest_sampling(npoint, seedIdx, xyz, temp, idx)
-        ctx.mark_non_differentiable(idx)
-        return idx
+        batch, n = xyz.shape[0], xyz.shape[1]
+        picked = torch.empty((batch, npoint), dtype=torch.int32, device=xyz.device)
+        running_min = xyz.new_full((batch, n), _FAR, dtype=torch.float32)
+        sampling.furthest_sampling(npoint, seedIdx, xyz, running_min, picked)
+        ctx.mark_non_differentiable(picked)
+        return picked
 
     @staticmethod
-    def backward(ctx, grad_idx=None):
+    def backward(ctx, *unused):
         return None, None, None
 
 
@@ -29,24 +31,13 @@ _furthest_point_sample = FurthestPointSampling.apply  # type: ignore
 
 
 def furthest_point_sample(xyz, npoint, NCHW=True, seedIdx=0):
-    """
-    :param
-        xyz (B, 3, N) or (B, N, 3)
-        npoint a constant
-    :return
-        torch.IntTensor
-            (B, npoint) tensor containing the indices
-        torch.FloatTensor
-            (B, npoint, 3) or (B, 3, npoint) point sets
-    (reference geo_operations.py:44-64)"""
+    """Sample ``npoint`` points; returns ``(idx (B,npoint) int32, points)`` with ``points`` in the layout of
+    the input: ``(B,3,npoint)`` for ``NCHW`` input ``(B,3,N)``, ``(B,npoint,3)`` for ``(B,N,3)``
+    (reference :44-64, same messages)."""
     assert (xyz.dim() == 3), "input for furthest sampling must be a 3D-tensor, but xyz.size() is {}".format(xyz.size())
-    # need transpose
-    if NCHW:
-        xyz = xyz.transpose(2, 1).contiguous()
-
-    assert (xyz.size(2) == 3), "furthest sampling is implemented for 3D points"
-    idx = _furthest_point_sample(xyz.contiguous(), npoint, seedIdx)
-    sampled_pc = gather_points(xyz.transpose(2, 1).contiguous(), idx)
-    if not NCHW:
-        sampled_pc = sampled_pc.transpose(2, 1).contiguous()
-    return idx, sampled_pc
+    points_last = xyz.transpose(2, 1) if NCHW else xyz          # (B, N, 3) view
+    assert (points_last.size(2) == 3), "furthest sampling is implemented for 3D points"
+    points_last = points_last.contiguous()
+    idx = _furthest_point_sample(points_last, npoint, seedIdx)
+    chosen = gather_points(points_last.transpose(2, 1).contiguous(), idx)   # (B, 3, npoint)
+    return idx, (chosen if NCHW else chosen.transpose(2, 1).contiguous())

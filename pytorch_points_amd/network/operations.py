@@ -7,33 +7,29 @@ from .._ext import sampling
 
 
 class GatherFunction(torch.autograd.Function):
-    """features (B,C,N), idx (B,npoint) -> (B,C,npoint)   (reference operations.py:38-82)"""
+    """``gather_points(features (B,C,N), idx (B,npoint))`` -> ``(B,C,npoint)``: columns of ``features``
+    picked by ``idx`` (int32; other integer types are converted, reference operations.py:55); the
+    gradient is scattered back to ``features`` (reference :38-82)."""
 
     @staticmethod
     def forward(ctx, features, idx):
-        features = features.contiguous()
-        idx = idx.contiguous()
-        idx = idx.to(dtype=torch.int32)
-
-        B, npoint = idx.size()
-        _, C, N = features.size()
-
-        output = torch.empty(B, C, npoint, dtype=features.dtype, device=features.device)
-        sampling.gather_forward(B, C, N, npoint, features, idx, output)
-
-        ctx.save_for_backward(idx)
-        ctx.C = C
-        ctx.N = N
-        return output
+        src = features.contiguous()
+        cols = idx.contiguous().to(torch.int32)
+        batch, channels, n = src.shape
+        picked = cols.shape[1]
+        out = src.new_empty((batch, channels, picked))
+        sampling.gather_forward(batch, channels, n, picked, src, cols, out)
+        ctx.save_for_backward(cols)
+        ctx.source_shape = (channels, n)
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, = ctx.saved_tensors
-        B, npoint = idx.size()
-
-        grad_features = torch.zeros(B, ctx.C, ctx.N, dtype=grad_out.dtype, device=grad_out.device)
-        sampling.gather_backward(B, ctx.C, ctx.N, npoint, grad_out.contiguous(), idx, grad_features)
-
+        (cols,) = ctx.saved_tensors
+        channels, n = ctx.source_shape
+        batch, picked = cols.shape
+        grad_features = grad_out.new_zeros((batch, channels, n))      # the kernel accumulates
+        sampling.gather_backward(batch, channels, n, picked, grad_out.contiguous(), cols, grad_features)
         return grad_features, None
 
 
@@ -41,17 +37,18 @@ gather_points = GatherFunction.apply  # type: ignore
 
 
 class BallQuery(torch.autograd.Function):
-    """(radius, nsample, xyz (B,N,3), new_xyz (B,npoint,3)) -> int32 (B,npoint,nsample)
-    (reference operations.py:88-111; note the argument order)"""
+    """``ball_query(radius, nsample, xyz (B,N,3), new_xyz (B,npoint,3))`` -> int32 ``(B,npoint,nsample)``:
+    per centre the first ``nsample`` points of ``xyz`` (in index order) closer than ``radius``, padded with
+    the first hit.  Argument order as the reference's (operations.py:88-111).  Not differentiable."""
 
     @staticmethod
     def forward(ctx, radius, nsample, xyz, new_xyz):
-        idx = sampling.ball_query(new_xyz, xyz, radius, nsample)
-        ctx.mark_non_differentiable(idx)
-        return idx
+        members = sampling.ball_query(new_xyz, xyz, radius, nsample)
+        ctx.mark_non_differentiable(members)
+        return members
 
     @staticmethod
-    def backward(ctx, a=None):
+    def backward(ctx, *unused):
         return None, None, None, None
 
 
@@ -59,25 +56,19 @@ ball_query = BallQuery.apply  # type: ignore
 
 
 class GroupingOperation(torch.autograd.Function):
-    """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)
-    (reference operations.py:117-156)"""
+    """``grouping_operation(features (B,C,N), idx (B,npoint,nsample))`` -> ``(B,C,npoint,nsample)``; the
+    gradient is scattered back to ``features`` (reference operations.py:117-156)."""
 
     @staticmethod
     def forward(ctx, features, idx):
-        B, nfeatures, nsample = idx.size()
-        _, C, N = features.size()
-
-        ctx.for_backwards = (idx, N)
-
+        ctx.save_for_backward(idx)
+        ctx.source_points = features.shape[2]
         return sampling.group_points(features, idx)
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, N = ctx.for_backwards
-
-        grad_features = sampling.group_points_grad(grad_out.contiguous(), idx, N)
-
-        return grad_features, None
+        (idx,) = ctx.saved_tensors
+        return sampling.group_points_grad(grad_out.contiguous(), idx, ctx.source_points), None
 
 
 grouping_operation = GroupingOperation.apply  # type: ignore
@@ -136,20 +127,16 @@ class QueryAndGroup(torch.nn.Module):
         return _QueryAndGroupFused.apply(xyz, new_xyz, features, self.radius, self.nsample, self.use_xyz)
 
     def forward_unfused(self, xyz, new_xyz, features=None):
-        """The reference's composition, op by op (operations.py:193-204); kept for the parity tests."""
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-        xyz_trans = xyz.transpose(1, 2).contiguous()
-        grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, nsample)
-        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
-
+        """The same result composed from the public operators the way the reference does it
+        (operations.py:193-204: ball_query, two grouping_operations, a subtraction and a concatenation);
+        kept as the yardstick of the parity tests and of ``bench.py --workload ball_group``."""
+        if features is None and not self.use_xyz:
+            raise AssertionError("Cannot have not features and not use xyz as a feature!")
+        members = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        parts = []
+        if self.use_xyz or features is None:
+            local = grouping_operation(xyz.transpose(1, 2).contiguous(), members)
+            parts.append(local - new_xyz.transpose(1, 2).unsqueeze(-1))     # relative to the centre
         if features is not None:
-            grouped_features = grouping_operation(features, idx)
-            if self.use_xyz:
-                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)  # (B, C + 3, npoint, nsample)
-            else:
-                new_features = grouped_features
-        else:
-            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            new_features = grouped_xyz
-
-        return new_features
+            parts.append(grouping_operation(features, members))
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
