@@ -378,7 +378,7 @@ def bench_chamfer(args, dist, world, rank, device):
         out["valu"] = {"achieved": laneops / (fwd_ms * 1e-3), "peak": VALU_PEAK_LANEOPS,
                        "unit": "lane-ops/s", "frac": laneops / (fwd_ms * 1e-3) / VALU_PEAK_LANEOPS,
                        "pairs_per_s_fwd": 2.0 * B * N * M / (fwd_ms * 1e-3)}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU leg runs at N=1 only
         out["cpu_baseline"] = cpu_baseline_chamfer(N, C)
     return out
 
