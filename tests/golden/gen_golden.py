@@ -96,5 +96,23 @@ def main():
         save(name, unknown=u, known=k, dist2=d2, idx=idx)
 
 
+def knn_case():
+    """K nearest neighbours: oracle.knn accepted by an fp64 evaluation"""
+    u, k, K = S.unit_sphere(160, 2, 600), S.unit_sphere(161, 2, 500), 8
+    k[:, 250:260] = k[:, :10]            # exact ties: the lower index first
+    d2, idx = oracle.knn(u, k, K)
+    D = ((u[:, :, None].astype(np.float64) - k[:, None].astype(np.float64)) ** 2).sum(-1)
+    ref = np.argsort(D, axis=-1, kind="stable")[..., :K]
+    dref = np.take_along_axis(D, ref, -1)
+    assert np.allclose(d2, dref, rtol=1e-5, atol=1e-7)
+    picked = np.take_along_axis(D, idx.astype(np.int64), -1)
+    assert np.allclose(picked, dref, rtol=1e-5, atol=1e-7)       # same neighbours up to fp32 near-ties
+    save("knn_b2_n600_m500_k8", p1=u, p2=k, dist2=d2, idx=idx, K=np.int32(K))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "knn":   # add the K-NN fixture without rewriting the others
+        knn_case()
+    else:
+        main()
+        knn_case()

@@ -100,3 +100,11 @@ def test_knn_gradients(cuda):
     (ref * w).sum().backward()
     assert torch.allclose(out.dists, ref, rtol=1e-5, atol=1e-6)
     assert torch.allclose(g1, p1.grad, rtol=1e-5, atol=1e-6) and torch.allclose(g2, p2.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_knn_golden_fixture(cuda, knn_path):
+    import os
+    from pytorch_points_amd.ops import knn_points
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "knn_b2_n600_m500_k8.npz")))
+    out = knn_points(_t(g["p1"], cuda), _t(g["p2"], cuda), K=int(g["K"]))
+    assert np.array_equal(out.idx.cpu().numpy(), g["idx"]) and np.array_equal(out.dists.cpu().numpy(), g["dist2"])

@@ -26,7 +26,7 @@ CHAMFER_GOLD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G
 def test_golden_files_present():
     assert len(CHAMFER_GOLD) == 5
     for n in ["labeled_b1_n512_m700", "fps_b2_n2048_m256", "fps_b1_n300_m64_seed7", "fps_b1_n5000_m128",
-              "ball_query_b2_n2048_m256", "three_nn_b2_n2048_m256", "three_nn_b1_n10_m2"]:
+              "ball_query_b2_n2048_m256", "three_nn_b2_n2048_m256", "three_nn_b1_n10_m2", "knn_b2_n600_m500_k8"]:
         assert os.path.exists(os.path.join(GOLD, n + ".npz"))
 
 
@@ -219,3 +219,9 @@ def test_knn_oracle_vs_fp64_bruteforce():
     r = np.array([[[1, 0, 0], [0, 1, 0], [0, 0, 1], [0.5, 0, 0], [-1, 0, 0]]], np.float32)
     d, i = oracle.knn(q, r, 5)
     assert i[0, 0].tolist() == [3, 0, 1, 2, 4]
+
+
+def test_knn_golden():
+    g = _load("knn_b2_n600_m500_k8")
+    d2, idx = oracle.knn(g["p1"], g["p2"], int(g["K"]))
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(d2, g["dist2"])
