@@ -222,6 +222,6 @@ def test_knn_oracle_vs_fp64_bruteforce():
 
 
 def test_knn_golden():
-    g = _load("knn_b2_n600_m500_k8")
+    g = gold("knn_b2_n600_m500_k8")
     d2, idx = oracle.knn(g["p1"], g["p2"], int(g["K"]))
     assert np.array_equal(idx, g["idx"]) and np.array_equal(d2, g["dist2"])
