@@ -354,9 +354,14 @@ def bench_chamfer(args, dist, world, rank, device):
         # the brute-force kernel over the unresolved list; timed together by the HIP events
         out["roofline"] = {"bound": "hbm", "kernel": "grid_build_kernel + grid_query_kernel + list fallback",
                            "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None,
-                           "note": "latency/L2-gather-bound search over a 17 MB workspace; 'bruteforce' "
-                                   "carries the every-pair kernel and its VALU roofline"}
+                           "frac": hbm_gbs / HBM_PEAK_GBS,
+                           # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, summed over the forward's kernels
+                           # (profiles/r1/pmc_summary.txt: build 9.7 + 53.5 MB, stage A 11.6 + 8.1, wide stages
+                           # 4.3 + 0.3); most of it is the search structure itself (sorted clouds + cell tables,
+                           # 25 MB, written with scattered 16-byte stores), not re-reads of the inputs
+                           "traffic": 87.5e6 if (B, N, M) == (32, 16384, 16384) else None,
+                           "note": "VALU-issue / L2-latency-bound search over a 17 MB workspace, not HBM-bound; "
+                                   "'bruteforce' carries the every-pair kernel and its VALU roofline"}
         if brute is not None:
             bg = alg_bytes_fwd / (brute["fwd_ms"] * 1e-3) / 1e9
             brute.update({
