@@ -249,12 +249,14 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
 // Generic point dimension (C != 3): one lane per query, reference point wave-uniform, plain
 // compare/select.  CT > 0: compile-time C, query in registers; CT == 0: run-time C, query re-read
 // from memory (L1) for every reference point.  Correctness path, not a tuned one.
-template <int CT>
+template <int CT, bool PAD>
 __global__ __launch_bounds__(256) void nmdist_fwd_generic_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
     int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M, int C,
     int tiles1, int tiles2) {
-  const int c = CT > 0 ? CT : C;
+  // CT > 0: the query sits in CT registers.  PAD (CT = 16 serves 9 <= C <= 16): coordinates beyond C are
+  // zeros on both sides, and fma(0, 0, d) == d leaves the distance untouched bit for bit
+  const int c = (CT > 0 && !PAD) ? CT : C;
   const int per_b = tiles1 + tiles2;
   const int b = blockIdx.x / per_b;
   const int r = blockIdx.x - b * per_b;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void nmdist_fwd_generic_kernel(
   float q[CT > 0 ? CT : 1];
   if (CT > 0) {
 #pragma unroll
-    for (int e = 0; e < CT; ++e) q[e] = qp[e];
+    for (int e = 0; e < CT; ++e) q[e] = (!PAD || e < c) ? qp[e] : 0.0f;
   }
   float best = __builtin_inff();
   int bi = 0;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void nmdist_fwd_generic_kernel(
     if (CT > 0) {
 #pragma unroll
       for (int e = 0; e < CT; ++e) {
-        const float t = rp[e] - q[e];
+        const float t = ((!PAD || e < c) ? rp[e] : 0.0f) - q[e];  // rp is wave-uniform: scalar loads
         d = __builtin_fmaf(t, t, d);
       }
     } else {
@@ -671,13 +673,13 @@ int launch_fwd_c3(const float* xyz1, const float* xyz2, float* dist1, int* idx1,
   return PP_OK;
 }
 
-template <int CT>
+template <int CT, bool PAD = false>
 int launch_fwd_generic(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
                        int* idx2, int B, int N, int M, int C, hipStream_t s) {
   const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
   const long long total = (long long)B * (tiles1 + tiles2);
   if (total > 0x7fffff00LL) return PP_EINVAL;
-  nmdist_fwd_generic_kernel<CT><<<dim3((unsigned)total), dim3(256), 0, s>>>(
+  nmdist_fwd_generic_kernel<CT, PAD><<<dim3((unsigned)total), dim3(256), 0, s>>>(
       xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, C, tiles1, tiles2);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
@@ -764,7 +766,13 @@ extern "C" int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, f
     case 1: return launch_fwd_generic<1>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
     case 2: return launch_fwd_generic<2>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
     case 4: return launch_fwd_generic<4>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
-    default: return launch_fwd_generic<0>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
+    case 5: return launch_fwd_generic<5>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
+    case 6: return launch_fwd_generic<6>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
+    case 7: return launch_fwd_generic<7>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
+    case 8: return launch_fwd_generic<8>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
+    default:
+      if (C <= 16) return launch_fwd_generic<16, true>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
+      return launch_fwd_generic<0>(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, C, s);
   }
 }
 

@@ -36,7 +36,8 @@ def _run(cuda, x1, x2):
 
 
 SHAPES = [(2, 1024, 1024, 3), (1, 1000, 777, 3), (2, 300, 1500, 3), (1, 64, 64, 2), (1, 513, 511, 5),
-          (3, 7, 5, 3), (1, 1, 1, 3), (2, 2050, 33, 3), (1, 129, 4099, 4), (1, 40, 50, 1)]
+          (3, 7, 5, 3), (1, 1, 1, 3), (2, 2050, 33, 3), (1, 129, 4099, 4), (1, 40, 50, 1),
+          (2, 300, 257, 6), (1, 100, 333, 7), (1, 257, 100, 8), (2, 64, 200, 9), (1, 130, 70, 16), (1, 50, 90, 17)]
 
 
 @pytest.mark.parametrize("shape", SHAPES)
@@ -110,7 +111,7 @@ def bwd_path(request, cuda):
 
 
 @pytest.mark.parametrize("shape", [(2, 1024, 1024, 3), (1, 1000, 777, 3), (1, 64, 64, 2), (1, 513, 511, 5),
-                                   (12, 2048, 3000, 3), (2, 5000, 1200, 3), (1, 4097, 4099, 3)])
+                                   (12, 2048, 3000, 3), (2, 5000, 1200, 3), (1, 4097, 4099, 3), (2, 300, 257, 6), (1, 130, 70, 16)])
 def test_backward_matches_oracle_and_fp64(cuda, bwd_path, shape):
     from pytorch_points_amd.network.model_loss import nndistance
     b, n, m, c = shape
