@@ -594,6 +594,45 @@ bool launch_group_lds(const float* points, const int* idx, float* out, int B, in
   return true;
 }
 
+// LDS-staged form without any alignment requirement (P, N, the batch stride or the pointers not
+// multiples of 4 elements) and for rows up to 152 KiB: 4-byte loads and stores, all coalesced; a thread
+// keeps V positions (stride 1024) for all channels.  Slower than the 16-byte forms above, but the
+// alternative for such shapes is the global-gather kernel at ~0.5 TB/s.
+template <int V>
+__global__ __launch_bounds__(1024) void group_points_lds_scalar_kernel(const float* __restrict__ points,
+                                                                       const int* __restrict__ idx,
+                                                                       float* __restrict__ out, int B, int C,
+                                                                       int N, long long P, int chunks,
+                                                                       long long obs) {
+  extern __shared__ __attribute__((aligned(16))) float s_srow[];
+  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
+  const int b = x + 8 * (y / chunks);
+  const int chunk = y % chunks;
+  if (b >= B) return;
+  const int t = threadIdx.x;
+  const long long p0 = (long long)chunk * (1024 * V) + t;
+  int ii[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const long long p = p0 + 1024LL * v;
+    ii[v] = p < P ? idx[(size_t)b * P + p] : 0;
+  }
+  const float* __restrict__ rows = points + (size_t)b * C * N;
+  float* __restrict__ out_b = out + (size_t)b * obs;
+  for (int c = 0; c < C; ++c) {
+    __syncthreads();  // the previous row has been gathered
+    const float* __restrict__ row = rows + (size_t)c * N;
+    for (int e = t; e < N; e += 1024) s_srow[e] = row[e];
+    __syncthreads();
+    float* __restrict__ o = out_b + (size_t)c * P;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const long long p = p0 + 1024LL * v;
+      if (p < P) o[p] = s_srow[ii[v]];
+    }
+  }
+}
+
 // group_points backward: grad_points[b,c,idx[b,j,k]] += grad_out[b,c,j,k]  (ref :482-503)
 __global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __restrict__ grad_out,
                                                                 const int* __restrict__ idx,
@@ -651,7 +690,7 @@ __global__ __launch_bounds__(1024) void group_points_grad_lds_kernel(const float
 // destinations (8 W bytes of LDS) of one (batch, channel): the whole column when N fits, otherwise
 // one of `nsplit` ranges, each workgroup streaming the column's grad_out and skipping the entries
 // of the other ranges.  U 16-byte load pairs are in flight per thread before the first atomic.
-template <int U>
+template <int U, bool VEC = true>
 __global__ __launch_bounds__(1024) void group_points_grad_lds64_kernel(const float* __restrict__ grad_out,
                                                                        const int* __restrict__ idx,
                                                                        float* __restrict__ grad_points,
@@ -689,20 +728,38 @@ __global__ __launch_bounds__(1024) void group_points_grad_lds64_kernel(const flo
     if (!e2) add1(i.z, sz);
     if (!e3) add1(i.w, sw);
   };
-  long long e = t;
-  for (; e + 1024 * (U - 1) < p4; e += 1024 * U) {
-    pp::f4 g[U];
-    pp::i4 i[U];
+  if constexpr (VEC) {
+    long long e = t;
+    for (; e + 1024 * (U - 1) < p4; e += 1024 * U) {
+      pp::f4 g[U];
+      pp::i4 i[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      g[u] = reinterpret_cast<const pp::f4*>(go)[e + 1024 * u];
-      i[u] = reinterpret_cast<const pp::i4*>(ib)[e + 1024 * u];
+      for (int u = 0; u < U; ++u) {
+        g[u] = reinterpret_cast<const pp::f4*>(go)[e + 1024 * u];
+        i[u] = reinterpret_cast<const pp::i4*>(ib)[e + 1024 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) add4(g[u], i[u]);
     }
+    for (; e < p4; e += 1024) add4(reinterpret_cast<const pp::f4*>(go)[e], reinterpret_cast<const pp::i4*>(ib)[e]);
+    for (long long q = (p4 << 2) + t; q < P; q += 1024) add1(ib[q], (double)go[q]);
+  } else {
+    // rows that are not 16-byte aligned (P or the batch stride not a multiple of 4): 4-byte loads, still
+    // coalesced, 2U in flight per thread -- slower than the vector form, far from the global-atomic one
+    long long e = t;
+    for (; e + 1024 * (2 * U - 1) < P; e += 1024 * 2 * U) {
+      float g[2 * U];
+      int i[2 * U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) add4(g[u], i[u]);
+      for (int u = 0; u < 2 * U; ++u) {
+        g[u] = go[e + 1024 * u];
+        i[u] = ib[e + 1024 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 2 * U; ++u) add1(i[u], (double)g[u]);
+    }
+    for (; e < P; e += 1024) add1(ib[e], (double)go[e]);
   }
-  for (; e < p4; e += 1024) add4(reinterpret_cast<const pp::f4*>(go)[e], reinterpret_cast<const pp::i4*>(ib)[e]);
-  for (long long q = (p4 << 2) + t; q < P; q += 1024) add1(ib[q], (double)go[q]);
   __syncthreads();
   float* __restrict__ gp = grad_points + ((size_t)b * C + c) * N + lo;
   for (int k = t; k < w; k += 1024) gp[k] += (float)s_col64[k];  // accumulate: the ABI's contract
@@ -1165,6 +1222,22 @@ extern "C" int pp_group_points_strided_f32(const float* points, const int* idx, 
       return PP_OK;
     }
   }
+  // unaligned shapes, or rows beyond 64 KiB: the 4-byte LDS-staged form
+  if (g_group_variant != 1 && (size_t)N * sizeof(float) <= 152 * 1024 && C >= 4 &&
+      (long long)B * P >= 256LL * 2048) {
+    constexpr int V = 16;
+    const long long chunks = (P + 1024LL * V - 1) / (1024LL * V);
+    const long long blocks = 8LL * ((B + 7) / 8) * chunks;
+    if (chunks <= 0x7fffffLL && blocks <= 0x7fffffffLL) {
+      static bool ok_s[64] = {};
+      const hipError_t e = pp::allow_big_lds(group_points_lds_scalar_kernel<V>, 152 * 1024, ok_s);
+      if (e != hipSuccess) return (int)e;
+      group_points_lds_scalar_kernel<V><<<dim3((unsigned)blocks), dim3(1024), (size_t)N * sizeof(float), s>>>(
+          points, idx, out, B, C, N, P, (int)chunks, obs);
+      PP_RETURN_IF_LAUNCH_FAILED();
+      return PP_OK;
+    }
+  }
   const long long threads = vec4 ? P / 4 : P;
   const long long cols = (threads + 255) / 256;
   const int cpb = pick_c_per_block(cols, B, C);
@@ -1201,24 +1274,32 @@ extern "C" int pp_group_points_grad_strided_f32(const float* grad_out, const int
   if (B == 0 || C == 0 || P == 0) return PP_OK;
   if (!grad_out || !idx || !grad_points || N == 0) return PP_EINVAL;
   // LDS-column forms: 16-byte aligned streams, enough work per column
-  if (g_group_grad_variant != 1 &&
-      (uintptr_t)grad_out % 16 == 0 && (uintptr_t)idx % 16 == 0 && P % 4 == 0 && gbs % 4 == 0 &&
+  const bool vec = (uintptr_t)grad_out % 16 == 0 && (uintptr_t)idx % 16 == 0 && P % 4 == 0 && gbs % 4 == 0;
+  if (g_group_grad_variant != 1 && (vec || g_group_grad_variant != 3) &&
       8LL * ((B + 7) / 8) * C <= 0x7fffffffLL && (g_group_grad_variant >= 2 || P >= 4096)) {
     constexpr int kW64 = 152 * 1024 / 8;  // destinations per workgroup with a double column
     const int nsplit = (N + kW64 - 1) / kW64;
     const long long wgs = 8LL * ((B + 7) / 8) * C * nsplit;
     if (g_group_grad_variant != 3 && nsplit <= 16 && wgs <= 0x7fffffffLL) {
       const int W = nsplit == 1 ? N : kW64;
-      static bool lds64_ok[64] = {};
-      const hipError_t e = pp::allow_big_lds(group_points_grad_lds64_kernel<8>, 152 * 1024, lds64_ok);
-      if (e != hipSuccess) return (int)e;
-      group_points_grad_lds64_kernel<8><<<dim3((unsigned)wgs), dim3(1024), (size_t)W * sizeof(double),
-                                          (hipStream_t)stream>>>(grad_out, idx, grad_points, B, C, N, P, gbs,
-                                                                 nsplit, W);
+      static bool lds64_ok[64] = {}, lds64s_ok[64] = {};
+      if (vec) {
+        const hipError_t e = pp::allow_big_lds(group_points_grad_lds64_kernel<8, true>, 152 * 1024, lds64_ok);
+        if (e != hipSuccess) return (int)e;
+        group_points_grad_lds64_kernel<8, true><<<dim3((unsigned)wgs), dim3(1024), (size_t)W * sizeof(double),
+                                                  (hipStream_t)stream>>>(grad_out, idx, grad_points, B, C, N, P,
+                                                                         gbs, nsplit, W);
+      } else {
+        const hipError_t e = pp::allow_big_lds(group_points_grad_lds64_kernel<8, false>, 152 * 1024, lds64s_ok);
+        if (e != hipSuccess) return (int)e;
+        group_points_grad_lds64_kernel<8, false><<<dim3((unsigned)wgs), dim3(1024), (size_t)W * sizeof(double),
+                                                   (hipStream_t)stream>>>(grad_out, idx, grad_points, B, C, N, P,
+                                                                          gbs, nsplit, W);
+      }
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
     }
-    if ((size_t)N * sizeof(float) <= 160 * 1024) {  // fp32 column (kept for comparison: ds_add_f32 is slow)
+    if (vec && (size_t)N * sizeof(float) <= 160 * 1024) {  // fp32 column (kept for comparison: ds_add_f32 is slow)
       static bool lds_ok[64] = {};
       const hipError_t e = pp::allow_big_lds(group_points_grad_lds_kernel, 160 * 1024, lds_ok);
       if (e != hipSuccess) return (int)e;

@@ -336,7 +336,10 @@ def test_three_interpolate_grad_large(cuda, interp_grad_path, b, c, n, m):
 
 
 @pytest.mark.parametrize("b,c,n,npoint,ns", [(2, 8, 2048, 256, 16), (1, 3, 100, 7, 5), (2, 67, 500, 33, 12), (1, 1, 10, 1, 1),
-                                             (9, 4, 4096, 512, 32), (4, 16, 4096, 1024, 32), (3, 10, 5000, 700, 48)])
+                                             (9, 4, 4096, 512, 32), (4, 16, 4096, 1024, 32), (3, 10, 5000, 700, 48),
+                                             # shapes without 16-byte alignment / rows beyond 64 KiB (4-byte LDS-staged forms)
+                                             (9, 5, 16383, 1024, 64), (2, 6, 20000, 4096, 64), (4, 7, 4096, 4095, 33),
+                                             (2, 5, 3000, 1023, 33), (5, 4, 30001, 999, 107)])
 def test_group_points_matches_torch_and_backward(cuda, group_grad_path, b, c, n, npoint, ns):
     from pytorch_points_amd.network.operations import grouping_operation
     f = _t(S.normal(40, (b, c, n)), cuda).requires_grad_(True)
