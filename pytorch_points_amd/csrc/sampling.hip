@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(const float* __restrict
 // and gathers from LDS, CPB channels in turn, the next row's loads in flight while this one is
 // gathered.  Reads 4 N bytes per row instead of one 64-byte sector per gathered element: the better
 // deal when N <= 16 M.  XCD mapping as group_points: idx of one batch element is read by one L2.
-template <int KR>
+template <int KR, bool VEC>
 __global__ __launch_bounds__(1024) void gather_fwd_lds_kernel(const float* __restrict__ points,
                                                               const int* __restrict__ idx,
                                                               float* __restrict__ out, int B, int C, int N,
@@ -47,27 +47,38 @@ __global__ __launch_bounds__(1024) void gather_fwd_lds_kernel(const float* __res
   const int c0 = (y % groups) * cpb;
   const int c1 = min(C, c0 + cpb);
   const int t = threadIdx.x;
-  const int n4 = N >> 2;
   const int* __restrict__ ib = idx + (size_t)b * M;
-  pp::f4 pre[KR];
-  auto load_row = [&](int c) {
-    const pp::f4* __restrict__ row = reinterpret_cast<const pp::f4*>(points + ((size_t)b * C + c) * N);
+  if constexpr (VEC) {
+    const int n4 = N >> 2;
+    pp::f4 pre[KR];
+    auto load_row = [&](int c) {
+      const pp::f4* __restrict__ row = reinterpret_cast<const pp::f4*>(points + ((size_t)b * C + c) * N);
 #pragma unroll
-    for (int k = 0; k < KR; ++k) pre[k] = row[min(t + 1024 * k, n4 - 1)];
-  };
-  load_row(c0);
-  for (int c = c0; c < c1; ++c) {
-    __syncthreads();  // the previous row has been gathered
+      for (int k = 0; k < KR; ++k) pre[k] = row[min(t + 1024 * k, n4 - 1)];
+    };
+    load_row(c0);
+    for (int c = c0; c < c1; ++c) {
+      __syncthreads();  // the previous row has been gathered
 #pragma unroll
-    for (int k = 0; k < KR; ++k)
-      if (t + 1024 * k < n4) reinterpret_cast<pp::f4*>(s_grow)[t + 1024 * k] = pre[k];
-    __syncthreads();
-    if (c + 1 < c1) load_row(c + 1);
-    float* __restrict__ o = out + ((size_t)b * C + c) * M;
-    for (int m = t * 4; m < M; m += 4096) {
-      const pp::i4 i = *reinterpret_cast<const pp::i4*>(ib + m);
-      pp::f4 r = {s_grow[i.x], s_grow[i.y], s_grow[i.z], s_grow[i.w]};
-      *reinterpret_cast<pp::f4*>(o + m) = r;
+      for (int k = 0; k < KR; ++k)
+        if (t + 1024 * k < n4) reinterpret_cast<pp::f4*>(s_grow)[t + 1024 * k] = pre[k];
+      __syncthreads();
+      if (c + 1 < c1) load_row(c + 1);
+      float* __restrict__ o = out + ((size_t)b * C + c) * M;
+      for (int m = t * 4; m < M; m += 4096) {
+        const pp::i4 i = *reinterpret_cast<const pp::i4*>(ib + m);
+        pp::f4 r = {s_grow[i.x], s_grow[i.y], s_grow[i.z], s_grow[i.w]};
+        *reinterpret_cast<pp::f4*>(o + m) = r;
+      }
+    }
+  } else {  // no alignment assumed: 4-byte accesses, all coalesced
+    for (int c = c0; c < c1; ++c) {
+      __syncthreads();
+      const float* __restrict__ row = points + ((size_t)b * C + c) * N;
+      for (int e = t; e < N; e += 1024) s_grow[e] = row[e];
+      __syncthreads();
+      float* __restrict__ o = out + ((size_t)b * C + c) * M;
+      for (int m = t; m < M; m += 1024) o[m] = s_grow[ib[m]];
     }
   }
 }
@@ -897,7 +908,7 @@ void launch_three_interpolate_lds(const float* points, const int* idx, const flo
 // four points are read once for the CG channels, 12 LDS gathers per channel, one 16-byte store per
 // channel.  The row-at-a-time form above pays two barriers per channel row for 12 gathers; here
 // the only serial part is the staging.  Same canonical fma order.
-template <int CG>
+template <int CG, bool VEC>
 __global__ __launch_bounds__(1024) void three_interpolate_rows_kernel(const float* __restrict__ points,
                                                                       const int* __restrict__ idx,
                                                                       const float* __restrict__ weight,
@@ -911,45 +922,64 @@ __global__ __launch_bounds__(1024) void three_interpolate_rows_kernel(const floa
   const int c0 = (y % groups) * CG;
   const int nc = min(CG, C - c0);
   const int t = threadIdx.x;
-  const int m4 = M >> 2;
   for (int k = 0; k < nc; ++k) {
-    const pp::f4* __restrict__ row = reinterpret_cast<const pp::f4*>(points + ((size_t)b * C + c0 + k) * M);
-    for (int e = t; e < m4; e += 1024) reinterpret_cast<pp::f4*>(s_irows + (size_t)k * M)[e] = row[e];
+    const float* __restrict__ rowf = points + ((size_t)b * C + c0 + k) * M;
+    if constexpr (VEC) {
+      const pp::f4* __restrict__ row = reinterpret_cast<const pp::f4*>(rowf);
+      for (int e = t; e < (M >> 2); e += 1024) reinterpret_cast<pp::f4*>(s_irows + (size_t)k * M)[e] = row[e];
+    } else {
+      for (int e = t; e < M; e += 1024) s_irows[(size_t)k * M + e] = rowf[e];
+    }
   }
   __syncthreads();
-  for (int n0 = 4 * t; n0 < N; n0 += 4096) {
-    int ii[12];
-    float ww[12];
+  if constexpr (VEC) {
+    for (int n0 = 4 * t; n0 < N; n0 += 4096) {
+      int ii[12];
+      float ww[12];
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      const pp::i4 q = reinterpret_cast<const pp::i4*>(idx + ((size_t)b * N + n0) * 3)[e];
-      const pp::f4 w = reinterpret_cast<const pp::f4*>(weight + ((size_t)b * N + n0) * 3)[e];
-      ii[4 * e] = q.x; ii[4 * e + 1] = q.y; ii[4 * e + 2] = q.z; ii[4 * e + 3] = q.w;
-      ww[4 * e] = w.x; ww[4 * e + 1] = w.y; ww[4 * e + 2] = w.z; ww[4 * e + 3] = w.w;
-    }
-#pragma unroll
-    for (int k = 0; k < CG; ++k)
-      if (k < nc) {
-        const float* __restrict__ sr = s_irows + (size_t)k * M;
-        pp::f4 r;
-        r.x = __builtin_fmaf(ww[2], sr[ii[2]], __builtin_fmaf(ww[0], sr[ii[0]], ww[1] * sr[ii[1]]));
-        r.y = __builtin_fmaf(ww[5], sr[ii[5]], __builtin_fmaf(ww[3], sr[ii[3]], ww[4] * sr[ii[4]]));
-        r.z = __builtin_fmaf(ww[8], sr[ii[8]], __builtin_fmaf(ww[6], sr[ii[6]], ww[7] * sr[ii[7]]));
-        r.w = __builtin_fmaf(ww[11], sr[ii[11]], __builtin_fmaf(ww[9], sr[ii[9]], ww[10] * sr[ii[10]]));
-        *reinterpret_cast<pp::f4*>(out + ((size_t)b * C + c0 + k) * N + n0) = r;
+      for (int e = 0; e < 3; ++e) {
+        const pp::i4 q = reinterpret_cast<const pp::i4*>(idx + ((size_t)b * N + n0) * 3)[e];
+        const pp::f4 w = reinterpret_cast<const pp::f4*>(weight + ((size_t)b * N + n0) * 3)[e];
+        ii[4 * e] = q.x; ii[4 * e + 1] = q.y; ii[4 * e + 2] = q.z; ii[4 * e + 3] = q.w;
+        ww[4 * e] = w.x; ww[4 * e + 1] = w.y; ww[4 * e + 2] = w.z; ww[4 * e + 3] = w.w;
       }
+#pragma unroll
+      for (int k = 0; k < CG; ++k)
+        if (k < nc) {
+          const float* __restrict__ sr = s_irows + (size_t)k * M;
+          pp::f4 r;
+          r.x = __builtin_fmaf(ww[2], sr[ii[2]], __builtin_fmaf(ww[0], sr[ii[0]], ww[1] * sr[ii[1]]));
+          r.y = __builtin_fmaf(ww[5], sr[ii[5]], __builtin_fmaf(ww[3], sr[ii[3]], ww[4] * sr[ii[4]]));
+          r.z = __builtin_fmaf(ww[8], sr[ii[8]], __builtin_fmaf(ww[6], sr[ii[6]], ww[7] * sr[ii[7]]));
+          r.w = __builtin_fmaf(ww[11], sr[ii[11]], __builtin_fmaf(ww[9], sr[ii[9]], ww[10] * sr[ii[10]]));
+          *reinterpret_cast<pp::f4*>(out + ((size_t)b * C + c0 + k) * N + n0) = r;
+        }
+    }
+  } else {  // no alignment assumed: one n per thread and step, 4-byte accesses (all coalesced)
+    for (int n = t; n < N; n += 1024) {
+      const int* __restrict__ id = idx + ((size_t)b * N + n) * 3;
+      const float* __restrict__ w = weight + ((size_t)b * N + n) * 3;
+      const int i0 = id[0], i1 = id[1], i2 = id[2];
+      const float w0 = w[0], w1 = w[1], w2 = w[2];
+#pragma unroll
+      for (int k = 0; k < CG; ++k)
+        if (k < nc) {
+          const float* __restrict__ sr = s_irows + (size_t)k * M;
+          out[((size_t)b * C + c0 + k) * N + n] = __builtin_fmaf(w2, sr[i2], __builtin_fmaf(w0, sr[i0], w1 * sr[i1]));
+        }
+    }
   }
 }
 
-template <int CG>
+template <int CG, bool VEC>
 static int launch_three_interpolate_rows(const float* points, const int* idx, const float* weight, float* out,
                                          int B, int C, int M, int N, hipStream_t s) {
   static bool ok[64] = {};
-  const hipError_t e = pp::allow_big_lds(three_interpolate_rows_kernel<CG>, 152 * 1024, ok);
+  const hipError_t e = pp::allow_big_lds(three_interpolate_rows_kernel<CG, VEC>, 152 * 1024, ok);
   if (e != hipSuccess) return (int)e;
   const long long wgs = 8LL * ((B + 7) / 8) * ((C + CG - 1) / CG);
   if (wgs > 0x7fffffffLL) return PP_EINVAL;
-  three_interpolate_rows_kernel<CG><<<dim3((unsigned)wgs), dim3(1024), (size_t)CG * M * sizeof(float), s>>>(
+  three_interpolate_rows_kernel<CG, VEC><<<dim3((unsigned)wgs), dim3(1024), (size_t)CG * M * sizeof(float), s>>>(
       points, idx, weight, out, B, C, M, N);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
@@ -1061,10 +1091,12 @@ extern "C" int pp_gather_forward_f32(const float* points, const int* idx, float*
   if (B < 0 || C < 0 || N < 0 || M < 0) return PP_EINVAL;
   if (B == 0 || C == 0 || M == 0) return PP_OK;
   if (!points || !idx || !out || N == 0) return PP_EINVAL;
-  // LDS-staged rows: 16-byte aligned rows and index quads, the row fits, reading whole rows pays
-  if (g_gather_variant != 1 && N % 4 == 0 && M % 4 == 0 && (size_t)N * sizeof(float) <= 64 * 1024 &&
-      (uintptr_t)points % 16 == 0 && (uintptr_t)idx % 16 == 0 && (uintptr_t)out % 16 == 0 &&
-      (long long)N <= 16LL * M && (long long)B * C >= 512 && M >= 1024) {
+  // LDS-staged rows: the row fits, reading whole rows pays (N <= 16 M); 16-byte variant when rows and
+  // index quads are aligned, 4-byte variant otherwise
+  if (g_gather_variant != 1 && (size_t)N * sizeof(float) <= 152 * 1024 && (long long)N <= 16LL * M &&
+      (long long)B * C >= 512 && M >= 1024) {
+    const bool vec = N % 4 == 0 && M % 4 == 0 && (uintptr_t)points % 16 == 0 && (uintptr_t)idx % 16 == 0 &&
+                     (uintptr_t)out % 16 == 0 && N <= 16384;
     int cpb = 4;
     while (cpb > 1 && 8LL * ((B + 7) / 8) * ((C + cpb - 1) / cpb) < 1024) cpb /= 2;
     const int groups = (C + cpb - 1) / cpb;
@@ -1074,16 +1106,19 @@ extern "C" int pp_gather_forward_f32(const float* points, const int* idx, float*
       const size_t lds = (size_t)N * sizeof(float);
       hipStream_t s = (hipStream_t)stream;
       const int n4 = N / 4;
-      static bool ok1[64] = {}, ok2[64] = {}, ok4[64] = {};
-      if (n4 <= 1024) {
-        if (pp::allow_big_lds(gather_fwd_lds_kernel<1>, 64 * 1024, ok1) != hipSuccess) return PP_EINVAL;
-        gather_fwd_lds_kernel<1><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
+      static bool ok1[64] = {}, ok2[64] = {}, ok4[64] = {}, oks[64] = {};
+      if (!vec) {
+        if (pp::allow_big_lds(gather_fwd_lds_kernel<1, false>, 152 * 1024, oks) != hipSuccess) return PP_EINVAL;
+        gather_fwd_lds_kernel<1, false><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
+      } else if (n4 <= 1024) {
+        if (pp::allow_big_lds(gather_fwd_lds_kernel<1, true>, 64 * 1024, ok1) != hipSuccess) return PP_EINVAL;
+        gather_fwd_lds_kernel<1, true><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
       } else if (n4 <= 2048) {
-        if (pp::allow_big_lds(gather_fwd_lds_kernel<2>, 64 * 1024, ok2) != hipSuccess) return PP_EINVAL;
-        gather_fwd_lds_kernel<2><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
+        if (pp::allow_big_lds(gather_fwd_lds_kernel<2, true>, 64 * 1024, ok2) != hipSuccess) return PP_EINVAL;
+        gather_fwd_lds_kernel<2, true><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
       } else {
-        if (pp::allow_big_lds(gather_fwd_lds_kernel<4>, 64 * 1024, ok4) != hipSuccess) return PP_EINVAL;
-        gather_fwd_lds_kernel<4><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
+        if (pp::allow_big_lds(gather_fwd_lds_kernel<4, true>, 64 * 1024, ok4) != hipSuccess) return PP_EINVAL;
+        gather_fwd_lds_kernel<4, true><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
       }
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
@@ -1356,16 +1391,27 @@ extern "C" int pp_three_interpolate_f32(const float* points, const int* idx, con
   if (B < 0 || C < 0 || N < 0 || M < 0) return PP_EINVAL;
   if (B == 0 || C == 0 || N == 0) return PP_OK;
   if (!points || !idx || !weight || !out || M == 0) return PP_EINVAL;
-  // LDS-staged form: 16-byte aligned rows and quads, row within 64 KiB, enough channels to amortise
-  if (g_interp_variant != 1 && M % 4 == 0 && N % 4 == 0 && M <= 16384 && C >= 4 &&
-      (uintptr_t)points % 16 == 0 && (uintptr_t)idx % 16 == 0 && (uintptr_t)weight % 16 == 0 &&
-      (uintptr_t)out % 16 == 0 && (long long)B * N >= 64 * 2048) {
-    hipStream_t s = (hipStream_t)stream;
-    // channel-group form: four whole rows fit 64 KiB (two workgroups per CU) and there are enough
-    // (batch, group) workgroups to fill the chip
-    if (g_interp_variant != 2 && (size_t)4 * M * sizeof(float) <= 64 * 1024 && N >= 4096 &&
-        8LL * ((B + 7) / 8) * ((C + 3) / 4) >= 512)
-      return launch_three_interpolate_rows<4>(points, idx, weight, out, B, C, M, N, s);
+  // channel-group form (rows staged once, §three_interpolate_rows_kernel): as many whole rows per
+  // workgroup as keep two workgroups on a CU (4 x 16 KiB at M = 4096), fewer for long rows; the 16-byte
+  // variant when everything is aligned, the 4-byte variant otherwise
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = M % 4 == 0 && N % 4 == 0 && (uintptr_t)points % 16 == 0 && (uintptr_t)idx % 16 == 0 &&
+                   (uintptr_t)weight % 16 == 0 && (uintptr_t)out % 16 == 0;
+  const size_t rowb = (size_t)M * sizeof(float);
+  if (g_interp_variant != 1 && g_interp_variant != 2 && rowb <= 152 * 1024 && N >= 2048 &&
+      8LL * ((B + 7) / 8) * ((C + 3) / 4) >= 256) {
+    const int cg = (4 * rowb <= 64 * 1024 && C >= 4) ? 4 : ((2 * rowb <= 152 * 1024 && C >= 2) ? 2 : 1);
+    if (vec) {
+      if (cg == 4) return launch_three_interpolate_rows<4, true>(points, idx, weight, out, B, C, M, N, s);
+      if (cg == 2) return launch_three_interpolate_rows<2, true>(points, idx, weight, out, B, C, M, N, s);
+      return launch_three_interpolate_rows<1, true>(points, idx, weight, out, B, C, M, N, s);
+    }
+    if (cg == 4) return launch_three_interpolate_rows<4, false>(points, idx, weight, out, B, C, M, N, s);
+    if (cg == 2) return launch_three_interpolate_rows<2, false>(points, idx, weight, out, B, C, M, N, s);
+    return launch_three_interpolate_rows<1, false>(points, idx, weight, out, B, C, M, N, s);
+  }
+  // row-at-a-time LDS form: 16-byte aligned rows and quads, row within 64 KiB, enough channels to amortise
+  if (g_interp_variant != 1 && vec && M <= 16384 && C >= 4 && (long long)B * N >= 64 * 2048) {
     const int m4 = M / 4;
     if (m4 <= 512) launch_three_interpolate_lds<1>(points, idx, weight, out, B, C, M, N, s);
     else if (m4 <= 1024) launch_three_interpolate_lds<2>(points, idx, weight, out, B, C, M, N, s);

@@ -267,7 +267,7 @@ def scatter_path(request, cuda):
 
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("b,c,n,m", [(9, 64, 16384, 4096), (4, 130, 4096, 1024), (17, 33, 8200, 8192), (2, 300, 1024, 2052),
-                                     (2, 256, 16380, 1028)])
+                                     (2, 256, 16380, 1028), (9, 64, 16383, 4096), (5, 120, 4097, 1025), (3, 200, 30000, 2048)])
 def test_gather_forward_large(cuda, variant, b, c, n, m):
     """shapes the LDS-staged gather takes (variant 0) and the same through the global-gather kernel"""
     import ctypes
@@ -570,7 +570,8 @@ def test_three_interpolate_forward_backward(cuda):
 
 @pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("b,c,m,n", [(9, 16, 4096, 16384), (2, 7, 1000, 70000), (3, 5, 16384, 40000), (1, 64, 512, 131072),
-                                     (17, 130, 2048, 4096), (32, 67, 4096, 8192)])
+                                     (17, 130, 2048, 4096), (32, 67, 4096, 8192), (9, 40, 4095, 16383), (8, 36, 4099, 16384),
+                                     (3, 90, 20000, 9000), (5, 70, 30001, 4097)])
 def test_three_interpolate_both_kernels(cuda, variant, b, c, m, n):
     """channel-group (0, where it applies), global-gather (1) and row-at-a-time LDS (2) forms == oracle
     bitwise (canonical fma order)."""
