@@ -87,7 +87,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
                                                int nslab) {
   __shared__ float s_red[kBuildThreads / 64];
   __shared__ unsigned s_part[kBuildThreads];
-  __shared__ float s_box[(kBuildThreads / 64) * 8];
+  __shared__ float s_box[(kBuildThreads / 64) * 16];
   static_assert(kBuildThreads / 64 == 16, "the bounding-box reduction assumes 16 waves");
   const int t = threadIdx.x;
 
@@ -139,8 +139,10 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     }
   };
   load_chunk(0);
-  // bounding box + finiteness (the clamped duplicates do not change either)
+  // bounding box + finiteness (the clamped duplicates do not change either) + first and second
+  // moments (over the real points only), for the outlier test below
   float mnx = __builtin_inff(), mny = mnx, mnz = mnx, mxx = -mnx, mxy = -mnx, mxz = -mnx;
+  float sm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // sum x, y, z; sum x^2, y^2, z^2
   bool bad = false;
   for (int ch = 0; ch < nchunks; ++ch) {
     if (ch > 0) load_chunk(ch * kBuildThreads * KP);
@@ -150,29 +152,98 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       bad |= !(__builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z));
       mnx = fminf(mnx, x); mny = fminf(mny, y); mnz = fminf(mnz, z);
       mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y); mxz = fmaxf(mxz, z);
+      const float live = kidx(ch * kBuildThreads * KP, i) < nr ? 1.0f : 0.0f;
+      sm[0] += live * x; sm[1] += live * y; sm[2] += live * z;
+      sm[3] += live * x * x; sm[4] += live * y * y; sm[5] += live * z * z;
     }
   }
   bool any_bad;
-  {  // seven max-reductions with one barrier: -min, max, and the non-finite flag
+  {  // seven max-reductions (-min, max, the non-finite flag) and six sums with one barrier
     float v[7] = {-mnx, -mny, -mnz, mxx, mxy, mxz, bad ? 1.0f : 0.0f};
 #pragma unroll
     for (int e = 0; e < 7; ++e)
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) v[e] = fmaxf(v[e], __shfl_xor(v[e], off));
-    if ((t & 63) == 0)
 #pragma unroll
-      for (int e = 0; e < 7; ++e) s_box[(t >> 6) * 8 + e] = v[e];
+    for (int e = 0; e < 6; ++e)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) sm[e] += __shfl_xor(sm[e], off);
+    if ((t & 63) == 0) {
+#pragma unroll
+      for (int e = 0; e < 7; ++e) s_box[(t >> 6) * 16 + e] = v[e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + 8 + e] = sm[e];
+    }
     __syncthreads();
     // 16 waves: lane l reads wave (l & 15)'s values, four more shuffle steps finish the job
 #pragma unroll
     for (int e = 0; e < 7; ++e) {
-      float r = s_box[(t & 15) * 8 + e];
+      float r = s_box[(t & 15) * 16 + e];
 #pragma unroll
       for (int off = 8; off >= 1; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
       v[e] = r;
     }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      float r = s_box[(t & 15) * 16 + 8 + e];
+#pragma unroll
+      for (int off = 8; off >= 1; off >>= 1) r += __shfl_xor(r, off);
+      sm[e] = r;
+    }
     mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
     any_bad = v[6] != 0.0f;
+  }
+  // Outliers: a few points far from the bulk would stretch the box until the bulk sits in a handful of
+  // cells.  Any box is valid -- cell_coord clamps, the points outside simply land in the boundary cells
+  // and every bound is stated in terms of the (monotone) cell coordinate -- so when the box reaches
+  // beyond 6 sigma of the mean on some side, it is replaced by the box of the points within 4 sigma on
+  // every axis.  Uniform over the workgroup; clouds without outliers skip the second pass.
+  if (!any_bad) {
+    const float inv_n = 1.0f / (float)nr;
+    const float mean[3] = {sm[0] * inv_n, sm[1] * inv_n, sm[2] * inv_n};
+    float sig[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) sig[a] = sqrtf(fmaxf(sm[3 + a] * inv_n - mean[a] * mean[a], 0.0f));
+    const bool stretched = mxx - mean[0] > 6.0f * sig[0] || mean[0] - mnx > 6.0f * sig[0] ||
+                           mxy - mean[1] > 6.0f * sig[1] || mean[1] - mny > 6.0f * sig[1] ||
+                           mxz - mean[2] > 6.0f * sig[2] || mean[2] - mnz > 6.0f * sig[2];
+    if (stretched) {
+      float w[6] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(),
+                    -__builtin_inff()};  // max of (-x, -y, -z, x, y, z) over the inliers
+      for (int ch = 0; ch < nchunks; ++ch) {
+        if (nchunks > 1) load_chunk(ch * kBuildThreads * KP);
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+          const float x = px[i], y = py[i], z = pz[i];
+          const bool in = fabsf(x - mean[0]) <= 4.0f * sig[0] && fabsf(y - mean[1]) <= 4.0f * sig[1] &&
+                          fabsf(z - mean[2]) <= 4.0f * sig[2];
+          if (in) {
+            w[0] = fmaxf(w[0], -x); w[1] = fmaxf(w[1], -y); w[2] = fmaxf(w[2], -z);
+            w[3] = fmaxf(w[3], x); w[4] = fmaxf(w[4], y); w[5] = fmaxf(w[5], z);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) w[e] = fmaxf(w[e], __shfl_xor(w[e], off));
+      __syncthreads();  // s_box is read above by every thread
+      if ((t & 63) == 0)
+#pragma unroll
+        for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + e] = w[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        float r = s_box[(t & 15) * 16 + e];
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
+        w[e] = r;
+      }
+      if (w[3] > -w[0] || w[4] > -w[1] || w[5] > -w[2]) {  // the trimmed set has an extent: use its box
+        mnx = -w[0]; mny = -w[1]; mnz = -w[2]; mxx = w[3]; mxy = w[4]; mxz = w[5];
+      }
+      if (nchunks > 1) load_chunk(0);  // (the passes below reload their chunks themselves)
+    }
   }
   const float ex = mxx - mnx, ey = mxy - mny, ez = mxz - mnz;
   const float emax = fmaxf(ex, fmaxf(ey, ez));
@@ -279,8 +350,9 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       }
     }
   if (t == 0) {
-    // a cell holding so many points that scanning it approaches a brute force
-    gs->crowd[slab] = (!degenerate && fmx > 64.0f + 0.25f * (float)nr) ? 1 : 0;
+    // a cell holding so many points (> 256 + N/32) that walking it lane by lane costs more than the
+    // brute-force kernel's share of the cloud
+    gs->crowd[slab] = (!degenerate && fmx > 256.0f + (float)nr * (1.0f / 32.0f)) ? 1 : 0;
     if (slab == 0) {
       gs->minx = mnx; gs->miny = mny; gs->minz = mnz; gs->h = h; gs->invh = invh;
       gs->gx = gx; gs->gy = gy; gs->gz = gz;
