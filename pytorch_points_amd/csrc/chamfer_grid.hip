@@ -37,7 +37,7 @@ using pp::kGridMax;
 using pp::kBuildThreads;
 
 constexpr float kBoundSlack = 0.999f;
-constexpr int kWideBlocksPerSet = 4;
+constexpr int kWideBlocksPerSet = 8;
 
 // Workspace layout (bytes), S = 2*B sets, T = B*(N+M) points:
 //   [0, 64*S)                      GridSet[S]
@@ -443,7 +443,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
       xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2);
   PP_RETURN_IF_LAUNCH_FAILED();
   // labeled: a candidate must also carry the query's label, so more queries outlive stage A
-  const int wide_per_set = LAB ? 4 * kWideBlocksPerSet : kWideBlocksPerSet;
+  const int wide_per_set = LAB ? 2 * kWideBlocksPerSet : kWideBlocksPerSet;
   const int wide_blocks = 2 * B * wide_per_set;  // a multiple of 8 (XCD mapping of the finish kernel)
   grid_finish_kernel<LAB><<<dim3((unsigned)wide_blocks), dim3(256), 0, s>>>(
       xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, wide_blocks, wide_per_set, label1, label2);
