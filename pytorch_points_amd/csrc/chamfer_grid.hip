@@ -25,7 +25,8 @@ namespace pp {
 // qcount[set], indices in qlist[set_offset ...])
 int nmdist_fwd_c3_list(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
                        int* idx2, int B, int N, int M, const int* qlist, const int* qcount,
-                       hipStream_t s, const float* label1 = nullptr, const float* label2 = nullptr);
+                       hipStream_t s, const float* label1, const float* label2, unsigned long long* lkey,
+                       int* ldone);
 }  // namespace pp
 
 namespace {
@@ -46,10 +47,12 @@ constexpr int kWideBlocksPerSet = 8;
 //   [.., +16*T)                    float4 sorted[T]   (x, y, z, original index bits)
 //   [.., +4*T)                     int qlist[T]           queries left to the brute force, per set
 //   [.., +4*T)                     int blist[T]           queries left to stages B/C, per set
+//   [.., +8*T)                     u64 lkey[T]            brute-force list: (distance, index) keys merged across slices
+//   [.., +4*S*tiles_l)             int ldone[S][tiles_l]  brute-force list: slices finished per tile of 128
 //   [.., +4*T)                     float slab[T]          labels in sorted order (labeled Chamfer only)
 // qcount has 4*B entries: [0, 2B) count qlist, [2B, 4B) count blist.
 struct Layout {
-  size_t sets, qcount, cell_start, sorted, qlist, blist, slab, total;
+  size_t sets, qcount, cell_start, sorted, qlist, blist, lkey, ldone, slab, total;
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
   Layout L;
@@ -60,7 +63,10 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   L.sorted = L.cell_start + ((4 * (size_t)(kGridCells + 1) * S + 255) / 256) * 256;
   L.qlist = L.sorted + 16 * T;
   L.blist = L.qlist + 4 * T;
-  L.slab = L.blist + 4 * T;
+  L.lkey = L.blist + 4 * T;
+  L.lkey = (L.lkey + 7) / 8 * 8;
+  L.ldone = L.lkey + 8 * T;
+  L.slab = L.ldone + ((4 * S * (size_t)(((N > M ? N : M) + 127) / 128) + 255) / 256) * 256;
   L.total = L.slab + (labeled ? 4 * T : 0);
   return L;
 }
@@ -97,6 +103,11 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
     counts[set] = 0;          // brute-force list of this set
     counts[2 * B + set] = 0;  // stage B/C list of this set
   }
+  if (slab == 0) {  // "slices finished" counters of this set's brute-force tiles
+    const int tiles_l = ((N > M ? N : M) + 127) / 128;
+    int* done = reinterpret_cast<int*>(ws + L.ldone) + (size_t)set * tiles_l;
+    for (int i = threadIdx.x; i < tiles_l; i += kBuildThreads) done[i] = 0;
+  }
   pp::grid_build_set(ref, nr, reinterpret_cast<GridSet*>(ws + L.sets) + set,
                      reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1),
                      reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M),
@@ -105,8 +116,10 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
                      slab, pp::kBuildSlabs);
 }
 
-// Append `value` to list[counter++] for the lanes with `want`: one atomic per wave.
-__device__ __forceinline__ void wave_append(bool want, int* counter, int* list, int value) {
+// Append `value` to list[counter++] for the lanes with `want`: one atomic per wave.  `keys`, if given,
+// is the brute-force list's key array: the new entry's key starts at "nothing found".
+__device__ __forceinline__ void wave_append(bool want, int* counter, int* list, int value,
+                                            unsigned long long* keys = nullptr) {
   const unsigned long long mask = __ballot(want);
   if (mask == 0) return;
   const int lane = threadIdx.x & 63;
@@ -114,7 +127,11 @@ __device__ __forceinline__ void wave_append(bool want, int* counter, int* list, 
   int base = 0;
   if (lane == leader) base = atomicAdd(counter, (int)__builtin_popcountll(mask));
   base = __shfl(base, leader);
-  if (want) list[base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull))] = value;
+  if (want) {
+    const int pos = base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    list[pos] = value;
+    if (keys) keys[pos] = ~0ull;
+  }
 }
 
 // Stage A for every query, one lane per query (dense launch).  Unresolved queries go to `blist`
@@ -154,7 +171,8 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
   int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
   const bool g_useless = pp::grid_useless(g), gp_useless = pp::grid_useless(gp);
   if (g_useless) {  // uniform over the workgroup (one set per workgroup)
-    wave_append(true, counts + set, qlist, jj);  // every query exactly once, any order
+    wave_append(true, counts + set, qlist, jj,  // every query exactly once, any order
+                reinterpret_cast<unsigned long long*>(ws + L.lkey) + set_query_offset(b, dir, N, M));
     return;
   }
   const unsigned* __restrict__ cell_start =
@@ -378,7 +396,8 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
       (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
       (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
     }
-    wave_append(active && !resolved, counts + set, qlist, j);
+    wave_append(active && !resolved, counts + set, qlist, j,
+                reinterpret_cast<unsigned long long*>(ws + L.lkey) + set_query_offset(b, dir, N, M));
   }
 }
 
@@ -451,7 +470,8 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
                                 reinterpret_cast<const int*>(ws + L.qlist),
                                 reinterpret_cast<const int*>(ws + L.qcount), s, LAB ? label1 : nullptr,
-                                LAB ? label2 : nullptr);
+                                LAB ? label2 : nullptr, reinterpret_cast<unsigned long long*>(ws + L.lkey),
+                                reinterpret_cast<int*>(ws + L.ldone));
 }
 
 extern "C" int pp_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2, float* dist1,
