@@ -38,7 +38,11 @@ using pp::kGridMax;
 using pp::kBuildThreads;
 
 constexpr float kBoundSlack = 0.999f;
-constexpr int kWideBlocksPerSet = 8;
+// the wide stages: one wave per workgroup and many workgroups per set -- the work per query is a long
+// chain of dependent loads, so what counts is how many waves are in flight, and a workgroup whose share of
+// the list is empty costs next to nothing
+constexpr int kWideThreads = 128;
+constexpr int kWideBlocksPerSet = 16;
 
 // Workspace layout (bytes), S = 2*B sets, T = B*(N+M) points:
 //   [0, 64*S)                      GridSet[S]
@@ -282,10 +286,10 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
   const int nlist = counts[2 * B + set];
   const int* __restrict__ blist = reinterpret_cast<const int*>(ws + L.blist) + set_query_offset(b, dir, N, M);
   int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
-  const int first = (block % wide_per_set) * 256;
+  const int first = (block % wide_per_set) * kWideThreads;
   const float* __restrict__ slab =
       LAB ? reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr;
-  for (int base = first; base < nlist; base += wide_per_set * 256) {  // uniform trip count per wave
+  for (int base = first; base < nlist; base += wide_per_set * kWideThreads) {  // uniform trip count per wave
     const int pos = base + threadIdx.x;
     const bool active = pos < nlist;
     const int j = blist[active ? pos : nlist - 1];
@@ -404,7 +408,7 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
 // After stage A: the wide stages for the queries it left over, one set per workgroup, on the XCD whose
 // L2 holds the set from grid_query_kernel (same blockIdx % 8 -> set mapping; the grid is a multiple of 8).
 template <bool LAB>
-__global__ __launch_bounds__(256) void grid_finish_kernel(const float* __restrict__ xyz1,
+__global__ __launch_bounds__(kWideThreads) void grid_finish_kernel(const float* __restrict__ xyz1,
                                                           const float* __restrict__ xyz2,
                                                           float* __restrict__ dist1, int* __restrict__ idx1,
                                                           float* __restrict__ dist2, int* __restrict__ idx2,
@@ -464,7 +468,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   // labeled: a candidate must also carry the query's label, so more queries outlive stage A
   const int wide_per_set = LAB ? 2 * kWideBlocksPerSet : kWideBlocksPerSet;
   const int wide_blocks = 2 * B * wide_per_set;  // a multiple of 8 (XCD mapping of the finish kernel)
-  grid_finish_kernel<LAB><<<dim3((unsigned)wide_blocks), dim3(256), 0, s>>>(
+  grid_finish_kernel<LAB><<<dim3((unsigned)wide_blocks), dim3(kWideThreads), 0, s>>>(
       xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, wide_blocks, wide_per_set, label1, label2);
   PP_RETURN_IF_LAUNCH_FAILED();
   return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,

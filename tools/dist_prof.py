@@ -11,6 +11,12 @@ def mk():
     if kind == "blobs8":
         c = rng.random((B, 8, 3), dtype=np.float32) * 2
         return (c[:, rng.integers(0, 8, N)] + rng.standard_normal((B, N, 3)).astype(np.float32) * 0.02).astype(np.float32)
+    if kind == "shapenet_like":
+        x = rng.random((B, N, 3), dtype=np.float32) - 0.5
+        q = N // 4
+        x[:, :q, 2] = -0.5; x[:, q:2 * q, 0] = 0.2
+        th = rng.random((B, q)) * 6.283; x[:, 2 * q:3 * q, 0] = 0.3 * np.cos(th); x[:, 2 * q:3 * q, 1] = 0.3 * np.sin(th)
+        return x.astype(np.float32)
     x = np.zeros((B, N, 3), np.float32); x[..., 0] = rng.random((B, N), dtype=np.float32); return x
 x1 = torch.from_numpy(mk()).to(dev); x2 = torch.from_numpy(mk()).to(dev)
 d1 = torch.empty(B, N, device=dev); d2 = torch.empty(B, N, device=dev)
