@@ -161,13 +161,9 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   {  // seven max-reductions (-min, max, the non-finite flag) and six sums with one barrier
     float v[7] = {-mnx, -mny, -mnz, mxx, mxy, mxz, bad ? 1.0f : 0.0f};
 #pragma unroll
-    for (int e = 0; e < 7; ++e)
+    for (int e = 0; e < 7; ++e) v[e] = wave_reduce_dpp<false>(v[e]);
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v[e] = fmaxf(v[e], __shfl_xor(v[e], off));
-#pragma unroll
-    for (int e = 0; e < 6; ++e)
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) sm[e] += __shfl_xor(sm[e], off);
+    for (int e = 0; e < 6; ++e) sm[e] = wave_reduce_dpp<true>(sm[e]);
     if ((t & 63) == 0) {
 #pragma unroll
       for (int e = 0; e < 7; ++e) s_box[(t >> 6) * 16 + e] = v[e];
@@ -175,21 +171,11 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + 8 + e] = sm[e];
     }
     __syncthreads();
-    // 16 waves: lane l reads wave (l & 15)'s values, four more shuffle steps finish the job
+    // 16 waves: lane l < 16 reads wave l's partial; one more wave-wide reduction finishes the job
 #pragma unroll
-    for (int e = 0; e < 7; ++e) {
-      float r = s_box[(t & 15) * 16 + e];
+    for (int e = 0; e < 7; ++e) v[e] = wave_reduce_dpp<false>(s_box[(t & 15) * 16 + e]);
 #pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
-      v[e] = r;
-    }
-#pragma unroll
-    for (int e = 0; e < 6; ++e) {
-      float r = s_box[(t & 15) * 16 + 8 + e];
-#pragma unroll
-      for (int off = 8; off >= 1; off >>= 1) r += __shfl_xor(r, off);
-      sm[e] = r;
-    }
+    for (int e = 0; e < 6; ++e) sm[e] = wave_reduce_dpp<true>((t & 63) < 16 ? s_box[(t & 15) * 16 + 8 + e] : 0.0f);
     mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
     any_bad = v[6] != 0.0f;
   }
@@ -224,21 +210,14 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
         }
       }
 #pragma unroll
-      for (int e = 0; e < 6; ++e)
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) w[e] = fmaxf(w[e], __shfl_xor(w[e], off));
+      for (int e = 0; e < 6; ++e) w[e] = wave_reduce_dpp<false>(w[e]);
       __syncthreads();  // s_box is read above by every thread
       if ((t & 63) == 0)
 #pragma unroll
         for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + e] = w[e];
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 6; ++e) {
-        float r = s_box[(t & 15) * 16 + e];
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) r = fmaxf(r, __shfl_xor(r, off));
-        w[e] = r;
-      }
+      for (int e = 0; e < 6; ++e) w[e] = wave_reduce_dpp<false>(s_box[(t & 15) * 16 + e]);
       if (w[3] > -w[0] || w[4] > -w[1] || w[5] > -w[2]) {  // the trimmed set has an extent: use its box
         mnx = -w[0]; mny = -w[1]; mnz = -w[2]; mxx = w[3]; mxy = w[4]; mxz = w[5];
       }

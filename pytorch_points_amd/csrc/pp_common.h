@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "pp_hip.h"
 
 #define PP_WAVE 64
@@ -66,6 +68,30 @@ __device__ __forceinline__ float min3(float a, float b, float c) {
   float r;
   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
+}
+
+// Wave-wide max / sum of a float through DPP (row shifts, then row broadcasts; lane 63 ends up with the
+// result, which is read back as a wave-uniform value).  VALU-rate, unlike the ds_bpermute behind __shfl_xor.
+// Every lane must be active.
+template <bool SUM>
+__device__ __forceinline__ float wave_reduce_dpp(float v) {
+  auto step = [](float x, auto ctrl, auto row_mask) {
+    // bound_ctrl = false, old = x: lanes without a source (and rows masked out) combine x with itself for
+    // max, and must add nothing for a sum -- hence old = 0 there
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(SUM ? 0 : __float_as_int(x), __float_as_int(x),
+                                                               decltype(ctrl)::value, decltype(row_mask)::value,
+                                                               0xf, false));
+    return SUM ? x + o : fmaxf(x, o);
+  };
+  using I = std::integral_constant<int, 0>;
+  (void)sizeof(I);
+  v = step(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});  // row_shr:1
+  v = step(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});  // row_shr:2
+  v = step(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});  // row_shr:4
+  v = step(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});  // row_shr:8
+  v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});  // row_bcast:15 -> rows 1, 3
+  v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});  // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ int wave_id_uniform() {
