@@ -49,9 +49,14 @@ __device__ __forceinline__ float block_reduce(float v, bool take_max, float* s_r
 }
 
 
-__host__ __device__ inline size_t grid_build_lds_bytes(int nslab) {
+// dynamic LDS of a build workgroup: one bank-skewed counter per cell of its slab, then the cell index of
+// every point the workgroup holds in registers (16 per thread), computed once and reused by the passes
+__host__ __device__ inline int grid_build_counter_words(int nslab) {
   const int per = (kGridCells + nslab - 1) / nslab + 1;
-  return (size_t)(per + per / 32 + 1) * sizeof(unsigned);
+  return (per + per / 32 + 1 + 3) & ~3;
+}
+__host__ __device__ inline size_t grid_build_lds_bytes(int nslab) {
+  return ((size_t)grid_build_counter_words(nslab) + (size_t)kBuildThreads * 16) * sizeof(unsigned);
 }
 
 // 15-bit Morton code of a cell (5 bits per axis)
@@ -245,6 +250,8 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     gz = degenerate ? 1 : cells(ez);
   };
   set_resolution(g0);
+  int* s_cid = reinterpret_cast<int*>(s_cnt + grid_build_counter_words(nslab));  // [KP][kBuildThreads]
+  const bool have_ids = !MORTON && !degenerate && nchunks == 1;  // filled by the occupancy pass below
   // The searches want ~4-5 points per OCCUPIED cell (then the first, smallest stage answers ~98 % of the
   // queries): the first guess is right for a surface in a cubic box, too fine for a volume (1.3 points per
   // occupied cell for a uniformly filled cube).  Measure the occupancy with a bitmap of cells (every
@@ -266,6 +273,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
             const int c = (cell_coord(pz[i], mnz, invh, gz) * gy + cell_coord(py[i], mny, invh, gy)) * gx +
                           cell_coord(px[i], mnx, invh, gx);
             atomicOr(&s_occ[c >> 5], 1u << (c & 31));
+            if (nchunks == 1) s_cid[i * kBuildThreads + t] = c;  // the last round's value is the one kept
           }
       }
       __syncthreads();
@@ -303,7 +311,9 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
 #pragma unroll
       for (int i = 0; i < KP; ++i)
         if (kidx(ch * kBuildThreads * KP, i) < nr) {
-          const int c = cell_of(px[i], py[i], pz[i]) - cell_lo;
+          const int cg = have_ids ? s_cid[i * kBuildThreads + t] : cell_of(px[i], py[i], pz[i]);
+          if (!have_ids && nchunks == 1) s_cid[i * kBuildThreads + t] = cg;  // (Morton mode: for the scatter)
+          const int c = cg - cell_lo;
           if (c < 0) ++below;
           else if (c < nloc) atomicAdd(&s_cnt[sk(c)], 1u);
         }
@@ -358,7 +368,8 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
         unsigned pos[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int cc = cell_of(px[i0 + i], py[i0 + i], pz[i0 + i]) - cell_lo;
+          const int cc = (nchunks == 1 ? s_cid[(i0 + i) * kBuildThreads + t]
+                                       : cell_of(px[i0 + i], py[i0 + i], pz[i0 + i])) - cell_lo;
           c[i] = (kidx(ch * kBuildThreads * KP, i0 + i) < nr && cc >= 0 && cc < nloc) ? cc : -1;
         }
 #pragma unroll
