@@ -360,7 +360,7 @@ def bench_chamfer(args, dist, world, rank, device):
                            # 4.3 + 0.3); most of it is the search structure itself (sorted clouds + cell tables,
                            # 25 MB, written with scattered 16-byte stores), not re-reads of the inputs
                            "traffic": 87.5e6 if (B, N, M) == (32, 16384, 16384) else None,
-                           "note": "VALU-issue / L2-latency-bound search over a 17 MB workspace, not HBM-bound; "
+                           "note": "VALU-issue / L2-latency-bound search over a 42 MB workspace (25 MB of it touched per call), not HBM-bound; "
                                    "'bruteforce' carries the every-pair kernel and its VALU roofline"}
         if brute is not None:
             bg = alg_bytes_fwd / (brute["fwd_ms"] * 1e-3) / 1e9
