@@ -612,3 +612,56 @@ def test_fp_module_style_pipeline(cuda):
     assert out.shape == (b, c, n) and torch.isfinite(out).all()
     e = oracle.three_interpolate(kf.cpu().numpy(), idx.cpu().numpy(), weight.cpu().numpy())
     assert np.array_equal(out.cpu().numpy(), e)
+
+
+def test_config4_full_size_properties(cuda):
+    """BASELINE config 4 at full size (ball_query r=0.1 nsample=64 + group_points, B=32 N=16384 C=128,
+    npoint=4096): size-independent properties instead of the CPU oracle (too slow at this size) --
+    every listed index is in radius, rows ascend up to the pad, the pad repeats the first hit, the row
+    count equals the number of points in radius (capped), grid == scan kernels bit for bit, two batch
+    elements equal the oracle; group_points equals torch.gather, its gradient equals scatter_add."""
+    import ctypes
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd._ext import sampling
+    B, N, C, ns, r = 32, 16384, 128, 64, 0.1
+    x = _t(S.unit_sphere(0, B, N), cuda)
+    centres = x[:, ::4].contiguous()
+    npoint = centres.shape[1]
+    idx = sampling.ball_query(centres, x, r, ns)
+    search = _lib.lib().pp_debug_set_ball_query_search
+    search.argtypes = [ctypes.c_int]
+    search.restype = None
+    search(1)
+    try:
+        assert torch.equal(idx, sampling.ball_query(centres, x, r, ns))            # grid == scan
+    finally:
+        search(0)
+    e = oracle.ball_query(centres[:2].cpu().numpy(), x[:2].cpu().numpy(), r, ns)
+    assert np.array_equal(idx[:2].cpu().numpy(), e)
+    li = idx.long()
+    pts = torch.gather(x.unsqueeze(1).expand(-1, npoint, -1, -1), 2, li.unsqueeze(-1).expand(-1, -1, -1, 3))
+    d = pts - centres.unsqueeze(2)
+    d2 = torch.addcmul(torch.addcmul(d[..., 1] * d[..., 1], d[..., 0], d[..., 0]), d[..., 2], d[..., 2])
+    assert bool((d2 < r * r * (1 + 1e-5)).all())                                   # every listed index is in radius
+    inc = li[..., 1:] > li[..., :-1]
+    cnt = 1 + inc.to(torch.int32).cumprod(-1).sum(-1)                              # length of the ascending prefix
+    slot = torch.arange(ns, device=cuda)[None, None, :]
+    assert bool(((slot < cnt[..., None]) | (li == li[..., :1])).all())             # beyond it: the first hit repeated
+    for b0 in range(0, B, 8):                                                       # true ball population, by chunks
+        dd = torch.cdist(centres[b0:b0 + 8].double(), x[b0:b0 + 8].double()) ** 2
+        inside = (dd < (r * r) * (1 - 1e-6)).sum(-1)
+        maybe = (dd < (r * r) * (1 + 1e-6)).sum(-1)
+        c = cnt[b0:b0 + 8]
+        assert bool(((c >= inside.clamp(max=ns)) & (c <= maybe.clamp(max=ns))).all())
+    feats = _t(S.normal(2, (B, C, N)), cuda)
+    out = sampling.group_points(feats, idx)
+    flat = li.reshape(B, 1, -1)
+    for c0 in range(0, C, 32):                                                      # 1 GiB at a time
+        ref = torch.gather(feats[:, c0:c0 + 32], 2, flat.expand(-1, 32, -1)).reshape(B, 32, npoint, ns)
+        assert torch.equal(out[:, c0:c0 + 32], ref)
+        del ref
+    grad = sampling.group_points_grad(out, idx, N)                                  # d/dfeats of 0.5 * |out|^2
+    ref = torch.zeros(B, C, N, device=cuda, dtype=torch.float64)
+    for c0 in range(0, C, 16):
+        ref[:, c0:c0 + 16].scatter_add_(2, flat.expand(-1, 16, -1), out[:, c0:c0 + 16].double().reshape(B, 16, -1))
+    assert torch.allclose(grad.double(), ref, rtol=1e-5, atol=1e-5)
