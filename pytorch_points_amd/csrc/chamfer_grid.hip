@@ -38,10 +38,8 @@ using pp::kGridMax;
 using pp::kBuildThreads;
 
 constexpr float kBoundSlack = 0.999f;
-// the wide stages: one wave per workgroup and many workgroups per set -- the work per query is a long
-// chain of dependent loads, so what counts is how many waves are in flight, and a workgroup whose share of
-// the list is empty costs next to nothing
-constexpr int kWideThreads = 128;
+// the wide stages: workgroups (of four waves, one query per wave and pass) per set; a workgroup whose share
+// of the list is empty costs next to nothing
 constexpr int kWideBlocksPerSet = 16;
 
 // Workspace layout (bytes), S = 2*B sets, T = B*(N+M) points:
@@ -269,59 +267,99 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
   wave_append(!resolved, counts + 2 * B + set, blist, j);
 }
 
-// Stages B and C for the queries stage A left over (grid-stride over the compacted list).
+// Stages B and C (cubes of Chebyshev radius 1 and 2 around the query's cell) for the queries stage A left
+// over, one WAVE per query.  The list is short (0.3 % of the queries at config 2), so what
+// a query costs is the LENGTH of its chain of dependent loads, not the lane-cycles: with one lane per
+// query that chain is 9 (then 25) cell rows walked one after the other (22 us at config 2); here a whole
+// wave takes one query (7 us), lane r fetches the range of row r, the rows are laid end to end (prefix sum over the lanes)
+// and the wave examines 64 candidates per step -- two dependent load rounds per stage.  Each lane keeps
+// the smallest (distance bits, index) key it has seen -- for non-negative non-NaN distances the order
+// of the packed key is the order of "d < best || (d == best && id < bidx)", and a NaN distance (bits
+// above +inf) is never taken, as in the lane-per-query form -- and one wave-wide minimum ends a stage.
 template <bool LAB>
-__device__ __forceinline__ void grid_query_wide_block(int block, const float* __restrict__ xyz1,
-                                                      const float* __restrict__ xyz2,
-                                                      float* __restrict__ dist1, int* __restrict__ idx1,
-                                                      float* __restrict__ dist2, int* __restrict__ idx2,
-                                                      unsigned char* __restrict__ ws, int B, int N, int M,
-                                                      int wide_per_set, const float* __restrict__ label1,
-                                                      const float* __restrict__ label2) {
+__device__ __forceinline__ unsigned long long wave_scan_rows(int nrows, unsigned rs, unsigned re,
+                                                             const pp::f4* __restrict__ sorted,
+                                                             const float* __restrict__ slab, float qx, float qy,
+                                                             float qz, float ql, unsigned long long key) {
+  const int lane = threadIdx.x & 63;
+  const unsigned len = lane < nrows ? re - rs : 0u;
+  unsigned incl = len;  // nrows <= 32: five steps
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const unsigned o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
+  const unsigned excl = incl - len;
+  const unsigned shift = rs - excl;  // candidate c of row r sits at sorted[c + shift_r]
+  for (unsigned c0 = 0; c0 < total; c0 += 64) {
+    const unsigned c = c0 + lane;
+    unsigned add = 0;
+    for (int r = 0; r < nrows; ++r) {  // the last row whose first candidate is <= c (empty rows are overridden)
+      const unsigned ex = (unsigned)__builtin_amdgcn_readlane((int)excl, r);
+      const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)shift, r);
+      add = c >= ex ? sh : add;
+    }
+    if (c < total) {
+      const pp::f4 p = sorted[c + add];
+      const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
+      const unsigned long long cand =
+          ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+      const bool ok = !LAB || slab[c + add] == ql;
+      key = (ok && cand < key) ? cand : key;
+    }
+  }
+  // wave-wide minimum
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    key = o < key ? o : key;
+  }
+  return key;
+}
+
+template <bool LAB>
+__global__ __launch_bounds__(256) void grid_finish_wave_kernel(const float* __restrict__ xyz1,
+                                                               const float* __restrict__ xyz2,
+                                                               float* __restrict__ dist1, int* __restrict__ idx1,
+                                                               float* __restrict__ dist2, int* __restrict__ idx2,
+                                                               unsigned char* __restrict__ ws, int B, int N, int M,
+                                                               int wide_blocks, int wide_per_set,
+                                                               const float* __restrict__ label1,
+                                                               const float* __restrict__ label2) {
+  const int block = pp::xcd_virtual_block(blockIdx.x, wide_blocks / 8);
   const Layout L = make_layout(B, N, M, LAB);
   int* counts = reinterpret_cast<int*>(ws + L.qcount);
   const int set = block / wide_per_set;  // one set per workgroup
   const int b = set >> 1, dir = set & 1;
   const int nq = dir ? M : N;
   const int nlist = counts[2 * B + set];
+  const int wave = pp::wave_id_uniform(), lane = threadIdx.x & 63;
+  const int first = (block % wide_per_set) * 4 + wave;
+  if (first >= nlist) return;
   const int* __restrict__ blist = reinterpret_cast<const int*>(ws + L.blist) + set_query_offset(b, dir, N, M);
   int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
-  const int first = (block % wide_per_set) * kWideThreads;
+  unsigned long long* lkey = reinterpret_cast<unsigned long long*>(ws + L.lkey) + set_query_offset(b, dir, N, M);
   const float* __restrict__ slab =
       LAB ? reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr;
-  for (int base = first; base < nlist; base += wide_per_set * kWideThreads) {  // uniform trip count per wave
-    const int pos = base + threadIdx.x;
-    const bool active = pos < nlist;
-    const int j = blist[active ? pos : nlist - 1];
-    const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[set];
-    const unsigned* __restrict__ cell_start =
-        reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
-    const pp::f4* __restrict__ sorted =
-        reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
+  const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[set];
+  const unsigned* __restrict__ cell_start =
+      reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
+  const pp::f4* __restrict__ sorted =
+      reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
+  for (int pos = first; pos < nlist; pos += wide_per_set * 4) {
+    const int j = __builtin_amdgcn_readfirstlane(blist[pos]);
     const float* __restrict__ q = (dir ? xyz2 : xyz1) + ((size_t)b * nq + j) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float ql = LAB ? (dir ? label2 : label1)[(size_t)b * nq + j] : 0.0f;
     const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
     const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
     const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
-    float best = __builtin_inff();
-    int bidx = 0x7fffffff;
-    auto scan_cells = [&](int z, int y, int x0, int x1) {  // cells (x0..x1, y, z): contiguous points
-      const int c = (z * g.gy + y) * g.gx;
-      const unsigned s = cell_start[c + x0], e = cell_start[c + x1 + 1];
-      for (unsigned i = s; i < e; ++i) {
-        const pp::f4 p = sorted[i];
-        const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
-        const int id = __float_as_int(p.w);
-        const bool take = (!LAB || slab[i] == ql) && (d < best || (d == best && id < bidx));
-        best = take ? d : best;
-        bidx = take ? id : bidx;
-      }
-    };
-    // distance (in cells) from q to the nearest face of the cube of Chebyshev radius rho around its
-    // cell that has grid beyond it: rho + f below, rho + 1 - f above (>= rho)
     const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
                 fz = (qz - g.minz) * g.invh - (float)cz;
+    // distance (in cells) from q to the nearest face of the cube of Chebyshev radius rho around its
+    // cell that has grid beyond it: rho + f below, rho + 1 - f above (>= rho)
     auto reach_cube = [&](int rho) {
       auto axis = [&](float f, int c, int gdim) {
         const float lo = c - rho >= 1 ? (float)rho + f : __builtin_inff();
@@ -330,94 +368,47 @@ __device__ __forceinline__ void grid_query_wide_block(int block, const float* __
       };
       return fminf(axis(fx, cx, g.gx), fminf(axis(fy, cy, g.gy), axis(fz, cz, g.gz)));
     };
+    unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, no index)
     bool resolved = false;
-    // Stage B (only if A could not stop): cube of radius 1 -- re-examining A's cells is harmless.
-    // The nine row ranges are fetched first (18 independent loads, cell
-    // coordinates clamped so that none is conditional), then walked four points at a time (the
-    // clamped duplicates of a ragged tail are the same candidate again: harmless)
-    if (!resolved) {
-      const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.gz - 1), y0 = max(cy - 1, 0), y1 = min(cy + 1, g.gy - 1);
-      const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.gx - 1);
-      unsigned rs[9], re[9];
-  #pragma unroll
-      for (int dz = -1; dz <= 1; ++dz)
-  #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-          const int z = cz + dz, y = cy + dy;
-          const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
-          const int c = (min(max(z, 0), g.gz - 1) * g.gy + min(max(y, 0), g.gy - 1)) * g.gx;
-          const unsigned s0 = cell_start[c + x0], e0 = cell_start[c + x1 + 1];
-          rs[(dz + 1) * 3 + dy + 1] = ok ? s0 : 0u;
-          re[(dz + 1) * 3 + dy + 1] = ok ? e0 : 0u;
-        }
-  #pragma unroll
-      for (int r9 = 0; r9 < 9; ++r9) {
-        for (unsigned i = rs[r9]; i < re[r9]; i += 4) {
-          const unsigned last = re[r9] - 1;
-          pp::f4 p[4];
-          float pl[4];
-  #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            p[u] = sorted[min(i + u, last)];
-            if (LAB) pl[u] = slab[min(i + u, last)];
-          }
-  #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
-            const int id = __float_as_int(p[u].w);
-            const bool take = (!LAB || pl[u] == ql) && (d < best || (d == best && id < bidx));
-            best = take ? d : best;
-            bidx = take ? id : bidx;
-          }
-        }
+#pragma unroll
+    for (int rho = 1; rho <= 2; ++rho) {  // cube of radius 1, then 2 (re-examining cells is harmless)
+      if (resolved) break;
+      const int side = 2 * rho + 1;
+      const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.gx - 1);
+      // lane r < side*side fetches the range of row (cz - rho + r / side, cy - rho + r % side)
+      const int z = cz - rho + lane / side, y = cy - rho + lane % side;
+      const bool ok = lane < side * side && z >= 0 && z < g.gz && y >= 0 && y < g.gy;
+      const int c = (min(max(z, 0), g.gz - 1) * g.gy + min(max(y, 0), g.gy - 1)) * g.gx;
+      unsigned rs = 0, re = 0;
+      if (ok) {
+        rs = cell_start[c + x0];
+        re = cell_start[c + x1 + 1];
       }
-      const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
-      const float reach = g.h * reach_cube(1);
+      key = wave_scan_rows<LAB>(side * side, rs, re, sorted, slab, qx, qy, qz, ql, key);
+      const float best = __uint_as_float((unsigned)(key >> 32));
+      const int bidx = (int)(unsigned)key;
+      const bool all = cz - rho <= 0 && cz + rho >= g.gz - 1 && cy - rho <= 0 && cy + rho >= g.gy - 1 &&
+                       cx - rho <= 0 && cx + rho >= g.gx - 1;
+      const float reach = g.h * reach_cube(rho);
       resolved = all ? (LAB || bidx != 0x7fffffff) : (best < reach * reach * kBoundSlack);
     }
-    if (!resolved) {  // shell of radius 2
-      const int z0 = max(cz - 2, 0), z1 = min(cz + 2, g.gz - 1), y0 = max(cy - 2, 0), y1 = min(cy + 2, g.gy - 1);
-      const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.gx - 1);
-      for (int z = z0; z <= z1; ++z)
-        for (int y = y0; y <= y1; ++y) {
-          const bool inner = z >= cz - 1 && z <= cz + 1 && y >= cy - 1 && y <= cy + 1;
-          if (!inner) {
-            scan_cells(z, y, x0, x1);
-          } else {
-            if (cx - 2 >= 0) scan_cells(z, y, cx - 2, cx - 2);
-            if (cx + 2 <= g.gx - 1) scan_cells(z, y, cx + 2, cx + 2);
-          }
-        }
-      const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
-      const float reach = g.h * reach_cube(2);
-      resolved = all ? (LAB || bidx != 0x7fffffff) : (best < reach * reach * kBoundSlack);
-    }
+    float best = __uint_as_float((unsigned)(key >> 32));
+    int bidx = (int)(unsigned)key;
     if (LAB && resolved && bidx == 0x7fffffff) {  // whole grid examined, nobody carries this label
       best = 0.0f;                                  // (ref nmdistance_cuda.cu:110-113)
       bidx = -1;
     }
-    if (active && resolved) {
-      (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
-      (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
+    if (lane == 0) {
+      if (resolved) {
+        (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
+        (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
+      } else {
+        const int at = atomicAdd(counts + set, 1);
+        qlist[at] = j;
+        lkey[at] = ~0ull;
+      }
     }
-    wave_append(active && !resolved, counts + set, qlist, j,
-                reinterpret_cast<unsigned long long*>(ws + L.lkey) + set_query_offset(b, dir, N, M));
   }
-}
-
-// After stage A: the wide stages for the queries it left over, one set per workgroup, on the XCD whose
-// L2 holds the set from grid_query_kernel (same blockIdx % 8 -> set mapping; the grid is a multiple of 8).
-template <bool LAB>
-__global__ __launch_bounds__(kWideThreads) void grid_finish_kernel(const float* __restrict__ xyz1,
-                                                          const float* __restrict__ xyz2,
-                                                          float* __restrict__ dist1, int* __restrict__ idx1,
-                                                          float* __restrict__ dist2, int* __restrict__ idx2,
-                                                          unsigned char* __restrict__ ws, int B, int N, int M,
-                                                          int wide_blocks, int wide_per_set,
-                                                          const float* __restrict__ label1,
-                                                          const float* __restrict__ label2) {
-  grid_query_wide_block<LAB>(pp::xcd_virtual_block(blockIdx.x, wide_blocks / 8), xyz1, xyz2, dist1, idx1, dist2,
-                             idx2, ws, B, N, M, wide_per_set, label1, label2);
 }
 
 }  // namespace
@@ -468,7 +459,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   // labeled: a candidate must also carry the query's label, so more queries outlive stage A
   const int wide_per_set = LAB ? 2 * kWideBlocksPerSet : kWideBlocksPerSet;
   const int wide_blocks = 2 * B * wide_per_set;  // a multiple of 8 (XCD mapping of the finish kernel)
-  grid_finish_kernel<LAB><<<dim3((unsigned)wide_blocks), dim3(kWideThreads), 0, s>>>(
+  grid_finish_wave_kernel<LAB><<<dim3((unsigned)wide_blocks), dim3(256), 0, s>>>(
       xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, wide_blocks, wide_per_set, label1, label2);
   PP_RETURN_IF_LAUNCH_FAILED();
   return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,

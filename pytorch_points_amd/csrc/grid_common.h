@@ -3,6 +3,11 @@
 #pragma once
 #include "pp_common.h"
 
+// phase marks of the build (tools/build_probe.hip defines PP_PHASE to record a clock; nothing otherwise)
+#ifndef PP_PHASE
+#define PP_PHASE(n)
+#endif
+
 namespace pp {
 
 constexpr int kGridMax = 32;                                  // cells per axis
@@ -143,6 +148,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       }
     }
   };
+  PP_PHASE(0);
   load_chunk(0);
   // bounding box + finiteness (the clamped duplicates do not change either) + first and second
   // moments (over the real points only), for the outlier test below
@@ -162,6 +168,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       sm[3] += live * x * x; sm[4] += live * y * y; sm[5] += live * z * z;
     }
   }
+  PP_PHASE(1);
   bool any_bad;
   {  // seven max-reductions (-min, max, the non-finite flag) and six sums with one barrier
     float v[7] = {-mnx, -mny, -mnz, mxx, mxy, mxz, bad ? 1.0f : 0.0f};
@@ -184,6 +191,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
     any_bad = v[6] != 0.0f;
   }
+  PP_PHASE(2);
   // Outliers: a few points far from the bulk would stretch the box until the bulk sits in a handful of
   // cells.  Any box is valid -- cell_coord clamps, the points outside simply land in the boundary cells
   // and every bound is stated in terms of the (monotone) cell coordinate -- so when the box reaches
@@ -229,6 +237,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       if (nchunks > 1) load_chunk(0);  // (the passes below reload their chunks themselves)
     }
   }
+  PP_PHASE(3);
   const float ex = mxx - mnx, ey = mxy - mny, ez = mxz - mnz;
   const float emax = fmaxf(ex, fmaxf(ey, ez));
   // first guess: ~2 points per cell if the cloud filled its box; cubic cells of side h
@@ -292,6 +301,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     }
     if (nchunks > 1) load_chunk(0);
   }
+  PP_PHASE(4);
   const int ncell = MORTON ? kGridCells : gx * gy * gz;
 
   const int cell_lo = (int)((long long)ncell * slab / nslab), cell_hi = (int)((long long)ncell * (slab + 1) / nslab);
@@ -303,6 +313,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     const int cx = cell_coord(x, mnx, invh, gx), cy = cell_coord(y, mny, invh, gy), cz = cell_coord(z, mnz, invh, gz);
     return MORTON ? morton3(cx, cy, cz) : (cz * gy + cy) * gx + cx;
   };
+  PP_PHASE(5);
   const bool place = MORTON || !degenerate;
   unsigned below = 0;  // points in the cells of lower slabs
   if (place)
@@ -319,6 +330,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
         }
     }
   __syncthreads();
+  PP_PHASE(6);
   // exclusive scan: each thread owns a contiguous run of cells
   const int per = (nloc + kBuildThreads - 1) / kBuildThreads;
   const int c0 = min(nloc, t * per), c1 = min(nloc, c0 + per);
@@ -353,11 +365,13 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     run += v;
   }
   __syncthreads();
+  PP_PHASE(7);
   if (cell_start) {
     for (int c = t; c < nloc; c += kBuildThreads) cell_start[cell_lo + c] = s_cnt[sk(c)];  // coalesced copy out
     if (t == 0 && slab == nslab - 1) cell_start[ncell] = degenerate ? 0u : (unsigned)nr;
   }
   __syncthreads();
+  PP_PHASE(8);
   if (place)
     for (int ch = 0; ch < nchunks; ++ch) {
       if (nchunks > 1) load_chunk(ch * kBuildThreads * KP);
@@ -385,6 +399,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
           }
       }
     }
+  PP_PHASE(9);
   if (t == 0) {
     // a cell holding so many points (> 256 + N/32) that walking it lane by lane costs more than the
     // brute-force kernel's share of the cloud
@@ -397,6 +412,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       for (int i = nslab; i < kBuildSlabs; ++i) gs->crowd[i] = 0;
     }
   }
+  PP_PHASE(10);
 }
 
 template <bool MORTON = false>
