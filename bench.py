@@ -51,8 +51,11 @@ def parse():
                     help="chamfer: auto = the operator's default (exact grid search, brute-force "
                          "fallback); bruteforce = evaluate every pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
-                    help="chamfer: replay the step as a hipGraph (default) or issue it eagerly")
+    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "ext", "eager"],
+                    help="chamfer: how the step's kernels are issued.  graph = hipGraph replay; ext = two calls "
+                         "of the _ext.losses functions (forward, backward) on static buffers; eager = through "
+                         "torch.autograd.Function; auto (default) = graph or ext, whichever a short calibration "
+                         "after the warm-up finds faster on this host")
     ap.add_argument("--with-backward", action="store_true", help="ball_group: also time group_points_grad")
     return ap.parse_args()
 
@@ -229,7 +232,7 @@ def bench_chamfer(args, dist, world, rank, device):
     # less time than the Python/autograd work that launches them, so the eager loop is host-bound
     gstep = None
     graph_note = None
-    if args.launch == "graph":
+    if args.launch in ("auto", "graph"):
         try:
             from pytorch_points_amd.graphs import GraphedChamferStep
             gstep = GraphedChamferStep(B, N, M, device)
@@ -255,36 +258,54 @@ def bench_chamfer(args, dist, world, rank, device):
                 exchange.wait(pending.pop())
             pending.append(exchange.launch(d1, d2, i1, i2))   # packs on this stream, before the next replay
 
+    # the step through the reference's extension-module API (pytorch_points._ext.losses: nmdistance_forward,
+    # nmdistance_backward -- what the reference's autograd.Function calls, _ext/nmdistance.cpp:30-34) on
+    # static buffers: two Python calls per step, no autograd bookkeeping, plain stream launches
+    from pytorch_points_amd._ext import losses as ext_losses
+    sx1, sx2 = x1.detach(), x2.detach()
+    od1, od2 = torch.empty(B, N, device=device), torch.empty(B, M, device=device)
+    oi1 = torch.empty(B, N, dtype=torch.int32, device=device)
+    oi2 = torch.empty(B, M, dtype=torch.int32, device=device)
+    ogx1, ogx2 = torch.empty_like(sx1), torch.empty_like(sx2)
+
+    def ext_step():
+        ext_losses.nmdistance_forward(sx1, sx2, od1, od2, oi1, oi2)
+        if exchange is not None:
+            if pending:
+                exchange.wait(pending.pop())
+            pending.append(exchange.launch(od1, od2, oi1, oi2))
+        ext_losses.nmdistance_backward(sx1, sx2, ogx1, ogx2, g1, g2, oi1, oi2)
+
+    instrument[0] = False
+    modes = {}   # launch mode -> ms per step over a short calibration run (reported; "auto" picks from it)
+    n_cal = 50
     if gstep is not None:
-        dt = run_timed(graph_step, args.warmup, args.steps)
-        n_eager = 200   # enough steps that the closing synchronize does not weigh on the per-step time
-        instrument[0] = False
-        eager_dt = run_timed(step, 3, n_eager) / n_eager
-        # forward duration: the forward's launches alone, replayed as a graph between two HIP events on
-        # the launch stream (no host gaps between the kernels)
-        with torch.no_grad():
-            fx1, fx2 = x1.detach(), x2.detach()
-            for _ in range(2):
-                nndistance(fx1, fx2)
-            torch.cuda.synchronize()
-            fgraph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(fgraph, capture_error_mode="thread_local"):
-                fout = nndistance(fx1, fx2)
-        fgraph.replay()
-        torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n_eager):
-            fgraph.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        fwd_ms = e0.elapsed_time(e1) / n_eager
-        del fout
-    else:
-        dt = run_timed(step, args.warmup, args.steps)
-        eager_dt = dt / args.steps
-        fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fwd_events[-args.steps:]]))
+        modes["graph"] = run_timed(graph_step, 5, n_cal) / n_cal * 1e3
+    modes["ext"] = run_timed(ext_step, 5, n_cal) / n_cal * 1e3
+    n_eager = 200   # enough steps that the closing synchronize does not weigh on the per-step time
+    eager_dt = run_timed(step, 3, n_eager) / n_eager
+    modes["eager"] = eager_dt * 1e3
+    want = args.launch
+    if want == "graph" and gstep is None:
+        want = "eager"
+    if want == "auto":
+        want = "graph" if (gstep is not None and modes["graph"] <= modes["ext"]) else "ext"
+    timed_fn = {"graph": graph_step, "ext": ext_step, "eager": step}[want]
+    dt = run_timed(timed_fn, args.warmup, args.steps)
+
+    # forward duration: the forward's launches alone, issued back to back on the launch stream between two
+    # HIP events (the _ext.losses call: the same launches as the operator's forward)
+    for _ in range(3):
+        ext_losses.nmdistance_forward(sx1, sx2, od1, od2, oi1, oi2)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n_eager):
+        ext_losses.nmdistance_forward(sx1, sx2, od1, od2, oi1, oi2)
+    e1.record()
+    torch.cuda.synchronize()
+    fwd_ms = e0.elapsed_time(e1) / n_eager
 
     # the same step with the search forced to the brute-force kernel (every pair evaluated)
     brute = None
@@ -343,8 +364,13 @@ def bench_chamfer(args, dist, world, rank, device):
                    "parallelism": "batch-shard x%d%s" % (world, " + RCCL all-gather(dist,idx), async" if world > 1 else "")},
         "fwd_ms": fwd_ms,
     }
-    out["config"]["launch"] = ("hipGraph replay of the step's launches (same kernels as the eager operator)"
-                               if gstep is not None else "eager (one Python call per operator)")
+    out["config"]["launch"] = {
+        "graph": "hipGraph replay of the step's launches (same kernels as the eager operator)",
+        "ext": "two calls per step of the extension-module API (_ext.losses.nmdistance_forward / _backward) on "
+               "static buffers: plain stream launches, same kernels as the autograd operator",
+        "eager": "eager (torch.autograd.Function, one Python call per operator)"}[want]
+    out["launch_modes_ms_per_step"] = dict(modes, note="same kernels in every mode; calibration runs of %d steps "
+                                           "(eager: %d); --launch auto times the faster of graph / ext" % (n_cal, n_eager))
     out["eager"] = {"ms_per_step": eager_dt * 1e3, "pairs_per_s": pairs_per_step / eager_dt,
                     "note": "same step issued through torch.autograd.Function calls, one Python call per operator"}
     if graph_note:

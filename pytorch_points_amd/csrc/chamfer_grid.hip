@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
       for (int bq = 0; bq < 2; ++bq) {
         const int z = cz + a * sz, y = cy + bq * sy;
         const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
-        const int c = (min(max(z, 0), g.gz - 1) * g.gy + min(max(y, 0), g.gy - 1)) * g.gx;
+        const int c = pp::cell_linear(0, min(max(y, 0), g.gy - 1), min(max(z, 0), g.gz - 1), g.gx, g.gy);
         const unsigned s0 = cell_start[c + x0], e0 = cell_start[c + x1 + 1];
         rs[a * 2 + bq] = ok ? s0 : 0u;
         re[a * 2 + bq] = ok ? e0 : 0u;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void grid_finish_wave_kernel(const float* __re
       // lane r < side*side fetches the range of row (cz - rho + r / side, cy - rho + r % side)
       const int z = cz - rho + lane / side, y = cy - rho + lane % side;
       const bool ok = lane < side * side && z >= 0 && z < g.gz && y >= 0 && y < g.gy;
-      const int c = (min(max(z, 0), g.gz - 1) * g.gy + min(max(y, 0), g.gy - 1)) * g.gx;
+      const int c = pp::cell_linear(0, min(max(y, 0), g.gy - 1), min(max(z, 0), g.gz - 1), g.gx, g.gy);
       unsigned rs = 0, re = 0;
       if (ok) {
         rs = cell_start[c + x0];

@@ -32,27 +32,22 @@ __device__ __forceinline__ bool grid_useless(const GridSet& g) {
 
 __device__ __forceinline__ int cell_coord(float p, float mn, float invh, int g) {
   const float f = (p - mn) * invh;
-  int c = (int)f;  // truncation; negative and NaN inputs end up clamped below
-  c = c < 0 ? 0 : c;
-  return c > g - 1 ? g - 1 : c;
-}
-
-
-__device__ __forceinline__ float block_reduce(float v, bool take_max, float* s_red) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const float o = __shfl_xor(v, off);
-    v = take_max ? fmaxf(v, o) : fminf(v, o);
-  }
-  const int wave = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) s_red[wave] = v;
-  __syncthreads();
-  float r = s_red[0];
-  for (int w = 1; w < kBuildThreads / 64; ++w) r = take_max ? fmaxf(r, s_red[w]) : fminf(r, s_red[w]);
+  const int c = (int)f;  // v_cvt_i32_f32: saturates, NaN -> 0; negative and huge inputs end up clamped below
+  int r;                 // clamp to [0, g - 1] (g >= 1) in one operation instead of max + min
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(c), "v"(g - 1));
   return r;
 }
 
+// linear index of cell (cx, cy, cz) in the z-major order; every factor and the result fit 24 bits
+// (<= 32 cells per axis), so the multiply-adds are the full-rate v_mad_u32_u24, not the quarter-rate
+// 32-bit multiplies
+__device__ __forceinline__ int cell_linear(int cx, int cy, int cz, int gx, int gy) {
+  int r;  // (spelled out: hipcc turns __umul24(a, b) + c into the 64-bit v_mad_u64_u32)
+  asm("v_mad_u32_u24 %0, %1, %2, %3\n\tv_mad_u32_u24 %0, %0, %4, %5"
+      : "=&v"(r)
+      : "v"(cz), "v"(gy), "v"(cy), "v"(gx), "v"(cx));
+  return r;
+}
 
 // dynamic LDS of a build workgroup: one bank-skewed counter per cell of its slab, then the cell index of
 // every point the workgroup holds in registers (16 per thread), computed once and reused by the passes
@@ -95,11 +90,12 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
                                                const float* __restrict__ payload,
                                                float* __restrict__ sorted_payload, int slab,
                                                int nslab) {
-  __shared__ float s_red[kBuildThreads / 64];
   __shared__ unsigned s_part[kBuildThreads];
+  __shared__ unsigned s_crowd;
   __shared__ float s_box[(kBuildThreads / 64) * 16];
   static_assert(kBuildThreads / 64 == 16, "the bounding-box reduction assumes 16 waves");
   const int t = threadIdx.x;
+  if (t == 0) s_crowd = 0u;
 
   // A thread keeps KP points in registers (one chunk = 1024*KP points; a single chunk covers
   // 16384 points, so the three passes read the cloud from memory once).  Loads are unconditional
@@ -150,17 +146,15 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   };
   PP_PHASE(0);
   load_chunk(0);
-  // bounding box + finiteness (the clamped duplicates do not change either) + first and second
-  // moments (over the real points only), for the outlier test below
+  // bounding box (the clamped duplicates do not change it) + first and second moments (over the real
+  // points only), for the outlier test below and for the finiteness test
   float mnx = __builtin_inff(), mny = mnx, mnz = mnx, mxx = -mnx, mxy = -mnx, mxz = -mnx;
   float sm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // sum x, y, z; sum x^2, y^2, z^2
-  bool bad = false;
   for (int ch = 0; ch < nchunks; ++ch) {
     if (ch > 0) load_chunk(ch * kBuildThreads * KP);
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
       const float x = px[i], y = py[i], z = pz[i];
-      bad |= !(__builtin_isfinite(x) && __builtin_isfinite(y) && __builtin_isfinite(z));
       mnx = fminf(mnx, x); mny = fminf(mny, y); mnz = fminf(mnz, z);
       mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y); mxz = fmaxf(mxz, z);
       const float live = kidx(ch * kBuildThreads * KP, i) < nr ? 1.0f : 0.0f;
@@ -170,26 +164,31 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   }
   PP_PHASE(1);
   bool any_bad;
-  {  // seven max-reductions (-min, max, the non-finite flag) and six sums with one barrier
-    float v[7] = {-mnx, -mny, -mnz, mxx, mxy, mxz, bad ? 1.0f : 0.0f};
+  {  // six max-reductions (-min, max) and six sums with one barrier; a non-finite coordinate (or one whose
+     // square overflows: treated alike, the set goes to the brute force) shows in the sums of squares
+    float v[6] = {-mnx, -mny, -mnz, mxx, mxy, mxz};
+    wave_reduce6_dpp<false, 6>(v);
+    wave_reduce6_dpp<true, 6>(sm);
+    if ((t & 63) == 63) {
 #pragma unroll
-    for (int e = 0; e < 7; ++e) v[e] = wave_reduce_dpp<false>(v[e]);
-#pragma unroll
-    for (int e = 0; e < 6; ++e) sm[e] = wave_reduce_dpp<true>(sm[e]);
-    if ((t & 63) == 0) {
-#pragma unroll
-      for (int e = 0; e < 7; ++e) s_box[(t >> 6) * 16 + e] = v[e];
+      for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + e] = v[e];
 #pragma unroll
       for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + 8 + e] = sm[e];
     }
     __syncthreads();
-    // 16 waves: lane l < 16 reads wave l's partial; one more wave-wide reduction finishes the job
+    // 16 waves: lane l of every row of 16 reads wave l's partial; four row steps finish the job in lane 15
 #pragma unroll
-    for (int e = 0; e < 7; ++e) v[e] = wave_reduce_dpp<false>(s_box[(t & 15) * 16 + e]);
+    for (int e = 0; e < 6; ++e) v[e] = s_box[(t & 15) * 16 + e];
 #pragma unroll
-    for (int e = 0; e < 6; ++e) sm[e] = wave_reduce_dpp<true>((t & 63) < 16 ? s_box[(t & 15) * 16 + 8 + e] : 0.0f);
+    for (int e = 0; e < 6; ++e) sm[e] = s_box[(t & 15) * 16 + 8 + e];
+    wave_reduce6_dpp<false, 4>(v);
+    wave_reduce6_dpp<true, 4>(sm);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) v[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), 15));
+#pragma unroll
+    for (int e = 0; e < 6; ++e) sm[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm[e]), 15));
     mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
-    any_bad = v[6] != 0.0f;
+    any_bad = !__builtin_isfinite(sm[3] + sm[4] + sm[5]);
   }
   PP_PHASE(2);
   // Outliers: a few points far from the bulk would stretch the box until the bulk sits in a handful of
@@ -260,30 +259,47 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   };
   set_resolution(g0);
   int* s_cid = reinterpret_cast<int*>(s_cnt + grid_build_counter_words(nslab));  // [KP][kBuildThreads]
-  const bool have_ids = !MORTON && !degenerate && nchunks == 1;  // filled by the occupancy pass below
   // The searches want ~4-5 points per OCCUPIED cell (then the first, smallest stage answers ~98 % of the
   // queries): the first guess is right for a surface in a cubic box, too fine for a volume (1.3 points per
   // occupied cell for a uniformly filled cube).  Measure the occupancy with a bitmap of cells (every
   // workgroup of the set sees all the points, so all of them take the same decision) and coarsen while
   // it is below 2.5 points per occupied cell.
+  auto sk = [](int c) { return c + (c >> 5); };
+  unsigned below = 0;    // points in the cells of lower slabs
+  bool counted = false;  // the occupancy pass has also counted the points of this slab's cells
   if (!MORTON && !degenerate) {
+    // One pass per round does both jobs: every point marks its cell in the bitmap (the occupancy is a
+    // property of the whole set) and, if the cell belongs to this slab, bumps the cell's counter -- the
+    // cell index is computed once.  A round that ends in "coarsen" (rare for surfaces) recounts.
     __shared__ unsigned s_occ[kGridCells / 32];
     __shared__ unsigned s_nocc;
     for (int round = 0; round < 4; ++round) {
       const int nc = gx * gy * gz;
+      const int lo = (int)((long long)nc * slab / nslab), nl = (int)((long long)nc * (slab + 1) / nslab) - lo;
       for (int wd = t; wd < (nc + 31) / 32; wd += kBuildThreads) s_occ[wd] = 0;
+      for (int c = t; c < nl; c += kBuildThreads) s_cnt[sk(c)] = 0;
       if (t == 0) s_nocc = 0;
       __syncthreads();
+      below = 0;
       for (int ch = 0; ch < nchunks; ++ch) {
         if (nchunks > 1) load_chunk(ch * kBuildThreads * KP);
+        auto mark = [&](int i) {
+          const int c = cell_linear(cell_coord(px[i], mnx, invh, gx), cell_coord(py[i], mny, invh, gy),
+                                    cell_coord(pz[i], mnz, invh, gz), gx, gy);
+          atomicOr(&s_occ[c >> 5], 1u << (c & 31));
+          s_cid[i * kBuildThreads + t] = c;  // kept for the scatter when the cloud is a single chunk (the last round's value)
+          const int cl = c - lo;
+          below += cl < 0 ? 1u : 0u;
+          if ((unsigned)cl < (unsigned)nl) atomicAdd(&s_cnt[sk(cl)], 1u);
+        };
+        if ((ch + 1) * kBuildThreads * KP <= nr) {  // uniform: a full chunk needs no per-point bounds test
 #pragma unroll
-        for (int i = 0; i < KP; ++i)
-          if (kidx(ch * kBuildThreads * KP, i) < nr) {
-            const int c = (cell_coord(pz[i], mnz, invh, gz) * gy + cell_coord(py[i], mny, invh, gy)) * gx +
-                          cell_coord(px[i], mnx, invh, gx);
-            atomicOr(&s_occ[c >> 5], 1u << (c & 31));
-            if (nchunks == 1) s_cid[i * kBuildThreads + t] = c;  // the last round's value is the one kept
-          }
+          for (int i = 0; i < KP; ++i) mark(i);
+        } else {
+#pragma unroll
+          for (int i = 0; i < KP; ++i)
+            if (kidx(ch * kBuildThreads * KP, i) < nr) mark(i);
+        }
       }
       __syncthreads();
       unsigned mine = 0;
@@ -299,37 +315,37 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       // coarsen by ~1/sqrt(2) per round: x2.8 points per cell for a volume, x2 for a surface
       set_resolution(max(4, (int)((float)gmax * 0.7071f)));
     }
-    if (nchunks > 1) load_chunk(0);
+    counted = true;
   }
   PP_PHASE(4);
   const int ncell = MORTON ? kGridCells : gx * gy * gz;
 
   const int cell_lo = (int)((long long)ncell * slab / nslab), cell_hi = (int)((long long)ncell * (slab + 1) / nslab);
   const int nloc = cell_hi - cell_lo;  // this slab's cells: local index = cell - cell_lo
-  auto sk = [](int c) { return c + (c >> 5); };
-  for (int c = t; c < nloc; c += kBuildThreads) s_cnt[sk(c)] = 0;
-  __syncthreads();
   auto cell_of = [&](float x, float y, float z) {
     const int cx = cell_coord(x, mnx, invh, gx), cy = cell_coord(y, mny, invh, gy), cz = cell_coord(z, mnz, invh, gz);
-    return MORTON ? morton3(cx, cy, cz) : (cz * gy + cy) * gx + cx;
+    return MORTON ? morton3(cx, cy, cz) : cell_linear(cx, cy, cz, gx, gy);
   };
   PP_PHASE(5);
   const bool place = MORTON || !degenerate;
-  unsigned below = 0;  // points in the cells of lower slabs
-  if (place)
-    for (int ch = 0; ch < nchunks; ++ch) {
-      if (nchunks > 1) load_chunk(ch * kBuildThreads * KP);
+  if (!counted) {  // Morton mode (and degenerate sets, which only need empty counters)
+    for (int c = t; c < nloc; c += kBuildThreads) s_cnt[sk(c)] = 0;
+    __syncthreads();
+    if (place)
+      for (int ch = 0; ch < nchunks; ++ch) {
+        if (nchunks > 1) load_chunk(ch * kBuildThreads * KP);
 #pragma unroll
-      for (int i = 0; i < KP; ++i)
-        if (kidx(ch * kBuildThreads * KP, i) < nr) {
-          const int cg = have_ids ? s_cid[i * kBuildThreads + t] : cell_of(px[i], py[i], pz[i]);
-          if (!have_ids && nchunks == 1) s_cid[i * kBuildThreads + t] = cg;  // (Morton mode: for the scatter)
-          const int c = cg - cell_lo;
-          if (c < 0) ++below;
-          else if (c < nloc) atomicAdd(&s_cnt[sk(c)], 1u);
-        }
-    }
-  __syncthreads();
+        for (int i = 0; i < KP; ++i)
+          if (kidx(ch * kBuildThreads * KP, i) < nr) {
+            const int cg = cell_of(px[i], py[i], pz[i]);
+            if (nchunks == 1) s_cid[i * kBuildThreads + t] = cg;  // for the scatter
+            const int c = cg - cell_lo;
+            if (c < 0) ++below;
+            else if (c < nloc) atomicAdd(&s_cnt[sk(c)], 1u);
+          }
+      }
+    __syncthreads();
+  }
   PP_PHASE(6);
   // exclusive scan: each thread owns a contiguous run of cells
   const int per = (nloc + kBuildThreads - 1) / kBuildThreads;
@@ -339,7 +355,9 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     sum += s_cnt[sk(c)];
     mx = max(mx, s_cnt[sk(c)]);
   }
-  const float fmx = block_reduce((float)mx, true, s_red);
+  // a cell holding so many points (> 256 + N/32) that walking it lane by lane costs more than the
+  // brute-force kernel's share of the cloud (flag cleared before the first barrier, read after the last)
+  if ((float)mx > 256.0f + (float)nr * (1.0f / 32.0f)) s_crowd = 1u;
   // exclusive scan of the 1024 per-thread sums: inclusive scan inside each wave (shuffles), then
   // the 16 wave totals; the points below this slab (summed the same way) are the starting offset
   unsigned incl = sum, bsum = below;
@@ -367,7 +385,8 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   __syncthreads();
   PP_PHASE(7);
   if (cell_start) {
-    for (int c = t; c < nloc; c += kBuildThreads) cell_start[cell_lo + c] = s_cnt[sk(c)];  // coalesced copy out
+    // coalesced copy out (storing from the scan loop above, 32-byte pieces per lane, measured 1.9 us slower)
+    for (int c = t; c < nloc; c += kBuildThreads) cell_start[cell_lo + c] = s_cnt[sk(c)];
     if (t == 0 && slab == nslab - 1) cell_start[ncell] = degenerate ? 0u : (unsigned)nr;
   }
   __syncthreads();
@@ -401,9 +420,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     }
   PP_PHASE(9);
   if (t == 0) {
-    // a cell holding so many points (> 256 + N/32) that walking it lane by lane costs more than the
-    // brute-force kernel's share of the cloud
-    gs->crowd[slab] = (!degenerate && fmx > 256.0f + (float)nr * (1.0f / 32.0f)) ? 1 : 0;
+    gs->crowd[slab] = (!degenerate && s_crowd != 0u) ? 1 : 0;
     if (slab == 0) {
       gs->minx = mnx; gs->miny = mny; gs->minz = mnz; gs->h = h; gs->invh = invh;
       gs->gx = gx; gs->gy = gy; gs->gz = gz;

@@ -94,6 +94,36 @@ __device__ __forceinline__ float wave_reduce_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Six wave reductions at once (max or sum), in place: `op v, v, v row_shr:k` leaves lanes without a source
+// untouched (bound_ctrl off), so after row_shr 1, 2, 4, 8 lane 15 of every row of 16 holds the row's result
+// (STEPS = 4), and after row_bcast 15 / 31 lane 63 holds the wave's (STEPS = 6).  The six chains are
+// interleaved: dependent DPP operations sit six instructions apart (a VGPR written by a VALU instruction
+// needs two wait states before a DPP read), and the block opens and closes with a nop for its neighbours.
+// Half the instructions of update_dpp + op, which the compiler does not fuse.  Every lane must be active.
+#define PP_DPP6_STEP(OP, CTRL)                                                                       \
+  OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\t" OP " %2, %2, %2 " CTRL "\n\t" OP     \
+     " %3, %3, %3 " CTRL "\n\t" OP " %4, %4, %4 " CTRL "\n\t" OP " %5, %5, %5 " CTRL "\n\t"
+#define PP_DPP6_ROWS(OP)                                                                             \
+  "s_nop 1\n\t" PP_DPP6_STEP(OP, "row_shr:1 row_mask:0xf bank_mask:0xf")                            \
+      PP_DPP6_STEP(OP, "row_shr:2 row_mask:0xf bank_mask:0xf")                                       \
+          PP_DPP6_STEP(OP, "row_shr:4 row_mask:0xf bank_mask:0xf")                                   \
+              PP_DPP6_STEP(OP, "row_shr:8 row_mask:0xf bank_mask:0xf")
+#define PP_DPP6_WAVE(OP)                                                                             \
+  PP_DPP6_ROWS(OP) PP_DPP6_STEP(OP, "row_bcast:15 row_mask:0xa bank_mask:0xf")                       \
+      PP_DPP6_STEP(OP, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+template <bool SUM, int STEPS>
+__device__ __forceinline__ void wave_reduce6_dpp(float (&v)[6]) {
+  static_assert(STEPS == 4 || STEPS == 6, "");
+  if constexpr (SUM && STEPS == 6)
+    asm volatile(PP_DPP6_WAVE("v_add_f32_dpp") "s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+  else if constexpr (SUM)
+    asm volatile(PP_DPP6_ROWS("v_add_f32_dpp") "s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+  else if constexpr (STEPS == 6)
+    asm volatile(PP_DPP6_WAVE("v_max_f32_dpp") "s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+  else
+    asm volatile(PP_DPP6_ROWS("v_max_f32_dpp") "s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+}
+
 __device__ __forceinline__ int wave_id_uniform() {
   return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
