@@ -38,9 +38,6 @@ using pp::kGridMax;
 using pp::kBuildThreads;
 
 constexpr float kBoundSlack = 0.999f;
-// the wide stages: workgroups (of four waves, one query per wave and pass) per set; a workgroup whose share
-// of the list is empty costs next to nothing
-constexpr int kWideBlocksPerSet = 16;
 
 // Workspace layout (bytes), S = 2*B sets, T = B*(N+M) points:
 //   [0, 64*S)                      GridSet[S]
@@ -48,24 +45,21 @@ constexpr int kWideBlocksPerSet = 16;
 //   [.., +4*(kGridCells+1)*S)      unsigned cell_start[S][kGridCells+1]
 //   [.., +16*T)                    float4 sorted[T]   (x, y, z, original index bits)
 //   [.., +4*T)                     int qlist[T]           queries left to the brute force, per set
-//   [.., +4*T)                     int blist[T]           queries left to stages B/C, per set
 //   [.., +8*T)                     u64 lkey[T]            brute-force list: (distance, index) keys merged across slices
 //   [.., +4*S*tiles_l)             int ldone[S][tiles_l]  brute-force list: slices finished per tile of 128
 //   [.., +4*T)                     float slab[T]          labels in sorted order (labeled Chamfer only)
-// qcount has 4*B entries: [0, 2B) count qlist, [2B, 4B) count blist.
 struct Layout {
-  size_t sets, qcount, cell_start, sorted, qlist, blist, lkey, ldone, slab, total;
+  size_t sets, qcount, cell_start, sorted, qlist, lkey, ldone, slab, total;
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
   Layout L;
   const size_t S = (size_t)2 * B, T = (size_t)B * ((size_t)N + M);
   L.sets = 0;
   L.qcount = L.sets + 64 * S;
-  L.cell_start = L.qcount + ((4 * 2 * S + 255) / 256) * 256;
+  L.cell_start = L.qcount + ((4 * S + 255) / 256) * 256;
   L.sorted = L.cell_start + ((4 * (size_t)(kGridCells + 1) * S + 255) / 256) * 256;
   L.qlist = L.sorted + 16 * T;
-  L.blist = L.qlist + 4 * T;
-  L.lkey = L.blist + 4 * T;
+  L.lkey = L.qlist + 4 * T;
   L.lkey = (L.lkey + 7) / 8 * 8;
   L.ldone = L.lkey + 8 * T;
   L.slab = L.ldone + ((4 * S * (size_t)(((N > M ? N : M) + 127) / 128) + 255) / 256) * 256;
@@ -102,8 +96,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   const float* __restrict__ lab = labeled ? (dir ? label1 : label2) + (size_t)b * nr : nullptr;
   if (threadIdx.x == 0 && slab == 0) {  // the lists this set's queries may be appended to start empty
     int* counts = reinterpret_cast<int*>(ws + L.qcount);
-    counts[set] = 0;          // brute-force list of this set
-    counts[2 * B + set] = 0;  // stage B/C list of this set
+    counts[set] = 0;  // brute-force list of this set
   }
   if (slab == 0) {  // "slices finished" counters of this set's brute-force tiles
     const int tiles_l = ((N > M ? N : M) + 127) / 128;
@@ -134,137 +127,6 @@ __device__ __forceinline__ void wave_append(bool want, int* counter, int* list, 
     list[pos] = value;
     if (keys) keys[pos] = ~0ull;
   }
-}
-
-// Stage A for every query, one lane per query (dense launch).  Unresolved queries go to `blist`
-// (compacted, so the rarely needed wider stages run in full waves instead of a few lanes of many).
-// LAB (labeled Chamfer): a reference point is a candidate only if its label equals the query's; the
-// stopping rule is unchanged (it bounds EVERY unexamined point, whatever its label).
-template <bool LAB>
-__global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict__ xyz1,
-                                                         const float* __restrict__ xyz2,
-                                                         float* __restrict__ dist1, int* __restrict__ idx1,
-                                                         float* __restrict__ dist2, int* __restrict__ idx2,
-                                                         unsigned char* __restrict__ ws, int B, int N, int M,
-                                                         int tiles1, int tiles2, int total, int per_xcd,
-                                                         const float* __restrict__ label1,
-                                                         const float* __restrict__ label2) {
-  // workgroups of one set on one XCD: its cells and points (384 KiB) stay in that L2
-  const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
-  if (V >= total) return;
-  const int per_b = tiles1 + tiles2;
-  const int b = V / per_b;
-  const int r = V - b * per_b;
-  const int dir = r >= tiles1 ? 1 : 0;
-  const int tile = dir ? r - tiles1 : r;
-  const int nq = dir ? M : N;
-  const int jj = tile * 256 + threadIdx.x;
-  if (jj >= nq) return;
-  const int set = 2 * b + dir;
-  const Layout L = make_layout(B, N, M, LAB);
-  const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[set];
-  // The query cloud is the reference cloud of the partner set (b, 1-dir), already sorted by cell
-  // there: walking the queries in that order makes the lanes of a wave spatial neighbours, so
-  // they read the same cells (coalesced, L1-resident) and run similar trip counts.
-  const GridSet gp = reinterpret_cast<const GridSet*>(ws + L.sets)[set ^ 1];
-  const pp::f4* __restrict__ qsorted =
-      reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir ^ 1, N, M);
-  int* counts = reinterpret_cast<int*>(ws + L.qcount);
-  int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
-  const bool g_useless = pp::grid_useless(g), gp_useless = pp::grid_useless(gp);
-  if (g_useless) {  // uniform over the workgroup (one set per workgroup)
-    wave_append(true, counts + set, qlist, jj,  // every query exactly once, any order
-                reinterpret_cast<unsigned long long*>(ws + L.lkey) + set_query_offset(b, dir, N, M));
-    return;
-  }
-  const unsigned* __restrict__ cell_start =
-      reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
-  const pp::f4* __restrict__ sorted =
-      reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
-  float qx, qy, qz, ql = 0.0f;
-  int j;
-  if (!gp_useless) {
-    const pp::f4 qq = qsorted[jj];
-    qx = qq.x; qy = qq.y; qz = qq.z;
-    j = __float_as_int(qq.w);
-    if (LAB) ql = (reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir ^ 1, N, M))[jj];
-  } else {
-    const float* __restrict__ q = (dir ? xyz2 : xyz1) + ((size_t)b * nq + jj) * 3;
-    qx = q[0]; qy = q[1]; qz = q[2];
-    j = jj;
-    if (LAB) ql = (dir ? label2 : label1)[(size_t)b * nq + jj];
-  }
-  const float* __restrict__ slab =
-      LAB ? reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr;
-  const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
-  const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
-  const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
-  float best = __builtin_inff();
-  int bidx = 0x7fffffff;
-  bool resolved = false;
-  // Stage A: the 2x2x2 block of cells nearest to q' (own cell + the neighbour on the side of the
-  // cell q' lies in, per axis).  A point outside that block is beyond the far face of q''s cell
-  // along some axis (>= h/2 away) or beyond the neighbour (>= h away): true distance >= h/2.
-  {
-    const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
-                fz = (qz - g.minz) * g.invh - (float)cz;  // position inside the cell, in cells
-    const int sx = fx < 0.5f ? -1 : 1, sy = fy < 0.5f ? -1 : 1, sz = fz < 0.5f ? -1 : 1;
-    const int x0 = max(min(cx, cx + sx), 0), x1 = min(max(cx, cx + sx), g.gx - 1);
-    unsigned rs[4], re[4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int bq = 0; bq < 2; ++bq) {
-        const int z = cz + a * sz, y = cy + bq * sy;
-        const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
-        const int c = pp::cell_linear(0, min(max(y, 0), g.gy - 1), min(max(z, 0), g.gz - 1), g.gx, g.gy);
-        const unsigned s0 = cell_start[c + x0], e0 = cell_start[c + x1 + 1];
-        rs[a * 2 + bq] = ok ? s0 : 0u;
-        re[a * 2 + bq] = ok ? e0 : 0u;
-      }
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      for (unsigned i = rs[r4]; i < re[r4]; i += 4) {
-        const unsigned last = re[r4] - 1;
-        pp::f4 p[4];
-        float pl[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          p[u] = sorted[min(i + u, last)];
-          if (LAB) pl[u] = slab[min(i + u, last)];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
-          const int id = __float_as_int(p[u].w);
-          const bool take = (!LAB || pl[u] == ql) && (d < best || (d == best && id < bidx));
-          best = take ? d : best;
-          bidx = take ? id : bidx;
-        }
-      }
-    }
-    // What the block guarantees for THIS query: along each axis the nearer face of the block that has
-    // grid beyond it (beyond the grid there are no points).  Lower face: 1 + f cells away when the
-    // block includes cell c-1, f when it starts at c; upper face: 1 - f or 2 - f.  Never below h/2.
-    auto reach1 = [](float f, int s, int c, int gdim) {
-      const float lo = s < 0 ? (c >= 1 ? f + 1.0f : __builtin_inff()) : (c >= 1 ? f : __builtin_inff());
-      const float hi = s < 0 ? (c + 1 <= gdim - 1 ? 1.0f - f : __builtin_inff())
-                             : (c + 1 <= gdim - 1 ? 2.0f - f : __builtin_inff());
-      return fminf(lo, hi);
-    };
-    const float reach = g.h * fminf(reach1(fx, sx, cx, g.gx), fminf(reach1(fy, sy, cy, g.gy), reach1(fz, sz, cz, g.gz)));
-    resolved = best < reach * reach * kBoundSlack;
-  }
-  // Results go straight to the query's original position: two scattered 4-byte stores per query.
-  // (Measured against leaving them in walked order, coalesced, plus an inverse permutation written by
-  // the build and an unsort pass: the direct form is 4 us faster per forward at config 2 and needs
-  // 12 bytes less workspace per point.)
-  if (resolved) {
-    (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
-    (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
-  }
-  int* blist = reinterpret_cast<int*>(ws + L.blist) + set_query_offset(b, dir, N, M);
-  wave_append(!resolved, counts + 2 * B + set, blist, j);
 }
 
 // Stages B and C (cubes of Chebyshev radius 1 and 2 around the query's cell) for the queries stage A left
@@ -319,93 +181,254 @@ __device__ __forceinline__ unsigned long long wave_scan_rows(int nrows, unsigned
   return key;
 }
 
+// The wide stages for one query, executed by a whole wave (every lane active, all arguments wave-uniform):
+// cube of Chebyshev radius 1 around the query's cell, then 2.  Returns whether the query is settled;
+// (best, bidx) is the nearest examined candidate ((0, -1) for a labeled query whose label nobody carries).
 template <bool LAB>
-__global__ __launch_bounds__(256) void grid_finish_wave_kernel(const float* __restrict__ xyz1,
-                                                               const float* __restrict__ xyz2,
-                                                               float* __restrict__ dist1, int* __restrict__ idx1,
-                                                               float* __restrict__ dist2, int* __restrict__ idx2,
-                                                               unsigned char* __restrict__ ws, int B, int N, int M,
-                                                               int wide_blocks, int wide_per_set,
-                                                               const float* __restrict__ label1,
-                                                               const float* __restrict__ label2) {
-  const int block = pp::xcd_virtual_block(blockIdx.x, wide_blocks / 8);
-  const Layout L = make_layout(B, N, M, LAB);
-  int* counts = reinterpret_cast<int*>(ws + L.qcount);
-  const int set = block / wide_per_set;  // one set per workgroup
-  const int b = set >> 1, dir = set & 1;
+__device__ __forceinline__ bool wide_stages_wave(float qx, float qy, float qz, float ql, const GridSet& g,
+                                                 const unsigned* __restrict__ cell_start,
+                                                 const pp::f4* __restrict__ sorted, const float* __restrict__ slab,
+                                                 float& best, int& bidx) {
+  const int lane = threadIdx.x & 63;
+  const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
+  const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
+  const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
+  const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
+              fz = (qz - g.minz) * g.invh - (float)cz;
+  // distance (in cells) from q to the nearest face of the cube of Chebyshev radius rho around its
+  // cell that has grid beyond it: rho + f below, rho + 1 - f above (>= rho)
+  auto reach_cube = [&](int rho) {
+    auto axis = [&](float f, int c, int gdim) {
+      const float lo = c - rho >= 1 ? (float)rho + f : __builtin_inff();
+      const float hi = c + rho <= gdim - 2 ? (float)(rho + 1) - f : __builtin_inff();
+      return fminf(lo, hi);
+    };
+    return fminf(axis(fx, cx, g.gx), fminf(axis(fy, cy, g.gy), axis(fz, cz, g.gz)));
+  };
+  unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, no index)
+  bool resolved = false;
+#pragma unroll
+  for (int rho = 1; rho <= 2; ++rho) {  // cube of radius 1, then 2 (re-examining cells is harmless)
+    if (resolved) break;
+    const int side = 2 * rho + 1;
+    const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.gx - 1);
+    // lane r < side*side fetches the range of row (cz - rho + r / side, cy - rho + r % side)
+    const int z = cz - rho + lane / side, y = cy - rho + lane % side;
+    const bool ok = lane < side * side && z >= 0 && z < g.gz && y >= 0 && y < g.gy;
+    const int c = pp::cell_linear(0, min(max(y, 0), g.gy - 1), min(max(z, 0), g.gz - 1), g.gx, g.gy);
+    unsigned rs = 0, re = 0;
+    if (ok) {
+      rs = cell_start[c + x0];
+      re = cell_start[c + x1 + 1];
+    }
+    key = wave_scan_rows<LAB>(side * side, rs, re, sorted, slab, qx, qy, qz, ql, key);
+    const float kbest = __uint_as_float((unsigned)(key >> 32));
+    const int kidx = (int)(unsigned)key;
+    const bool all = cz - rho <= 0 && cz + rho >= g.gz - 1 && cy - rho <= 0 && cy + rho >= g.gy - 1 &&
+                     cx - rho <= 0 && cx + rho >= g.gx - 1;
+    const float reach = g.h * reach_cube(rho);
+    resolved = all ? (LAB || kidx != 0x7fffffff) : (kbest < reach * reach * kBoundSlack);
+  }
+  best = __uint_as_float((unsigned)(key >> 32));
+  bidx = (int)(unsigned)key;
+  if (LAB && resolved && bidx == 0x7fffffff) {  // whole grid examined, nobody carries this label
+    best = 0.0f;                                  // (ref nmdistance_cuda.cu:110-113)
+    bidx = -1;
+  }
+  return resolved;
+}
+
+// Group k of a lane's stage-A sequence (see grid_query_kernel): four points of the row it falls in.
+// Everything per-row arrives BY VALUE: selects between variables captured by reference in a lambda come
+// out of hipcc as indexed loads from a pointer table in scratch memory.
+template <bool LAB>
+__device__ __forceinline__ void stage_a_fetch(unsigned k, unsigned T1, unsigned T2, unsigned T3, unsigned T4,
+                                              unsigned adj0, unsigned adj1, unsigned adj2, unsigned adj3,
+                                              unsigned last0, unsigned last1, unsigned last2, unsigned last3,
+                                              const pp::f4* __restrict__ sorted, const float* __restrict__ slab,
+                                              pp::f4 (&p)[4], float (&pl)[4]) {
+  const bool a = k < T1, b2 = k < T2, c = k < T3, live = k < T4;
+  const unsigned adj = a ? adj0 : (b2 ? adj1 : (c ? adj2 : adj3));
+  // a lane that has run out of groups re-reads point 0 of the set (a valid candidate: harmless), so
+  // that nothing in the loop is conditional and the compiler can count the loads in flight exactly
+  const unsigned last = live ? (a ? last0 : (b2 ? last1 : (c ? last2 : last3))) : 0u;
+  const unsigned i = live ? adj + 4 * k : 0u;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    p[u] = sorted[min(i + u, last)];
+    if (LAB) pl[u] = slab[min(i + u, last)];
+  }
+}
+
+// Stage A for every query, one lane per query (dense launch); the few queries it cannot settle are then
+// taken through the wide stages by their wave, one at a time (see the end of the kernel).
+// LAB (labeled Chamfer): a reference point is a candidate only if its label equals the query's; the
+// stopping rule is unchanged (it bounds EVERY unexamined point, whatever its label).
+template <bool LAB>
+__global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict__ xyz1,
+                                                         const float* __restrict__ xyz2,
+                                                         float* __restrict__ dist1, int* __restrict__ idx1,
+                                                         float* __restrict__ dist2, int* __restrict__ idx2,
+                                                         unsigned char* __restrict__ ws, int B, int N, int M,
+                                                         int tiles1, int tiles2, int total, int per_xcd,
+                                                         const float* __restrict__ label1,
+                                                         const float* __restrict__ label2) {
+  // workgroups of one set on one XCD: its cells and points (384 KiB) stay in that L2
+  const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
+  if (V >= total) return;
+  const int per_b = tiles1 + tiles2;
+  const int b = V / per_b;
+  const int r = V - b * per_b;
+  const int dir = r >= tiles1 ? 1 : 0;
+  const int tile = dir ? r - tiles1 : r;
   const int nq = dir ? M : N;
-  const int nlist = counts[2 * B + set];
-  const int wave = pp::wave_id_uniform(), lane = threadIdx.x & 63;
-  const int first = (block % wide_per_set) * 4 + wave;
-  if (first >= nlist) return;
-  const int* __restrict__ blist = reinterpret_cast<const int*>(ws + L.blist) + set_query_offset(b, dir, N, M);
-  int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
-  unsigned long long* lkey = reinterpret_cast<unsigned long long*>(ws + L.lkey) + set_query_offset(b, dir, N, M);
-  const float* __restrict__ slab =
-      LAB ? reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr;
+  // every lane stays alive (the waves cooperate on their leftover queries below): the lanes beyond a
+  // ragged last tile repeat the cloud's last query and are kept from storing or listing anything
+  const bool valid = tile * 256 + (int)threadIdx.x < nq;
+  const int jj = valid ? tile * 256 + (int)threadIdx.x : nq - 1;
+  const int set = 2 * b + dir;
+  const Layout L = make_layout(B, N, M, LAB);
   const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[set];
+  // The query cloud is the reference cloud of the partner set (b, 1-dir), already sorted by cell
+  // there: walking the queries in that order makes the lanes of a wave spatial neighbours, so
+  // they read the same cells (coalesced, L1-resident) and run similar trip counts.
+  const GridSet gp = reinterpret_cast<const GridSet*>(ws + L.sets)[set ^ 1];
+  const pp::f4* __restrict__ qsorted =
+      reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir ^ 1, N, M);
+  int* counts = reinterpret_cast<int*>(ws + L.qcount);
+  int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
+  const bool g_useless = pp::grid_useless(g), gp_useless = pp::grid_useless(gp);
+  if (g_useless) {  // uniform over the workgroup (one set per workgroup)
+    wave_append(valid, counts + set, qlist, jj,  // every query exactly once, any order
+                reinterpret_cast<unsigned long long*>(ws + L.lkey) + set_query_offset(b, dir, N, M));
+    return;
+  }
   const unsigned* __restrict__ cell_start =
       reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
   const pp::f4* __restrict__ sorted =
       reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
-  for (int pos = first; pos < nlist; pos += wide_per_set * 4) {
-    const int j = __builtin_amdgcn_readfirstlane(blist[pos]);
-    const float* __restrict__ q = (dir ? xyz2 : xyz1) + ((size_t)b * nq + j) * 3;
-    const float qx = q[0], qy = q[1], qz = q[2];
-    const float ql = LAB ? (dir ? label2 : label1)[(size_t)b * nq + j] : 0.0f;
-    const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
-    const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
-    const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
+  float qx, qy, qz, ql = 0.0f;
+  int j;
+  if (!gp_useless) {
+    const pp::f4 qq = qsorted[jj];
+    qx = qq.x; qy = qq.y; qz = qq.z;
+    j = __float_as_int(qq.w);
+    if (LAB) ql = (reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir ^ 1, N, M))[jj];
+  } else {
+    const float* __restrict__ q = (dir ? xyz2 : xyz1) + ((size_t)b * nq + jj) * 3;
+    qx = q[0]; qy = q[1]; qz = q[2];
+    j = jj;
+    if (LAB) ql = (dir ? label2 : label1)[(size_t)b * nq + jj];
+  }
+  const float* __restrict__ slab =
+      LAB ? reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr;
+  const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
+  const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
+  const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
+  float best = __builtin_inff();
+  int bidx = 0x7fffffff;
+  bool resolved = false;
+  // Stage A: the 2x2x2 block of cells nearest to q' (own cell + the neighbour on the side of the
+  // cell q' lies in, per axis).  A point outside that block is beyond the far face of q''s cell
+  // along some axis (>= h/2 away) or beyond the neighbour (>= h away): true distance >= h/2.
+  {
     const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
-                fz = (qz - g.minz) * g.invh - (float)cz;
-    // distance (in cells) from q to the nearest face of the cube of Chebyshev radius rho around its
-    // cell that has grid beyond it: rho + f below, rho + 1 - f above (>= rho)
-    auto reach_cube = [&](int rho) {
-      auto axis = [&](float f, int c, int gdim) {
-        const float lo = c - rho >= 1 ? (float)rho + f : __builtin_inff();
-        const float hi = c + rho <= gdim - 2 ? (float)(rho + 1) - f : __builtin_inff();
-        return fminf(lo, hi);
-      };
-      return fminf(axis(fx, cx, g.gx), fminf(axis(fy, cy, g.gy), axis(fz, cz, g.gz)));
-    };
-    unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, no index)
-    bool resolved = false;
-#pragma unroll
-    for (int rho = 1; rho <= 2; ++rho) {  // cube of radius 1, then 2 (re-examining cells is harmless)
-      if (resolved) break;
-      const int side = 2 * rho + 1;
-      const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.gx - 1);
-      // lane r < side*side fetches the range of row (cz - rho + r / side, cy - rho + r % side)
-      const int z = cz - rho + lane / side, y = cy - rho + lane % side;
-      const bool ok = lane < side * side && z >= 0 && z < g.gz && y >= 0 && y < g.gy;
+                fz = (qz - g.minz) * g.invh - (float)cz;  // position inside the cell, in cells
+    const int sx = fx < 0.5f ? -1 : 1, sy = fy < 0.5f ? -1 : 1, sz = fz < 0.5f ? -1 : 1;
+    const int x0 = max(min(cx, cx + sx), 0), x1 = min(max(cx, cx + sx), g.gx - 1);
+    // (named scalars, not arrays: hipcc turns a select between array elements into an indexed load
+    // from scratch memory)
+    auto row_range = [&](int a, int bq, unsigned& s_out, unsigned& e_out) {
+      const int z = cz + a * sz, y = cy + bq * sy;
+      const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
       const int c = pp::cell_linear(0, min(max(y, 0), g.gy - 1), min(max(z, 0), g.gz - 1), g.gx, g.gy);
-      unsigned rs = 0, re = 0;
-      if (ok) {
-        rs = cell_start[c + x0];
-        re = cell_start[c + x1 + 1];
+      const unsigned s0 = cell_start[c + x0], e0 = cell_start[c + x1 + 1];
+      s_out = ok ? s0 : 0u;
+      e_out = ok ? e0 : 0u;
+    };
+    unsigned rs0, rs1, rs2, rs3, re0, re1, re2, re3;
+    row_range(0, 0, rs0, re0);
+    row_range(0, 1, rs1, re1);
+    row_range(1, 0, rs2, re2);
+    row_range(1, 1, rs3, re3);
+    // The four rows are walked as ONE sequence of groups of four points: a lane's rows hold t_r =
+    // ceil(len_r / 4) groups each, group k of the sequence belongs to the row r with T_r <= k < T_{r+1}
+    // (T = running sums) and starts at rs_r + 4 (k - T_r).  k is wave-uniform, so the wave runs
+    // max over lanes of (t_0 + .. + t_3) steps instead of the sum over rows of the per-row maxima, and
+    // the loads of group k + 1 are in flight while group k is evaluated (a row-by-row walk waits for
+    // every group's loads before it can issue the next: 50 -> 3x us at config 2).  The clamped duplicates
+    // of a ragged tail are the same candidate again: harmless.
+    const unsigned t0 = (re0 - rs0 + 3) >> 2, t1 = (re1 - rs1 + 3) >> 2, t2 = (re2 - rs2 + 3) >> 2,
+                   t3 = (re3 - rs3 + 3) >> 2;
+    const unsigned T1 = t0, T2 = T1 + t1, T3 = T2 + t2, T4 = T3 + t3;
+    const unsigned adj0 = rs0, adj1 = rs1 - 4 * T1, adj2 = rs2 - 4 * T2, adj3 = rs3 - 4 * T3;
+    const unsigned last0 = re0 - 1, last1 = re1 - 1, last2 = re2 - 1, last3 = re3 - 1;
+    auto fetch = [&](unsigned k, pp::f4 (&p)[4], float (&pl)[4]) {
+      stage_a_fetch<LAB>(k, T1, T2, T3, T4, adj0, adj1, adj2, adj3, last0, last1, last2, last3, sorted, slab, p, pl);
+    };
+    auto examine = [&](const pp::f4 (&p)[4], const float (&pl)[4]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+        const int id = __float_as_int(p[u].w);
+        const bool take = (!LAB || pl[u] == ql) && (d < best || (d == best && id < bidx));
+        best = take ? d : best;
+        bidx = take ? id : bidx;
       }
-      key = wave_scan_rows<LAB>(side * side, rs, re, sorted, slab, qx, qy, qz, ql, key);
-      const float best = __uint_as_float((unsigned)(key >> 32));
-      const int bidx = (int)(unsigned)key;
-      const bool all = cz - rho <= 0 && cz + rho >= g.gz - 1 && cy - rho <= 0 && cy + rho >= g.gy - 1 &&
-                       cx - rho <= 0 && cx + rho >= g.gx - 1;
-      const float reach = g.h * reach_cube(rho);
-      resolved = all ? (LAB || bidx != 0x7fffffff) : (best < reach * reach * kBoundSlack);
+    };
+    pp::f4 pa[4], pb[4];
+    float la[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    fetch(0, pa, la);
+    for (unsigned k = 0; __any(k < T4); k += 2) {  // two steps per trip: the buffers swap roles without copies
+      fetch(k + 1, pb, lb);
+      examine(pa, la);
+      fetch(k + 2, pa, la);
+      examine(pb, lb);
     }
-    float best = __uint_as_float((unsigned)(key >> 32));
-    int bidx = (int)(unsigned)key;
-    if (LAB && resolved && bidx == 0x7fffffff) {  // whole grid examined, nobody carries this label
-      best = 0.0f;                                  // (ref nmdistance_cuda.cu:110-113)
-      bidx = -1;
-    }
-    if (lane == 0) {
-      if (resolved) {
-        (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
-        (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
+    // What the block guarantees for THIS query: along each axis the nearer face of the block that has
+    // grid beyond it (beyond the grid there are no points).  Lower face: 1 + f cells away when the
+    // block includes cell c-1, f when it starts at c; upper face: 1 - f or 2 - f.  Never below h/2.
+    auto reach1 = [](float f, int s, int c, int gdim) {
+      const float lo = s < 0 ? (c >= 1 ? f + 1.0f : __builtin_inff()) : (c >= 1 ? f : __builtin_inff());
+      const float hi = s < 0 ? (c + 1 <= gdim - 1 ? 1.0f - f : __builtin_inff())
+                             : (c + 1 <= gdim - 1 ? 2.0f - f : __builtin_inff());
+      return fminf(lo, hi);
+    };
+    const float reach = g.h * fminf(reach1(fx, sx, cx, g.gx), fminf(reach1(fy, sy, cy, g.gy), reach1(fz, sz, cz, g.gz)));
+    resolved = best < reach * reach * kBoundSlack;
+  }
+  // Results go straight to the query's original position: two scattered 4-byte stores per query.
+  // (Measured against leaving them in walked order, coalesced, plus an inverse permutation written by
+  // the build and an unsort pass: the direct form is 4 us faster per forward at config 2 and needs
+  // 12 bytes less workspace per point.)
+  if (resolved && valid) {
+    (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
+    (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
+  }
+  // The queries stage A could not settle (0.3 % at config 2: one in five waves has one) are served on the
+  // spot, one after the other, by the whole wave (wide_stages_wave): no second list, no second launch
+  // (a separate kernel over the compacted leftovers cost 7 us of launch and tail per forward).  What the
+  // cube of radius 2 cannot settle either goes to the brute-force list.
+  unsigned long long pending = __ballot(!resolved && valid);
+  while (pending) {  // wave-uniform
+    const int l = (int)__builtin_ctzll(pending);
+    pending &= pending - 1;
+    const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
+    const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), l));
+    const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), l));
+    const float wl = LAB ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ql), l)) : 0.0f;
+    const int wj = __builtin_amdgcn_readlane(j, l);
+    float wbest;
+    int widx;
+    const bool settled = wide_stages_wave<LAB>(wx, wy, wz, wl, g, cell_start, sorted, slab, wbest, widx);
+    if ((threadIdx.x & 63) == 0) {
+      if (settled) {
+        (dir ? dist2 : dist1)[(size_t)b * nq + wj] = wbest;
+        (dir ? idx2 : idx1)[(size_t)b * nq + wj] = widx;
       } else {
         const int at = atomicAdd(counts + set, 1);
-        qlist[at] = j;
-        lkey[at] = ~0ull;
+        qlist[at] = wj;
+        (reinterpret_cast<unsigned long long*>(ws + L.lkey) + set_query_offset(b, dir, N, M))[at] = ~0ull;
       }
     }
   }
@@ -435,7 +458,7 @@ extern "C" size_t pp_labeled_nmdistance_forward_workspace_bytes(int B, int N, in
   return make_layout(B, N, M, true).total;
 }
 
-// build -> stage A for every query -> wide stages -> brute force over what is left
+// build -> stage A for every query, wide stages for what it leaves -> brute force over what is left
 template <bool LAB>
 static int grid_forward(const float* xyz1, const float* xyz2, const float* label1, const float* label2,
                         float* dist1, int* idx1, float* dist2, int* idx2, int B, int N, int M,
@@ -455,12 +478,6 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   const int per_xcd = (int)((blocks + 7) / 8);
   grid_query_kernel<LAB><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(
       xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2);
-  PP_RETURN_IF_LAUNCH_FAILED();
-  // labeled: a candidate must also carry the query's label, so more queries outlive stage A
-  const int wide_per_set = LAB ? 2 * kWideBlocksPerSet : kWideBlocksPerSet;
-  const int wide_blocks = 2 * B * wide_per_set;  // a multiple of 8 (XCD mapping of the finish kernel)
-  grid_finish_wave_kernel<LAB><<<dim3((unsigned)wide_blocks), dim3(256), 0, s>>>(
-      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, wide_blocks, wide_per_set, label1, label2);
   PP_RETURN_IF_LAUNCH_FAILED();
   return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
                                 reinterpret_cast<const int*>(ws + L.qlist),
