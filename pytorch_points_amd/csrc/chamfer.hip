@@ -21,6 +21,11 @@
 //     8 XCDs in contiguous ranges so that workgroups sharing a reference cloud share an L2.
 #include "pp_common.h"
 
+// phase marks (tools/bwd_probe.hip defines PP_PHASE to record a clock; nothing otherwise)
+#ifndef PP_PHASE
+#define PP_PHASE(n)
+#endif
+
 namespace {
 
 using pp::chamfer_d3;
@@ -638,12 +643,17 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_csr_kernel(
 // than listing them (the CSR kernel above needs a count pass, a scan and a fill pass before it can
 // sum).  A workgroup owns a slice [k0,k1) of one target cloud: 3 doubles per point.  Every term is
 // computed in fp32 exactly as the reference does; only the running sum is wider.
+// VEC (clouds, gradients and indices 16-byte aligned, N, M and the slice length multiples of 4): a thread
+// takes four CONSECUTIVE points and reads them with 16-byte loads -- 20 fully coalesced loads per thread
+// in the scattered pass instead of 80 four-byte loads at a 12-byte lane stride, which is what bounded
+// the kernel (the address path handles a wave's 4-byte loads lane group by lane group).
+template <bool VEC>
 __global__ __launch_bounds__(1024) void nmdist_bwd_lds64_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, const float* __restrict__ gd1,
     const float* __restrict__ gd2, const int* __restrict__ idx1, const int* __restrict__ idx2,
     float* __restrict__ gx1, float* __restrict__ gx2, int N, int M, int slice_len, int slices, int total,
     int per_xcd) {
-  extern __shared__ __attribute__((aligned(16))) double s_acc64[];  // [slice_len][3]
+  extern __shared__ __attribute__((aligned(16))) double s_acc64[];  // [slice_len][3] doubles, then [slice_len][3] floats
   // the workgroups of a batch element share an XCD -- the one whose L2 holds its clouds and the
   // indices the forward pass has just written (same batch -> XCD mapping as chamfer_grid.hip)
   const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
@@ -665,21 +675,97 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_lds64_kernel(
   const int* __restrict__ io = (second ? idx1 : idx2) + (size_t)b * no;
   float* __restrict__ out = (second ? gx2 : gx1) + (size_t)b * nt * 3;
   const int t = threadIdx.x;
+  float* s_xt = reinterpret_cast<float*>(s_acc64 + 3 * (size_t)slice_len);  // the slice's coordinates [len][3]
+  // Scattered pass, in batches of KJ elements per thread: everything a batch needs from memory (index,
+  // gradient, coordinates of the other cloud's points) is loaded unconditionally up front (indices
+  // clamped); the target coordinates it also needs come from the LDS copy the own-term pass leaves behind.
+  // So a batch costs ONE memory round trip, and it is issued a batch ahead: the first before the own-term
+  // pass starts, the next before the current one is added.  (Before: two dependent round trips per batch,
+  // none overlapped: 17.8 -> 1x us at config 2.)
+  constexpr int KJ = 8;
+  struct Batch {
+    int kj[KJ];
+    float g[KJ], ox[KJ], oy[KJ], oz[KJ];
+  };
+  // batch starting at point jb of the other cloud: element u of thread t is point jb + 1024 u + t, or, in
+  // the vector form, point jb + 4096 (u / 4) + 4 t + (u % 4)
+  auto load_batch = [&](Batch& bt, int jb) {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int gq = 0; gq < KJ / 4; ++gq) {
+        const int p0 = jb + 4096 * gq + 4 * t;
+        const int pc = min(p0, no - 4);  // no is a multiple of 4 (>= 4): an aligned, in-range quad
+        const pp::i4 k4 = *reinterpret_cast<const pp::i4*>(io + pc);
+        const pp::f4 g4 = *reinterpret_cast<const pp::f4*>(go + pc);
+        const pp::f4* __restrict__ src = reinterpret_cast<const pp::f4*>(xo + 3 * (size_t)pc);
+        const pp::f4 a = src[0], b4 = src[1], c = src[2];
+        const int kr[4] = {k4.x - k0, k4.y - k0, k4.z - k0, k4.w - k0};
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float xs[4] = {a.x, a.w, b4.z, c.y}, ys[4] = {a.y, b4.x, b4.w, c.z}, zs[4] = {a.z, b4.y, c.x, c.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bt.kj[4 * gq + i] = (p0 < no && kr[i] >= 0 && kr[i] < len) ? kr[i] : -1;
+          bt.g[4 * gq + i] = gg[i];
+          bt.ox[4 * gq + i] = xs[i]; bt.oy[4 * gq + i] = ys[i]; bt.oz[4 * gq + i] = zs[i];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < KJ; ++u) {
+        const int j = jb + t + 1024 * u;
+        const int jc = min(j, no - 1);
+        const int kr = io[jc] - k0;
+        bt.kj[u] = (j < no && kr >= 0 && kr < len) ? kr : -1;
+        bt.g[u] = go[jc];
+        bt.ox[u] = xo[3 * (size_t)jc]; bt.oy[u] = xo[3 * (size_t)jc + 1]; bt.oz[u] = xo[3 * (size_t)jc + 2];
+      }
+    }
+  };
+  auto add_batch = [&](const Batch& bt) {  // -g*(x_O[j] - x_T[idx_O[j]]) onto row idx_O[j]              (:181)
+#pragma unroll
+    for (int u = 0; u < KJ; ++u)
+      if (bt.kj[u] >= 0) {
+        const int kr = bt.kj[u];
+        const float gg = bt.g[u] * 2;
+        atomicAdd(&s_acc64[3 * kr], (double)(-(gg * (bt.ox[u] - s_xt[3 * kr]))));
+        atomicAdd(&s_acc64[3 * kr + 1], (double)(-(gg * (bt.oy[u] - s_xt[3 * kr + 1]))));
+        atomicAdd(&s_acc64[3 * kr + 2], (double)(-(gg * (bt.oz[u] - s_xt[3 * kr + 2]))));
+      }
+  };
+  Batch ba, bb;
+  PP_PHASE(0);
+  load_batch(ba, 0);
   // own terms: +g*(x_T[k] - x_O[idx_T[k]])                              (ref nmdistance_cuda.cu:176-180)
   // (seeding the slice with plain stores and a barrier measured faster than zero-filling and adding
   // the own terms atomically in the same pass as the scattered ones)
-  // Both passes issue the loads of several elements before using any of them (indices clamped, so no
-  // load is conditional): a pass costs two memory round trips per batch instead of two per element.
+  // The loads of several elements are issued before any is used (indices clamped, so no load is
+  // conditional): the pass costs two memory round trips per batch instead of two per element.
   constexpr int KO = 4;
-  for (int kk0 = t; kk0 < len; kk0 += 1024 * KO) {
-    int j2[KO];
+  for (int kb = 0; kb < len; kb += 1024 * KO) {
+    int j2[KO], kkv[KO];
     float g[KO], tx[KO], ty[KO], tz[KO], ox[KO], oy[KO], oz[KO];
+    if constexpr (VEC) {  // slice start and length are multiples of 4: quads never straddle the end
+      const int p0 = kb + 4 * t;
+      const int pc = k0 + min(p0, len - 4);
+      const pp::i4 j4 = *reinterpret_cast<const pp::i4*>(it + pc);
+      const pp::f4 g4 = *reinterpret_cast<const pp::f4*>(gt + pc);
+      const pp::f4* __restrict__ src = reinterpret_cast<const pp::f4*>(xt + 3 * (size_t)pc);
+      const pp::f4 a = src[0], b4 = src[1], c = src[2];
+      j2[0] = j4.x; j2[1] = j4.y; j2[2] = j4.z; j2[3] = j4.w;
+      g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+      tx[0] = a.x; ty[0] = a.y; tz[0] = a.z; tx[1] = a.w; ty[1] = b4.x; tz[1] = b4.y;
+      tx[2] = b4.z; ty[2] = b4.w; tz[2] = c.x; tx[3] = c.y; ty[3] = c.z; tz[3] = c.w;
 #pragma unroll
-    for (int u = 0; u < KO; ++u) {
-      const int k = k0 + min(kk0 + 1024 * u, len - 1);
-      j2[u] = it[k];
-      g[u] = gt[k];
-      tx[u] = xt[3 * (size_t)k]; ty[u] = xt[3 * (size_t)k + 1]; tz[u] = xt[3 * (size_t)k + 2];
+      for (int u = 0; u < KO; ++u) kkv[u] = p0 < len ? p0 + u : len;  // len: "nothing to store"
+    } else {
+#pragma unroll
+      for (int u = 0; u < KO; ++u) {
+        kkv[u] = min(kb + t + 1024 * u, len);
+        const int k = k0 + min(kkv[u], len - 1);
+        j2[u] = it[k];
+        g[u] = gt[k];
+        tx[u] = xt[3 * (size_t)k]; ty[u] = xt[3 * (size_t)k + 1]; tz[u] = xt[3 * (size_t)k + 2];
+      }
     }
 #pragma unroll
     for (int u = 0; u < KO; ++u) {
@@ -688,7 +774,7 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_lds64_kernel(
     }
 #pragma unroll
     for (int u = 0; u < KO; ++u) {
-      const int kk = kk0 + 1024 * u;
+      const int kk = kkv[u];
       if (kk < len) {
         float ax = 0.0f, ay = 0.0f, az = 0.0f;
         if (j2[u] >= 0) {
@@ -700,40 +786,26 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_lds64_kernel(
         s_acc64[3 * kk] = (double)ax;
         s_acc64[3 * kk + 1] = (double)ay;
         s_acc64[3 * kk + 2] = (double)az;
+        s_xt[3 * kk] = tx[u];
+        s_xt[3 * kk + 1] = ty[u];
+        s_xt[3 * kk + 2] = tz[u];
       }
     }
   }
+  PP_PHASE(1);
   __syncthreads();
-  // scattered terms of the other direction: -g*(x_O[j] - x_T[idx_O[j]]) onto row idx_O[j]        (:181)
-  constexpr int KJ = 8;
-  for (int j0 = t; j0 < no; j0 += 1024 * KJ) {
-    int kj[KJ];
-    float g[KJ], ox[KJ], oy[KJ], oz[KJ], tx[KJ], ty[KJ], tz[KJ];
-#pragma unroll
-    for (int u = 0; u < KJ; ++u) {
-      const int j = j0 + 1024 * u;
-      const int jc = min(j, no - 1);
-      const int kr = io[jc] - k0;
-      kj[u] = (j < no && kr >= 0 && kr < len) ? kr : -1;
-      g[u] = go[jc];
-      ox[u] = xo[3 * (size_t)jc]; oy[u] = xo[3 * (size_t)jc + 1]; oz[u] = xo[3 * (size_t)jc + 2];
-    }
-#pragma unroll
-    for (int u = 0; u < KJ; ++u) {
-      const int k = k0 + (kj[u] >= 0 ? kj[u] : 0);
-      tx[u] = xt[3 * (size_t)k]; ty[u] = xt[3 * (size_t)k + 1]; tz[u] = xt[3 * (size_t)k + 2];
-    }
-#pragma unroll
-    for (int u = 0; u < KJ; ++u)
-      if (kj[u] >= 0) {
-        const float gg = g[u] * 2;
-        atomicAdd(&s_acc64[3 * kj[u]], (double)(-(gg * (ox[u] - tx[u]))));
-        atomicAdd(&s_acc64[3 * kj[u] + 1], (double)(-(gg * (oy[u] - ty[u]))));
-        atomicAdd(&s_acc64[3 * kj[u] + 2], (double)(-(gg * (oz[u] - tz[u]))));
-      }
+  PP_PHASE(2);
+  for (int jb = 0; jb < no; jb += 2 * 1024 * KJ) {  // two batches per trip: the buffers swap roles without copies
+    load_batch(bb, jb + 1024 * KJ);
+    add_batch(ba);
+    load_batch(ba, jb + 2 * 1024 * KJ);
+    add_batch(bb);
   }
+  PP_PHASE(3);
   __syncthreads();
+  PP_PHASE(4);
   for (int e = t; e < 3 * len; e += 1024) out[3 * (size_t)k0 + e] = (float)s_acc64[e];  // coalesced
+  PP_PHASE(5);
 }
 
 __global__ void fill_zero_kernel(float* __restrict__ a, int* __restrict__ b, long long n) {
@@ -922,7 +994,7 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
   }
   if (!xyz1 || !xyz2 || !graddist1 || !graddist2 || !idx1 || !idx2 || !gradxyz1 || !gradxyz2)
     return PP_EINVAL;
-  // double LDS accumulators: C == 3; slices of at most 4096 points (96 KiB), at least 4 per cloud
+  // double LDS accumulators: C == 3; slices of at most 4096 points (96 KiB + 48 KiB of coordinates), at least 4 per cloud
   if ((g_bwd_variant == 0 || g_bwd_variant == 4) && C == 3 && N + M >= 4096) {
     const int big = N > M ? N : M;
     int slices = (big + 4095) / 4096;
@@ -930,10 +1002,16 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
     const int slice_len = (big + slices - 1) / slices;
     if ((long long)B * 2 * slices <= 0x7fffffffLL) {
       static bool lds_ok[64] = {};
-      const hipError_t e = pp::allow_big_lds(nmdist_bwd_lds64_kernel, 152 * 1024, lds_ok);
+      static bool lds_ok_vec[64] = {};
+      const uintptr_t align = reinterpret_cast<uintptr_t>(xyz1) | reinterpret_cast<uintptr_t>(xyz2) |
+                              reinterpret_cast<uintptr_t>(graddist1) | reinterpret_cast<uintptr_t>(graddist2) |
+                              reinterpret_cast<uintptr_t>(idx1) | reinterpret_cast<uintptr_t>(idx2);
+      const bool vec = (align & 15) == 0 && N % 4 == 0 && M % 4 == 0 && slice_len % 4 == 0 && N >= 4 && M >= 4;
+      const hipError_t e = vec ? pp::allow_big_lds(nmdist_bwd_lds64_kernel<true>, 152 * 1024, lds_ok_vec)
+                               : pp::allow_big_lds(nmdist_bwd_lds64_kernel<false>, 152 * 1024, lds_ok);
       if (e != hipSuccess) return (int)e;
       const int total = B * 2 * slices, per_xcd = (total + 7) / 8;
-      nmdist_bwd_lds64_kernel<<<dim3((unsigned)(per_xcd * 8)), dim3(1024), (size_t)slice_len * 24, s>>>(
+      (vec ? nmdist_bwd_lds64_kernel<true> : nmdist_bwd_lds64_kernel<false>)<<<dim3((unsigned)(per_xcd * 8)), dim3(1024), (size_t)slice_len * 36, s>>>(
           xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, slice_len, slices, total, per_xcd);
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
