@@ -56,6 +56,7 @@ __host__ __device__ inline BqLayout bq_layout(int B, int N, int M) {
 
 // workgroups [0, S*B): slab s of the cloud of batch element b into its grid; [S*B, 2*S*B): slab s of
 // the centres of batch element b into Morton order (S = kBuildSlabs)
+template <bool VEC>
 __global__ __launch_bounds__(kBuildThreads) void bq_build_kernel(const float* __restrict__ xyz,
                                                                  const float* __restrict__ new_xyz,
                                                                  unsigned char* __restrict__ ws, int B, int N,
@@ -71,13 +72,13 @@ __global__ __launch_bounds__(kBuildThreads) void bq_build_kernel(const float* __
   GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
   if (set >= B) {
     const int b = set - B;
-    pp::grid_build_set<true>(new_xyz + (size_t)b * M * 3, M, gs, nullptr,
+    pp::grid_build_set<true, VEC>(new_xyz + (size_t)b * M * 3, M, gs, nullptr,
                              reinterpret_cast<pp::f4*>(ws + L.csorted) + (size_t)b * M, nullptr, s_cnt, nullptr,
                              nullptr, slab, pp::kBuildSlabs);
     return;
   }
   const int b = set;
-  pp::grid_build_set<false>(xyz + (size_t)b * N * 3, N, gs,
+  pp::grid_build_set<false, VEC>(xyz + (size_t)b * N * 3, N, gs,
                             reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
                             reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * N, nullptr, s_cnt, nullptr,
                             nullptr, slab, pp::kBuildSlabs);
@@ -381,9 +382,11 @@ extern "C" int pp_ball_query_ws_f32(const float* new_xyz, const float* xyz, int*
   const float rpad = radius * 1.00001f + 1e-30f;
   static bool lds_ok[64] = {};
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
-  hipError_t e = pp::allow_big_lds(bq_build_kernel, (int)lds, lds_ok);
+  static bool lds_ok_vec[64] = {};
+  const bool vec = pp::clouds_vec_aligned(xyz, N, B) && pp::clouds_vec_aligned(new_xyz, M, B);
+  hipError_t e = vec ? pp::allow_big_lds(bq_build_kernel<true>, (int)lds, lds_ok_vec) : pp::allow_big_lds(bq_build_kernel<false>, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  bq_build_kernel<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(xyz, new_xyz, ws, B, N, M);
+  (vec ? bq_build_kernel<true> : bq_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(xyz, new_xyz, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   // lanes per centre: 2 unless forced (tuning knob; 2 and 4 measure alike at config 4, 1 is 30 % slower)
   int lpc = g_bq_lpc ? g_bq_lpc : 2;

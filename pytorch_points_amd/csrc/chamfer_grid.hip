@@ -76,6 +76,7 @@ __host__ __device__ inline size_t set_query_offset(int b, int dir, int N, int M)
 
 // kBuildSlabs workgroups per set: bounding box, cell histogram (LDS), exclusive scan, scatter
 // (grid_common.h).
+template <bool VEC>
 __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* __restrict__ xyz1,
                                                                    const float* __restrict__ xyz2,
                                                                    unsigned char* __restrict__ ws, int B,
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
     int* done = reinterpret_cast<int*>(ws + L.ldone) + (size_t)set * tiles_l;
     for (int i = threadIdx.x; i < tiles_l; i += kBuildThreads) done[i] = 0;
   }
-  pp::grid_build_set(ref, nr, reinterpret_cast<GridSet*>(ws + L.sets) + set,
+  pp::grid_build_set<false, VEC>(ref, nr, reinterpret_cast<GridSet*>(ws + L.sets) + set,
                      reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1),
                      reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M),
                      nullptr, s_cnt, lab,
@@ -465,12 +466,14 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
                         unsigned char* ws, hipStream_t s) {
   const Layout L = make_layout(B, N, M, LAB);
   hipError_t e;
-  static bool lds_ok[64] = {};
+  static bool lds_ok[64] = {}, lds_ok_vec[64] = {};
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
-  e = pp::allow_big_lds(grid_build_kernel, (int)lds, lds_ok);
+  const bool vec = pp::clouds_vec_aligned(xyz1, N, B) && pp::clouds_vec_aligned(xyz2, M, B);
+  e = vec ? pp::allow_big_lds(grid_build_kernel<true>, (int)lds, lds_ok_vec)
+          : pp::allow_big_lds(grid_build_kernel<false>, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  grid_build_kernel<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr,
-                                                                  LAB ? label2 : nullptr);
+  (vec ? grid_build_kernel<true> : grid_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(
+      xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr);
   PP_RETURN_IF_LAUNCH_FAILED();
   const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
   const long long blocks = (long long)B * (tiles1 + tiles2);

@@ -432,17 +432,22 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   PP_PHASE(10);
 }
 
-template <bool MORTON = false>
+// VEC: the cloud is 16-byte aligned (read as float4).  A compile-time choice of the calling kernel: with both
+// load paths inlined into one kernel the register allocator spills (17 MB of scratch traffic per build at
+// config 2); the host picks the kernel with clouds_vec_aligned().
+template <bool MORTON, bool VEC>
 __device__ __forceinline__ void grid_build_set(const float* __restrict__ ref, int nr, GridSet* gs,
                                                unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
                                                int* __restrict__ inv, unsigned* s_cnt,
                                                const float* __restrict__ payload = nullptr,
                                                float* __restrict__ sorted_payload = nullptr, int slab = 0,
                                                int nslab = 1) {
-  if ((reinterpret_cast<uintptr_t>(ref) & 15) == 0)  // uniform over the workgroup
-    grid_build_set_impl<MORTON, true>(ref, nr, gs, cell_start, sorted, inv, s_cnt, payload, sorted_payload, slab, nslab);
-  else
-    grid_build_set_impl<MORTON, false>(ref, nr, gs, cell_start, sorted, inv, s_cnt, payload, sorted_payload, slab, nslab);
+  grid_build_set_impl<MORTON, VEC>(ref, nr, gs, cell_start, sorted, inv, s_cnt, payload, sorted_payload, slab, nslab);
+}
+
+// every batch element's cloud (base + b * n * 3 floats) is 16-byte aligned
+inline bool clouds_vec_aligned(const void* a, int na, int batch) {
+  return (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (batch <= 1 || na % 4 == 0);
 }
 
 }  // namespace pp

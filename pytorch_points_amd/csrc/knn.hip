@@ -108,6 +108,7 @@ __host__ __device__ inline KnLayout kn_layout(int B, int N, int M) {
   return L;
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(kBuildThreads) void kn_build_kernel(const float* __restrict__ p2,
                                                                  const float* __restrict__ p1,
                                                                  unsigned char* __restrict__ ws, int B, int N,
@@ -123,13 +124,13 @@ __global__ __launch_bounds__(kBuildThreads) void kn_build_kernel(const float* __
   GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
   if (set >= B) {
     const int b = set - B;
-    pp::grid_build_set<true>(p1 + (size_t)b * N * 3, N, gs, nullptr,
+    pp::grid_build_set<true, VEC>(p1 + (size_t)b * N * 3, N, gs, nullptr,
                              reinterpret_cast<pp::f4*>(ws + L.qsorted) + (size_t)b * N, nullptr, s_cnt, nullptr,
                              nullptr, slab, pp::kBuildSlabs);
     return;
   }
   const int b = set;
-  pp::grid_build_set<false>(p2 + (size_t)b * M * 3, M, gs,
+  pp::grid_build_set<false, VEC>(p2 + (size_t)b * M * 3, M, gs,
                             reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
                             reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * M, nullptr, s_cnt, nullptr,
                             nullptr, slab, pp::kBuildSlabs);
@@ -262,9 +263,11 @@ extern "C" int pp_knn_ws_f32(const float* p1, const float* p2, const int* length
   unsigned char* ws = (unsigned char*)workspace;
   static bool lds_ok[64] = {};
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
-  hipError_t e = pp::allow_big_lds(kn_build_kernel, (int)lds, lds_ok);
+  static bool lds_ok_vec[64] = {};
+  const bool vec = pp::clouds_vec_aligned(p1, N, B) && pp::clouds_vec_aligned(p2, M, B);
+  hipError_t e = vec ? pp::allow_big_lds(kn_build_kernel<true>, (int)lds, lds_ok_vec) : pp::allow_big_lds(kn_build_kernel<false>, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  kn_build_kernel<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(p2, p1, ws, B, N, M);
+  (vec ? kn_build_kernel<true> : kn_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(p2, p1, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   int rc;
   if (K <= 1) rc = knn_grid_launch<1>(dist2, idx, ws, B, N, M, K, s);

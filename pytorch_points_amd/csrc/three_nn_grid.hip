@@ -45,6 +45,7 @@ __host__ __device__ inline TnLayout tn_layout(int B, int N, int M) {
 
 // workgroups [0, S*B): slab s of the known points of batch element b into their grid; [S*B, 2*S*B):
 // slab s of the unknown points of batch element b into Morton order (S = kBuildSlabs)
+template <bool VEC>
 __global__ __launch_bounds__(kBuildThreads) void tn_build_kernel(const float* __restrict__ known,
                                                                  const float* __restrict__ unknown,
                                                                  unsigned char* __restrict__ ws, int B, int N,
@@ -60,13 +61,13 @@ __global__ __launch_bounds__(kBuildThreads) void tn_build_kernel(const float* __
   GridSet* gs = reinterpret_cast<GridSet*>(ws + L.sets) + set;
   if (set >= B) {
     const int b = set - B;
-    pp::grid_build_set<true>(unknown + (size_t)b * N * 3, N, gs, nullptr,
+    pp::grid_build_set<true, VEC>(unknown + (size_t)b * N * 3, N, gs, nullptr,
                              reinterpret_cast<pp::f4*>(ws + L.qsorted) + (size_t)b * N, nullptr, s_cnt, nullptr,
                              nullptr, slab, pp::kBuildSlabs);
     return;
   }
   const int b = set;
-  pp::grid_build_set<false>(known + (size_t)b * M * 3, M, gs,
+  pp::grid_build_set<false, VEC>(known + (size_t)b * M * 3, M, gs,
                             reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
                             reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * M, nullptr, s_cnt, nullptr,
                             nullptr, slab, pp::kBuildSlabs);
@@ -168,9 +169,11 @@ extern "C" int pp_three_nn_ws_f32(const float* unknown, const float* known, floa
   unsigned char* ws = (unsigned char*)workspace;
   static bool lds_ok[64] = {};
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
-  hipError_t e = pp::allow_big_lds(tn_build_kernel, (int)lds, lds_ok);
+  static bool lds_ok_vec[64] = {};
+  const bool vec = pp::clouds_vec_aligned(unknown, N, B) && pp::clouds_vec_aligned(known, M, B);
+  hipError_t e = vec ? pp::allow_big_lds(tn_build_kernel<true>, (int)lds, lds_ok_vec) : pp::allow_big_lds(tn_build_kernel<false>, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
-  tn_build_kernel<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(known, unknown, ws, B, N, M);
+  (vec ? tn_build_kernel<true> : tn_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(known, unknown, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   const int tiles = (N + 255) / 256;
   const long long per_xcd = ((long long)B * tiles + 7) / 8;

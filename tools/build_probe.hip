@@ -21,7 +21,7 @@ __global__ __launch_bounds__(pp::kBuildThreads) void probe_kernel(const float* x
   const int V = pp::xcd_virtual_block(blockIdx.x, (nsets * pp::kBuildSlabs + 7) / 8);
   if (V >= nsets * pp::kBuildSlabs) return;
   const int set = V / pp::kBuildSlabs, slab = V % pp::kBuildSlabs;
-  pp::grid_build_set(xyz + (size_t)set * n * 3, n, gs + set, cs + (size_t)set * (pp::kGridCells + 1),
+  pp::grid_build_set<false, true>(xyz + (size_t)set * n * 3, n, gs + set, cs + (size_t)set * (pp::kGridCells + 1),
                      sorted + (size_t)set * n, nullptr, s_cnt, nullptr, nullptr, slab, pp::kBuildSlabs);
 }
 
