@@ -376,16 +376,16 @@ def bench_chamfer(args, dist, world, rank, device):
     if graph_note:
         out["config"]["launch_note"] = graph_note
     if grid:
-        # forward = grid_build_kernel + grid_query_kernel (the dominant one, ~2/3 of the forward) +
-        # the brute-force kernel over the unresolved list; timed together by the HIP events
+        # forward = grid_build_kernel + grid_query_kernel (the dominant one, ~2/3 of the forward; stage A and
+        # the wide stages) + the brute-force kernel over the unresolved list; timed together by the HIP events
         out["roofline"] = {"bound": "hbm", "kernel": "grid_build_kernel + grid_query_kernel + list fallback",
                            "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": hbm_gbs / HBM_PEAK_GBS,
                            # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, summed over the forward's kernels
-                           # (profiles/r1/pmc_summary.txt: build 6.3 + 24.2 MB, stage A 11.6 + 8.2, wide stages
-                           # 4.3 + 0.3); most of it is the search structure itself (sorted clouds + cell tables,
+                           # (profiles/r1/pmc_summary.txt: build 6.2 + 24.2 MB, search 11.6 + 8.0); most of it
+                           # is the search structure itself (sorted clouds + cell tables,
                            # 25 MB, written with scattered 16-byte stores), not re-reads of the inputs
-                           "traffic": 54.9e6 if (B, N, M) == (32, 16384, 16384) else None,
+                           "traffic": 50.0e6 if (B, N, M) == (32, 16384, 16384) else None,
                            "note": "VALU-issue / L2-latency-bound search over a 42 MB workspace (25 MB of it touched per call), not HBM-bound; "
                                    "'bruteforce' carries the every-pair kernel and its VALU roofline"}
         if brute is not None:
