@@ -145,3 +145,70 @@ def test_labeled_grid_search_equals_oracle(cuda, name, labels):
     got = _run_labeled(cuda, x1, x2, l1, l2, 2)
     for g, e, what in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
         assert np.array_equal(g, e), "%s/%s: %s differs at %d places" % (name, labels, what, int((g != e).sum()))
+
+
+@pytest.mark.parametrize("shape,shift", [((3, 4096, 4096), 1), ((3, 4096, 4096), 0), ((2, 4099, 5001), 0),
+                                          ((2, 4099, 5001), 3), ((1, 2300, 2049), 2)])
+def test_alignment_paths_forward_and_backward(cuda, shape, shift):
+    """The grid build and the Chamfer backward each have a 16-byte-load kernel (aligned clouds, point
+    counts that are multiples of 4) and a 4-byte one, picked by the host from pointer alignment and shape.
+    Clouds carved out of a buffer at a 4-byte offset, and point counts that are not multiples of 4 (also not
+    of 256: ragged last tile of the query kernel), must take the scalar paths and give the same bits."""
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd.network.model_loss import nndistance
+    b, n, m = shape
+    x1, x2 = S.unit_sphere(41, b, n), S.unit_sphere(42, b, m)
+
+    def carve(x):  # a contiguous (B, N, 3) view whose first element sits `shift` floats into an allocation
+        buf = torch.empty(x.size + shift + 8, device=cuda)
+        v = buf[shift:shift + x.size].view(x.shape)
+        v.copy_(torch.from_numpy(x).to(cuda))
+        assert v.is_contiguous() and v.data_ptr() % 16 == (4 * shift) % 16
+        return v.requires_grad_(True)
+
+    t1, t2 = carve(x1), carve(x2)
+    setter = _lib.lib().pp_debug_set_nmdistance_search
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(2)
+    try:
+        d1, d2, i1, i2 = nndistance(t1, t2)
+        g1 = torch.from_numpy(S.uniform01(43, (b, n)).reshape(b, n).astype(np.float32)).to(cuda)
+        g2 = torch.from_numpy(S.uniform01(44, (b, m)).reshape(b, m).astype(np.float32)).to(cuda)
+        torch.autograd.backward([d1, d2], [g1, g2])
+        torch.cuda.synchronize()
+    finally:
+        setter(0)
+    e = oracle.chamfer_forward(x1, x2)
+    assert np.array_equal(i1.cpu().numpy(), e[1]) and np.array_equal(i2.cpu().numpy(), e[3])
+    assert np.array_equal(d1.detach().cpu().numpy(), e[0]) and np.array_equal(d2.detach().cpu().numpy(), e[2])
+    r1, r2 = oracle.chamfer_backward(x1, x2, g1.cpu().numpy(), g2.cpu().numpy(), e[1], e[3])
+    # tolerance of the backward (DESIGN.md: same terms, summation order unspecified): 1e-5 relative
+    assert np.allclose(t1.grad.cpu().numpy(), r1, rtol=1e-5, atol=1e-9)
+    assert np.allclose(t2.grad.cpu().numpy(), r2, rtol=1e-5, atol=1e-9)
+
+
+def test_alignment_paths_shared_grid_builds(cuda):
+    """ball_query, three_nn and knn_points build their grids with the same two kernels: unaligned clouds
+    and odd point counts against the oracle."""
+    from pytorch_points_amd._ext import sampling
+    from pytorch_points_amd.ops import knn_points
+    b, n, m = 2, 4099, 1027
+    x, c = S.unit_sphere(51, b, n), S.unit_sphere(52, b, m)
+    for shift in (0, 1):
+        def carve(a):
+            buf = torch.empty(a.size + shift + 8, device=cuda)
+            v = buf[shift:shift + a.size].view(a.shape)
+            v.copy_(torch.from_numpy(a).to(cuda))
+            return v
+        tx, tc = carve(x), carve(c)
+        idx = sampling.ball_query(tc, tx, 0.2, 16)
+        assert np.array_equal(idx.cpu().numpy(), oracle.ball_query(c, x, 0.2, 16))
+        d2 = torch.empty(b, n, 3, device=cuda)
+        i3 = torch.empty(b, n, 3, dtype=torch.int32, device=cuda)
+        sampling.three_nn_wrapper(b, n, m, tx, tc, d2, i3)
+        ed, ei = oracle.three_nn(x, c)
+        assert np.array_equal(i3.cpu().numpy(), ei) and np.array_equal(d2.cpu().numpy(), ed)
+        kn = knn_points(tc, tx, K=4)
+        od, oi = oracle.knn(c, x, 4)
+        assert np.array_equal(kn.idx.cpu().numpy().astype(np.int32), oi) and np.array_equal(kn.dists.cpu().numpy(), od)
