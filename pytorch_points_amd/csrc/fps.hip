@@ -17,6 +17,12 @@
 // coordinates are re-read from L2 every step, one barrier per step (double-buffered LDS slots).
 #include "pp_common.h"
 
+// per-step phase marks of the cluster kernel (tools/fps_probe.hip accumulates clocks; nothing otherwise)
+#ifndef PP_FPS_MARK
+#define PP_FPS_MARK(n)
+#define PP_FPS_MARK_END()
+#endif
+
 namespace {
 
 using pp::dist3;
@@ -46,6 +52,53 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
   return ((unsigned long long)hi << 32) | lo;
+}
+
+// The same maximum as two 32-bit passes -- the high words, then the low words of the lanes that hold the
+// maximal high word -- each a chain of six in-place `v_max_u32_dpp` (lanes without a source keep their
+// value; a nop between dependent DPP operations, which need two wait states after the VALU write): 12
+// VALU instructions instead of the 30 of the 64-bit compare-and-select steps above.  Every lane active.
+template <int STEPS>
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+  static_assert(STEPS == 3 || STEPS == 4 || STEPS == 6, "");
+  if constexpr (STEPS == 3) {  // values in lanes 0..7 -> lane 7
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+        : "+v"(x));
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 7);
+  } else if constexpr (STEPS == 4) {  // values in lanes 0..15 -> lane 15
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+        : "+v"(x));
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 15);
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+        "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+        : "+v"(x));
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+  }
+}
+// STEPS = 6: all 64 lanes; 4: the values sit in lanes 0..15; 3: in lanes 0..7 (what the other lanes hold is
+// ignored: row shifts only move values towards higher lanes)
+template <int STEPS>
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v) {
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mh = wave_max_u32<STEPS>(hi);
+  const unsigned ml = wave_max_u32<STEPS>(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | ml;
 }
 
 struct TieOrder {
@@ -204,29 +257,39 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
   if (c == 0 && t == 0) out[0] = old;
   bool dead = false;
   for (int j = 1; j < npoint; ++j) {
+    PP_FPS_MARK(0);
     const float ox = p[3 * (size_t)old + 0], oy = p[3 * (size_t)old + 1], oz = p[3 * (size_t)old + 2];
     const unsigned tag = (((unsigned)j & 63u) << 1) | 1u;  // odd, 7 bits: never 0, never 0xFF
-    u64 best = tag;  // a workgroup whose slice is empty still publishes a tagged (losing) granule
+    // A thread's points k0 + t + 512 i have tie ranks that grow with i (T = 512 = the stride: the launcher
+    // checks it), so "strictly greater, first wins" over i keeps exactly the point the packed key would:
+    // only the best distance and its slot are tracked per point, the key is built once per thread.
+    // Padding slots carry -1 (min(d, -1) = -1): they beat the initial -2 but produce the losing key below.
+    float bd = -2.0f;
+    int bi = 0;
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const int k = k0 + t + kClThreads * i;
       const float d = dist3(px[i], py[i], pz[i], ox, oy, oz);
       const float d2 = __builtin_fminf(d, td[i]);
       td[i] = d2;
-      // negative (padding) entries produce a key below every real one
-      const u64 key = d2 < 0.0f ? 0ull
-                                : (((u64)__float_as_uint(d2) << 32) |
-                                   ((u64)(0xFFFFFFu - order.rank(k)) << 8) | tag);
-      best = key > best ? key : best;
+      const bool take = d2 > bd;
+      bd = take ? d2 : bd;
+      bi = take ? i : bi;
     }
-    best = wave_max_u64(best);
+    // a workgroup whose slice is empty still publishes a tagged (losing) granule
+    u64 best = bd < 0.0f ? (u64)tag
+                         : (((u64)__float_as_uint(bd) << 32) |
+                            ((u64)(0xFFFFFFu - order.rank(k0 + t + kClThreads * bi)) << 8) | tag);
+    PP_FPS_MARK(1);
+    best = wave_max_key<6>(best);
     if (lane == 0) s_key[j & 1][wave] = best;
     __syncthreads();
+    PP_FPS_MARK(2);
     if (wave == 0) {
       u64 m = s_key[j & 1][lane & (kClWaves - 1)];
-      m = wave_max_u64(m);  // every lane: this workgroup's best
+      m = wave_max_key<3>(m);  // the eight wave results sit in lanes 0..7: three row steps
       gu64* slot = bring + (size_t)(j & 1) * geo.cl;
       if (lane == 0) __hip_atomic_store(slot + c, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      PP_FPS_MARK(3);
       // poll the cluster's granules of this step
       u64 v = m;
       const bool poller = lane < geo.cl && lane != c;
@@ -241,12 +304,14 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
         }
         __builtin_amdgcn_s_sleep(1);
       }
+      PP_FPS_MARK(4);
       if (lane >= geo.cl) v = 0ull;
-      v = wave_max_u64(v);
+      v = wave_max_key<6>(v);
       const unsigned r = 0xFFFFFFu - (unsigned)((v >> 8) & 0xFFFFFFull);
       if (lane == 0) s_old[j & 1] = dead ? -1 : order.unrank(r);
     }
     __syncthreads();
+    PP_FPS_MARK(5);
     old = __builtin_amdgcn_readfirstlane(s_old[j & 1]);
     if (old < 0) {  // timed out: flag and leave (uniform across the workgroup)
       if (t == 0) atomicOr(err, 1u);
@@ -254,6 +319,7 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
     }
     if (c == 0 && t == 0) out[j] = old;
   }
+  PP_FPS_MARK_END();
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int k = k0 + t + kClThreads * i;
@@ -327,7 +393,8 @@ extern "C" int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx,
   order.t_shift = __builtin_ctz((unsigned)T);
   order.rows = (N + T - 1) / T;
   if ((long long)T * order.rows > 0xFFFFFFFELL) return PP_EINVAL;
-  const int cl = g_fps_force_v1 ? 0 : pick_cluster(B, N);
+  // (the cluster kernel's per-thread tie rule assumes the reference's thread count equals its point stride)
+  const int cl = (g_fps_force_v1 || T != kClThreads) ? 0 : pick_cluster(B, N);
   if (cl >= 2 && npoint > 1) {
     const size_t need = pp_furthest_sampling_workspace_bytes(B, N, npoint);
     if (!workspace || workspace_bytes < need) return PP_EINVAL;
