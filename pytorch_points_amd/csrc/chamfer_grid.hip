@@ -444,9 +444,10 @@ extern "C" void pp_debug_set_nmdistance_search(int v) { g_grid_mode = v; }
 
 static bool grid_applicable(int B, int N, int M, int C) {
   if (!(C == 3 && B > 0 && N >= 2048 && M >= 2048 && (long long)B * ((long long)N + M) < (1LL << 31) - 1)) return false;
-  // the search costs ~45 us before the first query is answered; the brute force evaluates ~9e6 pairs per
-  // microsecond (tools/threshold_probe.py): below ~5e8 pairs it is the faster one
-  return g_grid_mode == 2 || (long long)B * N * M >= 250000000LL;
+  // the search costs ~40 us whatever the size; the brute force evaluates ~9e6 pairs per microsecond once it
+  // fills the chip and cannot fill it with a few large clouds (tools/threshold_probe.py: B=8, N=M=4096: 39
+  // vs 51 us; B=4, 4096: 39 vs 37; B=32, 2048: 47 vs 48; B=1, 8192: 38 vs 62)
+  return g_grid_mode == 2 || (long long)B * N * M >= 125000000LL || (N >= 8192 && M >= 8192);
 }
 
 extern "C" size_t pp_nmdistance_forward_workspace_bytes(int B, int N, int M, int C) {
