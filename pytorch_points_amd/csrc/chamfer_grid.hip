@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
   float best = __builtin_inff();
   int bidx = 0x7fffffff;
   bool resolved = false;
+  bool live = valid;  // after the re-deal below: this lane holds a real query
   // Stage A: the 2x2x2 block of cells nearest to q' (own cell + the neighbour on the side of the
   // cell q' lies in, per axis).  A point outside that block is beyond the far face of q''s cell
   // along some axis (>= h/2 away) or beyond the neighbour (>= h away): true distance >= h/2.
@@ -352,6 +353,63 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
     row_range(0, 1, rs1, re1);
     row_range(1, 0, rs2, re2);
     row_range(1, 1, rs3, re3);
+    // What the block guarantees for THIS query: along each axis the nearer face of the block that has
+    // grid beyond it (beyond the grid there are no points).  Lower face: 1 + f cells away when the
+    // block includes cell c-1, f when it starts at c; upper face: 1 - f or 2 - f.  Never below h/2.
+    auto reach1 = [](float f, int s, int c, int gdim) {
+      const float lo = s < 0 ? (c >= 1 ? f + 1.0f : __builtin_inff()) : (c >= 1 ? f : __builtin_inff());
+      const float hi = s < 0 ? (c + 1 <= gdim - 1 ? 1.0f - f : __builtin_inff())
+                             : (c + 1 <= gdim - 1 ? 2.0f - f : __builtin_inff());
+      return fminf(lo, hi);
+    };
+    const float reach = g.h * fminf(reach1(fx, sx, cx, g.gx), fminf(reach1(fy, sy, cy, g.gy), reach1(fz, sz, cz, g.gz)));
+    float thr = reach * reach * kBoundSlack;  // the query is settled if its best distance is below this
+    // The walk below runs, per wave, as long as the wave's LONGEST candidate list, and the lists differ a
+    // lot between neighbours (rocprofv3 counters at config 2: 13.5 groups walked per wave for a mean of
+    // ~5 per query; lanes that have finished keep re-examining point 0).  The lists' lengths are known
+    // here, before the first point is touched, so the workgroup's 256 queries are first re-dealt to the
+    // lanes in order of length (a counting sort through LDS: 32 buckets by number of groups, 13 words of
+    // state per query): each wave then walks queries of about the same length.  The queries of a tile are
+    // close in space whatever the order, so the candidates stay cache-resident.
+    {
+      constexpr int kWords = LAB ? 14 : 13;
+      __shared__ unsigned s_hist[32], s_base[32];
+      __shared__ unsigned s_st[kWords][256];
+      const int t = threadIdx.x;
+      auto groups_of = [](unsigned s_, unsigned e_) { return (e_ - s_ + 3) >> 2; };
+      const unsigned ng = valid ? groups_of(rs0, re0) + groups_of(rs1, re1) + groups_of(rs2, re2) + groups_of(rs3, re3) : 0u;
+      const unsigned key = min(ng, 31u);
+      if (t < 32) s_hist[t] = 0u;
+      __syncthreads();
+      const unsigned pos = atomicAdd(&s_hist[key], 1u);
+      __syncthreads();
+      if (t < 64) {  // exclusive prefix of the 32 bucket counts
+        const unsigned h = t < 32 ? s_hist[t] : 0u;
+        unsigned incl = h;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+          const unsigned o = __shfl_up(incl, off);
+          if (t >= off) incl += o;
+        }
+        if (t < 32) s_base[t] = incl - h;
+      }
+      __syncthreads();
+      const unsigned dest = s_base[key] + pos;
+      s_st[0][dest] = __float_as_uint(qx); s_st[1][dest] = __float_as_uint(qy); s_st[2][dest] = __float_as_uint(qz);
+      s_st[3][dest] = (unsigned)(valid ? j : -1);
+      s_st[4][dest] = __float_as_uint(thr);
+      s_st[5][dest] = rs0; s_st[6][dest] = rs1; s_st[7][dest] = rs2; s_st[8][dest] = rs3;
+      s_st[9][dest] = re0; s_st[10][dest] = re1; s_st[11][dest] = re2; s_st[12][dest] = re3;
+      if (LAB) s_st[kWords - 1][dest] = __float_as_uint(ql);
+      __syncthreads();
+      qx = __uint_as_float(s_st[0][t]); qy = __uint_as_float(s_st[1][t]); qz = __uint_as_float(s_st[2][t]);
+      j = (int)s_st[3][t];
+      thr = __uint_as_float(s_st[4][t]);
+      rs0 = s_st[5][t]; rs1 = s_st[6][t]; rs2 = s_st[7][t]; rs3 = s_st[8][t];
+      re0 = s_st[9][t]; re1 = s_st[10][t]; re2 = s_st[11][t]; re3 = s_st[12][t];
+      if (LAB) ql = __uint_as_float(s_st[kWords - 1][t]);
+      live = j >= 0;
+    }
     // The four rows are walked as ONE sequence of groups of four points: a lane's rows hold t_r =
     // ceil(len_r / 4) groups each, group k of the sequence belongs to the row r with T_r <= k < T_{r+1}
     // (T = running sums) and starts at rs_r + 4 (k - T_r).  k is wave-uniform, so the wave runs
@@ -386,23 +444,13 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
       fetch(k + 2, pa, la);
       examine(pb, lb);
     }
-    // What the block guarantees for THIS query: along each axis the nearer face of the block that has
-    // grid beyond it (beyond the grid there are no points).  Lower face: 1 + f cells away when the
-    // block includes cell c-1, f when it starts at c; upper face: 1 - f or 2 - f.  Never below h/2.
-    auto reach1 = [](float f, int s, int c, int gdim) {
-      const float lo = s < 0 ? (c >= 1 ? f + 1.0f : __builtin_inff()) : (c >= 1 ? f : __builtin_inff());
-      const float hi = s < 0 ? (c + 1 <= gdim - 1 ? 1.0f - f : __builtin_inff())
-                             : (c + 1 <= gdim - 1 ? 2.0f - f : __builtin_inff());
-      return fminf(lo, hi);
-    };
-    const float reach = g.h * fminf(reach1(fx, sx, cx, g.gx), fminf(reach1(fy, sy, cy, g.gy), reach1(fz, sz, cz, g.gz)));
-    resolved = best < reach * reach * kBoundSlack;
+    resolved = best < thr;
   }
   // Results go straight to the query's original position: two scattered 4-byte stores per query.
   // (Measured against leaving them in walked order, coalesced, plus an inverse permutation written by
   // the build and an unsort pass: the direct form is 4 us faster per forward at config 2 and needs
   // 12 bytes less workspace per point.)
-  if (resolved && valid) {
+  if (resolved && live) {
     (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
     (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
   }
@@ -410,7 +458,7 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
   // spot, one after the other, by the whole wave (wide_stages_wave): no second list, no second launch
   // (a separate kernel over the compacted leftovers cost 7 us of launch and tail per forward).  What the
   // cube of radius 2 cannot settle either goes to the brute-force list.
-  unsigned long long pending = __ballot(!resolved && valid);
+  unsigned long long pending = __ballot(!resolved && live);
   while (pending) {  // wave-uniform
     const int l = (int)__builtin_ctzll(pending);
     pending &= pending - 1;
