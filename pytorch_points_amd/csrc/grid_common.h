@@ -152,14 +152,28 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   float sm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // sum x, y, z; sum x^2, y^2, z^2
   for (int ch = 0; ch < nchunks; ++ch) {
     if (ch > 0) load_chunk(ch * kBuildThreads * KP);
+    // (the moments only steer the outlier heuristic -- every slab computes the same ones -- so they may use
+    // fused multiply-adds; a full chunk, the usual case, needs no per-point "is this a real point" factor:
+    // 12 instead of 23 VALU operations per point in a kernel that is bound by VALU issue)
+    if ((ch + 1) * kBuildThreads * KP <= nr) {
 #pragma unroll
-    for (int i = 0; i < KP; ++i) {
-      const float x = px[i], y = py[i], z = pz[i];
-      mnx = fminf(mnx, x); mny = fminf(mny, y); mnz = fminf(mnz, z);
-      mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y); mxz = fmaxf(mxz, z);
-      const float live = kidx(ch * kBuildThreads * KP, i) < nr ? 1.0f : 0.0f;
-      sm[0] += live * x; sm[1] += live * y; sm[2] += live * z;
-      sm[3] += live * x * x; sm[4] += live * y * y; sm[5] += live * z * z;
+      for (int i = 0; i < KP; ++i) {
+        const float x = px[i], y = py[i], z = pz[i];
+        mnx = fminf(mnx, x); mny = fminf(mny, y); mnz = fminf(mnz, z);
+        mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y); mxz = fmaxf(mxz, z);
+        sm[0] += x; sm[1] += y; sm[2] += z;
+        sm[3] = __builtin_fmaf(x, x, sm[3]); sm[4] = __builtin_fmaf(y, y, sm[4]); sm[5] = __builtin_fmaf(z, z, sm[5]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < KP; ++i) {
+        const float x = px[i], y = py[i], z = pz[i];
+        mnx = fminf(mnx, x); mny = fminf(mny, y); mnz = fminf(mnz, z);
+        mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y); mxz = fmaxf(mxz, z);
+        const float live = kidx(ch * kBuildThreads * KP, i) < nr ? 1.0f : 0.0f;
+        sm[0] += live * x; sm[1] += live * y; sm[2] += live * z;
+        sm[3] += live * x * x; sm[4] += live * y * y; sm[5] += live * z * z;
+      }
     }
   }
   PP_PHASE(1);
@@ -287,10 +301,14 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
           const int c = cell_linear(cell_coord(px[i], mnx, invh, gx), cell_coord(py[i], mny, invh, gy),
                                     cell_coord(pz[i], mnz, invh, gz), gx, gy);
           atomicOr(&s_occ[c >> 5], 1u << (c & 31));
-          s_cid[i * kBuildThreads + t] = c;  // kept for the scatter when the cloud is a single chunk (the last round's value)
           const int cl = c - lo;
           below += cl < 0 ? 1u : 0u;
-          if ((unsigned)cl < (unsigned)nl) atomicAdd(&s_cnt[sk(cl)], 1u);
+          const bool mine = (unsigned)cl < (unsigned)nl;
+          const int slot = sk(cl);
+          // kept for the scatter when the cloud is a single chunk (the last round's value): the counter of
+          // the point's cell if the cell is this slab's, else -1 -- the scatter then recomputes nothing
+          s_cid[i * kBuildThreads + t] = mine ? slot : -1;
+          if (mine) atomicAdd(&s_cnt[slot], 1u);
         };
         if ((ch + 1) * kBuildThreads * KP <= nr) {  // uniform: a full chunk needs no per-point bounds test
 #pragma unroll
@@ -401,12 +419,17 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
         unsigned pos[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int cc = (nchunks == 1 ? s_cid[(i0 + i) * kBuildThreads + t]
-                                       : cell_of(px[i0 + i], py[i0 + i], pz[i0 + i])) - cell_lo;
-          c[i] = (kidx(ch * kBuildThreads * KP, i0 + i) < nr && cc >= 0 && cc < nloc) ? cc : -1;
+          if (counted && nchunks == 1) {  // (uniform) the occupancy pass left the counter's index, or -1
+            c[i] = s_cid[(i0 + i) * kBuildThreads + t];  // (entries of points beyond nr were never written
+            if (kidx(ch * kBuildThreads * KP, i0 + i) >= nr) c[i] = -1;  //  in that pass: mask them here)
+          } else {
+            const int cc = (nchunks == 1 ? s_cid[(i0 + i) * kBuildThreads + t]
+                                         : cell_of(px[i0 + i], py[i0 + i], pz[i0 + i])) - cell_lo;
+            c[i] = (kidx(ch * kBuildThreads * KP, i0 + i) < nr && cc >= 0 && cc < nloc) ? sk(cc) : -1;
+          }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pos[i] = c[i] >= 0 ? atomicAdd(&s_cnt[sk(c[i])], 1u) : 0u;
+        for (int i = 0; i < 4; ++i) pos[i] = c[i] >= 0 ? atomicAdd(&s_cnt[c[i]], 1u) : 0u;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (c[i] >= 0) {
