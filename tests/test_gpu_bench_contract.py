@@ -1,0 +1,66 @@
+"""bench.py keeps its contract with the driver: one JSON line on stdout with the agreed fields, for every
+workload (small sizes here; the numbers are not checked, the shape of the line is)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+          "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", *extra],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_common(d, steps=3, warmup=1):
+    for k in COMMON:
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+
+
+def test_chamfer_line(cuda):
+    d = _run("--batch", "8", "--points", "4096")
+    _check_common(d)
+    assert d["metric"] == "chamfer_fwd_bwd_point_pairs_per_s" and d["unit"] == "pairs/s"
+    modes = d["launch_modes_ms_per_step"]
+    assert {"ext", "eager"} <= set(modes) and all(modes[k] > 0 for k in ("ext", "eager"))
+    # the timed value is whole-job pairs per second of the step it reports
+    assert abs(d["value"] - 2.0 * 8 * 4096 * 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    base = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in base, k
+    assert base["kind"] == "port" and base["cores"] >= 1
+
+
+def test_chamfer_launch_modes_agree_on_the_shape_of_the_line(cuda):
+    for mode in ("graph", "ext", "eager"):
+        d = _run("--batch", "8", "--points", "4096", "--launch", mode, "--no-cpu-baseline")
+        _check_common(d)
+        assert "cpu_baseline" not in d
+
+
+def test_fps_and_ball_group_lines(cuda):
+    d = _run("--workload", "fps", "--batch", "4", "--points", "8192")
+    _check_common(d)
+    assert d["metric"] == "fps_point_updates_per_s"
+    d = _run("--workload", "ball_group")
+    _check_common(d)
+    assert d["metric"] == "group_points_output_bytes_per_s" and 0.0 < d["roofline"]["frac"] < 1.0
