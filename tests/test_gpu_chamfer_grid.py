@@ -212,3 +212,17 @@ def test_alignment_paths_shared_grid_builds(cuda):
         kn = knn_points(tc, tx, K=4)
         od, oi = oracle.knn(c, x, 4)
         assert np.array_equal(kn.idx.cpu().numpy().astype(np.int32), oi) and np.array_equal(kn.dists.cpu().numpy(), od)
+
+
+def test_large_clouds_multi_chunk_build(cuda):
+    """Clouds beyond 16384 points take the build's multi-chunk path (points re-read per pass, no cached cell
+    slots) and put ~10x more points into every cell of the 32^3 grid: grid search == brute-force kernel ==
+    oracle, bit for bit, on odd sizes."""
+    x1, x2 = S.unit_sphere(61, 2, 40000), S.unit_sphere(62, 2, 70001)
+    got = _run(cuda, x1, x2, 2)
+    brute = _run(cuda, x1, x2, 1)
+    for a, b in zip(got, brute):
+        assert np.array_equal(a, b)
+    e = oracle.chamfer_forward(x1, x2)
+    assert np.array_equal(got[1], e[1]) and np.array_equal(got[3], e[3])
+    assert np.array_equal(got[0], e[0]) and np.array_equal(got[2], e[2])
