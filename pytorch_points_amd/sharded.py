@@ -107,6 +107,15 @@ class PackedShardGather:
                      for _ in range(depth)]
         self.inflight = [None] * depth
         self.turn = 0
+        # GPU buffers: the gathered bytes are unpacked (indices widened to int32, rank-major global batch) on
+        # a SIDE stream right behind the collective, into per-slot outputs allocated once -- at 8 ranks that
+        # is ~110 MiB of traffic per step that the stream issuing the searches never executes; it only waits
+        # for the slot's event when the result is asked for
+        self.on_gpu = self.send[0].is_cuda
+        if self.on_gpu:
+            self.side = torch.cuda.Stream(device=self.send[0].device)
+            self.done = [torch.cuda.Event() for _ in range(depth)]
+            self.out = [None] * depth
 
     def _views(self, buf):
         """(d1, d2, i1, i2) views of one rank's packed bytes (1-D uint8)"""
@@ -124,8 +133,7 @@ class PackedShardGather:
         slot = self.turn
         self.turn = (self.turn + 1) % len(self.send)
         if self.inflight[slot] is not None:   # the buffers of this slot are about to be overwritten
-            self.inflight[slot].wait()
-            self.inflight[slot] = None
+            self._finish(slot)
         if self._hip(self.send[slot]):
             from . import _lib
             d1 = d1.detach().contiguous(); d2 = d2.detach().contiguous()
@@ -146,29 +154,50 @@ class PackedShardGather:
             work = dist.all_gather(list(self.recv[slot].unbind(0)), self.send[slot], group=self.group,
                                    async_op=True)
         self.inflight[slot] = work
+        if self.on_gpu:
+            self._unpack_on_side_stream(slot, work)
         return slot
 
-    def wait(self, slot):
-        """Blocks the current stream (not the host, on RCCL) until the gather of ``slot`` is done and
-        returns (dist1, dist2, idx1, idx2) of the global batch in rank order."""
-        if self.inflight[slot] is not None:
-            self.inflight[slot].wait()
-            self.inflight[slot] = None
+    def _finish(self, slot):
+        """the current stream (GPU) or the host (CPU tensors) waits until the slot's exchange is complete"""
+        h = self.inflight[slot]
+        if h is None:
+            return
+        if self.on_gpu:
+            torch.cuda.current_stream(self.send[slot].device).wait_event(self.done[slot])
+        else:
+            h.wait()
+        self.inflight[slot] = None
+
+    def _unpack_on_side_stream(self, slot, work):
+        from . import _lib
         r = self.recv[slot]
-        o = self.off
+        dev = r.device
         w, b = self.world, self.b
-        if self._hip(r):
-            from . import _lib
-            dev = r.device
-            d1 = torch.empty(w * b, self.n, dtype=torch.float32, device=dev)
-            d2 = torch.empty(w * b, self.m, dtype=torch.float32, device=dev)
-            i1 = torch.empty(w * b, self.n, dtype=torch.int32, device=dev)
-            i2 = torch.empty(w * b, self.m, dtype=torch.int32, device=dev)
-            with _lib.on_device(dev) as stream:
+        if self.out[slot] is None:
+            self.out[slot] = (torch.empty(w * b, self.n, dtype=torch.float32, device=dev),
+                              torch.empty(w * b, self.m, dtype=torch.float32, device=dev),
+                              torch.empty(w * b, self.n, dtype=torch.int32, device=dev),
+                              torch.empty(w * b, self.m, dtype=torch.int32, device=dev))
+        d1, d2, i1, i2 = self.out[slot]
+        with torch.cuda.stream(self.side):
+            work.wait()   # RCCL: the side stream waits for the collective (no host block); gloo: the host does
+            with _lib.on_device(dev) as stream:   # the current stream is the side stream here
                 _lib.check(_lib.lib().pp_shard_unpack_f32(
                     _lib.ptr(r), w, self.nbytes_padded, b * self.n, b * self.m, 1 if self.compact else 0,
                     _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2), stream), "shard_unpack")
-            return d1, d2, i1, i2
+            self.done[slot].record(self.side)
+
+    def wait(self, slot):
+        """Blocks the current stream (not the host, on RCCL) until the gather of ``slot`` is done and unpacked,
+        and returns (dist1, dist2, idx1, idx2) of the global batch in rank order.  On the GPU these are the
+        slot's own buffers: valid until the slot is launched again (``depth`` launches later)."""
+        self._finish(slot)
+        r = self.recv[slot]
+        o = self.off
+        w, b = self.world, self.b
+        if self.on_gpu:   # unpacked on the side stream already; valid until the slot is launched again
+            return self.out[slot]
         d1 = r[:, o[0]:o[1]].view(torch.float32).reshape(w * b, self.n)
         d2 = r[:, o[1]:o[2]].view(torch.float32).reshape(w * b, self.m)
         if self.compact:
@@ -180,7 +209,5 @@ class PackedShardGather:
         return d1, d2, i1, i2
 
     def drain(self):
-        for s, h in enumerate(self.inflight):
-            if h is not None:
-                h.wait()
-                self.inflight[s] = None
+        for s in range(len(self.inflight)):
+            self._finish(s)

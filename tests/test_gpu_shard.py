@@ -43,3 +43,47 @@ def test_shard_pack_unpack_roundtrip(cuda, b, n, m):
     else:
         i = row[4 * b * (n + m): 8 * b * (n + m)].view(torch.int32)
     assert torch.equal(i[: b * n], I1[b:2 * b].reshape(-1).cpu()) and torch.equal(i[b * n:], I2[b:2 * b].reshape(-1).cpu())
+
+
+_ONE_RANK_EXCHANGE = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pytorch_points_amd.sharded import PackedShardGather
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+dev = torch.device("cuda:0")
+B, N, M = 3, 5000, 70000                                  # M > 65536: 32-bit indices; then a 16-bit case
+for (n, m) in ((N, M), (4096, 2048)):
+    ex = PackedShardGather(B, n, m, dev)
+    gen = torch.Generator(device="cpu").manual_seed(n)
+    steps = []
+    for s in range(5):                                     # more launches than slots: the slots are reused
+        d1 = torch.rand(B, n, generator=gen).to(dev); d2 = torch.rand(B, m, generator=gen).to(dev)
+        i1 = torch.randint(0, m, (B, n), generator=gen, dtype=torch.int32).to(dev)
+        i2 = torch.randint(0, n, (B, m), generator=gen, dtype=torch.int32).to(dev)
+        h = ex.launch(d1, d2, i1, i2)
+        # something else on the launch stream while the exchange runs beside it
+        torch.empty(1 << 22, device=dev).normal_()
+        g = ex.wait(h)
+        for a, e in zip(g, (d1, d2, i1, i2)):
+            assert a.dtype == e.dtype and torch.equal(a, e), (n, m, s)
+    ex.drain()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("exchange ok")
+"""
+
+
+def test_packed_exchange_on_one_rank_rccl_group(cuda, tmp_path):
+    """PackedShardGather on the GPU path proper: RCCL all-gather (a one-rank group: this box has one GPU),
+    unpack on the side stream into the slot's buffers, slot reuse, 16- and 32-bit indices.  In a subprocess:
+    the process group must not leak into the other tests."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "one_rank_exchange.py"
+    script.write_text(_ONE_RANK_EXCHANGE)
+    out = subprocess.run([sys.executable, str(script), root, "29541"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "exchange ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
