@@ -254,10 +254,14 @@ __device__ __forceinline__ void stage_a_fetch(unsigned k, unsigned T1, unsigned 
   // that nothing in the loop is conditional and the compiler can count the loads in flight exactly
   const unsigned last = live ? (a ? last0 : (b2 ? last1 : (c ? last2 : last3))) : 0u;
   const unsigned i = live ? adj + 4 * k : 0u;
+  // (32-bit byte offsets from the wave-uniform bases: one VGPR per address instead of two)
+  const char* __restrict__ sp = reinterpret_cast<const char*>(sorted);
+  const char* __restrict__ lp = reinterpret_cast<const char*>(slab);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    p[u] = sorted[min(i + u, last)];
-    if (LAB) pl[u] = slab[min(i + u, last)];
+    const unsigned e = min(i + u, last);
+    p[u] = *reinterpret_cast<const pp::f4*>(sp + (e << 4));
+    if (LAB) pl[u] = *reinterpret_cast<const float*>(lp + (e << 2));
   }
 }
 
