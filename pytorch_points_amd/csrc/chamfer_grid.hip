@@ -434,7 +434,9 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
       for (int u = 0; u < 4; ++u) {
         const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
         const int id = __float_as_int(p[u].w);
-        const bool take = (!LAB || pl[u] == ql) && (d < best || (d == best && id < bidx));
+        // (bitwise, not short-circuit: the compiler turns `||` / `&&` into exec-mask branches, five scalar
+        // instructions and two branches per candidate for a tie that almost never happens)
+        const bool take = (!LAB || pl[u] == ql) & ((d < best) | ((d == best) & (id < bidx)));
         best = take ? d : best;
         bidx = take ? id : bidx;
       }
