@@ -33,12 +33,13 @@ struct KList {
     }
   }
   __device__ __forceinline__ bool beats_last(float nd, int ni) const {
-    return nd < d[KT - 1] || (nd == d[KT - 1] && ni < i[KT - 1]);
+    // (bitwise operators here and in insert(): hipcc turns the short-circuit forms into exec-mask branches)
+    return (nd < d[KT - 1]) | ((nd == d[KT - 1]) & (ni < i[KT - 1]));
   }
   __device__ __forceinline__ void insert(float nd, int ni) {
     bool lt[KT];
 #pragma unroll
-    for (int j = 0; j < KT; ++j) lt[j] = nd < d[j] || (nd == d[j] && ni < i[j]);
+    for (int j = 0; j < KT; ++j) lt[j] = (nd < d[j]) | ((nd == d[j]) & (ni < i[j]));
 #pragma unroll
     for (int j = KT - 1; j >= 1; --j) {
       d[j] = lt[j - 1] ? d[j - 1] : (lt[j] ? nd : d[j]);

@@ -76,9 +76,10 @@ __global__ __launch_bounds__(kBuildThreads) void tn_build_kernel(const float* __
 // (d, k) enters the ascending triple if it is lexicographically smaller than an entry
 __device__ __forceinline__ void insert3(float d, int k, float& b1, float& b2, float& b3, int& i1, int& i2,
                                         int& i3) {
-  const bool l1 = d < b1 || (d == b1 && k < i1);
-  const bool l2 = d < b2 || (d == b2 && k < i2);
-  const bool l3 = d < b3 || (d == b3 && k < i3);
+  // (bitwise operators: hipcc turns the short-circuit forms into exec-mask branches)
+  const bool l1 = (d < b1) | ((d == b1) & (k < i1));
+  const bool l2 = (d < b2) | ((d == b2) & (k < i2));
+  const bool l3 = (d < b3) | ((d == b3) & (k < i3));
   b3 = l2 ? b2 : (l3 ? d : b3);
   i3 = l2 ? i2 : (l3 ? k : i3);
   b2 = l1 ? b1 : (l2 ? d : b2);
