@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void labeled_nmdist_fwd_kernel(
     const float qx = qp[0], qy = qp[1], qz = qp[2];
     for (int k = 0; k < nr; ++k) {
       const float d = chamfer_d3(ref[3 * (size_t)k], ref[3 * (size_t)k + 1], ref[3 * (size_t)k + 2], qx, qy, qz);
-      const bool take = (l1 == rl[k]) && (bi < 0 || d < best);
+      const bool take = (l1 == rl[k]) & ((bi < 0) | (d < best));  // (bitwise: no exec-mask branches)
       best = take ? d : best;
       bi = take ? k : bi;
     }
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void labeled_nmdist_fwd_kernel(
         const float t = rp[e] - qp[e];
         d = __builtin_fmaf(t, t, d);
       }
-      const bool take = (l1 == rl[k]) && (bi < 0 || d < best);
+      const bool take = (l1 == rl[k]) & ((bi < 0) | (d < best));  // (bitwise: no exec-mask branches)
       best = take ? d : best;
       bi = take ? k : bi;
     }
