@@ -178,8 +178,14 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(float* __restrict__ dist,
     for (int z = z0; z <= z1; ++z)
       for (int y = y0; y <= y1; ++y) {
         const int c = (z * g.gy + y) * g.gx;
-        const unsigned e = cell_start[c + x1 + 1];
-        for (unsigned i = cell_start[c + x0]; i < e; ++i) {
+        // (one 16-byte load for both bounds of a row up to three cells wide: see three_nn_grid.hip)
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        u4 v;
+        __builtin_memcpy(&v, cell_start + c + x0, sizeof(v));
+        const int wd = x1 + 1 - x0;
+        unsigned e = wd == 1 ? v.y : (wd == 2 ? v.z : v.w);
+        if (wd > 3) e = cell_start[c + x1 + 1];
+        for (unsigned i = v.x; i < e; ++i) {
           const pp::f4 p = sorted[i];
           const float d = pp::chamfer_d3(p.x, p.y, p.z, q.x, q.y, q.z);
           const int id = __float_as_int(p.w);

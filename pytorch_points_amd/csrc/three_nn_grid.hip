@@ -129,8 +129,16 @@ __global__ __launch_bounds__(256) void tn_query_kernel(float* __restrict__ dist2
     for (int z = z0; z <= z1; ++z)
       for (int y = y0; y <= y1; ++y) {
         const int c = (z * g.gy + y) * g.gx;
-        const unsigned e = cell_start[c + x1 + 1];
-        for (unsigned i = cell_start[c + x0]; i < e; i += 2) {
+        // a row's two bounds are a few table entries apart: up to three cells wide (the usual first round)
+        // ONE 16-byte load fetches both (the entries after a set's table are the next set's or the sorted
+        // cloud: valid memory); this kernel is bound by the L1's handling of scattered loads
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        u4 v;
+        __builtin_memcpy(&v, cell_start + c + x0, sizeof(v));
+        const int wd = x1 + 1 - x0;
+        unsigned e = wd == 1 ? v.y : (wd == 2 ? v.z : v.w);
+        if (wd > 3) e = cell_start[c + x1 + 1];
+        for (unsigned i = v.x; i < e; i += 2) {
           const pp::f4 p0 = sorted[i];
           const pp::f4 p1 = sorted[min(i + 1, e - 1)];
           insert3(pp::dist3(q.x, q.y, q.z, p0.x, p0.y, p0.z), __float_as_int(p0.w), b1, b2, b3, i1, i2, i3);
