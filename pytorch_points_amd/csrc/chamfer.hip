@@ -38,36 +38,20 @@ constexpr int kBlock = 64 * kWavesPerBlock;
 // operations per element, so the bits do not change; measured on MI355X a v_sub_f32 with an SGPR
 // operand issues at half the rate of the VGPR-only form while v_pk_add_f32 with an SGPR source
 // does two subtractions in the same slot (tools/valu_microbench2.hip, DESIGN.md "VALU roof").
-// LIST: the queries of a set are not 0..nq-1 but the `qcount[set]` indices stored in
-// qlist[set's query offset ...] (the grid search's unresolved queries, chamfer_grid.hip); tiles
-// beyond the list exit at once.
 // LAB: labeled Chamfer (ref LabeledNmDistanceKernel, nmdistance_cuda.cu:55-115): a reference point
 // is a candidate only if its label equals the query's (compared as floats, :89) -- its distance
 // is replaced by +inf otherwise (one v_cmp_eq + one v_cndmask per pair); a query whose minimum is
 // still +inf has no candidate: idx -1, dist 0 (:110-113).
-// SPLIT > 0 (with LIST): the tile's scan is shared by SPLIT workgroups, each taking a slice of the
-// reference cloud and merging its (distance, index) pairs into a 64-bit key per listed query with a
-// global atomic min -- the packed pair orders like (distance, index), i.e. like the scan itself; the
-// workgroup that finishes a tile last writes the results.  A handful of listed queries then costs a
-// sixteenth of a cloud scan in latency instead of a whole one (chamfer_grid.hip).
-constexpr int kListSplit = 16;   // workgroups per listed tile
-constexpr int kListSlots = 32;   // workgroups launched per set; each walks its share of (tile, slice) items
-typedef unsigned long long u64k;
-
-template <int Q, int G, bool PK, bool PF, bool LIST, bool LAB, int SPLIT>
+template <int Q, int G, bool PK, bool PF, bool LAB>
 __device__ __forceinline__ void nmdist_tile(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
     int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M, const int b,
-    const bool second, const int tile, const int split, const int* __restrict__ qlist,
-    const int* __restrict__ qcount, const float* __restrict__ label1, const float* __restrict__ label2,
-    u64k* __restrict__ lkey, int* __restrict__ ldone, int ldone_index, int nsplit) {
+    const bool second, const int tile, const float* __restrict__ label1, const float* __restrict__ label2) {
   static_assert(!(LAB && PF), "labels are not combined with the prefetch form");
   static_assert(G % 2 == 0, "groups are consumed two reference points per v_min3");
-  static_assert(SPLIT == 0 || LIST, "slices are for listed queries");
   constexpr int TQ = 64 * Q;  // queries per workgroup
   __shared__ float s_best[kWavesPerBlock][TQ];
   __shared__ int s_idx[kWavesPerBlock][TQ];
-  __shared__ int s_last;
 
   const int nq = second ? M : N;
   const int nr = second ? N : M;
@@ -76,13 +60,7 @@ __device__ __forceinline__ void nmdist_tile(
 
   const int wave = pp::wave_id_uniform();
   const int lane = threadIdx.x & 63;
-  int count = nq;
-  const int* __restrict__ ql = nullptr;
-  if constexpr (LIST) {
-    count = qcount[2 * b + (second ? 1 : 0)];
-    if (tile * TQ >= count) return;  // uniform per workgroup
-    ql = qlist + (size_t)b * ((size_t)N + M) + (second ? (size_t)N : 0);
-  }
+  const int count = nq;
 
   const float* __restrict__ qlab = LAB ? (second ? label2 : label1) + (size_t)b * nq : nullptr;
   const float* __restrict__ rlab = LAB ? (second ? label1 : label2) + (size_t)b * nr : nullptr;
@@ -92,7 +70,6 @@ __device__ __forceinline__ void nmdist_tile(
   for (int i = 0; i < Q; ++i) {
     int j = tile * TQ + i * 64 + lane;
     j = j < count ? j : count - 1;  // clamp: out-of-range lanes compute a valid query, never stored
-    if constexpr (LIST) j = ql[j];
     lq[i] = LAB ? qlab[j] : 0.0f;
     qx[i] = qry[3 * (size_t)j + 0];
     qy[i] = qry[3 * (size_t)j + 1];
@@ -103,11 +80,8 @@ __device__ __forceinline__ void nmdist_tile(
 
   // ---- grouped scan of this wave's quarter of the reference cloud -----------------------------
   const int ngroups = nr / G;
-  // the groups of this workgroup's slice (all of them without SPLIT), then this wave's quarter of those
-  const int gs0 = SPLIT > 0 ? (int)(((long long)ngroups * split) / nsplit) : 0;
-  const int gs1 = SPLIT > 0 ? (int)(((long long)ngroups * (split + 1)) / nsplit) : ngroups;
-  const int g0 = gs0 + (int)(((long long)(gs1 - gs0) * wave) / kWavesPerBlock);
-  const int g1 = gs0 + (int)(((long long)(gs1 - gs0) * (wave + 1)) / kWavesPerBlock);
+  const int g0 = (int)(((long long)ngroups * wave) / kWavesPerBlock);  // this wave's quarter of the groups
+  const int g1 = (int)(((long long)ngroups * (wave + 1)) / kWavesPerBlock);
   auto load_group = [&](float (&rr)[G * 3], int g) {
     const float* __restrict__ rp = ref + (size_t)g * (G * 3);  // wave-uniform -> s_load
 #pragma unroll
@@ -209,7 +183,7 @@ __device__ __forceinline__ void nmdist_tile(
   }
 
   // ---- tail (nr % G points, highest indices): exact compare/select, done by the last wave ------
-  if (wave == kWavesPerBlock - 1 && (SPLIT == 0 || split == nsplit - 1)) {
+  if (wave == kWavesPerBlock - 1) {
     for (int k = ngroups * G; k < nr; ++k) {
       const float rx = ref[3 * (size_t)k + 0], ry = ref[3 * (size_t)k + 1], rz = ref[3 * (size_t)k + 2];
       const float rlk = LAB ? rlab[k] : 0.0f;
@@ -246,56 +220,22 @@ __device__ __forceinline__ void nmdist_tile(
     }
     int j = tile * TQ + e;
     if (j < count) {
-      if (SPLIT > 0 && nsplit > 1) {
-        // (distance bits, index): unsigned order == (distance, index) order for distances >= +0
-        const u64k key = ((u64k)__float_as_uint(bb) << 32) | (u64k)(unsigned)bi;
-        atomicMin(lkey + (size_t)b * ((size_t)N + M) + (second ? (size_t)N : 0) + j, key);
-      } else {
-        if constexpr (LIST) j = ql[j];
-        if constexpr (LAB) {
-          const bool none = !(bb < __builtin_inff());  // no reference point with this query's label
-          bb = none ? 0.0f : bb;
-          bi = none ? -1 : bi;
-        }
-        od[j] = bb;
-        oi[j] = bi;
+      if constexpr (LAB) {
+        const bool none = !(bb < __builtin_inff());  // no reference point with this query's label
+        bb = none ? 0.0f : bb;
+        bi = none ? -1 : bi;
       }
-    }
-  }
-  if (SPLIT > 0 && nsplit > 1) {
-    // the workgroup that finishes the tile last turns the keys into results
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(ldone + ldone_index, 1) == nsplit - 1 ? 1 : 0;
-    __syncthreads();
-    if (s_last) {
-      const u64k* keys = lkey + (size_t)b * ((size_t)N + M) + (second ? (size_t)N : 0);
-      for (int e = threadIdx.x; e < TQ; e += kBlock) {
-        const int pos = tile * TQ + e;
-        if (pos < count) {
-          const u64k key = __hip_atomic_load(keys + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          float bb = __uint_as_float((unsigned)(key >> 32));
-          int bi = (int)(unsigned)(key & 0xFFFFFFFFull);
-          if constexpr (LAB) {
-            const bool none = !(bb < __builtin_inff());
-            bb = none ? 0.0f : bb;
-            bi = none ? -1 : bi;
-          }
-          od[ql[pos]] = bb;
-          oi[ql[pos]] = bi;
-        }
-      }
-      if (threadIdx.x == 0) ldone[ldone_index] = 0;  // ready for the next call
+      od[j] = bb;
+      oi[j] = bi;
     }
   }
 }
 
-template <int Q, int G, bool PK, bool PF, bool LIST = false, bool LAB = false>
+template <int Q, int G, bool PK, bool PF, bool LAB = false>
 __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
     int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M,
-    int tiles1, int tiles2, int total, int per_xcd, const int* __restrict__ qlist = nullptr,
-    const int* __restrict__ qcount = nullptr, const float* __restrict__ label1 = nullptr,
+    int tiles1, int tiles2, int total, int per_xcd, const float* __restrict__ label1 = nullptr,
     const float* __restrict__ label2 = nullptr) {
   const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
   if (V >= total) return;  // uniform per workgroup
@@ -303,37 +243,8 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
   const int b = V / per_b;
   const int r = V - b * per_b;
   const bool second = r >= tiles1;
-  nmdist_tile<Q, G, PK, PF, LIST, LAB, 0>(xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, b, second,
-                                          second ? r - tiles1 : r, 0, qlist, qcount, label1, label2, nullptr,
-                                          nullptr, 0, 1);
-}
-
-// Listed queries, sliced (see nmdist_tile): kListSlots workgroups per set walk the set's (tile, slice) work
-// items; a set with an empty list costs its workgroups one load.  tiles_l = tiles of 128 per cloud side
-// (the stride of ldone).
-template <bool LAB>
-__global__ __launch_bounds__(kBlock) void nmdist_list_split_kernel(
-    const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
-    int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M, int total,
-    int per_xcd, int tiles_l, const int* __restrict__ qlist, const int* __restrict__ qcount,
-    const float* __restrict__ label1, const float* __restrict__ label2, u64k* __restrict__ lkey,
-    int* __restrict__ ldone) {
-  constexpr int TQ = 128;
-  const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);  // a set stays on the XCD that built and searched it
-  if (V >= total) return;
-  const int set = V / kListSlots, slot = V - set * kListSlots;
-  const int count = qcount[set];
-  // slices pay when the list is short (latency); a long list fills the chip with whole-tile scans, and
-  // the per-slice epilogue (index recovery, merge, atomics) would only cost
-  const int nsplit = count <= 256 ? kListSplit : (count <= 2048 ? 4 : 1);
-  const int nwork = ((count + TQ - 1) / TQ) * nsplit;
-  for (int w = slot; w < nwork; w += kListSlots) {
-    const int tile = w / nsplit;
-    nmdist_tile<2, 8, true, false, true, LAB, kListSplit>(xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, set >> 1,
-                                                          (set & 1) != 0, tile, w - tile * nsplit, qlist, qcount,
-                                                          label1, label2, lkey, ldone, set * tiles_l + tile, nsplit);
-    __syncthreads();  // the LDS merge buffers are reused by the next item
-  }
+  nmdist_tile<Q, G, PK, PF, LAB>(xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, b, second,
+                                 second ? r - tiles1 : r, label1, label2);
 }
 
 // Generic point dimension (C != 3): one lane per query, reference point wave-uniform, plain
@@ -858,29 +769,6 @@ int zero_outputs(float* dist1, int* idx1, float* dist2, int* idx2, int B, int N,
 
 }  // namespace
 
-// Brute force over listed queries only (see LIST above); used by chamfer_grid.hip.
-namespace pp {
-int nmdist_fwd_c3_list(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
-                       int* idx2, int B, int N, int M, const int* qlist, const int* qcount,
-                       hipStream_t s, const float* label1, const float* label2, unsigned long long* lkey,
-                       int* ldone) {
-  const long long total = (long long)2 * B * kListSlots;
-  if (total > 0x7fffff00LL) return PP_EINVAL;
-  const int per_xcd = (int)((total + 7) / 8);
-  const int tiles_l = ((N > M ? N : M) + 127) / 128;
-  if (label1)
-    nmdist_list_split_kernel<true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
-        xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, (int)total, per_xcd, tiles_l, qlist, qcount, label1, label2, lkey,
-        ldone);
-  else
-    nmdist_list_split_kernel<false><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
-        xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, (int)total, per_xcd, tiles_l, qlist, qcount, nullptr, nullptr,
-        lkey, ldone);
-  PP_RETURN_IF_LAUNCH_FAILED();
-  return PP_OK;
-}
-}  // namespace pp
-
 // Tuning override for benchmarking variants in one process (bench.py --variant); 0 = automatic.
 static int g_fwd_variant = 0;
 extern "C" void pp_debug_set_nmdistance_variant(int v) { g_fwd_variant = v; }
@@ -956,8 +844,8 @@ extern "C" int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float*
     const long long tot = (long long)B * (t1 + t2);
     if (tot > 0x7fffff00LL) return PP_EINVAL;
     const int per_xcd = (int)((tot + 7) / 8);
-    nmdist_fwd_c3_kernel<Q, G, true, false, false, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
-        xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, t1, t2, (int)tot, per_xcd, nullptr, nullptr, label1, label2);
+    nmdist_fwd_c3_kernel<Q, G, true, false, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
+        xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, t1, t2, (int)tot, per_xcd, label1, label2);
     PP_RETURN_IF_LAUNCH_FAILED();
     return PP_OK;
   }

@@ -15,19 +15,26 @@
 //     assignment (one subtraction, one multiplication, one truncation) can misplace a point by
 //     <= 1e-5 h; both are covered by stopping only if  best < bound^2 * 0.999  (strict).
 //     Then no unexamined point can have a computed distance <= best, i.e. none can win or tie;
-//   * a query that cannot stop at rho = 2 (far from the cloud, or degenerate data) is appended to
-//     a list and resolved by the brute-force kernel (LIST mode), as is every query of a set whose
-//     grid is useless (non-finite coordinates, almost all points in one cell).
+//   * a query that cannot stop at rho = 2 (far from the cloud) is finished inside the search kernel by a
+//     scan of the whole cloud -- by its wave, or, when a wave has many such queries, by every lane for its
+//     own query with the brute-force kernel's inner loop; so is every query of a set whose grid is useless
+//     (non-finite coordinates, almost all points in one cell).  Two launches per forward, no list.
 #include "grid_common.h"
 
-namespace pp {
-// implemented in chamfer.hip: brute force over the queries listed in `qlist` (per set: count in
-// qcount[set], indices in qlist[set_offset ...])
-int nmdist_fwd_c3_list(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2,
-                       int* idx2, int B, int N, int M, const int* qlist, const int* qcount,
-                       hipStream_t s, const float* label1, const float* label2, unsigned long long* lkey,
-                       int* ldone);
-}  // namespace pp
+#ifdef PP_QUERY_PROBE
+// diagnostic build only (tools/query_probe.py): 100 MHz clock at the phase boundaries of a few workgroups
+__device__ unsigned long long g_qphase[8][16];
+extern "C" int pp_debug_read_query_phases(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qphase), sizeof(g_qphase));
+}
+#define PP_QPHASE(n)                                                                     \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && (blockIdx.x & 511) == 0 && (blockIdx.x >> 9) < 8)            \
+      g_qphase[blockIdx.x >> 9][n] = wall_clock64();                                     \
+  } while (0)
+#else
+#define PP_QPHASE(n)
+#endif
 
 namespace {
 
@@ -41,37 +48,25 @@ constexpr float kBoundSlack = 0.999f;
 
 // Workspace layout (bytes), S = 2*B sets, T = B*(N+M) points:
 //   [0, 64*S)                      GridSet[S]
-//   [.., +4*S)  (padded to 256)    int qcount[S]
 //   [.., +4*(kGridCells+1)*S)      unsigned cell_start[S][kGridCells+1]
 //   [.., +16*T)                    float4 sorted[T]   (x, y, z, original index bits)
-//   [.., +4*T)                     int qlist[T]           queries left to the brute force, per set
-//   [.., +8*T)                     u64 lkey[T]            brute-force list: (distance, index) keys merged across slices
-//   [.., +4*S*tiles_l)             int ldone[S][tiles_l]  brute-force list: slices finished per tile of 128
-//   [.., +4*T)                     float slab[T]          labels in sorted order (labeled Chamfer only)
+//   [.., +4*T)                     float slab[T]      labels in sorted order (labeled Chamfer only)
 struct Layout {
-  size_t sets, qcount, cell_start, sorted, qlist, lkey, ldone, slab, total;
+  size_t sets, cell_start, sorted, slab, total;
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
   Layout L;
   const size_t S = (size_t)2 * B, T = (size_t)B * ((size_t)N + M);
   L.sets = 0;
-  L.qcount = L.sets + 64 * S;
-  L.cell_start = L.qcount + ((4 * S + 255) / 256) * 256;
+  L.cell_start = L.sets + ((64 * S + 255) / 256) * 256;
   L.sorted = L.cell_start + ((4 * (size_t)(kGridCells + 1) * S + 255) / 256) * 256;
-  L.qlist = L.sorted + 16 * T;
-  L.lkey = L.qlist + 4 * T;
-  L.lkey = (L.lkey + 7) / 8 * 8;
-  L.ldone = L.lkey + 8 * T;
-  L.slab = L.ldone + ((4 * S * (size_t)(((N > M ? N : M) + 127) / 128) + 255) / 256) * 256;
+  L.slab = L.sorted + 16 * T;
   L.total = L.slab + (labeled ? 4 * T : 0);
   return L;
 }
 // set s = 2*b + dir; dir 0: queries = cloud 1 (N), references = cloud 2 (M)
 __host__ __device__ inline size_t set_point_offset(int b, int dir, int N, int M) {
   return (size_t)b * ((size_t)N + M) + (dir ? (size_t)M : 0);  // references of (b,0) first (M), then (b,1) (N)
-}
-__host__ __device__ inline size_t set_query_offset(int b, int dir, int N, int M) {
-  return (size_t)b * ((size_t)N + M) + (dir ? (size_t)N : 0);  // queries of (b,0) first (N), then (b,1) (M)
 }
 
 // kBuildSlabs workgroups per set: bounding box, cell histogram (LDS), exclusive scan, scatter
@@ -84,7 +79,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
                                                                    const float* __restrict__ label1,
                                                                    const float* __restrict__ label2) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // pp::grid_build_lds_bytes(kBuildSlabs)
-  // a set is built on the XCD that will search it (grid_query_kernel's set -> XCD mapping): its sorted
+  // a set is built on the XCD that will search it (the search kernel's set -> XCD mapping): its sorted
   // points and cell table are then already in that L2
   const int V = pp::xcd_virtual_block(blockIdx.x, (2 * B * pp::kBuildSlabs + 7) / 8);
   if (V >= 2 * B * pp::kBuildSlabs) return;
@@ -95,39 +90,12 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   const bool labeled = label1 != nullptr;
   const Layout L = make_layout(B, N, M, labeled);
   const float* __restrict__ lab = labeled ? (dir ? label1 : label2) + (size_t)b * nr : nullptr;
-  if (threadIdx.x == 0 && slab == 0) {  // the lists this set's queries may be appended to start empty
-    int* counts = reinterpret_cast<int*>(ws + L.qcount);
-    counts[set] = 0;  // brute-force list of this set
-  }
-  if (slab == 0) {  // "slices finished" counters of this set's brute-force tiles
-    const int tiles_l = ((N > M ? N : M) + 127) / 128;
-    int* done = reinterpret_cast<int*>(ws + L.ldone) + (size_t)set * tiles_l;
-    for (int i = threadIdx.x; i < tiles_l; i += kBuildThreads) done[i] = 0;
-  }
   pp::grid_build_set<false, VEC>(ref, nr, reinterpret_cast<GridSet*>(ws + L.sets) + set,
                      reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1),
                      reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M),
                      nullptr, s_cnt, lab,
                      labeled ? reinterpret_cast<float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr,
                      slab, pp::kBuildSlabs);
-}
-
-// Append `value` to list[counter++] for the lanes with `want`: one atomic per wave.  `keys`, if given,
-// is the brute-force list's key array: the new entry's key starts at "nothing found".
-__device__ __forceinline__ void wave_append(bool want, int* counter, int* list, int value,
-                                            unsigned long long* keys = nullptr) {
-  const unsigned long long mask = __ballot(want);
-  if (mask == 0) return;
-  const int lane = threadIdx.x & 63;
-  const int leader = (int)__builtin_ctzll(mask);
-  int base = 0;
-  if (lane == leader) base = atomicAdd(counter, (int)__builtin_popcountll(mask));
-  base = __shfl(base, leader);
-  if (want) {
-    const int pos = base + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-    list[pos] = value;
-    if (keys) keys[pos] = ~0ull;
-  }
 }
 
 // Stages B and C (cubes of Chebyshev radius 1 and 2 around the query's cell) for the queries stage A left
@@ -239,7 +207,8 @@ __device__ __forceinline__ bool wide_stages_wave(float qx, float qy, float qz, f
   return resolved;
 }
 
-// Group k of a lane's stage-A sequence (see grid_query_kernel): four points of the row it falls in.
+// Group k of a lane's stage-A sequence (see grid_query_wave_kernel): four points of the row it falls in,
+// read from global memory (waves whose region does not fit their LDS slice).
 // Everything per-row arrives BY VALUE: selects between variables captured by reference in a lambda come
 // out of hipcc as indexed loads from a pointer table in scratch memory.
 template <bool LAB>
@@ -265,53 +234,153 @@ __device__ __forceinline__ void stage_a_fetch(unsigned k, unsigned T1, unsigned 
   }
 }
 
-// Stage A for every query, one lane per query (dense launch); the few queries it cannot settle are then
-// taken through the wide stages by their wave, one at a time (see the end of the kernel).
-// LAB (labeled Chamfer): a reference point is a candidate only if its label equals the query's; the
-// stopping rule is unchanged (it bounds EVERY unexamined point, whatever its label).
+// LDS pointers carry their address space (a generic pointer would make the loads flat)
+typedef const pp::f4 __attribute__((address_space(3))) * lds_f4_ptr;
+typedef const float __attribute__((address_space(3))) * lds_f_ptr;
+
+// helpers of the search kernels' in-kernel fallbacks (no brute-force list, no third launch)
+constexpr int kStageLayers = 8;
+
+// One wave, one query: the whole sorted cloud, 64 candidates per step.  Returns the (distance, index) key;
+// the brute force's result for degenerate inputs (no candidate with a distance below +inf: index 0, or -1 / 0
+// for a labeled query) is restored by finish_key.
 template <bool LAB>
-__global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict__ xyz1,
-                                                         const float* __restrict__ xyz2,
-                                                         float* __restrict__ dist1, int* __restrict__ idx1,
-                                                         float* __restrict__ dist2, int* __restrict__ idx2,
-                                                         unsigned char* __restrict__ ws, int B, int N, int M,
-                                                         int tiles1, int tiles2, int total, int per_xcd,
-                                                         const float* __restrict__ label1,
-                                                         const float* __restrict__ label2) {
-  // workgroups of one set on one XCD: its cells and points (384 KiB) stay in that L2
+__device__ __forceinline__ unsigned long long wave_scan_cloud(const pp::f4* __restrict__ sorted,
+                                                              const float* __restrict__ slab, int nr, float qx,
+                                                              float qy, float qz, float ql) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;
+  for (int c0 = 0; c0 < nr; c0 += 64) {
+    const int c = c0 + lane;
+    if (c < nr) {
+      const pp::f4 p = sorted[c];
+      const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
+      const unsigned long long cand =
+          ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+      const bool ok = !LAB || slab[c] == ql;
+      key = (ok && cand < key) ? cand : key;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    key = o < key ? o : key;
+  }
+  return key;
+}
+
+template <bool LAB>
+__device__ __forceinline__ void finish_key(unsigned long long key, float& best, int& bidx) {
+  best = __uint_as_float((unsigned)(key >> 32));
+  bidx = (int)(unsigned)key;
+  if (!(best < __builtin_inff())) {  // nothing below +inf (non-finite input, or no point with the label)
+    best = LAB ? 0.0f : __builtin_inff();
+    bidx = LAB ? -1 : 0;
+  }
+}
+
+// Every lane scans the whole reference cloud (original order, so "strictly smaller" keeps the lowest index)
+// for its own query; the reference point is wave-uniform and arrives through scalar loads.  Lanes without
+// `want` run along and discard the result.  Same values as nmdist_fwd_c3_kernel for every input.
+template <bool LAB>
+__device__ __forceinline__ void lane_scan_cloud(const float* __restrict__ ref, const float* __restrict__ rlab,
+                                                int nr, float qx, float qy, float qz, float ql, float& best,
+                                                int& bidx) {
+  best = __builtin_inff();
+  bidx = 0;
+  int k = 0;
+  for (; k + 8 <= nr; k += 8) {
+    float rr[24], rl[8];
+    const float* __restrict__ rp = ref + 3 * (size_t)k;  // wave-uniform -> s_load
+#pragma unroll
+    for (int e = 0; e < 24; ++e) rr[e] = rp[e];
+    if (LAB) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rl[e] = rlab[k + e];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float d = pp::chamfer_d3(rr[3 * u], rr[3 * u + 1], rr[3 * u + 2], qx, qy, qz);
+      if (LAB) d = rl[u] == ql ? d : __builtin_inff();
+      const bool lt = d < best;
+      best = lt ? d : best;
+      bidx = lt ? k + u : bidx;
+    }
+  }
+  for (; k < nr; ++k) {
+    float d = pp::chamfer_d3(ref[3 * (size_t)k], ref[3 * (size_t)k + 1], ref[3 * (size_t)k + 2], qx, qy, qz);
+    if (LAB) d = rlab[k] == ql ? d : __builtin_inff();
+    const bool lt = d < best;
+    best = lt ? d : best;
+    bidx = lt ? k : bidx;
+  }
+  if (LAB && !(best < __builtin_inff())) {
+    best = 0.0f;
+    bidx = -1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The search kernel.  One lane per query; the queries are walked in the SORTED ORDER OF THEIR OWN CLOUD --
+// available for free because each cloud is the other direction's reference set -- so a wave's 64 queries are
+// neighbours in space.  Walking the candidates straight from global memory (round 1) made every lane's
+// 16-byte load touch its own cache line: 3.0e7 L1 accesses per launch at config 2.  Here the wave first
+// copies the part of the sorted reference cloud its queries can reach in stage A into its own slice of LDS
+// with coalesced loads and walks it from there (1.4e7 L1 accesses, and no brute-force list / third launch).
+// A wave's 64 queries are consecutive in the cell order of their own cloud, so their stage-A blocks touch a handful of
+// rows in two to four z-layers of the reference grid (~150-300 points on a surface).  The wave finds the
+// layers and the row range in each with DPP reductions, fetches the spans' bounds (two loads per layer),
+// copies the spans into its own slice of LDS and walks them from there.  No workgroup barrier anywhere: the
+// four waves of a workgroup are independent, 28-32 of them share a CU, and the chain of dependent loads of
+// one (query -> span bounds -> span copy) is covered by the others.
+// first staged position of group k of a lane's sequence (by value: see stage_a_fetch)
+__device__ __forceinline__ unsigned stage_first(unsigned k, unsigned T1, unsigned T2, unsigned T3, unsigned T4,
+                                                unsigned adj0, unsigned adj1, unsigned adj2, unsigned adj3) {
+  const unsigned adj = k < T1 ? adj0 : (k < T2 ? adj1 : (k < T3 ? adj2 : adj3));
+  return k < T4 ? adj + 4 * k : 0u;
+}
+
+// v_min_f32 without the canonicalising v_max the compiler puts in front of fminf (operands are results of
+// fma chains; a NaN operand is dropped, as v_min3 does)
+__device__ __forceinline__ float min2(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <bool LAB, int CAPW>
+__global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __restrict__ xyz1,
+                                                              const float* __restrict__ xyz2,
+                                                              float* __restrict__ dist1, int* __restrict__ idx1,
+                                                              float* __restrict__ dist2, int* __restrict__ idx2,
+                                                              unsigned char* __restrict__ ws, int B, int N, int M,
+                                                              int tiles1, int tiles2, int total, int per_xcd,
+                                                              const float* __restrict__ label1,
+                                                              const float* __restrict__ label2) {
   const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
   if (V >= total) return;
+  PP_QPHASE(0);
   const int per_b = tiles1 + tiles2;
   const int b = V / per_b;
   const int r = V - b * per_b;
   const int dir = r >= tiles1 ? 1 : 0;
   const int tile = dir ? r - tiles1 : r;
-  const int nq = dir ? M : N;
-  // every lane stays alive (the waves cooperate on their leftover queries below): the lanes beyond a
-  // ragged last tile repeat the cloud's last query and are kept from storing or listing anything
-  const bool valid = tile * 256 + (int)threadIdx.x < nq;
-  const int jj = valid ? tile * 256 + (int)threadIdx.x : nq - 1;
+  const int nq = dir ? M : N, nr = dir ? N : M;
+  const int t = threadIdx.x, lane = t & 63;
+  const bool valid = tile * 256 + t < nq;
+  const int jj = valid ? tile * 256 + t : nq - 1;
   const int set = 2 * b + dir;
   const Layout L = make_layout(B, N, M, LAB);
   const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[set];
-  // The query cloud is the reference cloud of the partner set (b, 1-dir), already sorted by cell
-  // there: walking the queries in that order makes the lanes of a wave spatial neighbours, so
-  // they read the same cells (coalesced, L1-resident) and run similar trip counts.
   const GridSet gp = reinterpret_cast<const GridSet*>(ws + L.sets)[set ^ 1];
   const pp::f4* __restrict__ qsorted =
       reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir ^ 1, N, M);
-  int* counts = reinterpret_cast<int*>(ws + L.qcount);
-  int* qlist = reinterpret_cast<int*>(ws + L.qlist) + set_query_offset(b, dir, N, M);
   const bool g_useless = pp::grid_useless(g), gp_useless = pp::grid_useless(gp);
-  if (g_useless) {  // uniform over the workgroup (one set per workgroup)
-    wave_append(valid, counts + set, qlist, jj,  // every query exactly once, any order
-                reinterpret_cast<unsigned long long*>(ws + L.lkey) + set_query_offset(b, dir, N, M));
-    return;
-  }
-  const unsigned* __restrict__ cell_start =
-      reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
-  const pp::f4* __restrict__ sorted =
-      reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
+  const float* __restrict__ ref_raw = (dir ? xyz1 : xyz2) + (size_t)b * nr * 3;
+  const float* __restrict__ rlab_raw = LAB ? (dir ? label1 : label2) + (size_t)b * nr : nullptr;
+  float* __restrict__ od = (dir ? dist2 : dist1) + (size_t)b * nq;
+  int* __restrict__ oi = (dir ? idx2 : idx1) + (size_t)b * nq;
   float qx, qy, qz, ql = 0.0f;
   int j;
   if (!gp_useless) {
@@ -325,122 +394,190 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
     j = jj;
     if (LAB) ql = (dir ? label2 : label1)[(size_t)b * nq + jj];
   }
+  if (g_useless) {  // no grid for this set (non-finite or zero-extent data, crowded cells): every pair
+    float best;
+    int bidx;
+    lane_scan_cloud<LAB>(ref_raw, rlab_raw, nr, qx, qy, qz, ql, best, bidx);
+    if (valid) {
+      od[j] = best;
+      oi[j] = bidx;
+    }
+    return;
+  }
+  const unsigned* __restrict__ cell_start =
+      reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
+  const pp::f4* __restrict__ sorted =
+      reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
   const float* __restrict__ slab =
       LAB ? reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr;
+
+  // (+4: a group of four is read from any staged position without clamping; the tail repeats a real point)
+  __shared__ pp::f4 s_pts[4][CAPW + 4];
+  __shared__ float s_lab[4][LAB ? CAPW + 4 : 1];
+  const int wave = pp::wave_id_uniform();
+
+  // Stage A: the 2x2x2 block of cells nearest to q' (own cell + the neighbour on the side of the cell q' lies
+  // in, per axis).  A point outside that block is beyond the far face of q''s cell along some axis (>= h/2
+  // away) or beyond the neighbour (>= h away).  The block is four rows (y, z) of one or two cells (x0..x1).
   const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
   const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
   const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
-  float best = __builtin_inff();
-  int bidx = 0x7fffffff;
-  bool resolved = false;
-  bool live = valid;  // after the re-deal below: this lane holds a real query
-  // Stage A: the 2x2x2 block of cells nearest to q' (own cell + the neighbour on the side of the
-  // cell q' lies in, per axis).  A point outside that block is beyond the far face of q''s cell
-  // along some axis (>= h/2 away) or beyond the neighbour (>= h away): true distance >= h/2.
+  const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
+              fz = (qz - g.minz) * g.invh - (float)cz;  // position inside the cell, in cells
+  const int sx = fx < 0.5f ? -1 : 1, sy = fy < 0.5f ? -1 : 1, sz = fz < 0.5f ? -1 : 1;
+  const int x0 = max(min(cx, cx + sx), 0), x1 = min(max(cx, cx + sx), g.gx - 1);
+  const int y0 = max(min(cy, cy + sy), 0), y1 = min(max(cy, cy + sy), g.gy - 1);
+  const int z0 = max(min(cz, cz + sz), 0), z1 = min(max(cz, cz + sz), g.gz - 1);
+  unsigned rs0, rs1, rs2, rs3, re0, re1, re2, re3;
   {
-    const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
-                fz = (qz - g.minz) * g.invh - (float)cz;  // position inside the cell, in cells
-    const int sx = fx < 0.5f ? -1 : 1, sy = fy < 0.5f ? -1 : 1, sz = fz < 0.5f ? -1 : 1;
-    const int x0 = max(min(cx, cx + sx), 0), x1 = min(max(cx, cx + sx), g.gx - 1);
-    // (named scalars, not arrays: hipcc turns a select between array elements into an indexed load
-    // from scratch memory)
+    // (named scalars, not arrays: hipcc turns a select between array elements into an indexed load from
+    // scratch memory)
     auto row_range = [&](int a, int bq, unsigned& s_out, unsigned& e_out) {
       const int z = cz + a * sz, y = cy + bq * sy;
       const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
       const int c = pp::cell_linear(0, min(max(y, 0), g.gy - 1), min(max(z, 0), g.gz - 1), g.gx, g.gy);
       // the row is one or two cells wide: its two bounds are at most two entries apart, so ONE 12-byte load
-      // fetches both (the entry after a set's table is the next set's or the sorted cloud: valid memory) --
-      // four scattered load instructions per query less
+      // fetches both (the entry after a set's table is the next set's or the sorted cloud: valid memory)
       typedef unsigned u3 __attribute__((ext_vector_type(3)));
       u3 v;
       __builtin_memcpy(&v, cell_start + c + x0, sizeof(v));
       s_out = ok ? v.x : 0u;
       e_out = ok ? (x1 > x0 ? v.z : v.y) : 0u;
     };
-    unsigned rs0, rs1, rs2, rs3, re0, re1, re2, re3;
     row_range(0, 0, rs0, re0);
     row_range(0, 1, rs1, re1);
     row_range(1, 0, rs2, re2);
     row_range(1, 1, rs3, re3);
-    // What the block guarantees for THIS query: along each axis the nearer face of the block that has
-    // grid beyond it (beyond the grid there are no points).  Lower face: 1 + f cells away when the
-    // block includes cell c-1, f when it starts at c; upper face: 1 - f or 2 - f.  Never below h/2.
-    auto reach1 = [](float f, int s, int c, int gdim) {
-      const float lo = s < 0 ? (c >= 1 ? f + 1.0f : __builtin_inff()) : (c >= 1 ? f : __builtin_inff());
-      const float hi = s < 0 ? (c + 1 <= gdim - 1 ? 1.0f - f : __builtin_inff())
-                             : (c + 1 <= gdim - 1 ? 2.0f - f : __builtin_inff());
-      return fminf(lo, hi);
-    };
-    const float reach = g.h * fminf(reach1(fx, sx, cx, g.gx), fminf(reach1(fy, sy, cy, g.gy), reach1(fz, sz, cz, g.gz)));
-    float thr = reach * reach * kBoundSlack;  // the query is settled if its best distance is below this
-    // The walk below runs, per wave, as long as the wave's LONGEST candidate list, and the lists differ a
-    // lot between neighbours (rocprofv3 counters at config 2: 13.5 groups walked per wave for a mean of
-    // ~5 per query; lanes that have finished keep re-examining point 0).  The lists' lengths are known
-    // here, before the first point is touched, so the workgroup's 256 queries are first re-dealt to the
-    // lanes in order of length (a counting sort through LDS: 32 buckets by number of groups, 13 words of
-    // state per query): each wave then walks queries of about the same length.  The queries of a tile are
-    // close in space whatever the order, so the candidates stay cache-resident.
-    {
-      constexpr int kWords = LAB ? 14 : 13;
-      __shared__ unsigned s_hist[32], s_base[32];
-      __shared__ unsigned s_st[kWords][256];
-      const int t = threadIdx.x;
-      auto groups_of = [](unsigned s_, unsigned e_) { return (e_ - s_ + 3) >> 2; };
-      const unsigned ng = valid ? groups_of(rs0, re0) + groups_of(rs1, re1) + groups_of(rs2, re2) + groups_of(rs3, re3) : 0u;
-      const unsigned key = min(ng, 31u);
-      if (t < 32) s_hist[t] = 0u;
-      __syncthreads();
-      const unsigned pos = atomicAdd(&s_hist[key], 1u);
-      __syncthreads();
-      if (t < 64) {  // exclusive prefix of the 32 bucket counts
-        const unsigned h = t < 32 ? s_hist[t] : 0u;
-        unsigned incl = h;
+  }
+  // What the block guarantees for THIS query: along each axis the nearer face of the block that has grid
+  // beyond it (beyond the grid there are no points).  Lower face: 1 + f cells away when the block includes
+  // cell c-1, f when it starts at c; upper face: 1 - f or 2 - f.  Never below h/2.  The query is settled if
+  // its best distance is below reach^2 * kBoundSlack (strict).
+  auto reach1 = [](float f, int s, int c, int gdim) {
+    const float lo = s < 0 ? (c >= 1 ? f + 1.0f : __builtin_inff()) : (c >= 1 ? f : __builtin_inff());
+    const float hi = s < 0 ? (c + 1 <= gdim - 1 ? 1.0f - f : __builtin_inff())
+                           : (c + 1 <= gdim - 1 ? 2.0f - f : __builtin_inff());
+    return fminf(lo, hi);
+  };
+  const float reach = g.h * fminf(reach1(fx, sx, cx, g.gx), fminf(reach1(fy, sy, cy, g.gy), reach1(fz, sz, cz, g.gz)));
+  const float thr = reach * reach * kBoundSlack;
+  PP_QPHASE(1);
+
+  // ---- the wave's region: its z-layers and the row range in each (cell coordinates are < 2^24: exact as floats)
+  const float ninf = -__builtin_inff();
+  auto lane63 = [](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); };
+  int Lz, nz;
+  {
+    float v[6] = {-(float)z0, (float)z1, ninf, ninf, ninf, ninf};
+    pp::wave_reduce6_dpp<false, 6>(v);
+    Lz = -(int)lane63(v[0]);
+    nz = (int)lane63(v[1]) - Lz + 1;
+  }
+  bool staged = nz <= kStageLayers;
+  unsigned n_staged = 0, delta = 0, offv = 0;  // lanes 0..7: the layer's (global start - LDS start), LDS start
+  if (staged) {
+    int ya = 1, yb = 0;  // lane l < nz: row range of layer Lz + l
+    for (int base = 0; base < nz; base += 3) {  // wave-uniform
+      float v[6];
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-          const unsigned o = __shfl_up(incl, off);
-          if (t >= off) incl += o;
-        }
-        if (t < 32) s_base[t] = incl - h;
+      for (int i = 0; i < 3; ++i) {
+        const int z = Lz + base + i;
+        const bool m = z0 == z || z1 == z;
+        v[2 * i] = m ? -(float)y0 : ninf;
+        v[2 * i + 1] = m ? (float)y1 : ninf;
       }
-      __syncthreads();
-      const unsigned dest = s_base[key] + pos;
-      s_st[0][dest] = __float_as_uint(qx); s_st[1][dest] = __float_as_uint(qy); s_st[2][dest] = __float_as_uint(qz);
-      s_st[3][dest] = (unsigned)(valid ? j : -1);
-      s_st[4][dest] = __float_as_uint(thr);
-      s_st[5][dest] = rs0; s_st[6][dest] = rs1; s_st[7][dest] = rs2; s_st[8][dest] = rs3;
-      s_st[9][dest] = re0; s_st[10][dest] = re1; s_st[11][dest] = re2; s_st[12][dest] = re3;
-      if (LAB) s_st[kWords - 1][dest] = __float_as_uint(ql);
-      __syncthreads();
-      qx = __uint_as_float(s_st[0][t]); qy = __uint_as_float(s_st[1][t]); qz = __uint_as_float(s_st[2][t]);
-      j = (int)s_st[3][t];
-      thr = __uint_as_float(s_st[4][t]);
-      rs0 = s_st[5][t]; rs1 = s_st[6][t]; rs2 = s_st[7][t]; rs3 = s_st[8][t];
-      re0 = s_st[9][t]; re1 = s_st[10][t]; re2 = s_st[11][t]; re3 = s_st[12][t];
-      if (LAB) ql = __uint_as_float(s_st[kWords - 1][t]);
-      live = j >= 0;
+      pp::wave_reduce6_dpp<false, 6>(v);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float a = lane63(v[2 * i]), bmax = lane63(v[2 * i + 1]);
+        if (lane == base + i && bmax >= 0.0f) {
+          ya = -(int)a;
+          yb = (int)bmax;
+        }
+      }
     }
-    // The four rows are walked as ONE sequence of groups of four points: a lane's rows hold t_r =
-    // ceil(len_r / 4) groups each, group k of the sequence belongs to the row r with T_r <= k < T_{r+1}
-    // (T = running sums) and starts at rs_r + 4 (k - T_r).  k is wave-uniform, so the wave runs
-    // max over lanes of (t_0 + .. + t_3) steps instead of the sum over rows of the per-row maxima, and
-    // the loads of group k + 1 are in flight while group k is evaluated (a row-by-row walk waits for
-    // every group's loads before it can issue the next: 50 -> 3x us at config 2).  The clamped duplicates
-    // of a ragged tail are the same candidate again: harmless.
+    unsigned gs = 0, ge = 0;
+    if (lane < nz && ya <= yb) {
+      gs = cell_start[pp::cell_linear(0, ya, Lz + lane, g.gx, g.gy)];
+      ge = cell_start[pp::cell_linear(0, yb, Lz + lane, g.gx, g.gy) + g.gx];
+    }
+    const unsigned len = ge - gs;
+    unsigned incl = len;
+#pragma unroll
+    for (int off = 1; off < kStageLayers; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    offv = incl - len;
+    delta = gs - offv;
+    n_staged = (unsigned)__builtin_amdgcn_readlane((int)incl, kStageLayers - 1);
+    staged = n_staged <= (unsigned)CAPW;
+  }
+  PP_QPHASE(2);
+  const lds_f4_ptr lpts = (lds_f4_ptr)(&s_pts[wave][0]);
+  const lds_f_ptr llab = (lds_f_ptr)(&s_lab[wave][0]);
+  if (staged) {
+    // every lane's rows live in its two layers: global position -> LDS position
+    const unsigned dA = __shfl(delta, cz - Lz);
+    const int zb = cz + sz;
+    const unsigned dB = __shfl(delta, (zb >= 0 && zb < g.gz) ? zb - Lz : 0);
+    rs0 -= dA; re0 -= dA; rs1 -= dA; re1 -= dA;
+    rs2 -= dB; re2 -= dB; rs3 -= dB; re3 -= dB;
+    // copy layer by layer: everything but the lane offset is wave-uniform (a span's last piece may be partial)
+    for (int l = 0; l < nz; ++l) {
+      const unsigned o0 = (unsigned)__builtin_amdgcn_readlane((int)offv, l);
+      const unsigned dlt = (unsigned)__builtin_amdgcn_readlane((int)delta, l);
+      const unsigned end = l + 1 < nz ? (unsigned)__builtin_amdgcn_readlane((int)offv, l + 1) : n_staged;
+      for (unsigned p0 = o0; p0 < end; p0 += 4 * 64) {
+        pp::f4 v[4];
+        float vl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned p = min(p0 + (unsigned)(u * 64 + lane), end - 1);  // (duplicates store the same value)
+          v[u] = sorted[p + dlt];
+          if (LAB) vl[u] = slab[p + dlt];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned p = min(p0 + (unsigned)(u * 64 + lane), end - 1);
+          (&s_pts[wave][0])[p] = v[u];
+          if (LAB) (&s_lab[wave][0])[p] = vl[u];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (n_staged > 0) {  // the padding repeats the last point (a real candidate)
+      const pp::f4 padv = lpts[n_staged - 1];
+      const float padl = LAB ? llab[n_staged - 1] : 0.0f;
+      if (lane < 4) {
+        (&s_pts[wave][0])[n_staged + lane] = padv;
+        if (LAB) (&s_lab[wave][0])[n_staged + lane] = padl;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  PP_QPHASE(3);
+
+  // ---- stage A: the four rows as ONE sequence of groups of four points -----------------------------------
+  // A lane's rows hold t_r = ceil(len_r / 4) groups each; group k of the sequence belongs to the row r with
+  // T_r <= k < T_{r+1} (T = running sums).  k is wave-uniform, so the wave runs max over lanes of the TOTAL
+  // group count instead of the sum over rows of the per-row maxima, and the loads of group k + 1 are in
+  // flight while group k is evaluated.
+  float best = __builtin_inff();
+  int bidx = 0x7fffffff;
+  {
     const unsigned t0 = (re0 - rs0 + 3) >> 2, t1 = (re1 - rs1 + 3) >> 2, t2 = (re2 - rs2 + 3) >> 2,
                    t3 = (re3 - rs3 + 3) >> 2;
     const unsigned T1 = t0, T2 = T1 + t1, T3 = T2 + t2, T4 = T3 + t3;
     const unsigned adj0 = rs0, adj1 = rs1 - 4 * T1, adj2 = rs2 - 4 * T2, adj3 = rs3 - 4 * T3;
     const unsigned last0 = re0 - 1, last1 = re1 - 1, last2 = re2 - 1, last3 = re3 - 1;
-    auto fetch = [&](unsigned k, pp::f4 (&p)[4], float (&pl)[4]) {
-      stage_a_fetch<LAB>(k, T1, T2, T3, T4, adj0, adj1, adj2, adj3, last0, last1, last2, last3, sorted, slab, p, pl);
-    };
-    auto examine = [&](const pp::f4 (&p)[4], const float (&pl)[4]) {
+    auto examine = [&](const pp::f4 (&p)[4], const float (&pl)[4]) {  // exact (distance, index) order
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
         const int id = __float_as_int(p[u].w);
-        // (bitwise, not short-circuit: the compiler turns `||` / `&&` into exec-mask branches, five scalar
-        // instructions and two branches per candidate for a tie that almost never happens)
         const bool take = (!LAB || pl[u] == ql) & ((d < best) | ((d == best) & (id < bidx)));
         best = take ? d : best;
         bidx = take ? id : bidx;
@@ -448,29 +585,90 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
     };
     pp::f4 pa[4], pb[4];
     float la[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    fetch(0, pa, la);
-    for (unsigned k = 0; __any(k < T4); k += 2) {  // two steps per trip: the buffers swap roles without copies
-      fetch(k + 1, pb, lb);
-      examine(pa, la);
-      fetch(k + 2, pa, la);
-      examine(pb, lb);
+    if (staged) {
+      // Staged walk, trimmed for VALU issue (the kernel's roof once the candidates come from LDS).  A group is
+      // four CONSECUTIVE staged points from its first position on -- one address, four ds_read_b128 with
+      // immediate offsets; running past the end of a row only examines more real points of the set, which is
+      // harmless, and the region is padded so that nothing is clamped.  Per group only the running minimum
+      // is kept (v_min3 + v_min) and the number of the first group that lowered it; the winner's index is
+      // recovered afterwards by re-examining that one group.  A distance EQUAL to the running minimum seen
+      // in a later group (an exact tie across groups: duplicated points, lattices) cannot be ordered that
+      // way: the wave then repeats the walk with the exact (distance, index) comparison.
+      auto first_of = [&](unsigned k) { return stage_first(k, T1, T2, T3, T4, adj0, adj1, adj2, adj3); };
+      auto fetch4 = [&](unsigned e0, pp::f4 (&p)[4], float (&pl)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          p[u] = lpts[e0 + u];
+          if (LAB) pl[u] = llab[e0 + u];
+        }
+      };
+      if (n_staged > 0) {
+        unsigned gk = 0xffffffffu;
+        bool tie = false;
+        auto track = [&](unsigned k, const pp::f4 (&p)[4], const float (&pl)[4]) {
+          float d[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            d[u] = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+            if (LAB) d[u] = pl[u] == ql ? d[u] : __builtin_inff();
+          }
+          const float gmin = min2(pp::min3(d[0], d[1], d[2]), d[3]);
+          const bool lt = gmin < best;
+          tie = tie | ((gmin == best) & (k < T4));
+          gk = lt ? k : gk;
+          best = lt ? gmin : best;
+        };
+        fetch4(first_of(0), pa, la);
+        for (unsigned k = 0; __any(k < T4); k += 2) {
+          fetch4(first_of(k + 1), pb, lb);
+          track(k, pa, la);
+          fetch4(first_of(k + 2), pa, la);
+          track(k + 1, pb, lb);
+        }
+        if (__any(tie)) {  // exact redo (rare)
+          best = __builtin_inff();
+          fetch4(first_of(0), pa, la);
+          for (unsigned k = 0; __any(k < T4); k += 2) {
+            fetch4(first_of(k + 1), pb, lb);
+            examine(pa, la);
+            fetch4(first_of(k + 2), pa, la);
+            examine(pb, lb);
+          }
+        } else if (gk != 0xffffffffu) {  // the winner is in group gk: lowest index among its minima
+          fetch4(first_of(gk), pa, la);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float d = pp::chamfer_d3(pa[u].x, pa[u].y, pa[u].z, qx, qy, qz);
+            if (LAB) d = la[u] == ql ? d : __builtin_inff();
+            const int id = __float_as_int(pa[u].w);
+            const bool take = (d == best) & (id < bidx);
+            bidx = take ? id : bidx;
+          }
+        }
+      }
+    } else {
+      auto fetch = [&](unsigned k, pp::f4 (&p)[4], float (&pl)[4]) {
+        stage_a_fetch<LAB>(k, T1, T2, T3, T4, adj0, adj1, adj2, adj3, last0, last1, last2, last3, sorted, slab, p, pl);
+      };
+      fetch(0, pa, la);
+      for (unsigned k = 0; __any(k < T4); k += 2) {
+        fetch(k + 1, pb, lb);
+        examine(pa, la);
+        fetch(k + 2, pa, la);
+        examine(pb, lb);
+      }
     }
-    resolved = best < thr;
   }
-  // Results go straight to the query's original position: two scattered 4-byte stores per query.
-  // (Measured against leaving them in walked order, coalesced, plus an inverse permutation written by
-  // the build and an unsort pass: the direct form is 4 us faster per forward at config 2 and needs
-  // 12 bytes less workspace per point.)
-  if (resolved && live) {
-    (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
-    (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
+  PP_QPHASE(4);
+  const bool resolved = best < thr;
+  if (resolved && valid) {
+    od[j] = best;
+    oi[j] = bidx;
   }
-  // The queries stage A could not settle (0.3 % at config 2: one in five waves has one) are served on the
-  // spot, one after the other, by the whole wave (wide_stages_wave): no second list, no second launch
-  // (a separate kernel over the compacted leftovers cost 7 us of launch and tail per forward).  What the
-  // cube of radius 2 cannot settle either goes to the brute-force list.
-  unsigned long long pending = __ballot(!resolved && live);
-  while (pending) {  // wave-uniform
+  // ---- what stage A left: wide stages by the whole wave; then the whole cloud ---------------------------
+  unsigned long long pending = __ballot(!resolved && valid);
+  unsigned long long open = 0ull;  // lanes whose query the cube of radius 2 could not settle
+  while (pending) {
     const int l = (int)__builtin_ctzll(pending);
     pending &= pending - 1;
     const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
@@ -481,25 +679,59 @@ __global__ __launch_bounds__(256) void grid_query_kernel(const float* __restrict
     float wbest;
     int widx;
     const bool settled = wide_stages_wave<LAB>(wx, wy, wz, wl, g, cell_start, sorted, slab, wbest, widx);
-    if ((threadIdx.x & 63) == 0) {
-      if (settled) {
-        (dir ? dist2 : dist1)[(size_t)b * nq + wj] = wbest;
-        (dir ? idx2 : idx1)[(size_t)b * nq + wj] = widx;
-      } else {
-        const int at = atomicAdd(counts + set, 1);
-        qlist[at] = wj;
-        (reinterpret_cast<unsigned long long*>(ws + L.lkey) + set_query_offset(b, dir, N, M))[at] = ~0ull;
+    if (settled) {
+      if (lane == 0) {
+        od[wj] = wbest;
+        oi[wj] = widx;
+      }
+    } else {
+      open |= 1ull << l;
+    }
+  }
+  PP_QPHASE(5);
+  if (open) {  // wave-uniform
+    if (__builtin_popcountll(open) >= 12) {
+      // many: one pass of the wave over the cloud serves them all, a lane per query
+      float sb;
+      int si;
+      lane_scan_cloud<LAB>(ref_raw, rlab_raw, nr, qx, qy, qz, ql, sb, si);
+      if ((open >> lane) & 1ull) {
+        od[j] = sb;
+        oi[j] = si;
+      }
+    } else {
+      while (open) {
+        const int l = (int)__builtin_ctzll(open);
+        open &= open - 1;
+        const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
+        const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), l));
+        const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), l));
+        const float wl = LAB ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ql), l)) : 0.0f;
+        const int wj = __builtin_amdgcn_readlane(j, l);
+        const unsigned long long key = wave_scan_cloud<LAB>(sorted, slab, nr, wx, wy, wz, wl);
+        float wbest;
+        int widx;
+        finish_key<LAB>(key, wbest, widx);
+        if (lane == 0) {
+          od[wj] = wbest;
+          oi[wj] = widx;
+        }
       }
     }
   }
+  PP_QPHASE(6);
+  PP_QPHASE(7);
 }
 
 }  // namespace
 
-// 0 = automatic (grid when a workspace is given and the problem is large enough to pay for its four
+// 0 = automatic (grid when a workspace is given and the problem is large enough to pay for its two
 // launches); 1 = brute force; 2 = grid wherever it is structurally possible (tests)
 static int g_grid_mode = 0;
 extern "C" void pp_debug_set_nmdistance_search(int v) { g_grid_mode = v; }
+// LDS points per wave of the search kernel: 0 = default (384); 320 / 512 for comparison
+static int g_stage_cap = 0;
+extern "C" void pp_debug_set_nmdistance_stage_cap(int v) { g_stage_cap = v; }
 
 static bool grid_applicable(int B, int N, int M, int C) {
   if (!(C == 3 && B > 0 && N >= 2048 && M >= 2048 && (long long)B * ((long long)N + M) < (1LL << 31) - 1)) return false;
@@ -519,12 +751,11 @@ extern "C" size_t pp_labeled_nmdistance_forward_workspace_bytes(int B, int N, in
   return make_layout(B, N, M, true).total;
 }
 
-// build -> stage A for every query, wide stages for what it leaves -> brute force over what is left
+// build -> search (stage A from LDS, wide stages and whole-cloud scans for what it leaves): two launches
 template <bool LAB>
 static int grid_forward(const float* xyz1, const float* xyz2, const float* label1, const float* label2,
                         float* dist1, int* idx1, float* dist2, int* idx2, int B, int N, int M,
                         unsigned char* ws, hipStream_t s) {
-  const Layout L = make_layout(B, N, M, LAB);
   hipError_t e;
   static bool lds_ok[64] = {}, lds_ok_vec[64] = {};
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
@@ -539,14 +770,17 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   const long long blocks = (long long)B * (tiles1 + tiles2);
   if (blocks > 0x7fffffffLL) return PP_EINVAL;
   const int per_xcd = (int)((blocks + 7) / 8);
-  grid_query_kernel<LAB><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(
-      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2);
+#define PP_LAUNCH_W(CAP_)                                                                                  \
+  grid_query_wave_kernel<LAB, CAP_><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(                       \
+      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2)
+  switch (g_stage_cap) {
+    case 320: PP_LAUNCH_W(320); break;
+    case 512: PP_LAUNCH_W(512); break;
+    default: PP_LAUNCH_W(384); break;
+  }
+#undef PP_LAUNCH_W
   PP_RETURN_IF_LAUNCH_FAILED();
-  return pp::nmdist_fwd_c3_list(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
-                                reinterpret_cast<const int*>(ws + L.qlist),
-                                reinterpret_cast<const int*>(ws + L.qcount), s, LAB ? label1 : nullptr,
-                                LAB ? label2 : nullptr, reinterpret_cast<unsigned long long*>(ws + L.lkey),
-                                reinterpret_cast<int*>(ws + L.ldone));
+  return PP_OK;
 }
 
 extern "C" int pp_nmdistance_forward_ws_f32(const float* xyz1, const float* xyz2, float* dist1,

@@ -1,0 +1,56 @@
+"""forward time of nndistance at config-2 size on several point distributions, for three sizes of the search
+kernel's per-wave LDS region (pp_debug_set_nmdistance_stage_cap); checks that they agree bit for bit"""
+import ctypes, sys, numpy as np, torch
+sys.path.insert(0, ".")
+from pytorch_points_amd import _lib, synthetic as S
+from pytorch_points_amd._ext import losses
+dev = torch.device("cuda:0")
+B, N = 32, 16384
+rng = np.random.default_rng(0)
+L = _lib.lib()
+setq = L.pp_debug_set_nmdistance_stage_cap; setq.argtypes = [ctypes.c_int]; setq.restype = None
+def run(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+def clouds(kind, seed):
+    if kind == "sphere": return S.unit_sphere(seed, B, N)
+    if kind == "cube": return rng.random((B, N, 3), dtype=np.float32)
+    if kind == "gaussian": return rng.standard_normal((B, N, 3)).astype(np.float32)
+    if kind == "blobs8":
+        c = rng.random((B, 8, 3), dtype=np.float32) * 2
+        return (c[:, rng.integers(0, 8, N)] + rng.standard_normal((B, N, 3)).astype(np.float32) * 0.02).astype(np.float32)
+    if kind == "two_scales":
+        x = rng.random((B, N, 3), dtype=np.float32); x[:, : N // 2] *= 1e-2; return x
+    if kind == "plane":
+        x = rng.random((B, N, 3), dtype=np.float32); x[..., 2] = 0.3; return x
+    if kind == "line":
+        x = np.zeros((B, N, 3), np.float32); x[..., 0] = rng.random((B, N), dtype=np.float32); return x
+    if kind == "shapenet_like":
+        x = rng.random((B, N, 3), dtype=np.float32) - 0.5
+        q = N // 4
+        x[:, :q, 2] = -0.5; x[:, q:2 * q, 0] = 0.2
+        th = rng.random((B, q)) * 6.283; x[:, 2 * q:3 * q, 0] = 0.3 * np.cos(th); x[:, 2 * q:3 * q, 1] = 0.3 * np.sin(th)
+        return x.astype(np.float32)
+    if kind == "disjoint":
+        x = rng.random((B, N, 3), dtype=np.float32)
+        if seed: x += 5.0
+        return x
+kinds = sys.argv[1:] or ["sphere", "cube", "gaussian", "blobs8", "two_scales", "plane", "line", "shapenet_like", "disjoint"]
+for kind in kinds:
+    x1 = torch.from_numpy(np.ascontiguousarray(clouds(kind, 0))).to(dev); x2 = torch.from_numpy(np.ascontiguousarray(clouds(kind, 1))).to(dev)
+    res = {}
+    outs = {}
+    for mode in (384, 320, 512):
+        setq(mode)
+        d1 = torch.empty(B, N, device=dev); d2 = torch.empty(B, N, device=dev)
+        i1 = torch.empty(B, N, dtype=torch.int32, device=dev); i2 = torch.empty(B, N, dtype=torch.int32, device=dev)
+        res[mode] = run(lambda: losses.nmdistance_forward(x1, x2, d1, d2, i1, i2))
+        outs[mode] = (d1, d2, i1, i2)
+    setq(0)
+    same = all(all(torch.equal(a, b) for a, b in zip(outs[m], outs[384])) for m in (320, 512))
+    print("%-14s fwd ms: cap 384 %.4f | 320 %.4f | 512 %.4f | identical %s" % (kind, res[384], res[320], res[512], same), flush=True)
