@@ -4,21 +4,29 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload chamfer|fps|ball_group]
 
 Default workload = BASELINE.json configs[1]: Chamfer forward+backward, B=32 (per GPU), N=M=16384,
-C=3, fp32, synthetic area-uniform unit-sphere clouds, through the public autograd API
-(pytorch_points_amd.network.model_loss.nndistance -> _ext.losses -> C ABI -> HIP kernels).
-A "step" is one forward + one backward over that batch, inputs resident in HBM.
+C=3, fp32, synthetic area-uniform unit-sphere clouds (two input sets alternating), through the public
+autograd API: pytorch_points_amd.network.model_loss.nndistance (torch.autograd.Function) -> C ABI ->
+HIP kernels, backward through torch.autograd.  A "step" is one forward + one backward over that batch,
+inputs resident in HBM.  `value` is that eager operator path; the same kernels issued through the
+extension-module functions on static buffers and as a hipGraph replay are reported beside it
+(`launch_modes_ms_per_step`).
 
-Metric: point-pairs/s = n_gpus * 2*B*N*M / t(step) (both directions counted).
+Metric: point-pairs/s = n_gpus * 2*B*N*M / t(step) (both directions counted): NOMINAL
+pairs -- the exact grid search evaluates well under 1 % of them; `bruteforce` carries the every-pair
+kernel and its VALU roofline.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL): the batch is
-sharded, B=32 per rank (weak scaling); each step also all-gathers the per-shard (dist, idx) over
-xGMI as BASELINE.json's north_star specifies.  Timing = barrier + synchronize on both sides, MAX
-over ranks; rank 0 prints ONE JSON line.
+sharded, B=32 per rank (weak scaling); every `--gather-every`-th step (default: every step) also
+all-gathers the per-shard (dist, idx) over xGMI as BASELINE.json's north_star specifies.  Timing =
+barrier + synchronize on both sides, MAX over ranks; rank 0 prints ONE JSON line; `compute_ms` and
+`exchange_ms` give the two legs by themselves.
 
 The JSON line also carries
-  roofline      HBM roofline of the dominant kernel (the forward scan): algorithmic bytes per
-                launch / its average duration, HIP events on the launch stream inside the timed loop
-  valu          the roof that actually binds that kernel (fp32 VALU issue)
+  roofline      HBM roofline of the dominant kernel (the search): SURVEY.md §8(d) algorithmic forward bytes /
+                that kernel's average duration, HIP events on the launch stream around it
+  roofline_step the whole step's algorithmic bytes / ms_per_step
+  fps, ball_group   short runs of BASELINE.json configs 3 and 4, each with its own roofline
+  other_distributions_fwd_ms   the forward on clouds that are not a uniform sphere
   cpu_baseline  the CPU oracle (a port of the reference semantics; the reference has no CPU
                 path) timed on this host's cores on a bounded sample of the same workload
 """
@@ -41,7 +49,7 @@ VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz fp32 lane-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="chamfer", choices=["chamfer", "fps", "ball_group"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's)")
@@ -51,11 +59,15 @@ def parse():
                     help="chamfer: auto = the operator's default (exact grid search, brute-force "
                          "fallback); bruteforce = evaluate every pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--launch", default="auto", choices=["auto", "graph", "ext", "eager"],
-                    help="chamfer: how the step's kernels are issued.  graph = hipGraph replay; ext = two calls "
-                         "of the _ext.losses functions (forward, backward) on static buffers; eager = through "
-                         "torch.autograd.Function; auto (default) = graph or ext, whichever a short calibration "
-                         "after the warm-up finds faster on this host")
+    ap.add_argument("--launch", default="all", choices=["all", "eager", "ext", "graph"],
+                    help="chamfer: how the timed steps are issued.  eager = the torch.autograd.Function operator "
+                         "(what 'value' reports by default); ext = two calls of the _ext.losses functions on static "
+                         "buffers; graph = hipGraph replay.  all (default) = eager is timed as 'value' and the other "
+                         "two are reported beside it")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N > 1: all-gather the shard outputs every k-th step (default 1: every step)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="chamfer: skip the short runs of the other workloads (fps, ball_group) and distributions")
     ap.add_argument("--with-backward", action="store_true", help="ball_group: also time group_points_grad")
     return ap.parse_args()
 
@@ -142,59 +154,118 @@ def cpu_baseline_chamfer(N, C):
             % (bs, N, C, dt, dt * cores)}
 
 
+def _knob(name):
+    """a test / benchmark knob of include/pp_hip_debug.h"""
+    import ctypes
+    from pytorch_points_amd import _lib
+    fn = getattr(_lib.lib(), name)
+    fn.argtypes = [ctypes.c_int]
+    fn.restype = None
+    return fn
+
+
+def _search_kernel_ms(fwd, n=40):
+    """Average duration of the forward's two kernels (grid build, search), HIP events recorded by the library
+    on the launch stream around each launch (pp_debug_set_nmdistance_kernel_timing, include/pp_hip_debug.h)."""
+    import ctypes
+    from pytorch_points_amd import _lib
+    L = _lib.lib()
+    read = L.pp_debug_nmdistance_kernel_ms
+    read.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    read.restype = ctypes.c_int
+    on = _knob("pp_debug_set_nmdistance_kernel_timing")
+    on(1)
+    try:
+        for _ in range(3):
+            fwd()
+        torch.cuda.synchronize()
+        bs, ss = [], []
+        for _ in range(n):
+            fwd()
+            bm, sm = ctypes.c_float(0), ctypes.c_float(0)
+            if read(ctypes.byref(bm), ctypes.byref(sm)) != 0:
+                return None, None
+            bs.append(bm.value)
+            ss.append(sm.value)
+    finally:
+        on(0)
+    return float(np.mean(bs)), float(np.mean(ss))
+
+
+def _distribution(kind, seed, B, N):
+    """point clouds that are NOT a uniform sphere (VERDICT r1 #3): (B, N, 3) float32"""
+    rng = np.random.default_rng(1000 + seed)
+    if kind == "gaussian":
+        return rng.standard_normal((B, N, 3)).astype(np.float32)
+    if kind == "blobs8":
+        c = rng.random((B, 8, 3), dtype=np.float32) * 2
+        pick = rng.integers(0, 8, N)
+        return (c[:, pick] + rng.standard_normal((B, N, 3)).astype(np.float32) * 0.02).astype(np.float32)
+    if kind == "two_scales":
+        x = rng.random((B, N, 3), dtype=np.float32)
+        x[:, : N // 2] *= 1e-2
+        return x
+    if kind == "shapenet_like":   # thin surfaces: two planes and a cylinder in a box
+        x = rng.random((B, N, 3), dtype=np.float32) - 0.5
+        q = N // 4
+        x[:, :q, 2] = -0.5
+        x[:, q:2 * q, 0] = 0.2
+        th = rng.random((B, q)) * 6.283
+        x[:, 2 * q:3 * q, 0] = 0.3 * np.cos(th)
+        x[:, 2 * q:3 * q, 1] = 0.3 * np.sin(th)
+        return x.astype(np.float32)
+    raise ValueError(kind)
+
+
 def bench_chamfer(args, dist, world, rank, device):
     from pytorch_points_amd import _lib, synthetic as S
     from pytorch_points_amd.network.model_loss import nndistance
-    import ctypes
+    from pytorch_points_amd._ext import losses as ext_losses
     B = args.batch or 32
     N = args.points or 16384
     M, C = N, 3
     if args.search == "bruteforce":
-        fs = _lib.lib().pp_debug_set_nmdistance_search
-        fs.argtypes = [ctypes.c_int]
-        fs.restype = None
-        fs(1)
+        _knob("pp_debug_set_nmdistance_search")(1)
     if args.variant:
-        fn = _lib.lib().pp_debug_set_nmdistance_variant
-        fn.argtypes = [ctypes.c_int]
-        fn.restype = None
-        fn(args.variant)
-    # rank r owns batch elements [r*B, (r+1)*B) of the global batch; seeds 0 / 1 as SURVEY.md §8d
-    x1 = torch.from_numpy(S.unit_sphere(0, B, N, C, batch_offset=rank * B)).to(device)
-    x2 = torch.from_numpy(S.unit_sphere(1, B, M, C, batch_offset=rank * B)).to(device)
-    x1.requires_grad_(True)
-    x2.requires_grad_(True)
+        _knob("pp_debug_set_nmdistance_variant")(args.variant)
+    # rank r owns batch elements [r*B, (r+1)*B) of the global batch; seeds 0 / 1 as SURVEY.md §8d.  Two input
+    # sets (A: seeds 0/1, B: seeds 2/3) alternate from step to step, so no step sees the clouds -- or the grid
+    # its predecessor built -- again.
+    sets = []
+    for s1, s2 in ((0, 1), (2, 3)):
+        x1 = torch.from_numpy(S.unit_sphere(s1, B, N, C, batch_offset=rank * B)).to(device).requires_grad_(True)
+        x2 = torch.from_numpy(S.unit_sphere(s2, B, M, C, batch_offset=rank * B)).to(device).requires_grad_(True)
+        sets.append((x1, x2))
     g1 = torch.full((B, N), 1.0 / (B * N), device=device)   # gradient of dist.mean()
     g2 = torch.full((B, M), 1.0 / (B * M), device=device)
     exchange = None
     if dist is not None:
-        # one asynchronous collective per step: (dist1 | dist2 | idx1 | idx2) of the shard, packed (idx as
+        # one asynchronous collective per gathered step: (dist1 | dist2 | idx1 | idx2) of the shard, packed (idx as
         # 16-bit words: 6 MiB per rank at B=32, N=M=16384), double-buffered (pytorch_points_amd/sharded.py)
         from pytorch_points_amd.sharded import PackedShardGather
         exchange = PackedShardGather(B, N, M, device)
-    fwd_events = []
-    pending = []   # slot of the previous step's all-gather
+    pending = []        # slot of the previous gathered step
+    counter = [0]
+    gather_every = max(1, args.gather_every)
 
-    instrument = [True]   # HIP events around the forward (they cost host time: off for the eager timing)
+    def maybe_exchange(d1, d2, i1, i2):
+        """all-gather of the per-shard (dist, idx) over xGMI (RCCL), asynchronous: it runs on the collective's
+        stream beside this step's backward and the next step's forward; the previous gathered result is consumed
+        (unpacked to the global-batch tensors) first"""
+        if exchange is None or counter[0] % gather_every:
+            return
+        if pending:
+            exchange.wait(pending.pop())
+        pending.append(exchange.launch(d1, d2, i1, i2))
 
-    def step():
+    def eager_step():
+        """the operator as a user calls it: torch.autograd.Function forward, autograd backward"""
+        x1, x2 = sets[counter[0] & 1]
+        counter[0] += 1
         x1.grad = None
         x2.grad = None
-        if instrument[0]:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
         d1, d2, i1, i2 = nndistance(x1, x2)
-        if instrument[0]:
-            e1.record()
-            fwd_events.append((e0, e1))
-        if exchange is not None:
-            # all-gather of the per-shard (dist, idx) over xGMI (RCCL), asynchronous: it runs on the
-            # collective stream beside this step's backward and the next step's forward; the previous
-            # step's gathered result is consumed (unpacked to the global-batch tensors) first
-            if pending:
-                exchange.wait(pending.pop())
-            pending.append(exchange.launch(d1, d2, i1, i2))
+        maybe_exchange(d1, d2, i1, i2)
         torch.autograd.backward([d1, d2], [g1, g2])
 
     def drain():
@@ -228,23 +299,37 @@ def bench_chamfer(args, dist, world, rank, device):
             t = float(tt.item())
         return t
 
-    # hipGraph replay of the same step (pytorch_points_amd/graphs.py): the kernels of one step take
-    # less time than the Python/autograd work that launches them, so the eager loop is host-bound
-    gstep = None
-    graph_note = None
-    if args.launch in ("auto", "graph"):
+    # the same step on static buffers through the reference's extension-module API (pytorch_points._ext.losses:
+    # nmdistance_forward / nmdistance_backward -- what the reference's autograd.Function calls,
+    # _ext/nmdistance.cpp:30-34): no autograd bookkeeping, plain stream launches
+    od1, od2 = torch.empty(B, N, device=device), torch.empty(B, M, device=device)
+    oi1 = torch.empty(B, N, dtype=torch.int32, device=device)
+    oi2 = torch.empty(B, M, dtype=torch.int32, device=device)
+    ogx1, ogx2 = torch.empty(B, N, C, device=device), torch.empty(B, M, C, device=device)
+    dsets = [(a.detach(), b.detach()) for a, b in sets]
+
+    def ext_step():
+        sx1, sx2 = dsets[counter[0] & 1]
+        counter[0] += 1
+        ext_losses.nmdistance_forward(sx1, sx2, od1, od2, oi1, oi2)
+        maybe_exchange(od1, od2, oi1, oi2)
+        ext_losses.nmdistance_backward(sx1, sx2, ogx1, ogx2, g1, g2, oi1, oi2)
+
+    # hipGraph replay of one step (pytorch_points_amd/graphs.py; static inputs: set A)
+    gstep, graph_note = None, None
+    if args.launch in ("all", "graph"):
         try:
             from pytorch_points_amd.graphs import GraphedChamferStep
             gstep = GraphedChamferStep(B, N, M, device)
             with torch.no_grad():
-                gstep.xyz1.copy_(x1)
-                gstep.xyz2.copy_(x2)
+                gstep.xyz1.copy_(sets[0][0])
+                gstep.xyz2.copy_(sets[0][1])
                 gstep.grad_dist1.copy_(g1)
                 gstep.grad_dist2.copy_(g2)
             gstep.capture()
-        except Exception as exc:  # capture not available: report the eager loop and say so
+        except Exception as exc:
             gstep = None
-            graph_note = "graph capture failed (%s: %s); eager launches timed instead" % (type(exc).__name__, exc)
+            graph_note = "graph capture failed (%s: %s)" % (type(exc).__name__, exc)
     if dist is not None:  # every rank must take the same path
         flag = torch.tensor([1 if gstep is not None else 0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -252,163 +337,170 @@ def bench_chamfer(args, dist, world, rank, device):
             gstep = None
 
     def graph_step():
+        counter[0] += 1
         d1, d2, i1, i2, _, _ = gstep.replay()
-        if exchange is not None:
-            if pending:
-                exchange.wait(pending.pop())
-            pending.append(exchange.launch(d1, d2, i1, i2))   # packs on this stream, before the next replay
+        maybe_exchange(d1, d2, i1, i2)
 
-    # the step through the reference's extension-module API (pytorch_points._ext.losses: nmdistance_forward,
-    # nmdistance_backward -- what the reference's autograd.Function calls, _ext/nmdistance.cpp:30-34) on
-    # static buffers: two Python calls per step, no autograd bookkeeping, plain stream launches
-    from pytorch_points_amd._ext import losses as ext_losses
-    sx1, sx2 = x1.detach(), x2.detach()
-    od1, od2 = torch.empty(B, N, device=device), torch.empty(B, M, device=device)
-    oi1 = torch.empty(B, N, dtype=torch.int32, device=device)
-    oi2 = torch.empty(B, M, dtype=torch.int32, device=device)
-    ogx1, ogx2 = torch.empty_like(sx1), torch.empty_like(sx2)
+    # ---- the timed region: the autograd operator (eager) unless another issue mode is asked for ---------------
+    want = "eager" if args.launch == "all" else args.launch
+    if want == "graph" and gstep is None:
+        want = "eager"
+    timed_fn = {"graph": graph_step, "ext": ext_step, "eager": eager_step}[want]
+    dt = run_timed(timed_fn, args.warmup, args.steps)
+    ms = dt / args.steps * 1e3
 
-    def ext_step():
-        ext_losses.nmdistance_forward(sx1, sx2, od1, od2, oi1, oi2)
-        if exchange is not None:
+    modes = {want: ms}
+    n_cal = 100
+    if args.launch == "all":   # the other issue modes, short runs, reported beside the headline
+        modes["ext"] = run_timed(ext_step, 5, n_cal) / n_cal * 1e3
+        if gstep is not None:
+            modes["graph"] = run_timed(graph_step, 5, n_cal) / n_cal * 1e3
+    compute_ms = exchange_ms = None
+    if dist is not None:
+        # the two legs by themselves: the same steps without the exchange, and the exchange with nothing beside it
+        ex_saved, exchange = exchange, None
+        compute_ms = run_timed(timed_fn, 5, n_cal) / n_cal * 1e3
+        exchange = ex_saved
+
+        def only_exchange():
             if pending:
                 exchange.wait(pending.pop())
             pending.append(exchange.launch(od1, od2, oi1, oi2))
-        ext_losses.nmdistance_backward(sx1, sx2, ogx1, ogx2, g1, g2, oi1, oi2)
+        exchange_ms = run_timed(only_exchange, 5, n_cal) / n_cal * 1e3
 
-    instrument[0] = False
-    modes = {}   # launch mode -> ms per step over a short calibration run (reported; "auto" picks from it)
-    n_cal = 50
-    if gstep is not None:
-        modes["graph"] = run_timed(graph_step, 5, n_cal) / n_cal * 1e3
-    modes["ext"] = run_timed(ext_step, 5, n_cal) / n_cal * 1e3
-    n_eager = 200   # enough steps that the closing synchronize does not weigh on the per-step time
-    eager_dt = run_timed(step, 3, n_eager) / n_eager
-    modes["eager"] = eager_dt * 1e3
-    want = args.launch
-    if want == "graph" and gstep is None:
-        want = "eager"
-    if want == "auto":
-        want = "graph" if (gstep is not None and modes["graph"] <= modes["ext"]) else "ext"
-    timed_fn = {"graph": graph_step, "ext": ext_step, "eager": step}[want]
-    dt = run_timed(timed_fn, args.warmup, args.steps)
-
-    # forward duration: the forward's launches alone, issued back to back on the launch stream between two
-    # HIP events (the _ext.losses call: the same launches as the operator's forward)
+    # forward duration: the forward's two launches issued back to back between two HIP events on the launch stream
+    def fwd_only():
+        sx1, sx2 = dsets[counter[0] & 1]
+        counter[0] += 1
+        ext_losses.nmdistance_forward(sx1, sx2, od1, od2, oi1, oi2)
     for _ in range(3):
-        ext_losses.nmdistance_forward(sx1, sx2, od1, od2, oi1, oi2)
+        fwd_only()
     torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nf = 200
     e0.record()
-    for _ in range(n_eager):
-        ext_losses.nmdistance_forward(sx1, sx2, od1, od2, oi1, oi2)
+    for _ in range(nf):
+        fwd_only()
     e1.record()
     torch.cuda.synchronize()
-    fwd_ms = e0.elapsed_time(e1) / n_eager
+    fwd_ms = e0.elapsed_time(e1) / nf
+    grid = args.search == "auto" and int(_lib.lib().pp_nmdistance_forward_workspace_bytes(B, N, M, C)) > 0
+    build_ms = search_ms = None
+    if grid:
+        build_ms, search_ms = _search_kernel_ms(fwd_only)
 
     # the same step with the search forced to the brute-force kernel (every pair evaluated)
     brute = None
-    if args.search == "auto":
-        setter = _lib.lib().pp_debug_set_nmdistance_search
-        setter.argtypes = [ctypes.c_int]
-        setter.restype = None
+    if args.search == "auto" and args.launch == "all":
+        setter = _knob("pp_debug_set_nmdistance_search")
         setter(1)
         try:
-            bev = []
-
-            def bstep():
-                x1.grad = None
-                x2.grad = None
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                d1, d2, i1, i2 = nndistance(x1, x2)
-                e1.record()
-                bev.append((e0, e1))
-                torch.autograd.backward([d1, d2], [g1, g2])
-
-            for _ in range(3):
-                bstep()
+            nb = 10
+            tb = run_timed(eager_step, 2, nb) / nb
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(5):
+                fwd_only()
+            ev1.record()
             torch.cuda.synchronize()
-            bev.clear()
-            tb = time.perf_counter()
-            nb = max(5, min(args.steps, 20))
-            for _ in range(nb):
-                bstep()
-            torch.cuda.synchronize()
-            tb = (time.perf_counter() - tb) / nb
-            bfwd = float(np.mean([a.elapsed_time(b) for a, b in bev]))
-            brute = {"ms_per_step": tb * 1e3, "fwd_ms": bfwd, "pairs_per_s_per_gpu": 2.0 * B * N * M / tb}
+            brute = {"ms_per_step": tb * 1e3, "fwd_ms": ev0.elapsed_time(ev1) / 5, "pairs_per_s_per_gpu": 2.0 * B * N * M / tb}
         finally:
             setter(0)
 
     pairs_per_step = 2.0 * B * N * M * world
-    ms = dt / args.steps * 1e3
-    alg_bytes_fwd = 4.0 * C * B * (N + M) + 8.0 * B * (N + M)
-    hbm_gbs = alg_bytes_fwd / (fwd_ms * 1e-3) / 1e9
+    alg_bytes_fwd = 4.0 * C * B * (N + M) + 8.0 * B * (N + M)     # 20 971 520 at config 2
+    alg_bytes_step = alg_bytes_fwd + (4.0 * C + 8.0) * B * (N + M) + 4.0 * C * B * (N + M)   # + backward: 54 525 952
     # VALU lane-ops the brute-force kernel issues per pair: 3 sub + 1 mul + 2 fma + 1/2 min3 + 13/64
     # per-group bookkeeping (DESIGN.md "nmdist_fwd_c3_kernel")
     laneops = 2.0 * B * N * M * 6.703125
-    grid = args.search == "auto" and int(_lib.lib().pp_nmdistance_forward_workspace_bytes(B, N, M, C)) > 0
+    c2 = (B, N, M) == (32, 16384, 16384)
+    launch_text = {
+        "eager": "torch.autograd.Function operator (nndistance forward, autograd backward), one Python call each: "
+                 "what a user of the drop-in API runs",
+        "ext": "two calls per step of the extension-module API (_ext.losses.nmdistance_forward / _backward) on "
+               "static buffers: plain stream launches, same kernels as the autograd operator",
+        "graph": "hipGraph replay of the step's launches (same kernels as the eager operator)"}
     out = {
         "metric": "chamfer_fwd_bwd_point_pairs_per_s", "value": pairs_per_step / (dt / args.steps),
         "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Chamfer fwd+bwd B=%d/GPU N=M=%d C=3 fp32, area-uniform unit sphere"
-                               % (B, N), "global_batch": B * world,
-                   "search": ("exact uniform-grid search with brute-force fallback (operator default): "
-                              "outputs bit-identical to the brute force, most pairs pruned, value = "
-                              "2*B*N*M/t" if grid else "brute force: every pair evaluated"),
-                   "parallelism": "batch-shard x%d%s" % (world, " + RCCL all-gather(dist,idx), async" if world > 1 else "")},
+        "config": {"workload": "Chamfer fwd+bwd B=%d/GPU N=M=%d C=3 fp32, area-uniform unit sphere, two input sets "
+                               "alternating" % (B, N), "global_batch": B * world,
+                   "search": ("exact uniform-grid search, brute-force scans inside the search kernel as fallback "
+                              "(operator default): outputs bit-identical to the brute force, most pairs pruned; value "
+                              "= nominal pairs 2*B*N*M/t, not pairs evaluated" if grid else
+                              "brute force: every pair evaluated"),
+                   "parallelism": "batch-shard x%d%s" % (world, " + RCCL all-gather(dist,idx) every %d step(s), async"
+                                                         % gather_every if world > 1 else ""),
+                   "launch": launch_text[want]},
         "fwd_ms": fwd_ms,
+        "launch_modes_ms_per_step": dict(modes, note="same kernels in every mode; 'value' is the '%s' mode" % want),
     }
-    out["config"]["launch"] = {
-        "graph": "hipGraph replay of the step's launches (same kernels as the eager operator)",
-        "ext": "two calls per step of the extension-module API (_ext.losses.nmdistance_forward / _backward) on "
-               "static buffers: plain stream launches, same kernels as the autograd operator",
-        "eager": "eager (torch.autograd.Function, one Python call per operator)"}[want]
-    out["launch_modes_ms_per_step"] = dict(modes, note="same kernels in every mode; calibration runs of %d steps "
-                                           "(eager: %d); --launch auto times the faster of graph / ext" % (n_cal, n_eager))
-    out["eager"] = {"ms_per_step": eager_dt * 1e3, "pairs_per_s": pairs_per_step / eager_dt,
-                    "note": "same step issued through torch.autograd.Function calls, one Python call per operator"}
     if graph_note:
         out["config"]["launch_note"] = graph_note
+    if dist is not None:
+        out["compute_ms"] = compute_ms
+        out["exchange_ms"] = exchange_ms
+        out["exchange_note"] = ("compute_ms: the same steps without the exchange; exchange_ms: pack + all_gather_into_tensor + "
+                                "unpack of one step's outputs with nothing beside it; ms_per_step has them overlapped "
+                                "(gather every %d step(s))" % gather_every)
     if grid:
-        # forward = grid_build_kernel + grid_query_kernel (the dominant one, ~2/3 of the forward; stage A and
-        # the wide stages) + the brute-force kernel over the unresolved list; timed together by the HIP events
-        out["roofline"] = {"bound": "hbm", "kernel": "grid_build_kernel + grid_query_kernel + list fallback",
-                           "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": hbm_gbs / HBM_PEAK_GBS,
-                           # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, summed over the forward's kernels
-                           # (profiles/r1/pmc_summary.txt: build 6.2 + 24.2 MB, search 11.6 + 8.0); most of it
-                           # is the search structure itself (sorted clouds + cell tables,
-                           # 25 MB, written with scattered 16-byte stores), not re-reads of the inputs
-                           "traffic": 50.0e6 if (B, N, M) == (32, 16384, 16384) else None,
-                           "note": "VALU-issue / L2-latency-bound search over a 42 MB workspace (25 MB of it touched per call), not HBM-bound; "
-                                   "'bruteforce' carries the every-pair kernel and its VALU roofline"}
+        dom_ms = search_ms if search_ms else fwd_ms
+        gbs = alg_bytes_fwd / (dom_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "grid_query_wave_kernel (the search; dominant kernel of the step)",
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            # rocprofv3 --pmc FETCH_SIZE (x2: 16-byte loads count half on gfx950) + WRITE_SIZE of this kernel
+            # per launch (profiles/r2/pmc_summary.txt)
+            "traffic": 30.9e6 if c2 else None,
+            "kernel_ms": search_ms, "build_kernel_ms": build_ms,
+            "note": "SURVEY.md §8(d): algorithmic forward bytes (%.0f) / the search kernel's average duration, HIP events "
+                    "on the launch stream around that kernel (pp_hip_debug.h), %d forwards after the timed region. The "
+                    "search is bound by VALU issue and LDS, not by HBM; 'bruteforce' carries the every-pair kernel with "
+                    "its VALU roofline" % (alg_bytes_fwd, 40)}
+        sgbs = alg_bytes_step / (ms * 1e-3) / 1e9
+        out["roofline_step"] = {"bound": "hbm", "achieved": sgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": sgbs / HBM_PEAK_GBS,
+                                "note": "whole step: %.0f algorithmic bytes (forward + backward) / ms_per_step" % alg_bytes_step}
         if brute is not None:
             bg = alg_bytes_fwd / (brute["fwd_ms"] * 1e-3) / 1e9
             brute.update({
                 "roofline": {"bound": "hbm", "kernel": "nmdist_fwd_c3_kernel", "achieved": bg,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bg / HBM_PEAK_GBS,
-                             "traffic": 14.4e6 if (B, N, M) == (32, 16384, 16384) else None,
+                             "traffic": 14.4e6 if c2 else None,
                              "note": "6500 flop/B: VALU-bound, see valu"},
                 "valu": {"achieved": laneops / (brute["fwd_ms"] * 1e-3), "peak": VALU_PEAK_LANEOPS,
                          "unit": "lane-ops/s", "frac": laneops / (brute["fwd_ms"] * 1e-3) / VALU_PEAK_LANEOPS}})
             out["bruteforce"] = brute
     else:
+        hbm_gbs = alg_bytes_fwd / (fwd_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "nmdist_fwd_c3_kernel", "achieved": hbm_gbs,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
-                           # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/r1/pmc_summary.txt):
-                           # 6.1 MB + 8.0 MB per launch; reads are scalar/dword loads (uncalibrated on
-                           # gfx950) -- at most the algorithmic 20.97 MB either way: no re-reads beyond L2
-                           "traffic": 14.4e6 if (B, N, M) == (32, 16384, 16384) else None,
+                           "traffic": 14.4e6 if c2 else None,
                            "note": "exact brute force is fp32-VALU-bound (6500 flop/B); see 'valu'"}
         out["valu"] = {"achieved": laneops / (fwd_ms * 1e-3), "peak": VALU_PEAK_LANEOPS,
                        "unit": "lane-ops/s", "frac": laneops / (fwd_ms * 1e-3) / VALU_PEAK_LANEOPS,
                        "pairs_per_s_fwd": 2.0 * B * N * M / (fwd_ms * 1e-3)}
+    if rank == 0 and world == 1 and grid and args.launch == "all" and not args.no_extras:
+        # other point distributions, forward only: same shapes, clouds that are not a sphere
+        od = {}
+        for kind in ("gaussian", "blobs8", "two_scales", "shapenet_like"):
+            a = torch.from_numpy(_distribution(kind, 0, B, N)).to(device)
+            b_ = torch.from_numpy(_distribution(kind, 1, B, N)).to(device)
+            for _ in range(2):
+                ext_losses.nmdistance_forward(a, b_, od1, od2, oi1, oi2)
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(5):
+                ext_losses.nmdistance_forward(a, b_, od1, od2, oi1, oi2)
+            ev1.record()
+            torch.cuda.synchronize()
+            od[kind] = ev0.elapsed_time(ev1) / 5
+        od["note"] = "nndistance forward, ms, B=%d N=M=%d; the every-pair kernel takes %s ms" % (
+            B, N, ("%.2f" % brute["fwd_ms"]) if brute else "1.8")
+        out["other_distributions_fwd_ms"] = od
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU leg runs at N=1 only
         out["cpu_baseline"] = cpu_baseline_chamfer(N, C)
     return out
@@ -514,6 +606,13 @@ def bench_ball_group(args, dist, world, rank, device):
                          "traffic": 4583e6 if (B, N, C, ns) == (32, 16384, 128, 64) else None}}
 
 
+def _short(line):
+    """a secondary workload's line as a sub-object of the headline: drop the keys that repeat the contract"""
+    for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        line.pop(k, None)
+    return line
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -522,6 +621,19 @@ def main():
     device = torch.device("cuda", local)
     fn = {"chamfer": bench_chamfer, "fps": bench_fps, "ball_group": bench_ball_group}[args.workload]
     out = fn(args, dist, world, rank, device)
+    if args.workload == "chamfer" and world == 1 and args.launch == "all" and not args.no_extras \
+            and args.batch is None and args.points is None:
+        # BASELINE.json configs 3 and 4 as short runs beside the headline, each with its own roofline (the driver
+        # only runs the default command: VERDICT r1 #4); `--workload fps|ball_group` gives the full lines
+        import copy
+        torch.cuda.empty_cache()
+        a3 = copy.copy(args)
+        a3.steps, a3.warmup = 5, 2
+        out["fps"] = _short(bench_fps(a3, None, 1, 0, device))
+        torch.cuda.empty_cache()
+        a4 = copy.copy(args)
+        a4.steps, a4.warmup, a4.with_backward = 10, 3, True
+        out["ball_group"] = _short(bench_ball_group(a4, None, 1, 0, device))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -10,7 +10,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous memory; fp32 data, int32 indices;
  *   - the caller allocates every output and every workspace; nothing is allocated, retained or
- *     synchronised inside the library; no global mutable state (thread-safe);
+ *     synchronised inside the library.  Thread-safe: the only process-wide state is a set of atomic
+ *     test / benchmark knobs, declared separately in pp_hip_debug.h and never set by product code,
+ *     and idempotent per-device "LDS limit raised" flags;
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); all work is
  *     enqueued on it, on the device that is current when the call is made;
  *   - return value: 0 on success, otherwise a hipError_t value (PP_EINVAL = hipErrorInvalidValue
@@ -82,10 +84,16 @@ int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2, const float
  *   (_ext/sampling.cpp:68-82 -> furthest_sampling_cuda_forward, _ext/sampling_cuda.cu:235-325).
  * xyz (B,N,3); temp (B,N) in/out running min squared distance (caller pre-fills 1e10,
  * network/geo_operations.py:33); idx (B,npoint) out, idx[:,0] = seed_idx.
- * workspace: pp_furthest_sampling_workspace_bytes(...) bytes of scratch (may be NULL if that is 0). */
+ * workspace: pp_furthest_sampling_workspace_bytes(...) bytes of scratch (may be NULL if that is 0); a pure
+ * host computation (an upper bound over devices).  Its first 256 bytes hold a STICKY status word: the caller
+ * zeroes them once after allocating the buffer.  The fast kernel shares a batch element between workgroups
+ * that wait for each other; it is only launched with as many workgroups as the current device keeps resident
+ * (its real CU count and the occupancy query), and every wait is bounded: if one times out (CUs held by a
+ * kernel of another stream), the call leaves zeros from that step on in idx and sets the status word, which
+ * stays set until the caller clears it. */
 size_t pp_furthest_sampling_workspace_bytes(int B, int N, int npoint);
-/* Debug/test aid (synchronises `stream`): 0 = ok, 1 = a bounded inter-workgroup wait of an earlier
- * pp_furthest_sampling_f32 call on this workspace timed out (its indices are invalid). */
+/* Reads the status word (synchronises `stream`): 0 = ok, 1 = a wait of some pp_furthest_sampling_f32 call
+ * on this workspace has timed out since the word was last zeroed. */
 int pp_furthest_sampling_status(const void* workspace, void* stream);
 int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx, int B, int N, int npoint,
                              int seed_idx, void* workspace, size_t workspace_bytes, void* stream);

@@ -1,0 +1,48 @@
+/*
+ * pp_hip_debug.h -- test and benchmark knobs of libpp_hip.so.  NOT part of the drop-in C ABI (pp_hip.h).
+ *
+ * Every operator of pp_hip.h picks its kernel variant from the problem size.  The functions below override
+ * that choice process-wide so that tests can compare the variants with each other bit for bit and benchmarks
+ * can time them; 0 always restores the automatic choice.  They are the library's only global mutable state
+ * besides idempotent per-device "LDS limit raised" flags: each is one relaxed std::atomic<int>, safe to set
+ * from any thread, read by the next call of the operator.  Product code (pytorch_points_amd/network, _ext)
+ * never calls them.
+ */
+#ifndef PP_HIP_DEBUG_H
+#define PP_HIP_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Chamfer forward: 0 automatic, 1 brute force (every pair), 2 grid search wherever structurally possible */
+void pp_debug_set_nmdistance_search(int mode);
+/* brute-force kernel variant (Q queries per lane, G points per group, packed / prefetch forms; chamfer.hip) */
+void pp_debug_set_nmdistance_variant(int variant);
+/* grid search: staged points per wave of the search kernel (0 = 384; 320, 512) */
+void pp_debug_set_nmdistance_stage_cap(int points);
+/* labeled Chamfer brute force: 1 = the one-lane-per-query kernel */
+void pp_debug_set_labeled_variant(int variant);
+/* Chamfer backward: 1 LDS doubles, 2 CSR lists, 3 LDS fp32 columns, 4 global atomics, 5 deterministic */
+void pp_debug_set_nmdistance_backward_variant(int variant);
+/* per-kernel HIP-event timing of the grid forward (build, search), read back after the call */
+void pp_debug_set_nmdistance_kernel_timing(int on);
+int pp_debug_nmdistance_kernel_ms(float* build_ms, float* search_ms);
+
+void pp_debug_set_fps_v1(int on); /* 1 = one workgroup per batch element instead of the CU cluster */
+void pp_debug_set_gather_variant(int variant);
+void pp_debug_set_ball_query_variant(int variant); /* scan kernels: 1 = one wave per 64 centres */
+void pp_debug_set_ball_query_search(int mode);     /* 0 automatic, 1 scan, 2 grid wherever possible */
+void pp_debug_set_ball_query_lpc(int lanes_per_centre);
+void pp_debug_set_group_points_variant(int variant);
+void pp_debug_set_group_points_grad_variant(int variant);
+void pp_debug_set_three_nn_search(int mode);       /* 0 automatic, 1 scan */
+void pp_debug_set_three_interpolate_variant(int variant);
+void pp_debug_set_three_interpolate_grad_variant(int variant);
+void pp_debug_set_scatter_mode(int mode);          /* 1 = never use the sorted scatter-add form */
+void pp_debug_set_knn_search(int mode);            /* 0 automatic, 1 scan */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PP_HIP_DEBUG_H */

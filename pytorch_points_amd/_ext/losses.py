@@ -10,20 +10,17 @@ import torch
 
 from .. import _lib
 
-# scratch for the exact grid search: one growing buffer per (device, stream) -- calls on one
-# stream are ordered, calls on different streams must not share scratch
-_nmd_workspace = {}
+# PP_NMDISTANCE_SEARCH=bruteforce (read once, at import): every pair evaluated, no grid search
+_FORCE_BRUTE = os.environ.get("PP_NMDISTANCE_SEARCH") == "bruteforce"
 
 
-def _workspace(device, nbytes):
-    if nbytes == 0:
-        return None
-    key = (device, _lib.raw_stream(device))
-    buf = _nmd_workspace.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _nmd_workspace[key] = buf
-    return buf
+def _workspace_bytes(L, b, n, m, c, labeled):
+    """bytes of scratch the grid search wants for this shape (0: the brute force serves it)"""
+    if _FORCE_BRUTE:
+        return 0
+    if labeled:
+        return L.pp_labeled_nmdistance_forward_workspace_bytes(b, n, m, c)
+    return L.pp_nmdistance_forward_workspace_bytes(b, n, m, c)
 
 
 def _shapes(xyz1, xyz2):
@@ -48,16 +45,28 @@ def nmdistance_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
     _lib.require_int(*ints)
     if dist1.numel() != b * n or idx1.numel() != b * n or dist2.numel() != b * m or idx2.numel() != b * m:
         raise RuntimeError("output tensors must be (B, N) and (B, M)")
-    L = _lib.lib()
-    nbytes = 0 if os.environ.get("PP_NMDISTANCE_SEARCH") == "bruteforce" else \
-        int(L.pp_nmdistance_forward_workspace_bytes(b, n, m, c))
-    ws = _workspace(dev, nbytes)
-    with _lib.on_device(dev) as stream:
-        _lib.check(L.pp_nmdistance_forward_ws_f32(
-            _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(idx1), _lib.ptr(dist2),
-            _lib.ptr(idx2), b, n, m, c, _lib.ptr(ws) if ws is not None else None, nbytes, stream),
-            "nmdistance_forward")
+    _launch_forward(xyz1, xyz2, dist1, dist2, idx1, idx2, b, n, m, c, dev)
     return 1
+
+
+def _launch_forward(xyz1, xyz2, dist1, dist2, idx1, idx2, b, n, m, c, dev):
+    """the launch itself; arguments already validated (the autograd operator validates its two inputs and
+    allocates the four outputs itself, so it comes straight here)"""
+    L = _lib.lib()
+    nbytes = _workspace_bytes(L, b, n, m, c, False)
+    ws = _lib.workspace(dev, "nmdistance", nbytes)
+    idx = dev.index
+    if idx is not None and idx != _lib.current_device():
+        with torch.cuda.device(dev):
+            code = L.pp_nmdistance_forward_ws_f32(
+                xyz1.data_ptr(), xyz2.data_ptr(), dist1.data_ptr(), idx1.data_ptr(), dist2.data_ptr(), idx2.data_ptr(),
+                b, n, m, c, ws.data_ptr() if ws is not None else None, nbytes, _lib.raw_stream(dev))
+    else:
+        code = L.pp_nmdistance_forward_ws_f32(
+            xyz1.data_ptr(), xyz2.data_ptr(), dist1.data_ptr(), idx1.data_ptr(), dist2.data_ptr(), idx2.data_ptr(),
+            b, n, m, c, ws.data_ptr() if ws is not None else None, nbytes, _lib.raw_stream(dev))
+    if code:
+        _lib.check(code, "nmdistance_forward")
 
 
 def labeled_nmdistance_forward(xyz1, xyz2, label1, label2, dist1, dist2, idx1, idx2):
@@ -76,9 +85,8 @@ def labeled_nmdistance_forward(xyz1, xyz2, label1, label2, dist1, dist2, idx1, i
     if label1.numel() != b * n or label2.numel() != b * m:
         raise RuntimeError("labels must be (B, N) and (B, M)")
     L = _lib.lib()
-    nbytes = 0 if os.environ.get("PP_NMDISTANCE_SEARCH") == "bruteforce" else \
-        int(L.pp_labeled_nmdistance_forward_workspace_bytes(b, n, m, c))
-    ws = _workspace(dev, nbytes)
+    nbytes = _workspace_bytes(L, b, n, m, c, True)
+    ws = _lib.workspace(dev, "nmdistance", nbytes)
     with _lib.on_device(dev) as stream:
         _lib.check(L.pp_labeled_nmdistance_forward_ws_f32(
             _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(label1), _lib.ptr(label2), _lib.ptr(dist1),
@@ -99,9 +107,22 @@ def nmdistance_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, id
     _lib.require_int(*ints)
     if gradxyz1.shape != xyz1.shape or gradxyz2.shape != xyz2.shape:
         raise RuntimeError("gradxyz tensors must have the shapes of xyz1 / xyz2")
-    with _lib.on_device(dev) as stream:
-        _lib.check(_lib.lib().pp_nmdistance_backward_f32(
-            _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(graddist1), _lib.ptr(graddist2),
-            _lib.ptr(idx1), _lib.ptr(idx2), _lib.ptr(gradxyz1), _lib.ptr(gradxyz2), b, n, m, c,
-            stream), "nmdistance_backward")
+    _launch_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2, b, n, m, c, dev)
     return 1
+
+
+def _launch_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2, b, n, m, c, dev):
+    """the launch itself; arguments already validated"""
+    L = _lib.lib()
+    idx = dev.index
+    if idx is not None and idx != _lib.current_device():
+        with torch.cuda.device(dev):
+            code = L.pp_nmdistance_backward_f32(
+                xyz1.data_ptr(), xyz2.data_ptr(), graddist1.data_ptr(), graddist2.data_ptr(), idx1.data_ptr(),
+                idx2.data_ptr(), gradxyz1.data_ptr(), gradxyz2.data_ptr(), b, n, m, c, _lib.raw_stream(dev))
+    else:
+        code = L.pp_nmdistance_backward_f32(
+            xyz1.data_ptr(), xyz2.data_ptr(), graddist1.data_ptr(), graddist2.data_ptr(), idx1.data_ptr(),
+            idx2.data_ptr(), gradxyz1.data_ptr(), gradxyz2.data_ptr(), b, n, m, c, _lib.raw_stream(dev))
+    if code:
+        _lib.check(code, "nmdistance_backward")

@@ -10,35 +10,21 @@ import torch
 
 from .. import _lib
 
-_fps_workspace = {}
+# device index -> pinned int32[1]: host mirror of the FPS workspace's sticky status word (see furthest_sampling)
+_fps_status_mirror = {}
 
 
 def _workspace(device, nbytes):
-    if nbytes == 0:
-        return None
-    key = (device, _lib.raw_stream(device))  # never shared between streams
-    buf = _fps_workspace.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _fps_workspace[key] = buf
-    return buf
-
-
-_scatter_workspace = {}
+    return _lib.workspace(device, "fps", nbytes)
 
 
 def _scatter_ws(device, b, triples, destinations, per_source, weighted):
-    """(pointer, bytes) of the per-(device, stream) scratch for the sorted scatter-add; (None, 0) when
-    the problem does not qualify."""
+    """(buffer, bytes) of the per-(device, stream) scratch for the sorted scatter-add; (None, 0) when
+    the problem does not qualify.  The caller keeps the buffer alive until its launch is issued."""
     nbytes = int(_lib.lib().pp_scatter_workspace_bytes(b, triples, destinations, per_source, weighted))
     if nbytes == 0:
         return None, 0
-    key = (device, _lib.raw_stream(device))
-    buf = _scatter_workspace.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _scatter_workspace[key] = buf
-    return _lib.ptr(buf), nbytes
+    return _lib.workspace(device, "scatter", nbytes), nbytes
 
 
 def furthest_sampling_status(device):
@@ -46,10 +32,9 @@ def furthest_sampling_status(device):
     device's workspace since its last call (synchronises the current stream)."""
     device = torch.device(device)
     status = 0
-    for (dev, _), ws in list(_fps_workspace.items()):
-        if dev == device:
-            with _lib.on_device(dev) as stream:
-                status |= int(_lib.lib().pp_furthest_sampling_status(_lib.ptr(ws), stream))
+    for ws in _lib.cached_workspaces("fps", device):
+        with _lib.on_device(device) as stream:
+            status |= int(_lib.lib().pp_furthest_sampling_status(_lib.ptr(ws), stream))
     return status
 
 
@@ -68,10 +53,30 @@ def furthest_sampling(m, seedIdx, input, temp, idx):
     L = _lib.lib()
     nbytes = int(L.pp_furthest_sampling_workspace_bytes(b, n, int(m)))
     ws = _workspace(dev, nbytes)
+    capturing = _lib.is_capturing()
+    key = dev.index if dev.index is not None else _lib.current_device()
+    mirror = _fps_status_mirror.get(key)
+    if mirror is not None and not capturing and int(mirror[0]) != 0:
+        # The status word of an EARLIER call, copied to pinned host memory behind that call (no synchronisation
+        # here): a bounded wait between the workgroups of the cluster kernel timed out, e.g. because a kernel of
+        # another stream held the CUs its members were waiting for.  That call left zeros in its indices.
+        mirror.zero_()
+        for w in _lib.cached_workspaces("fps", dev):
+            w[:4].zero_()
+        raise RuntimeError("pytorch_points_amd: an earlier furthest_sampling call on %s timed out waiting for "
+                           "its workgroups to be co-resident (another stream kept the GPU busy); its indices "
+                           "are zeros from the failing step on.  Re-run it, or serialise it with the other stream." % dev)
+    if ws is not None and not getattr(ws, "_pp_status_zeroed", False):
+        ws[:256].zero_()             # the sticky status word in front of the scratch (include/pp_hip.h)
+        ws._pp_status_zeroed = True
     with _lib.on_device(dev) as stream:
         _lib.check(L.pp_furthest_sampling_f32(
             _lib.ptr(input), _lib.ptr(temp), _lib.ptr(idx), b, n, int(m), int(seedIdx),
             _lib.ptr(ws) if ws is not None else None, nbytes, stream), "furthest_sampling")
+    if ws is not None and not capturing:
+        if mirror is None:
+            mirror = _fps_status_mirror[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        mirror.copy_(ws[:4].view(torch.int32), non_blocking=True)   # looked at by the NEXT call, never waited for
     return idx
 
 
@@ -102,21 +107,14 @@ def gather_backward(b, c, n, npoints, grad_out, idx, grad_points):
     with _lib.on_device(dev) as stream:
         ws, nbytes = _scatter_ws(dev, b, npoints, n, 1, 0)
         _lib.check(_lib.lib().pp_gather_backward_ws_f32(
-            _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_points), b, c, n, npoints, ws, nbytes, stream),
+            _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_points), b, c, n, npoints, _lib.ptr(ws) if ws is not None else None, nbytes, stream),
             "gather_backward")
     return 1
 
 
 def _named_workspace(dev, name, nbytes):
     """scratch for the grid searches, one per (device, stream, op); None when nbytes == 0"""
-    if not nbytes:
-        return None
-    key = (dev, _lib.raw_stream(dev), name)
-    ws = _scatter_workspace.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _scatter_workspace[key] = ws
-    return ws
+    return _lib.workspace(dev, name, nbytes)
 
 
 def ball_query(new_xyz, xyz, radius, nsample):
@@ -178,7 +176,7 @@ def group_points_grad(grad_out, idx, n):
         ws, nbytes = _scatter_ws(dev, b, npoint * nsample, int(n), 1, 0)
         _lib.check(_lib.lib().pp_group_points_grad_ws_f32(
             _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(out), b, c, int(n), npoint, nsample,
-            c * npoint * nsample, ws, nbytes, stream), "group_points_grad")
+            c * npoint * nsample, _lib.ptr(ws) if ws is not None else None, nbytes, stream), "group_points_grad")
     return out
 
 
@@ -220,7 +218,7 @@ def group_points_grad_from(grad_out, idx, n, channel_offset, channels):
         ws, nbytes = _scatter_ws(dev, b, p, int(n), 1, 0)
         _lib.check(_lib.lib().pp_group_points_grad_ws_f32(
             _lib._c_void_p(grad_out.data_ptr() + 4 * channel_offset * p), _lib.ptr(idx), _lib.ptr(out),
-            b, channels, int(n), npoint, nsample, ctot * p, ws, nbytes, stream), "group_points_grad_from")
+            b, channels, int(n), npoint, nsample, ctot * p, _lib.ptr(ws) if ws is not None else None, nbytes, stream), "group_points_grad_from")
     return out
 
 
@@ -274,4 +272,4 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
         ws, nbytes = _scatter_ws(dev, b, 3 * n, m, 3, 1)
         _lib.check(_lib.lib().pp_three_interpolate_grad_ws_f32(
             _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(grad_points), b, c, n, m,
-            ws, nbytes, stream), "three_interpolate_grad_wrapper")
+            _lib.ptr(ws) if ws is not None else None, nbytes, stream), "three_interpolate_grad_wrapper")

@@ -5,6 +5,7 @@ operator raises.  Tensors are passed as raw device pointers, the stream as torch
 stream on the tensor's device, under a device guard (the reference launches Chamfer and FPS on the
 legacy default stream with no guard -- SURVEY.md F10; this is a deliberate correction).
 """
+import collections
 import ctypes
 import os
 
@@ -133,14 +134,25 @@ def ptr(t):
     return _c_void_p(t.data_ptr())
 
 
+# the cheap forms of torch.cuda.current_device() / is_current_stream_capturing() / current_stream().cuda_stream
+# (the public wrappers cost a microsecond each; an operator call makes several)
+try:
+    current_device = torch._C._cuda_getDevice
+    is_capturing = torch._C._cuda_isCurrentStreamCapturing
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # private API moved: the public one is slower, not different
+    current_device = torch.cuda.current_device
+    is_capturing = torch.cuda.is_current_stream_capturing
+    _raw_stream = None
+
+
 def raw_stream(device):
     """handle (int) of the current HIP stream of ``device`` -- the cheap form of
     torch.cuda.current_stream(device).cuda_stream"""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    try:
-        return torch._C._cuda_getCurrentRawStream(idx)
-    except AttributeError:  # private API moved: the public one is slower, not different
-        return torch.cuda.current_stream(device).cuda_stream
+    idx = device.index if device.index is not None else current_device()
+    if _raw_stream is not None:
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 class on_device(object):
@@ -153,7 +165,7 @@ class on_device(object):
 
     def __enter__(self):
         idx = self.device.index
-        if idx is not None and idx != torch.cuda.current_device():
+        if idx is not None and idx != current_device():
             self._guard = torch.cuda.device(self.device)
             self._guard.__enter__()
         return _c_void_p(raw_stream(self.device))
@@ -162,3 +174,40 @@ class on_device(object):
         if self._guard is not None:
             return self._guard.__exit__(*exc)
         return False
+
+
+# ------------------------------------------------------------------------------------------ scratch
+# One growing uint8 buffer per (device, stream, operator): calls on one stream are ordered, calls on
+# different streams must not share scratch.  Least recently used entries are dropped beyond _WS_MAX
+# (a buffer is ~40 MB at Chamfer config 2).
+_WS = collections.OrderedDict()
+_WS_MAX = 16
+
+
+def workspace(device, name, nbytes):
+    """Scratch of at least ``nbytes`` for operator ``name`` on the current stream of ``device`` (None
+    for 0 bytes).  While the stream is being captured into a graph (``torch.cuda.graph``) nothing is
+    cached: the buffer comes from the capturing graph's private pool, serves the launches being
+    recorded and is released by the caller, so every graph owns its scratch and no block of a graph's
+    pool outlives the capture in this table (two graphs replayed on different streams, or a replay
+    beside an eager call, would otherwise share one buffer)."""
+    if not nbytes:
+        return None
+    if is_capturing():
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    key = (device.index, raw_stream(device), name)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+        while len(_WS) > _WS_MAX:
+            _WS.popitem(last=False)
+    else:
+        _WS.move_to_end(key)
+    return buf
+
+
+def cached_workspaces(name, device=None):
+    """the cached scratch buffers of operator ``name`` (tests and debug aids)"""
+    idx = None if device is None else (device.index if device.index is not None else current_device())
+    return [buf for (d, _, n), buf in _WS.items() if n == name and (idx is None or d is None or d == idx)]

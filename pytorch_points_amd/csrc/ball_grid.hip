@@ -335,10 +335,10 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
 
 // 0 = automatic (grid when a workspace is given and N >= 4096: below, the scan's ~27 us are less than
 // the grid's two launches); 1 = scan kernels only; 2 = grid from N = 2048 (tests)
-static int g_bq_grid_mode = 0;
-static int g_bq_lpc = 0;
-extern "C" void pp_debug_set_ball_query_lpc(int v) { g_bq_lpc = v; }
-extern "C" void pp_debug_set_ball_query_search(int v) { g_bq_grid_mode = v; }
+static pp::Knob g_bq_grid_mode;
+static pp::Knob g_bq_lpc;
+extern "C" void pp_debug_set_ball_query_lpc(int v) { g_bq_lpc.set(v); }
+extern "C" void pp_debug_set_ball_query_search(int v) { g_bq_grid_mode.set(v); }
 
 static size_t bq_query_lds(int N, int nsample, int G) {
   const size_t npw = ((size_t)N + 31) / 32;
@@ -360,7 +360,7 @@ static int bq_launch_query(const float* xyz, int* idx, unsigned char* ws, int B,
   const int tiles = (M + G - 1) / G;
   const long long per_xcd = ((long long)B * tiles + 7) / 8;
   if (per_xcd * 8 > 0x7fffffffLL) return PP_EINVAL;
-  static bool ok[64] = {};
+  static pp::DeviceFlags ok;
   hipError_t e = pp::allow_big_lds(bq_query_kernel<IT, LPC>, 152 * 1024, ok);
   if (e != hipSuccess) return (int)e;
   bq_query_kernel<IT, LPC><<<dim3((unsigned)(per_xcd * 8)), dim3(64), bq_query_lds(N, nsample, G), s>>>(
@@ -380,9 +380,9 @@ extern "C" int pp_ball_query_ws_f32(const float* new_xyz, const float* xyz, int*
   unsigned char* ws = (unsigned char*)workspace;
   const float radius2 = radius * radius;  // fp32, as the reference (sampling_cuda.cu:354)
   const float rpad = radius * 1.00001f + 1e-30f;
-  static bool lds_ok[64] = {};
+  static pp::DeviceFlags lds_ok;
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
-  static bool lds_ok_vec[64] = {};
+  static pp::DeviceFlags lds_ok_vec;
   const bool vec = pp::clouds_vec_aligned(xyz, N, B) && pp::clouds_vec_aligned(new_xyz, M, B);
   hipError_t e = vec ? pp::allow_big_lds(bq_build_kernel<true>, (int)lds, lds_ok_vec) : pp::allow_big_lds(bq_build_kernel<false>, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;

@@ -770,8 +770,8 @@ int zero_outputs(float* dist1, int* idx1, float* dist2, int* idx2, int B, int N,
 }  // namespace
 
 // Tuning override for benchmarking variants in one process (bench.py --variant); 0 = automatic.
-static int g_fwd_variant = 0;
-extern "C" void pp_debug_set_nmdistance_variant(int v) { g_fwd_variant = v; }
+static pp::Knob g_fwd_variant;
+extern "C" void pp_debug_set_nmdistance_variant(int v) { g_fwd_variant.set(v); }
 
 extern "C" int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, float* dist1,
                                          int* idx1, float* dist2, int* idx2, int B, int N, int M,
@@ -823,8 +823,8 @@ extern "C" int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, f
 }
 
 // 0 = automatic; 1 = force the one-lane-per-query kernel (tests and tuning)
-static int g_labeled_variant = 0;
-extern "C" void pp_debug_set_labeled_variant(int v) { g_labeled_variant = v; }
+static pp::Knob g_labeled_variant;
+extern "C" void pp_debug_set_labeled_variant(int v) { g_labeled_variant.set(v); }
 
 extern "C" int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float* xyz2,
                                                  const float* label1, const float* label2,
@@ -860,8 +860,8 @@ extern "C" int pp_labeled_nmdistance_forward_f32(const float* xyz1, const float*
 
 // 0 = automatic (double LDS accumulators for C == 3); 1 = force the global-atomic form; 2 = force
 // the fp32 LDS-column form; 3 = the CSR form; 4 = same as 0   (tests and tuning)
-static int g_bwd_variant = 0;
-extern "C" void pp_debug_set_nmdistance_backward_variant(int v) { g_bwd_variant = v; }
+static pp::Knob g_bwd_variant;
+extern "C" void pp_debug_set_nmdistance_backward_variant(int v) { g_bwd_variant.set(v); }
 
 extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
                                           const float* graddist1, const float* graddist2,
@@ -889,8 +889,8 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
     if (slices < 4) slices = 4;  // 4 measured best at config 2 (8: 38 us, 16: 40 us)
     const int slice_len = (big + slices - 1) / slices;
     if ((long long)B * 2 * slices <= 0x7fffffffLL) {
-      static bool lds_ok[64] = {};
-      static bool lds_ok_vec[64] = {};
+      static pp::DeviceFlags lds_ok;
+      static pp::DeviceFlags lds_ok_vec;
       const uintptr_t align = reinterpret_cast<uintptr_t>(xyz1) | reinterpret_cast<uintptr_t>(xyz2) |
                               reinterpret_cast<uintptr_t>(graddist1) | reinterpret_cast<uintptr_t>(graddist2) |
                               reinterpret_cast<uintptr_t>(idx1) | reinterpret_cast<uintptr_t>(idx2);
@@ -911,7 +911,7 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
     const int slice_len = (big + kCsrSlices - 1) / kCsrSlices;
     const size_t lds = ((size_t)2 * slice_len + 1 + big) * sizeof(unsigned);
     if (lds <= 150 * 1024 && (long long)B * 2 * kCsrSlices <= 0x7fffffffLL) {
-      static bool lds_ok[64] = {};
+      static pp::DeviceFlags lds_ok;
       // (the kernel also has 64 bytes of static LDS: the dynamic limit must leave room for them)
       const hipError_t e = pp::allow_big_lds(nmdist_bwd_csr_kernel, 152 * 1024, lds_ok);
       if (e != hipSuccess) return (int)e;
@@ -926,7 +926,7 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
   const size_t col_bytes = (size_t)(N > M ? N : M) * sizeof(float);
   if (g_bwd_variant != 1 && col_bytes <= 160 * 1024 && (long long)B * 2 * C <= 0x7fffffffLL &&
       (g_bwd_variant == 2 || ((long long)B * 2 * C >= 64 && N + M >= 4096))) {
-    static bool lds_ok[64] = {};
+    static pp::DeviceFlags lds_ok;
     const hipError_t e = pp::allow_big_lds(nmdist_bwd_lds_kernel, 160 * 1024, lds_ok);
     if (e != hipSuccess) return (int)e;
     nmdist_bwd_lds_kernel<<<dim3((unsigned)(B * 2 * C)), dim3(1024), col_bytes, s>>>(

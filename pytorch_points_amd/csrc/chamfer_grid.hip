@@ -19,6 +19,8 @@
 //     scan of the whole cloud -- by its wave, or, when a wave has many such queries, by every lane for its
 //     own query with the brute-force kernel's inner loop; so is every query of a set whose grid is useless
 //     (non-finite coordinates, almost all points in one cell).  Two launches per forward, no list.
+#include <mutex>
+
 #include "grid_common.h"
 
 #ifdef PP_QUERY_PROBE
@@ -727,11 +729,36 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
 
 // 0 = automatic (grid when a workspace is given and the problem is large enough to pay for its two
 // launches); 1 = brute force; 2 = grid wherever it is structurally possible (tests)
-static int g_grid_mode = 0;
-extern "C" void pp_debug_set_nmdistance_search(int v) { g_grid_mode = v; }
+static pp::Knob g_grid_mode;
+extern "C" void pp_debug_set_nmdistance_search(int v) { g_grid_mode.set(v); }
 // LDS points per wave of the search kernel: 0 = default (384); 320 / 512 for comparison
-static int g_stage_cap = 0;
-extern "C" void pp_debug_set_nmdistance_stage_cap(int v) { g_stage_cap = v; }
+static pp::Knob g_stage_cap;
+extern "C" void pp_debug_set_nmdistance_stage_cap(int v) { g_stage_cap.set(v); }
+
+// Per-kernel timing of the grid forward (bench.py's roofline of the dominant kernel): when switched on, HIP
+// events are recorded on the launch stream before the build, between the two kernels and after the search;
+// pp_debug_nmdistance_kernel_ms waits for the last one and reports the two durations of the most recent
+// forward.  One set of events per process (a measurement aid for one stream at a time, not a product feature).
+static pp::Knob g_time_kernels;
+static std::mutex g_ev_mutex;
+static hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+static bool g_ev_valid = false;
+extern "C" void pp_debug_set_nmdistance_kernel_timing(int on) { g_time_kernels.set(on); }
+extern "C" int pp_debug_nmdistance_kernel_ms(float* build_ms, float* search_ms) {
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  if (!g_ev_valid || !build_ms || !search_ms) return PP_EINVAL;
+  hipError_t e = hipEventSynchronize(g_ev[2]);
+  if (e == hipSuccess) e = hipEventElapsedTime(build_ms, g_ev[0], g_ev[1]);
+  if (e == hipSuccess) e = hipEventElapsedTime(search_ms, g_ev[1], g_ev[2]);
+  return (int)e;
+}
+static void record_timing_event(int i, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  if (!g_ev[0])
+    for (int k = 0; k < 3; ++k)
+      if (hipEventCreate(&g_ev[k]) != hipSuccess) return;
+  if (hipEventRecord(g_ev[i], s) == hipSuccess && i == 2) g_ev_valid = true;
+}
 
 static bool grid_applicable(int B, int N, int M, int C) {
   if (!(C == 3 && B > 0 && N >= 2048 && M >= 2048 && (long long)B * ((long long)N + M) < (1LL << 31) - 1)) return false;
@@ -757,15 +784,18 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
                         float* dist1, int* idx1, float* dist2, int* idx2, int B, int N, int M,
                         unsigned char* ws, hipStream_t s) {
   hipError_t e;
-  static bool lds_ok[64] = {}, lds_ok_vec[64] = {};
+  static pp::DeviceFlags lds_ok, lds_ok_vec;
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
   const bool vec = pp::clouds_vec_aligned(xyz1, N, B) && pp::clouds_vec_aligned(xyz2, M, B);
   e = vec ? pp::allow_big_lds(grid_build_kernel<true>, (int)lds, lds_ok_vec)
           : pp::allow_big_lds(grid_build_kernel<false>, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;
+  const bool timing = g_time_kernels != 0;
+  if (timing) record_timing_event(0, s);
   (vec ? grid_build_kernel<true> : grid_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(
       xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr);
   PP_RETURN_IF_LAUNCH_FAILED();
+  if (timing) record_timing_event(1, s);
   const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
   const long long blocks = (long long)B * (tiles1 + tiles2);
   if (blocks > 0x7fffffffLL) return PP_EINVAL;
@@ -780,6 +810,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   }
 #undef PP_LAUNCH_W
   PP_RETURN_IF_LAUNCH_FAILED();
+  if (timing) record_timing_event(2, s);
   return PP_OK;
 }
 

@@ -313,8 +313,10 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
     __syncthreads();
     PP_FPS_MARK(5);
     old = __builtin_amdgcn_readfirstlane(s_old[j & 1]);
-    if (old < 0) {  // timed out: flag and leave (uniform across the workgroup)
+    if (old < 0) {  // timed out: flag, leave defined (zero) indices behind and go (uniform across the workgroup)
       if (t == 0) atomicOr(err, 1u);
+      if (c == 0)
+        for (int jj = j + t; jj < npoint; jj += kClThreads) out[jj] = 0;
       return;
     }
     if (c == 0 && t == 0) out[j] = old;
@@ -335,12 +337,28 @@ void launch_fps_cluster(const float* xyz, float* temp, int* idx, int B, int N, i
       xyz, temp, idx, B, N, npoint, seed, order, geo, ring, err);
 }
 
-// cluster size: as many workgroups per batch element as keeps B*CL <= 256 (co-residency), at
+// Workgroups the cluster kernel may count on being resident together: one 512-thread workgroup per CU of the
+// device that is current (its real CU count: a partitioned or masked device reports fewer than the chip's
+// 256), provided the occupancy query admits the kernel at all.  The cluster's members wait for each other,
+// so the launch must never exceed this; kMaxClusterBlocks (the whole chip) only sizes the workspace, which
+// must not depend on a device being present.
+constexpr int kMaxClusterBlocks = 256;
+template <int R>
+int resident_cluster_blocks() {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_cluster_kernel<R>, kClThreads, 0) != hipSuccess) return 0;
+  if (per_cu < 1) return 0;
+  return cus < kMaxClusterBlocks ? cus : kMaxClusterBlocks;  // one per CU, whatever the query allows beyond that
+}
+
+// cluster size: as many workgroups per batch element as keeps B*CL <= `blocks` (co-residency), at
 // least 512 points each; 0 = do not use the cluster kernel
-int pick_cluster(int B, int N) {
+int pick_cluster(int B, int N, int blocks = kMaxClusterBlocks) {
   if (N > (1 << 24) - 1024) return 0;  // tie rank (< N + 512) must fit 24 bits
   int cl = 1;
-  while (cl * 2 <= 64 && (long long)8 * ((B + 7) / 8) * (cl * 2) <= 256 && (N + cl * 2 - 1) / (cl * 2) >= kClThreads)
+  while (cl * 2 <= 64 && (long long)8 * ((B + 7) / 8) * (cl * 2) <= blocks && (N + cl * 2 - 1) / (cl * 2) >= kClThreads)
     cl *= 2;
   if (cl < 2) return 0;
   const int slice = ((N + cl - 1) / cl + kClThreads - 1) / kClThreads * kClThreads;
@@ -358,8 +376,8 @@ void launch_fps(const float* xyz, float* temp, int* idx, int B, int N, int npoin
 
 }  // namespace
 
-static int g_fps_force_v1 = 0;
-extern "C" void pp_debug_set_fps_v1(int on) { g_fps_force_v1 = on; }
+static pp::Knob g_fps_force_v1;
+extern "C" void pp_debug_set_fps_v1(int on) { g_fps_force_v1.set(on); }
 
 extern "C" size_t pp_furthest_sampling_workspace_bytes(int B, int N, int npoint) {
   (void)npoint;
@@ -369,8 +387,9 @@ extern "C" size_t pp_furthest_sampling_workspace_bytes(int B, int N, int npoint)
   return kFpsErrBytes + (size_t)8 * ((B + 7) / 8) * 2 * cl * sizeof(u64);
 }
 
-// 0 = ok; 1 = a cluster spin timed out in some earlier call that used this workspace (the indices
-// of that call are invalid).  Synchronises the stream: a debugging / test aid, not a hot-path call.
+// 0 = ok; 1 = a cluster wait timed out in some earlier call that used this workspace (that call's
+// indices are zeros from the step of the failure on) and the word has not been cleared since.
+// Synchronises the stream: a debugging / test aid, not a hot-path call.
 extern "C" int pp_furthest_sampling_status(const void* workspace, void* stream) {
   if (!workspace) return 0;
   unsigned v = 0;
@@ -394,7 +413,21 @@ extern "C" int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx,
   order.rows = (N + T - 1) / T;
   if ((long long)T * order.rows > 0xFFFFFFFELL) return PP_EINVAL;
   // (the cluster kernel's per-thread tie rule assumes the reference's thread count equals its point stride)
-  const int cl = (g_fps_force_v1 || T != kClThreads) ? 0 : pick_cluster(B, N);
+  int cl = (g_fps_force_v1 || T != kClThreads) ? 0 : pick_cluster(B, N);
+  if (cl >= 2 && npoint > 1) {
+    // the members of a cluster spin on each other: never launch more workgroups than this device keeps
+    // resident at once (a partitioned device, a CU mask).  Fewer CUs -> a smaller cluster or the
+    // single-workgroup kernel.  A kernel of ANOTHER stream holding CUs can still delay members: the waits are
+    // bounded, the kernel then leaves zeros and raises the workspace's error word (pp_furthest_sampling_status).
+    auto blocks_for = [](int r) {
+      return r <= 1 ? resident_cluster_blocks<1>() : r <= 2 ? resident_cluster_blocks<2>() : r <= 4 ? resident_cluster_blocks<4>()
+           : r <= 8 ? resident_cluster_blocks<8>() : r <= 16 ? resident_cluster_blocks<16>() : resident_cluster_blocks<32>();
+    };
+    auto r_of = [&](int c) { return (((N + c - 1) / c + kClThreads - 1) / kClThreads * kClThreads) / kClThreads; };
+    const int blocks = blocks_for(r_of(cl));
+    cl = blocks > 0 ? pick_cluster(B, N, blocks) : 0;  // (a smaller cluster means more points per thread)
+    if (cl >= 2 && (long long)8 * ((B + 7) / 8) * cl > blocks_for(r_of(cl))) cl = 0;
+  }
   if (cl >= 2 && npoint > 1) {
     const size_t need = pp_furthest_sampling_workspace_bytes(B, N, npoint);
     if (!workspace || workspace_bytes < need) return PP_EINVAL;
@@ -402,10 +435,10 @@ extern "C" int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx,
     geo.cl = cl;
     geo.slice = ((N + cl - 1) / cl + kClThreads - 1) / kClThreads * kClThreads;
     geo.per_xcd8 = cl * ((B + 7) / 8);
-    // reset the error word and the ring (tag 0xFF never matches a step tag)
-    hipError_t e = hipMemsetAsync(workspace, 0, kFpsErrBytes, s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync((char*)workspace + kFpsErrBytes, 0xFF, need - kFpsErrBytes, s);
+    // reset the ring (tag 0xFF never matches a step tag).  The status word in front of it is STICKY: the
+    // caller zeroes it once after allocating the workspace, a timed-out wait sets it, and it stays set until
+    // the caller clears it -- so a failure cannot be wiped out by the next call before anybody has looked.
+    hipError_t e = hipMemsetAsync((char*)workspace + kFpsErrBytes, 0xFF, need - kFpsErrBytes, s);
     if (e != hipSuccess) return (int)e;
     u64* ring = (u64*)((char*)workspace + kFpsErrBytes);
     unsigned* err = (unsigned*)workspace;

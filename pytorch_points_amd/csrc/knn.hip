@@ -237,8 +237,8 @@ int knn_grid_launch(float* dist, int* idx, unsigned char* ws, int B, int N, int 
 }  // namespace
 
 // 0 = automatic (grid when a workspace is given); 1 = scan kernel only (tests and tuning)
-static int g_knn_grid_mode = 0;
-extern "C" void pp_debug_set_knn_search(int v) { g_knn_grid_mode = v; }
+static pp::Knob g_knn_grid_mode;
+extern "C" void pp_debug_set_knn_search(int v) { g_knn_grid_mode.set(v); }
 
 static bool knn_args_ok(const float* p1, const float* p2, const float* dist, const int* idx, int B, int N, int M,
                         int K) {
@@ -268,9 +268,9 @@ extern "C" int pp_knn_ws_f32(const float* p1, const float* p2, const int* length
   if (!knn_args_ok(p1, p2, dist2, idx, B, N, M, K)) return PP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
-  static bool lds_ok[64] = {};
+  static pp::DeviceFlags lds_ok;
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
-  static bool lds_ok_vec[64] = {};
+  static pp::DeviceFlags lds_ok_vec;
   const bool vec = pp::clouds_vec_aligned(p1, N, B) && pp::clouds_vec_aligned(p2, M, B);
   hipError_t e = vec ? pp::allow_big_lds(kn_build_kernel<true>, (int)lds, lds_ok_vec) : pp::allow_big_lds(kn_build_kernel<false>, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;

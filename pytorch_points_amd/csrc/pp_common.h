@@ -11,9 +11,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "pp_hip.h"
+#include "pp_hip_debug.h"
 
 #define PP_WAVE 64
 
@@ -25,17 +27,29 @@
 
 namespace pp {
 
+// Process-wide state of the library is limited to two kinds of atomics: the debug knobs declared in
+// include/pp_hip_debug.h (tests and benchmarks select kernel variants with them; product code never sets one)
+// and the "this kernel's LDS limit has been raised on device d" flags below (idempotent).
+struct Knob {
+  std::atomic<int> v{0};
+  operator int() const { return v.load(std::memory_order_relaxed); }
+  void set(int x) { v.store(x, std::memory_order_relaxed); }
+};
+struct DeviceFlags {
+  std::atomic<bool> f[64] = {};
+};
+
 // Raise a kernel's dynamic-LDS limit (needed above 64 KiB).  Once per device per kernel: `flags`
-// is a zero-initialised static array owned by the call site.
+// is a zero-initialised static owned by the call site.
 template <typename K>
-inline hipError_t allow_big_lds(K kernel, int bytes, bool (&flags)[64]) {
+inline hipError_t allow_big_lds(K kernel, int bytes, DeviceFlags& flags) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   if (dev < 0 || dev >= 64) dev = 63;
-  if (dev != 63 && flags[dev]) return hipSuccess;
+  if (dev != 63 && flags.f[dev].load(std::memory_order_acquire)) return hipSuccess;
   e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e == hipSuccess) flags[dev] = true;
+  if (e == hipSuccess) flags.f[dev].store(true, std::memory_order_release);
   return e;
 }
 

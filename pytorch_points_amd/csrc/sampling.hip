@@ -576,7 +576,7 @@ bool launch_group_dma(const float* points, const int* idx, float* out, int B, in
   const size_t lds = (size_t)2 * buf_floats * sizeof(float);
   if (lds > 160 * 1024 || chunks > 0x7fffffLL || blocks > 0x7fffffffLL) return false;
   if (PACK16 && N > 65536) return false;
-  static bool lds_ok[64] = {};  // one set of flags per instantiation of this function template
+  static pp::DeviceFlags lds_ok;  // one set of flags per instantiation of this function template
   if (pp::allow_big_lds(group_points_dma_kernel<V, PACK16>, 160 * 1024, lds_ok) != hipSuccess) return false;
   group_points_dma_kernel<V, PACK16><<<dim3((unsigned)blocks), dim3(kDmaThreads), lds, s>>>(
       points, idx, out, B, C, N, P, (int)chunks, passes, buf_floats, cgroups, c_per_group, obs);
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(1024) void three_interpolate_rows_kernel(const floa
 template <int CG, bool VEC>
 static int launch_three_interpolate_rows(const float* points, const int* idx, const float* weight, float* out,
                                          int B, int C, int M, int N, hipStream_t s) {
-  static bool ok[64] = {};
+  static pp::DeviceFlags ok;
   const hipError_t e = pp::allow_big_lds(three_interpolate_rows_kernel<CG, VEC>, 152 * 1024, ok);
   if (e != hipSuccess) return (int)e;
   const long long wgs = 8LL * ((B + 7) / 8) * ((C + CG - 1) / CG);
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(1024) void three_interpolate_grad_lds64_kernel(
 template <int CG>
 static int launch_three_interpolate_grad_lds64(const float* grad_out, const int* idx, const float* weight,
                                                float* grad_points, int B, int C, int N, int M, hipStream_t s) {
-  static bool ok[64] = {};
+  static pp::DeviceFlags ok;
   const hipError_t e = pp::allow_big_lds(three_interpolate_grad_lds64_kernel<CG>, 152 * 1024, ok);
   if (e != hipSuccess) return (int)e;
   const long long wgs = 8LL * ((B + 7) / 8) * ((C + CG - 1) / CG);
@@ -1083,8 +1083,8 @@ bool grid_ok(long long x, long long y, long long z) {
 }  // namespace
 
 // 0 = automatic; 1 = force the global-gather kernel (tests and tuning)
-static int g_gather_variant = 0;
-extern "C" void pp_debug_set_gather_variant(int v) { g_gather_variant = v; }
+static pp::Knob g_gather_variant;
+extern "C" void pp_debug_set_gather_variant(int v) { g_gather_variant.set(v); }
 
 extern "C" int pp_gather_forward_f32(const float* points, const int* idx, float* out, int B, int C,
                                      int N, int M, void* stream) {
@@ -1106,7 +1106,7 @@ extern "C" int pp_gather_forward_f32(const float* points, const int* idx, float*
       const size_t lds = (size_t)N * sizeof(float);
       hipStream_t s = (hipStream_t)stream;
       const int n4 = N / 4;
-      static bool ok1[64] = {}, ok2[64] = {}, ok4[64] = {}, oks[64] = {};
+      static pp::DeviceFlags ok1, ok2, ok4, oks;
       if (!vec) {
         if (pp::allow_big_lds(gather_fwd_lds_kernel<1, false>, 152 * 1024, oks) != hipSuccess) return PP_EINVAL;
         gather_fwd_lds_kernel<1, false><<<grid, block, lds, s>>>(points, idx, out, B, C, N, M, cpb, groups);
@@ -1150,8 +1150,8 @@ extern "C" int pp_gather_backward_f32(const float* grad_out, const int* idx, flo
 }
 
 // 0 = automatic; 1 = force the one-wave-per-64-centres kernel (tests and tuning)
-static int g_ball_variant = 0;
-extern "C" void pp_debug_set_ball_query_variant(int v) { g_ball_variant = v; }
+static pp::Knob g_ball_variant;
+extern "C" void pp_debug_set_ball_query_variant(int v) { g_ball_variant.set(v); }
 
 static int ball_query_launch(const float* new_xyz, const float* xyz, int* idx, int B, int N, int M,
                              float radius, int nsample, const pp::GridSet* skip, void* stream) {
@@ -1207,8 +1207,8 @@ int ball_query_scan_unusable(const float* new_xyz, const float* xyz, int* idx, i
 
 // 0 = automatic; 1 = force the global-gather kernel; 2/4/8 = force the LDS-staged kernel with that
 // many index quads per thread (tests and tuning)
-static int g_group_variant = 0;
-extern "C" void pp_debug_set_group_points_variant(int v) { g_group_variant = v; }
+static pp::Knob g_group_variant;
+extern "C" void pp_debug_set_group_points_variant(int v) { g_group_variant.set(v); }
 
 extern "C" int pp_group_points_f32(const float* points, const int* idx, float* out, int B, int C,
                                    int N, int npoint, int nsample, void* stream) {
@@ -1264,7 +1264,7 @@ extern "C" int pp_group_points_strided_f32(const float* points, const int* idx, 
     const long long chunks = (P + 1024LL * V - 1) / (1024LL * V);
     const long long blocks = 8LL * ((B + 7) / 8) * chunks;
     if (chunks <= 0x7fffffLL && blocks <= 0x7fffffffLL) {
-      static bool ok_s[64] = {};
+      static pp::DeviceFlags ok_s;
       const hipError_t e = pp::allow_big_lds(group_points_lds_scalar_kernel<V>, 152 * 1024, ok_s);
       if (e != hipSuccess) return (int)e;
       group_points_lds_scalar_kernel<V><<<dim3((unsigned)blocks), dim3(1024), (size_t)N * sizeof(float), s>>>(
@@ -1289,8 +1289,8 @@ extern "C" int pp_group_points_strided_f32(const float* points, const int* idx, 
 
 // 0 = automatic; 1 = force global atomics; 2 = force the LDS-column form (double column when it
 // fits); 3 = force the LDS-column form with the fp32 column (tests and tuning)
-static int g_group_grad_variant = 0;
-extern "C" void pp_debug_set_group_points_grad_variant(int v) { g_group_grad_variant = v; }
+static pp::Knob g_group_grad_variant;
+extern "C" void pp_debug_set_group_points_grad_variant(int v) { g_group_grad_variant.set(v); }
 
 extern "C" int pp_group_points_grad_f32(const float* grad_out, const int* idx, float* grad_points,
                                         int B, int C, int N, int npoint, int nsample,
@@ -1317,7 +1317,7 @@ extern "C" int pp_group_points_grad_strided_f32(const float* grad_out, const int
     const long long wgs = 8LL * ((B + 7) / 8) * C * nsplit;
     if (g_group_grad_variant != 3 && nsplit <= 16 && wgs <= 0x7fffffffLL) {
       const int W = nsplit == 1 ? N : kW64;
-      static bool lds64_ok[64] = {}, lds64s_ok[64] = {};
+      static pp::DeviceFlags lds64_ok, lds64s_ok;
       if (vec) {
         const hipError_t e = pp::allow_big_lds(group_points_grad_lds64_kernel<8, true>, 152 * 1024, lds64_ok);
         if (e != hipSuccess) return (int)e;
@@ -1335,7 +1335,7 @@ extern "C" int pp_group_points_grad_strided_f32(const float* grad_out, const int
       return PP_OK;
     }
     if (vec && (size_t)N * sizeof(float) <= 160 * 1024) {  // fp32 column (kept for comparison: ds_add_f32 is slow)
-      static bool lds_ok[64] = {};
+      static pp::DeviceFlags lds_ok;
       const hipError_t e = pp::allow_big_lds(group_points_grad_lds_kernel, 160 * 1024, lds_ok);
       if (e != hipSuccess) return (int)e;
       group_points_grad_lds_kernel<<<dim3((unsigned)(8 * ((B + 7) / 8) * C)), dim3(1024),
@@ -1383,8 +1383,8 @@ int three_nn_scan_unusable(const float* unknown, const float* known, float* dist
 
 // 0 = automatic; 1 = force the global-gather kernel; 2 = no channel-group form (row-at-a-time LDS
 // form where it applies)   (tests and tuning)
-static int g_interp_variant = 0;
-extern "C" void pp_debug_set_three_interpolate_variant(int v) { g_interp_variant = v; }
+static pp::Knob g_interp_variant;
+extern "C" void pp_debug_set_three_interpolate_variant(int v) { g_interp_variant.set(v); }
 
 extern "C" int pp_three_interpolate_f32(const float* points, const int* idx, const float* weight,
                                         float* out, int B, int C, int M, int N, void* stream) {
@@ -1432,8 +1432,8 @@ extern "C" int pp_three_interpolate_f32(const float* points, const int* idx, con
 
 // 0 = automatic; 1 = force global atomics; 2 = force the LDS-column form and, in the _ws entry point,
 // skip the sorted form; 3 = the _ws entry point prefers the sorted form (tests and tuning)
-static int g_interp_grad_variant = 0;
-extern "C" void pp_debug_set_three_interpolate_grad_variant(int v) { g_interp_grad_variant = v; }
+static pp::Knob g_interp_grad_variant;
+extern "C" void pp_debug_set_three_interpolate_grad_variant(int v) { g_interp_grad_variant.set(v); }
 
 extern "C" int pp_three_interpolate_grad_f32(const float* grad_out, const int* idx,
                                              const float* weight, float* grad_points, int B,
@@ -1466,8 +1466,8 @@ extern "C" int pp_three_interpolate_grad_f32(const float* grad_out, const int* i
 // ---- scatter-add backwards with a caller-provided workspace: sorted triples instead of atomics ----
 // (scatter.hip).  Each falls back to its atomic form when the workspace is absent / too small or
 // the problem does not qualify (destinations per batch element > 20480, tiny problems).
-static int g_scatter_mode = 0;  // 0 = automatic; 1 = never use the sorted form (tests and tuning)
-extern "C" void pp_debug_set_scatter_mode(int v) { g_scatter_mode = v; }
+static pp::Knob g_scatter_mode;  // 0 = automatic; 1 = never use the sorted form (tests and tuning)
+extern "C" void pp_debug_set_scatter_mode(int v) { g_scatter_mode.set(v); }
 
 extern "C" size_t pp_scatter_workspace_bytes(int B, long long triples_per_batch, int destinations,
                                              int per_source, int weighted) {

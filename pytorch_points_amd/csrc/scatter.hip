@@ -210,7 +210,7 @@ int ssa_run(const float* src, const int* dst, const float* weight, float* out, i
   const long long Ps = P / R;
   const int S = ssa_chunk(R, Nd, weight != nullptr);
   const int nchunks = (int)((Ps + S - 1) / S);
-  static bool ok_build[64] = {}, ok_a[64] = {}, ok_b[64] = {};
+  static pp::DeviceFlags ok_build, ok_a, ok_b;
   hipError_t e = allow_big_lds(ssa_build_kernel, 152 * 1024, ok_build);
   if (e != hipSuccess) return (int)e;
   e = allow_big_lds(ssa_apply_kernel<false>, 160 * 1024, ok_a);

@@ -3,7 +3,9 @@
 // gathered buffer.  Layout of one rank's packed bytes (n1 = B_local*N, n2 = B_local*M):
 //     [ dist1: n1 f32 | dist2: n2 f32 | idx1: n1 (u16 | i32) | idx2: n2 (u16 | i32) ]
 // Indices travel as 16-bit words when every index fits (compact != 0): 6 instead of 8 bytes per
-// point pair over xGMI.  One launch each way instead of a dozen small tensor ops.
+// point pair over xGMI.  The word 0xFFFF stands for -1 (labeled Chamfer's "no partner with this label"),
+// so the compact form needs every real index <= 65534, i.e. N, M <= 65535 -- the caller's condition.
+// One launch each way instead of a dozen small tensor ops.
 #include "pp_common.h"
 
 namespace {
@@ -47,7 +49,13 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const unsigned char* 
     const bool first = k < n1;
     const long long j = first ? k : k - n1;
     const float d = rd[k];
-    const int v = compact ? (int)reinterpret_cast<const unsigned short*>(ri)[k] : reinterpret_cast<const int*>(ri)[k];
+    int v;
+    if (compact) {
+      const unsigned short w16 = reinterpret_cast<const unsigned short*>(ri)[k];
+      v = w16 == 0xFFFFu ? -1 : (int)w16;
+    } else {
+      v = reinterpret_cast<const int*>(ri)[k];
+    }
     if (first) {
       D1[(long long)r * n1 + j] = d;
       I1[(long long)r * n1 + j] = v;

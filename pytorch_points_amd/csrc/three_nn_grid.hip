@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void tn_query_kernel(float* __restrict__ dist2
 }  // namespace
 
 // 0 = automatic (grid when a workspace is given); 1 = scan kernel only (tests and tuning)
-static int g_tn_grid_mode = 0;
-extern "C" void pp_debug_set_three_nn_search(int v) { g_tn_grid_mode = v; }
+static pp::Knob g_tn_grid_mode;
+extern "C" void pp_debug_set_three_nn_search(int v) { g_tn_grid_mode.set(v); }
 
 extern "C" size_t pp_three_nn_workspace_bytes(int B, int N, int M) {
   if (B <= 0 || N < 1024 || M < 1024) return 0;
@@ -176,9 +176,9 @@ extern "C" int pp_three_nn_ws_f32(const float* unknown, const float* known, floa
   if (!unknown || !known || !dist2 || !idx) return PP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
-  static bool lds_ok[64] = {};
+  static pp::DeviceFlags lds_ok;
   const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
-  static bool lds_ok_vec[64] = {};
+  static pp::DeviceFlags lds_ok_vec;
   const bool vec = pp::clouds_vec_aligned(unknown, N, B) && pp::clouds_vec_aligned(known, M, B);
   hipError_t e = vec ? pp::allow_big_lds(tn_build_kernel<true>, (int)lds, lds_ok_vec) : pp::allow_big_lds(tn_build_kernel<false>, (int)lds, lds_ok);
   if (e != hipSuccess) return (int)e;

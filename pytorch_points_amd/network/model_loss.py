@@ -6,16 +6,29 @@ import torch
 from .._ext import losses
 
 
-def _outputs(xyz1, xyz2):
+def _inputs(xyz1, xyz2):
+    """contiguous fp32 GPU clouds (B,N,C), (B,M,C) on one device -> (xyz1, xyz2, B, N, M, C, device); the checks
+    the reference leaves out (its launcher validates nothing, _ext/nmdistance.cpp:13-15)"""
+    assert xyz1.dtype == xyz2.dtype
+    xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
+    if xyz1.dtype is not torch.float32:
+        raise RuntimeError("xyz1 must be a float tensor")
+    if not (xyz1.is_cuda and xyz2.is_cuda):
+        raise RuntimeError("%s must be a CUDA tensor" % ("xyz2" if xyz1.is_cuda else "xyz1"))
+    dev = xyz1.device
+    if xyz2.device != dev:
+        raise RuntimeError("xyz2 is on %s, expected %s" % (xyz2.device, dev))
+    b, n, m, c = losses._shapes(xyz1, xyz2)
+    return xyz1, xyz2, b, n, m, c, dev
+
+
+def _outputs(b, n, m, dev):
     """(dist1 (B,N), dist2 (B,M), idx1, idx2) uninitialised, on the inputs' device.  The kernels write
     every element (and zero-fill by themselves when one cloud is empty, the only case in which the
     reference's zero initialisation survives), so no fill launches are spent.  The reference allocates on
     the CPU and moves to the *current* device (:412-421)."""
-    n, m = xyz1.shape[1], xyz2.shape[1]
-    batch = xyz1.shape[0]
-    return (xyz1.new_empty((batch, n)), xyz1.new_empty((batch, m)),
-            torch.empty((batch, n), dtype=torch.int32, device=xyz1.device),
-            torch.empty((batch, m), dtype=torch.int32, device=xyz1.device))
+    return (torch.empty((b, n), dtype=torch.float32, device=dev), torch.empty((b, m), dtype=torch.float32, device=dev),
+            torch.empty((b, n), dtype=torch.int32, device=dev), torch.empty((b, m), dtype=torch.int32, device=dev))
 
 
 def _finish_forward(ctx, xyz1, xyz2, dist1, dist2, idx1, idx2):
@@ -31,8 +44,14 @@ def _chamfer_backward(ctx, grad1, grad2):
     xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
     grad1 = xyz1.new_zeros(idx1.shape) if grad1 is None else grad1.contiguous()
     grad2 = xyz2.new_zeros(idx2.shape) if grad2 is None else grad2.contiguous()
+    if grad1.dtype is not torch.float32 or grad2.dtype is not torch.float32:
+        raise RuntimeError("graddist1 must be a float tensor")
+    dev = xyz1.device
+    if grad1.device != dev or grad2.device != dev:
+        raise RuntimeError("graddist is on another device than xyz1 (%s)" % (dev,))
     out1, out2 = torch.empty_like(xyz1), torch.empty_like(xyz2)      # fully overwritten by the kernel
-    losses.nmdistance_backward(xyz1, xyz2, out1, out2, grad1, grad2, idx1, idx2)
+    b, n, c = xyz1.shape
+    losses._launch_backward(xyz1, xyz2, out1, out2, grad1, grad2, idx1, idx2, b, n, xyz2.shape[1], c, dev)
     return out1, out2
 
 
@@ -43,10 +62,9 @@ class NmDistanceFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz1, xyz2):
-        assert xyz1.dtype == xyz2.dtype
-        xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
-        out = _outputs(xyz1, xyz2)
-        losses.nmdistance_forward(xyz1, xyz2, *out)
+        xyz1, xyz2, b, n, m, c, dev = _inputs(xyz1, xyz2)
+        out = _outputs(b, n, m, dev)
+        losses._launch_forward(xyz1, xyz2, *out, b, n, m, c, dev)
         return _finish_forward(ctx, xyz1, xyz2, *out)
 
     @staticmethod
@@ -65,9 +83,8 @@ class LabeledNmdistanceFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xyz1, xyz2, label1, label2):
-        assert xyz1.dtype == xyz2.dtype
-        xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
-        out = _outputs(xyz1, xyz2)
+        xyz1, xyz2, b, n, m, c, dev = _inputs(xyz1, xyz2)
+        out = _outputs(b, n, m, dev)
         losses.labeled_nmdistance_forward(xyz1, xyz2, label1.to(xyz1.dtype), label2.to(xyz1.dtype), *out)
         return _finish_forward(ctx, xyz1, xyz2, *out)
 

@@ -81,7 +81,8 @@ class PackedShardGather:
     collectives and a size exchange).  In a training loop with equal shards the exchange should cost
     one RCCL call that overlaps the backward pass and the next forward: this class packs
     (dist1 | dist2 | idx1 | idx2) of the local shard into a preallocated byte buffer -- indices as
-    16-bit words when every index fits (N, M <= 65536: 6 instead of 8 bytes per point pair, and on
+    16-bit words when every index fits (N, M <= 65535; -1, labeled Chamfer's "no partner", travels as
+    0xFFFF: 6 instead of 8 bytes per point pair, and on
     xGMI the exchange, not the search, is the longer leg at 8 GPUs) -- and all-gathers it on the
     backend's own stream.  Buffers are double-buffered so that step k+1 can pack while step k is
     still in flight.
@@ -96,7 +97,8 @@ class PackedShardGather:
         self.group = group
         self.world = dist.get_world_size(group)
         self.b, self.n, self.m = int(b_local), int(n), int(m)
-        self.compact = max(self.n, self.m) <= 65536
+        # 16-bit indices: every real index <= 65534, the word 0xFFFF carries labeled Chamfer's -1
+        self.compact = max(self.n, self.m) <= 65535
         isz = 2 if self.compact else 4
         self.off = [0, 4 * self.b * self.n, 4 * self.b * (self.n + self.m),
                     4 * self.b * (self.n + self.m) + isz * self.b * self.n]
@@ -203,6 +205,8 @@ class PackedShardGather:
         if self.compact:
             i1 = (r[:, o[2]:o[3]].view(torch.int16).to(torch.int32) & 0xFFFF).reshape(w * b, self.n)
             i2 = (r[:, o[3]:self.nbytes].view(torch.int16).to(torch.int32) & 0xFFFF).reshape(w * b, self.m)
+            i1 = torch.where(i1 == 0xFFFF, torch.full_like(i1, -1), i1)
+            i2 = torch.where(i2 == 0xFFFF, torch.full_like(i2, -1), i2)
         else:
             i1 = r[:, o[2]:o[3]].view(torch.int32).reshape(w * b, self.n)
             i2 = r[:, o[3]:self.nbytes].view(torch.int32).reshape(w * b, self.m)

@@ -13,8 +13,8 @@ from pytorch_points_amd import _build, _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "pp_hip.h")).read()
+def declared_symbols(header="pp_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(pp_[a-z0-9_]+)\s*\(", text)))
 
@@ -37,6 +37,44 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     # and the ctypes table binds exactly the declared functions
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     assert _lib.version().startswith("pp_hip") and "gfx950" in _lib.version()
+
+
+def test_debug_knobs_are_declared_and_nothing_else_is_exported():
+    """VERDICT r1 #9: every exported pp_* symbol is declared in include/pp_hip.h (the drop-in ABI) or
+    include/pp_hip_debug.h (test / benchmark knobs); the library exports no undeclared entry point."""
+    import subprocess
+    _build.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", _build.LIB], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("pp_")})
+    declared = sorted(set(declared_symbols()) | set(declared_symbols("pp_hip_debug.h")))
+    assert exported == declared, (sorted(set(exported) - set(declared)), sorted(set(declared) - set(exported)))
+    assert all(s.startswith("pp_debug_") for s in declared_symbols("pp_hip_debug.h"))
+    assert not any(s.startswith("pp_debug_") for s in declared_symbols())
+
+
+def test_product_code_never_touches_a_debug_knob():
+    pkg = os.path.join(ROOT, "pytorch_points_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py") and f != "graphs.py":
+                assert "pp_debug_" not in open(os.path.join(d, f)).read(), os.path.join(d, f)
+
+
+def test_reference_import_name_resolves_without_an_install_call():
+    """``import pytorch_points`` (repo root on sys.path) is this package: the reference's hot-path import lines
+    work as written (VERDICT r1 #13)."""
+    import subprocess
+    import sys
+    code = ("import pytorch_points, pytorch_points_amd;"
+            "from pytorch_points.network.model_loss import nndistance, labeled_nndistance;"
+            "from pytorch_points.network.operations import QueryAndGroup, gather_points, ball_query, grouping_operation;"
+            "from pytorch_points.network.geo_operations import furthest_point_sample;"
+            "from pytorch_points.network.pointnet2_utils import three_nn, three_interpolate, GroupAll;"
+            "from pytorch_points._ext import losses, sampling;"
+            "import pytorch_points_amd.network.model_loss as m;"
+            "assert nndistance is m.nndistance and pytorch_points is pytorch_points_amd;print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
 
 
 def test_code_object_is_gfx950_only():

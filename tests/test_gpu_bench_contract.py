@@ -64,3 +64,20 @@ def test_fps_and_ball_group_lines(cuda):
     d = _run("--workload", "ball_group")
     _check_common(d)
     assert d["metric"] == "group_points_output_bytes_per_s" and 0.0 < d["roofline"]["frac"] < 1.0
+
+
+def test_default_line_is_the_autograd_operator_and_carries_configs_3_and_4(cuda):
+    """`value` is timed on the torch.autograd.Function path; the default command also runs
+    BASELINE.json configs 3 and 4 briefly, each with its own roofline, and the other point distributions."""
+    d = _run("--no-cpu-baseline")
+    _check_common(d)
+    assert d["config"]["launch"].startswith("torch.autograd.Function")
+    assert {"eager", "ext"} <= set(d["launch_modes_ms_per_step"])
+    assert d["roofline"]["kernel"].startswith("grid_query_wave_kernel") and d["roofline"]["kernel_ms"] > 0
+    assert d["roofline"]["kernel_ms"] < d["fwd_ms"] < d["ms_per_step"]
+    for key, metric in (("fps", "fps_point_updates_per_s"), ("ball_group", "group_points_output_bytes_per_s")):
+        sub = d[key]
+        assert sub["metric"] == metric and sub["value"] > 0 and 0.0 < sub["roofline"]["frac"] < 1.0
+        assert "workload" in sub["config"]
+    od = d["other_distributions_fwd_ms"]
+    assert all(od[k] > 0 for k in ("gaussian", "blobs8", "two_scales", "shapenet_like"))

@@ -9,10 +9,10 @@ from pytorch_points_amd import _lib
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("b,n,m", [(3, 1000, 777), (2, 65536, 40), (1, 5, 70000), (4, 16384, 16384)])
+@pytest.mark.parametrize("b,n,m", [(3, 1000, 777), (2, 65535, 40), (2, 65536, 40), (1, 5, 70000), (4, 16384, 16384)])
 def test_shard_pack_unpack_roundtrip(cuda, b, n, m):
     world = 3
-    compact = max(n, m) <= 65536
+    compact = max(n, m) <= 65535
     g = torch.Generator(device="cpu").manual_seed(b * 131 + n)
     D1 = torch.rand(world * b, n, generator=g).to(cuda)
     D2 = torch.rand(world * b, m, generator=g).to(cuda)
@@ -20,6 +20,7 @@ def test_shard_pack_unpack_roundtrip(cuda, b, n, m):
     I2 = torch.randint(0, n, (world * b, m), generator=g, dtype=torch.int32).to(cuda)
     I1[:, 0] = m - 1
     I2[:, -1] = n - 1
+    I1[:, 1] = -1      # labeled Chamfer's "no partner" (0xFFFF in the 16-bit form)
     L = _lib.lib()
     stride = int(L.pp_shard_packed_bytes(b * n, b * m, 1 if compact else 0))
     assert stride % 16 == 0 and stride >= (b * n + b * m) * (6 if compact else 8)
@@ -40,6 +41,7 @@ def test_shard_pack_unpack_roundtrip(cuda, b, n, m):
     assert torch.equal(f[: b * n], D1[b:2 * b].reshape(-1).cpu()) and torch.equal(f[b * n:], D2[b:2 * b].reshape(-1).cpu())
     if compact:
         i = row[4 * b * (n + m): 6 * b * (n + m)].view(torch.int16).to(torch.int32) & 0xFFFF
+        i = torch.where(i == 0xFFFF, torch.full_like(i, -1), i)
     else:
         i = row[4 * b * (n + m): 8 * b * (n + m)].view(torch.int32)
     assert torch.equal(i[: b * n], I1[b:2 * b].reshape(-1).cpu()) and torch.equal(i[b * n:], I2[b:2 * b].reshape(-1).cpu())

@@ -99,8 +99,9 @@ def _packed_worker(rank, world, port, n, m, q):
             D2 = torch.rand(world * B, m, generator=g)
             I1 = torch.randint(0, m, (world * B, n), generator=g, dtype=torch.int32)
             I2 = torch.randint(0, n, (world * B, m), generator=g, dtype=torch.int32)
-            I1[:, 0] = m - 1        # the largest index (65535 in the compact case: above int16's range)
+            I1[:, 0] = m - 1        # the largest index (65534 in the compact case: above int16's range)
             I2[:, -1] = n - 1
+            I1[:, 1] = -1           # labeled Chamfer's "no partner": must survive the 16-bit packing
             lo, hi = rank * B, (rank + 1) * B
             h = ex.launch(D1[lo:hi], D2[lo:hi], I1[lo:hi], I2[lo:hi])
             d1, d2, i1, i2 = ex.wait(h)
@@ -112,7 +113,7 @@ def _packed_worker(rank, world, port, n, m, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,m,compact", [(50, 65536, True), (70000, 33, False)])
+@pytest.mark.parametrize("n,m,compact", [(50, 65535, True), (50, 65536, False), (70000, 33, False)])
 def test_packed_shard_gather_world2(n, m, compact):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
