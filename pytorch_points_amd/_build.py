@@ -1,7 +1,12 @@
-"""Builds libpp_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+"""Builds the two native artefacts in-tree:
 
-The .so is git-ignored but travels to the GPU box with the repo snapshot.  -ffp-contract=off pins
-the fp32 rounding sequence to the source (DESIGN.md "Arithmetic contract").
+  libpp_hip.so   the C-ABI library: hand-written HIP for gfx950, compiled with hipcc.  -ffp-contract=off
+                 pins the fp32 rounding sequence to the source (DESIGN.md "Arithmetic contract").
+  _pp_torch.so   the host-side bridge (csrc/torch_bridge.cpp): the Chamfer operators as C++
+                 torch::autograd::Function nodes that call the C ABI; plain C++ compiled with g++ against the
+                 installed torch (no device code in it).
+
+Both are git-ignored but travel to the GPU box with the repo snapshot.
 """
 import glob
 import os
@@ -11,6 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libpp_hip.so")
+BRIDGE = os.path.join(HERE, "_pp_torch.so")
+BRIDGE_SRC = os.path.join(CSRC, "torch_bridge.cpp")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
                "-shared", "-std=c++17", "-Wall", "-Wno-unused-function"]
@@ -29,15 +36,44 @@ def is_stale():
 
 
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip -> libpp_hip.so.  No-op when up to date."""
-    if not force and not is_stale():
-        return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *HIPCC_FLAGS, "-I" + INCLUDE, "-I" + CSRC, *sources(), "-o", LIB]
+    """Compile csrc/*.hip -> libpp_hip.so and csrc/torch_bridge.cpp -> _pp_torch.so.  No-op when up to date."""
+    if force or is_stale():
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, *HIPCC_FLAGS, "-I" + INCLUDE, "-I" + CSRC, *sources(), "-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    build_bridge(force=force, verbose=verbose)
+    return LIB
+
+
+def bridge_is_stale():
+    if not os.path.exists(BRIDGE):
+        return True
+    t = os.path.getmtime(BRIDGE)
+    return any(os.path.getmtime(d) > t for d in (BRIDGE_SRC, os.path.join(INCLUDE, "pp_hip.h")))
+
+
+def build_bridge(force=False, verbose=False):
+    """g++ torch_bridge.cpp against the installed (ROCm) torch; links libpp_hip.so by $ORIGIN.  ~1 minute."""
+    if not force and not bridge_is_stale():
+        return BRIDGE
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as ce
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    tlib = ce.library_paths()[0]
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", BRIDGE_SRC, "-o", BRIDGE,
+           "-DTORCH_EXTENSION_NAME=_pp_torch", "-DTORCH_API_INCLUDE_EXTENSION_H", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-I" + INCLUDE,
+           *["-I" + p for p in ce.include_paths()], "-I" + os.path.join(rocm, "include"),
+           "-I" + sysconfig.get_paths()["include"], "-L" + tlib, "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10",
+           "-lc10_hip", "-ltorch_hip", "-L" + HERE, "-l:libpp_hip.so", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB
+    return BRIDGE
 
 
 if __name__ == "__main__":

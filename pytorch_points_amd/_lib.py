@@ -91,6 +91,26 @@ def version():
     return lib().pp_version().decode()
 
 
+_bridge = None
+
+
+def bridge():
+    """The C++ autograd nodes (csrc/torch_bridge.cpp -> _pp_torch.so).  Raises RuntimeError when the module has
+    not been built: like the kernels, the operators' native host side has no substitute that is picked silently."""
+    global _bridge
+    if _bridge is None:
+        lib()   # the C-ABI library first: the bridge links it
+        if not os.path.exists(_build.BRIDGE):
+            raise RuntimeError(
+                "pytorch_points_amd: %s not found. Build it with `python -m pytorch_points_amd._build` (g++ against "
+                "the installed torch)." % _build.BRIDGE)
+        import importlib
+        mod = importlib.import_module("pytorch_points_amd._pp_torch")
+        mod.set_force_bruteforce(os.environ.get("PP_NMDISTANCE_SEARCH") == "bruteforce")
+        _bridge = mod
+    return _bridge
+
+
 def check(code, what):
     if code != 0:
         raise RuntimeError("pytorch_points_amd: %s failed with HIP error %d" % (what, code))

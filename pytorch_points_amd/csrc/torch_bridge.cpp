@@ -1,0 +1,182 @@
+// torch_bridge.cpp -- the Chamfer operators as C++ torch::autograd::Function nodes over the C ABI.
+//
+// The kernels of one nndistance step take ~0.08 ms at BASELINE config 2; issued from Python
+// (torch.autograd.Function: model_loss.NmDistanceFunction) the same step costs ~0.12 ms of host time -- the
+// autograd engine hands the backward to its device thread, which has to take the GIL to run Python -- so the
+// operator was host-bound.  Here the operator's host side is native, as the reference's is
+// (a pybind11 C++ extension, _ext/nmdistance.cpp): input checks, four output allocations, the C-ABI call on
+// torch's current HIP stream, and a backward node that runs on the engine's thread without Python.
+// Same checks, same outputs and gradients as the Python classes (tests/test_gpu_chamfer.py runs both).
+//
+// PyTorch is plumbing here: tensors, the caching allocator, the current stream, autograd bookkeeping.  The
+// compute is libpp_hip.so (include/pp_hip.h), which this module links and which has no torch types in it.
+// Built in-tree by pytorch_points_amd/_build.py with g++ against the installed torch (ROCm build).
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>  // a ROCm build of torch names its HIP devices "cuda"
+#include <c10/core/DeviceGuard.h>
+#include <torch/extension.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "pp_hip.h"
+
+namespace {
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+// Scratch of the grid search: one growing buffer per (device, stream), as in _lib.workspace (Python); while the
+// stream is being captured into a graph nothing is cached (the buffer then belongs to the capturing graph's pool).
+std::mutex g_ws_mutex;
+std::map<std::tuple<int, void*, bool>, Tensor> g_ws;
+
+Tensor workspace(const c10::Device& dev, hipStream_t stream, size_t nbytes, bool labeled) {
+  if (nbytes == 0) return Tensor();
+  const auto opts = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+    return torch::empty({(int64_t)nbytes}, opts);
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  if (g_ws.size() > 16) g_ws.clear();
+  Tensor& slot = g_ws[std::make_tuple((int)dev.index(), (void*)stream, labeled)];
+  if (!slot.defined() || (size_t)slot.numel() < nbytes) slot = torch::empty({(int64_t)nbytes}, opts);
+  return slot;
+}
+
+struct Shapes {
+  int b, n, m, c;
+};
+
+// the checks the reference leaves out (its launcher validates nothing, _ext/nmdistance.cpp:13-15), with the
+// messages of the Python operator
+Shapes check_inputs(const Tensor& xyz1, const Tensor& xyz2) {
+  TORCH_CHECK(xyz1.scalar_type() == xyz2.scalar_type(), "xyz1 and xyz2 must have the same dtype");
+  TORCH_CHECK(xyz1.scalar_type() == torch::kFloat32, "xyz1 must be a float tensor");
+  TORCH_CHECK(xyz1.is_cuda(), "xyz1 must be a CUDA tensor");
+  TORCH_CHECK(xyz2.is_cuda(), "xyz2 must be a CUDA tensor");
+  TORCH_CHECK(xyz2.device() == xyz1.device(), "xyz2 is on ", xyz2.device(), ", expected ", xyz1.device());
+  TORCH_CHECK(xyz1.dim() == 3 && xyz2.dim() == 3, "xyz1 and xyz2 must be (B, N, C) and (B, M, C)");
+  TORCH_CHECK(xyz1.size(0) == xyz2.size(0) && xyz1.size(2) == xyz2.size(2), "xyz1 ", xyz1.sizes(), " and xyz2 ",
+              xyz2.sizes(), " disagree in batch or point dimension");
+  TORCH_CHECK(xyz1.size(0) < (1LL << 31) && xyz1.size(1) < (1LL << 31) && xyz2.size(1) < (1LL << 31) &&
+                  xyz1.size(2) < (1LL << 31),
+              "sizes beyond int32");
+  return {(int)xyz1.size(0), (int)xyz1.size(1), (int)xyz2.size(1), (int)xyz1.size(2)};
+}
+
+void check_code(int code, const char* what) {
+  TORCH_CHECK(code == 0, "pytorch_points_amd: ", what, " failed with HIP error ", code);
+}
+
+variable_list chamfer_backward(AutogradContext* ctx, const variable_list& grads) {
+  const auto saved = ctx->get_saved_variables();
+  const Tensor &xyz1 = saved[0], &xyz2 = saved[1], &idx1 = saved[2], &idx2 = saved[3];
+  // a missing upstream gradient counts as zero
+  Tensor g1 = grads[0].defined() ? grads[0].contiguous() : torch::zeros_like(idx1, xyz1.options());
+  Tensor g2 = grads[1].defined() ? grads[1].contiguous() : torch::zeros_like(idx2, xyz2.options());
+  TORCH_CHECK(g1.scalar_type() == torch::kFloat32 && g2.scalar_type() == torch::kFloat32,
+              "graddist1 must be a float tensor");
+  TORCH_CHECK(g1.device() == xyz1.device() && g2.device() == xyz1.device(),
+              "graddist is on another device than xyz1 (", xyz1.device(), ")");
+  Tensor out1 = torch::empty_like(xyz1), out2 = torch::empty_like(xyz2);  // fully overwritten by the kernel
+  const c10::DeviceGuard guard(xyz1.device());
+  const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(xyz1.device().index()).stream();
+  check_code(pp_nmdistance_backward_f32(xyz1.data_ptr<float>(), xyz2.data_ptr<float>(), g1.data_ptr<float>(),
+                                        g2.data_ptr<float>(), idx1.data_ptr<int>(), idx2.data_ptr<int>(),
+                                        out1.data_ptr<float>(), out2.data_ptr<float>(), (int)xyz1.size(0),
+                                        (int)xyz1.size(1), (int)xyz2.size(1), (int)xyz1.size(2), (void*)stream),
+             "nmdistance_backward");
+  return {out1, out2};
+}
+
+bool g_force_brute = false;  // PP_NMDISTANCE_SEARCH=bruteforce, read once by the Python package at import
+
+// nndistance(xyz1 (B,N,C), xyz2 (B,M,C)) -> (dist1 (B,N), dist2 (B,M), idx1, idx2); reference
+// network/model_loss.py:401-439 + _ext/nmdistance.cpp:13-27
+struct NmDistance : public torch::autograd::Function<NmDistance> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& a, const Tensor& b) {
+    const Tensor xyz1 = a.contiguous(), xyz2 = b.contiguous();
+    const Shapes s = check_inputs(xyz1, xyz2);
+    const auto fopts = xyz1.options();
+    const auto iopts = fopts.dtype(torch::kInt32);
+    // uninitialised: the kernels write every element (and zero-fill when one cloud is empty)
+    Tensor dist1 = torch::empty({s.b, s.n}, fopts), dist2 = torch::empty({s.b, s.m}, fopts);
+    Tensor idx1 = torch::empty({s.b, s.n}, iopts), idx2 = torch::empty({s.b, s.m}, iopts);
+    const c10::DeviceGuard guard(xyz1.device());
+    const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(xyz1.device().index()).stream();
+    const size_t nbytes = g_force_brute ? 0 : pp_nmdistance_forward_workspace_bytes(s.b, s.n, s.m, s.c);
+    const Tensor ws = workspace(xyz1.device(), stream, nbytes, false);
+    check_code(pp_nmdistance_forward_ws_f32(xyz1.data_ptr<float>(), xyz2.data_ptr<float>(), dist1.data_ptr<float>(),
+                                            idx1.data_ptr<int>(), dist2.data_ptr<float>(), idx2.data_ptr<int>(), s.b,
+                                            s.n, s.m, s.c, ws.defined() ? ws.data_ptr() : nullptr, nbytes,
+                                            (void*)stream),
+               "nmdistance_forward");
+    ctx->save_for_backward({xyz1, xyz2, idx1, idx2});
+    ctx->mark_non_differentiable({idx1, idx2});
+    ctx->set_materialize_grads(false);
+    return {dist1, dist2, idx1, idx2};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) { return chamfer_backward(ctx, grads); }
+};
+
+// labeled_nndistance(xyz1, xyz2, label1 (B,N), label2 (B,M)); reference network/model_loss.py:445-481.  Labels
+// are compared in the coordinates' dtype, as the reference's kernel does (_ext/nmdistance_cuda.cu:153).
+struct LabeledNmDistance : public torch::autograd::Function<LabeledNmDistance> {
+  static variable_list forward(AutogradContext* ctx, const Tensor& a, const Tensor& b, const Tensor& la,
+                               const Tensor& lb) {
+    const Tensor xyz1 = a.contiguous(), xyz2 = b.contiguous();
+    const Shapes s = check_inputs(xyz1, xyz2);
+    const Tensor label1 = la.to(xyz1.scalar_type()).contiguous(), label2 = lb.to(xyz1.scalar_type()).contiguous();
+    TORCH_CHECK(label1.is_cuda() && label1.device() == xyz1.device(), "label1 must be a CUDA tensor on ", xyz1.device());
+    TORCH_CHECK(label2.is_cuda() && label2.device() == xyz1.device(), "label2 must be a CUDA tensor on ", xyz1.device());
+    TORCH_CHECK(label1.numel() == (int64_t)s.b * s.n && label2.numel() == (int64_t)s.b * s.m,
+                "labels must be (B, N) and (B, M)");
+    const auto fopts = xyz1.options();
+    const auto iopts = fopts.dtype(torch::kInt32);
+    Tensor dist1 = torch::empty({s.b, s.n}, fopts), dist2 = torch::empty({s.b, s.m}, fopts);
+    Tensor idx1 = torch::empty({s.b, s.n}, iopts), idx2 = torch::empty({s.b, s.m}, iopts);
+    const c10::DeviceGuard guard(xyz1.device());
+    const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(xyz1.device().index()).stream();
+    const size_t nbytes = g_force_brute ? 0 : pp_labeled_nmdistance_forward_workspace_bytes(s.b, s.n, s.m, s.c);
+    const Tensor ws = workspace(xyz1.device(), stream, nbytes, true);
+    check_code(pp_labeled_nmdistance_forward_ws_f32(
+                   xyz1.data_ptr<float>(), xyz2.data_ptr<float>(), label1.data_ptr<float>(), label2.data_ptr<float>(),
+                   dist1.data_ptr<float>(), idx1.data_ptr<int>(), dist2.data_ptr<float>(), idx2.data_ptr<int>(), s.b, s.n,
+                   s.m, s.c, ws.defined() ? ws.data_ptr() : nullptr, nbytes, (void*)stream),
+               "labeled_nmdistance_forward");
+    ctx->save_for_backward({xyz1, xyz2, idx1, idx2});
+    ctx->mark_non_differentiable({idx1, idx2});
+    ctx->set_materialize_grads(false);
+    return {dist1, dist2, idx1, idx2};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    variable_list g = chamfer_backward(ctx, grads);
+    g.push_back(Tensor());
+    g.push_back(Tensor());
+    return g;
+  }
+};
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> nndistance(const Tensor& xyz1, const Tensor& xyz2) {
+  auto r = NmDistance::apply(xyz1, xyz2);
+  return std::make_tuple(r[0], r[1], r[2], r[3]);
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> labeled_nndistance(const Tensor& xyz1, const Tensor& xyz2, const Tensor& l1,
+                                                              const Tensor& l2) {
+  auto r = LabeledNmDistance::apply(xyz1, xyz2, l1, l2);
+  return std::make_tuple(r[0], r[1], r[2], r[3]);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "C++ autograd nodes of pytorch_points_amd over the C ABI of libpp_hip.so";
+  m.def("nndistance", &nndistance, "nndistance(xyz1, xyz2) -> (dist1, dist2, idx1, idx2)");
+  m.def("labeled_nndistance", &labeled_nndistance,
+        "labeled_nndistance(xyz1, xyz2, label1, label2) -> (dist1, dist2, idx1, idx2)");
+  m.def("set_force_bruteforce", [](bool on) { g_force_brute = on; });
+  m.def("library_version", []() { return std::string(pp_version()); });
+}

@@ -1,8 +1,15 @@
 """Drop-in for the hot-path names of ``pytorch_points.network.model_loss``: NmDistanceFunction /
 nndistance and LabeledNmdistanceFunction / labeled_nndistance (reference network/model_loss.py:401-483).
-The twelve torch-composed loss modules of that file are out of scope."""
+The twelve torch-composed loss modules of that file are out of scope.
+
+``nndistance`` / ``labeled_nndistance`` are the C++ autograd nodes of csrc/torch_bridge.cpp (the reference's
+host side is a C++ extension too): at config 2 the step's kernels take less time than Python needs to issue
+them through ``torch.autograd.Function``, and the autograd engine has to take the GIL on its device thread for
+a Python backward.  The Python classes below are the same operators over the same C ABI (the reference's class
+names; ``NmDistanceFunction.apply`` works as in the reference) and are tested to agree bit for bit."""
 import torch
 
+from .. import _lib
 from .._ext import losses
 
 
@@ -72,7 +79,10 @@ class NmDistanceFunction(torch.autograd.Function):
         return _chamfer_backward(ctx, graddist1, graddist2)
 
 
-nndistance = NmDistanceFunction.apply  # type: ignore
+def nndistance(xyz1, xyz2):
+    """``nndistance(xyz1 (B,N,C), xyz2 (B,M,C))`` -> ``(dist1 (B,N), dist2 (B,M), idx1, idx2)`` (reference :442:
+    ``nndistance = NmDistanceFunction.apply``), through the native autograd node."""
+    return _lib.bridge().nndistance(xyz1, xyz2)
 
 
 class LabeledNmdistanceFunction(torch.autograd.Function):
@@ -93,4 +103,7 @@ class LabeledNmdistanceFunction(torch.autograd.Function):
         return _chamfer_backward(ctx, graddist1, graddist2) + (None, None)
 
 
-labeled_nndistance = LabeledNmdistanceFunction.apply
+def labeled_nndistance(xyz1, xyz2, label1, label2):
+    """``labeled_nndistance(xyz1, xyz2, label1 (B,N), label2 (B,M))`` (reference :483), through the native
+    autograd node."""
+    return _lib.bridge().labeled_nndistance(xyz1, xyz2, label1, label2)

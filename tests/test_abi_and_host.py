@@ -77,6 +77,15 @@ def test_reference_import_name_resolves_without_an_install_call():
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
 
 
+def test_native_autograd_bridge_builds_and_loads():
+    """csrc/torch_bridge.cpp -> _pp_torch.so (g++ against the installed torch); it links the C-ABI library."""
+    _build.build()
+    assert os.path.exists(_build.BRIDGE)
+    b = _lib.bridge()
+    assert b.library_version() == _lib.version()
+    assert callable(b.nndistance) and callable(b.labeled_nndistance)
+
+
 def test_code_object_is_gfx950_only():
     blob = open(_build.LIB, "rb").read()
     assert b"gfx950" in blob

@@ -276,3 +276,43 @@ def test_graph_replay_equals_eager(cuda):
         torch.autograd.backward([e1, e2], [g1, g2])
         assert torch.equal(d1, e1) and torch.equal(d2, e2) and torch.equal(i1, j1) and torch.equal(i2, j2)
         assert torch.allclose(gx1, t1.grad, rtol=1e-6, atol=1e-7) and torch.allclose(gx2, t2.grad, rtol=1e-6, atol=1e-7)
+
+
+def test_native_autograd_nodes_equal_the_python_functions(cuda):
+    """nndistance / labeled_nndistance are the C++ autograd nodes of csrc/torch_bridge.cpp; the Python classes
+    NmDistanceFunction / LabeledNmdistanceFunction (the reference's class names) are the same operators over the
+    same C ABI: outputs and non-differentiable indices agree bit for bit, gradients to 1e-5 (the default backward
+    sums in no fixed order), on a brute-force shape and on a grid-search shape."""
+    from pytorch_points_amd.network import model_loss as ml
+    for b, n, m in ((2, 300, 500), (2, 8192, 8192)):
+        x1n, x2n = S.unit_sphere(70, b, n), S.unit_sphere(71, b, m)
+        l1 = torch.from_numpy((S.uniform01(72, (b, n)) * 3).astype(np.int64).reshape(b, n)).to(cuda)
+        l2 = torch.from_numpy((S.uniform01(73, (b, m)) * 3).astype(np.int64).reshape(b, m)).to(cuda)
+        for labeled in (False, True):
+            res = []
+            for fn in ((ml.labeled_nndistance, ml.LabeledNmdistanceFunction.apply) if labeled
+                       else (ml.nndistance, ml.NmDistanceFunction.apply)):
+                x1 = torch.from_numpy(x1n).to(cuda).requires_grad_(True)
+                x2 = torch.from_numpy(x2n).to(cuda).requires_grad_(True)
+                out = fn(x1, x2, l1, l2) if labeled else fn(x1, x2)
+                d1, d2, i1, i2 = out
+                assert d1.requires_grad and not i1.requires_grad and i1.dtype == torch.int32
+                (d1.sum() * 0.5 + (d2 * d2).sum()).backward()
+                res.append((d1.detach(), d2.detach(), i1, i2, x1.grad, x2.grad))
+            for k, (a, c) in enumerate(zip(*res)):
+                if k < 4:
+                    assert torch.equal(a, c)
+                else:   # gradients: same terms, summation order of the default backward is not fixed (1e-5)
+                    assert torch.allclose(a, c, rtol=1e-5, atol=1e-9)
+    # a missing upstream gradient (only dist1 used) counts as zero in both
+    x1 = torch.from_numpy(S.unit_sphere(74, 1, 64)).to(cuda).requires_grad_(True)
+    x2 = torch.from_numpy(S.unit_sphere(75, 1, 80)).to(cuda).requires_grad_(True)
+    ml.nndistance(x1, x2)[0].sum().backward()
+    ga, gb = x1.grad.clone(), x2.grad.clone()
+    x1.grad = x2.grad = None
+    ml.NmDistanceFunction.apply(x1, x2)[0].sum().backward()
+    assert torch.allclose(ga, x1.grad, rtol=1e-5, atol=1e-9) and torch.allclose(gb, x2.grad, rtol=1e-5, atol=1e-9)
+    with pytest.raises(RuntimeError, match="float tensor"):
+        ml.nndistance(x1.double(), x2.double())
+    with pytest.raises(RuntimeError, match="disagree"):
+        ml.nndistance(x1, torch.zeros(2, 4, 3, device=cuda))
