@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 #define PP_OK 0
-#define PP_EINVAL 1 /* == hipErrorInvalidValue */
+#define PP_EINVAL 1    /* == hipErrorInvalidValue */
+#define PP_ENOTSUP 801 /* == hipErrorNotSupported: an *_ordered_* entry point cannot serve this shape */
 
 /* library / build identification: "pp_hip <version> gfx950" */
 const char* pp_version(void);
@@ -211,6 +212,31 @@ int pp_gather_backward_ws_f32(const float* grad_out, const int* idx, float* grad
 int pp_three_interpolate_grad_ws_f32(const float* grad_out, const int* idx, const float* weight,
                                      float* grad_points, int B, int C, int N, int M, void* workspace,
                                      size_t workspace_bytes, void* stream);
+
+/* ---- deterministic ("ordered") backward passes --------------------------------------------------
+ * The reference adds every gradient term with a global fp32 atomic, so its sums depend on the order
+ * the hardware happens to serve (nmdistance_cuda.cu:180-181, sampling_cuda.cu:63,499-500,
+ * interpolate_gpu.cu:139-141); the default entry points above keep the same freedom.  These four add
+ * each destination's terms in ASCENDING SOURCE ORDER with no floating-point atomics: the result is
+ * identical from run to run, and identical bit for bit to a sequential loop over the reference's
+ * launches (the CPU oracle under oracle/).  The host side selects them when
+ * torch.are_deterministic_algorithms_enabled().  They return PP_ENOTSUP for shapes the ordered forms
+ * cannot serve (Chamfer: C != 3 or a cloud beyond ~19000 points; scatter ops: more than 20480
+ * destinations per batch element, or a workspace smaller than pp_scatter_workspace_bytes): there is no
+ * deterministic substitute.  Workspaces as for the *_ws_* entry points; grad_points must be zero-filled
+ * by the caller for the three scatter ops (they accumulate), gradxyz is overwritten. */
+int pp_nmdistance_backward_ordered_f32(const float* xyz1, const float* xyz2, const float* graddist1,
+                                       const float* graddist2, const int* idx1, const int* idx2,
+                                       float* gradxyz1, float* gradxyz2, int B, int N, int M, int C,
+                                       void* stream);
+int pp_group_points_grad_ordered_f32(const float* grad_out, const int* idx, float* grad_points, int B, int C,
+                                     int N, int npoint, int nsample, long long grad_out_batch_stride,
+                                     void* workspace, size_t workspace_bytes, void* stream);
+int pp_gather_backward_ordered_f32(const float* grad_out, const int* idx, float* grad_points, int B, int C,
+                                   int N, int M, void* workspace, size_t workspace_bytes, void* stream);
+int pp_three_interpolate_grad_ordered_f32(const float* grad_out, const int* idx, const float* weight,
+                                          float* grad_points, int B, int C, int N, int M, void* workspace,
+                                          size_t workspace_bytes, void* stream);
 
 /* The library also exports pp_debug_set_* switches that force one kernel variant or another; they
  * exist for the parity tests and for tuning and are deliberately not declared here. */

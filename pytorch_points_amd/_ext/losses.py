@@ -112,8 +112,15 @@ def nmdistance_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, id
 
 
 def _launch_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2, b, n, m, c, dev):
-    """the launch itself; arguments already validated"""
+    """the launch itself; arguments already validated.  torch.use_deterministic_algorithms(True) selects the
+    ordered form (ascending source order, no floating-point atomics: include/pp_hip.h)"""
     L = _lib.lib()
+    if _lib.deterministic():
+        with _lib.on_device(dev) as stream:
+            if _lib.ordered_or_fallback(L.pp_nmdistance_backward_ordered_f32(
+                    xyz1.data_ptr(), xyz2.data_ptr(), graddist1.data_ptr(), graddist2.data_ptr(), idx1.data_ptr(),
+                    idx2.data_ptr(), gradxyz1.data_ptr(), gradxyz2.data_ptr(), b, n, m, c, stream), "nmdistance_backward"):
+                return
     idx = dev.index
     if idx is not None and idx != _lib.current_device():
         with torch.cuda.device(dev):

@@ -106,9 +106,11 @@ def gather_backward(b, c, n, npoints, grad_out, idx, grad_points):
         raise RuntimeError("gather_backward: tensor sizes do not match (b, c, n, npoints)")
     with _lib.on_device(dev) as stream:
         ws, nbytes = _scatter_ws(dev, b, npoints, n, 1, 0)
-        _lib.check(_lib.lib().pp_gather_backward_ws_f32(
-            _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_points), b, c, n, npoints, _lib.ptr(ws) if ws is not None else None, nbytes, stream),
-            "gather_backward")
+        args = (_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(grad_points), b, c, n, npoints,
+                _lib.ptr(ws) if ws is not None else None, nbytes, stream)
+        L = _lib.lib()
+        if not (_lib.deterministic() and _lib.ordered_or_fallback(L.pp_gather_backward_ordered_f32(*args), "gather_backward")):
+            _lib.check(L.pp_gather_backward_ws_f32(*args), "gather_backward")
     return 1
 
 
@@ -174,9 +176,11 @@ def group_points_grad(grad_out, idx, n):
     out = torch.zeros(b, c, int(n), dtype=torch.float32, device=dev)
     with _lib.on_device(dev) as stream:
         ws, nbytes = _scatter_ws(dev, b, npoint * nsample, int(n), 1, 0)
-        _lib.check(_lib.lib().pp_group_points_grad_ws_f32(
-            _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(out), b, c, int(n), npoint, nsample,
-            c * npoint * nsample, _lib.ptr(ws) if ws is not None else None, nbytes, stream), "group_points_grad")
+        args = (_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(out), b, c, int(n), npoint, nsample,
+                c * npoint * nsample, _lib.ptr(ws) if ws is not None else None, nbytes, stream)
+        L = _lib.lib()
+        if not (_lib.deterministic() and _lib.ordered_or_fallback(L.pp_group_points_grad_ordered_f32(*args), "group_points_grad")):
+            _lib.check(L.pp_group_points_grad_ws_f32(*args), "group_points_grad")
     return out
 
 
@@ -216,9 +220,11 @@ def group_points_grad_from(grad_out, idx, n, channel_offset, channels):
     out = torch.zeros(b, channels, int(n), dtype=torch.float32, device=dev)
     with _lib.on_device(dev) as stream:
         ws, nbytes = _scatter_ws(dev, b, p, int(n), 1, 0)
-        _lib.check(_lib.lib().pp_group_points_grad_ws_f32(
-            _lib._c_void_p(grad_out.data_ptr() + 4 * channel_offset * p), _lib.ptr(idx), _lib.ptr(out),
-            b, channels, int(n), npoint, nsample, ctot * p, _lib.ptr(ws) if ws is not None else None, nbytes, stream), "group_points_grad_from")
+        args = (_lib._c_void_p(grad_out.data_ptr() + 4 * channel_offset * p), _lib.ptr(idx), _lib.ptr(out),
+                b, channels, int(n), npoint, nsample, ctot * p, _lib.ptr(ws) if ws is not None else None, nbytes, stream)
+        L = _lib.lib()
+        if not (_lib.deterministic() and _lib.ordered_or_fallback(L.pp_group_points_grad_ordered_f32(*args), "group_points_grad")):
+            _lib.check(L.pp_group_points_grad_ws_f32(*args), "group_points_grad_from")
     return out
 
 
@@ -270,6 +276,9 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
         raise RuntimeError("three_interpolate_grad_wrapper: tensor sizes do not match (b, c, n, m)")
     with _lib.on_device(dev) as stream:
         ws, nbytes = _scatter_ws(dev, b, 3 * n, m, 3, 1)
-        _lib.check(_lib.lib().pp_three_interpolate_grad_ws_f32(
-            _lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(grad_points), b, c, n, m,
-            _lib.ptr(ws) if ws is not None else None, nbytes, stream), "three_interpolate_grad_wrapper")
+        args = (_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(grad_points), b, c, n, m,
+                _lib.ptr(ws) if ws is not None else None, nbytes, stream)
+        L = _lib.lib()
+        if not (_lib.deterministic() and _lib.ordered_or_fallback(L.pp_three_interpolate_grad_ordered_f32(*args),
+                                                                  "three_interpolate_grad")):
+            _lib.check(L.pp_three_interpolate_grad_ws_f32(*args), "three_interpolate_grad_wrapper")

@@ -51,6 +51,10 @@ SIGNATURES = {
     "pp_group_points_grad_ws_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P, _c_size_t, _P],
     "pp_gather_backward_ws_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_three_interpolate_grad_ws_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
+    "pp_nmdistance_backward_ordered_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_group_points_grad_ordered_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P, _c_size_t, _P],
+    "pp_gather_backward_ordered_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
+    "pp_three_interpolate_grad_ordered_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_three_nn_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
     "pp_three_interpolate_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_three_interpolate_grad_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -114,6 +118,31 @@ def bridge():
 def check(code, what):
     if code != 0:
         raise RuntimeError("pytorch_points_amd: %s failed with HIP error %d" % (what, code))
+
+
+PP_ENOTSUP = 801   # include/pp_hip.h: an *_ordered_* entry point cannot serve this shape
+
+
+def deterministic():
+    """torch.use_deterministic_algorithms(True): the scatter-add backward passes take their ordered forms
+    (ascending source order, no floating-point atomics: reproducible bit for bit, equal to the CPU oracle)"""
+    return torch.are_deterministic_algorithms_enabled()
+
+
+def ordered_or_fallback(code, what):
+    """outcome of an *_ordered_* call: True = done; False = this shape has no ordered form and torch is in
+    warn-only mode (the caller takes the default path); raises otherwise"""
+    if code == 0:
+        return True
+    if code != PP_ENOTSUP:
+        check(code, what)
+    msg = ("pytorch_points_amd: %s has no deterministic implementation for this shape "
+           "(torch.use_deterministic_algorithms(True) is set)" % what)
+    if torch.is_deterministic_algorithms_warn_only_enabled():
+        import warnings
+        warnings.warn(msg)
+        return False
+    raise RuntimeError(msg)
 
 
 def require_cuda(*named):

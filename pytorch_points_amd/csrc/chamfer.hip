@@ -440,6 +440,13 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_lds_kernel(
 // scans the counts, fills the lists (integer atomics again), and then one lane per k sums its own
 // term and its list in registers and writes the 12-byte gradient row once.
 constexpr int kCsrSlices = 4;  // workgroups per (batch, target cloud)
+// ORDERED (deterministic mode, pp_nmdistance_backward_ordered_f32): every list is sorted by source index and
+// the terms are added in the order of a sequential loop over the reference's two launches -- first launch
+// (cloud 1 -> cloud 2): own terms into gradxyz1, scattered terms into gradxyz2 in ascending source order;
+// second launch mirrored -- i.e. gradxyz1[j] = (0 + own) - s(i1) - s(i2) ... and gradxyz2[k] = ((0 - s(j1)) -
+// s(j2) ...) + own.  No floating-point atomics anywhere, so the result is reproducible bit for bit, and it
+// equals the CPU oracle's (the restatement under oracle/: oracle_chamfer_backward) bit for bit.
+template <bool ORDERED>
 __global__ __launch_bounds__(1024) void nmdist_bwd_csr_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, const float* __restrict__ gd1,
     const float* __restrict__ gd2, const int* __restrict__ idx1, const int* __restrict__ idx2,
@@ -527,20 +534,42 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_csr_kernel(
   for (int kk = t; kk < len; kk += 1024) {
     const int k = k0 + kk;
     const float tx = xt[3 * (size_t)k], ty = xt[3 * (size_t)k + 1], tz = xt[3 * (size_t)k + 2];
-    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    float ox_ = 0.0f, oy_ = 0.0f, oz_ = 0.0f;
     const int j2 = it[k];
     if (j2 >= 0) {  // own term: +g*(x_T[k] - x_O[idx_T[k]])          (ref nmdistance_cuda.cu:176-180)
       const float g = gt[k] * 2;
-      ax = g * (tx - xo[3 * (size_t)j2]);
-      ay = g * (ty - xo[3 * (size_t)j2 + 1]);
-      az = g * (tz - xo[3 * (size_t)j2 + 2]);
+      ox_ = g * (tx - xo[3 * (size_t)j2]);
+      oy_ = g * (ty - xo[3 * (size_t)j2 + 1]);
+      oz_ = g * (tz - xo[3 * (size_t)j2 + 2]);
     }
-    for (unsigned e = s_start[kk]; e < s_start[kk + 1]; ++e) {  // scattered terms (:181)
+    const unsigned e0 = s_start[kk], e1 = s_start[kk + 1];
+    if (ORDERED) {  // ascending source index (the cursors filled the list in arrival order)
+      for (unsigned i = e0 + 1; i < e1; ++i) {
+        const unsigned v = s_list[i];
+        unsigned j = i;
+        while (j > e0 && s_list[j - 1] > v) {
+          s_list[j] = s_list[j - 1];
+          --j;
+        }
+        s_list[j] = v;
+      }
+    }
+    // cloud 1's rows receive their own term first (first launch), cloud 2's last (second launch); a row
+    // without an own term (labeled Chamfer, idx < 0) receives none at all, as in the reference (:175)
+    const bool own_first = !ORDERED || !second;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    if (own_first && j2 >= 0) {
+      ax += ox_; ay += oy_; az += oz_;
+    }
+    for (unsigned e = e0; e < e1; ++e) {  // scattered terms (:181)
       const unsigned j = s_list[e];
       const float g = go[j] * 2;
       ax += -(g * (xo[3 * (size_t)j] - tx));
       ay += -(g * (xo[3 * (size_t)j + 1] - ty));
       az += -(g * (xo[3 * (size_t)j + 2] - tz));
+    }
+    if (!own_first && j2 >= 0) {
+      ax += ox_; ay += oy_; az += oz_;
     }
     out[3 * (size_t)k] = ax;
     out[3 * (size_t)k + 1] = ay;
@@ -913,9 +942,9 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
     if (lds <= 150 * 1024 && (long long)B * 2 * kCsrSlices <= 0x7fffffffLL) {
       static pp::DeviceFlags lds_ok;
       // (the kernel also has 64 bytes of static LDS: the dynamic limit must leave room for them)
-      const hipError_t e = pp::allow_big_lds(nmdist_bwd_csr_kernel, 152 * 1024, lds_ok);
+      const hipError_t e = pp::allow_big_lds(nmdist_bwd_csr_kernel<false>, 152 * 1024, lds_ok);
       if (e != hipSuccess) return (int)e;
-      nmdist_bwd_csr_kernel<<<dim3((unsigned)(B * 2 * kCsrSlices)), dim3(1024), lds, s>>>(
+      nmdist_bwd_csr_kernel<false><<<dim3((unsigned)(B * 2 * kCsrSlices)), dim3(1024), lds, s>>>(
           xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, slice_len);
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
@@ -941,6 +970,32 @@ extern "C" int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2,
   PP_RETURN_IF_LAUNCH_FAILED();
   nmdist_bwd_kernel<true><<<dim3((unsigned)blocks), dim3(256), 0, s>>>(
       xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, C, t1, t2);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+
+// Deterministic mode: the CSR form with ordered lists (see nmdist_bwd_csr_kernel<true>).  C == 3 and clouds whose
+// bookkeeping fits the LDS (max(N, M) up to ~19000 points); PP_ENOTSUP otherwise -- there is no deterministic
+// substitute for other shapes.
+extern "C" int pp_nmdistance_backward_ordered_f32(const float* xyz1, const float* xyz2, const float* graddist1,
+                                                  const float* graddist2, const int* idx1, const int* idx2,
+                                                  float* gradxyz1, float* gradxyz2, int B, int N, int M, int C,
+                                                  void* stream) {
+  if (B < 0 || N < 0 || M < 0 || C < 1) return PP_EINVAL;
+  if ((long long)B * ((long long)N + M) == 0) return PP_OK;
+  if (N == 0 || M == 0)  // no pairs: zeros, as in the unordered entry point
+    return pp_nmdistance_backward_f32(xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, B, N, M, C, stream);
+  if (!xyz1 || !xyz2 || !graddist1 || !graddist2 || !idx1 || !idx2 || !gradxyz1 || !gradxyz2) return PP_EINVAL;
+  if (C != 3) return PP_ENOTSUP;
+  const int big = N > M ? N : M;
+  const int slice_len = (big + kCsrSlices - 1) / kCsrSlices;
+  const size_t lds = ((size_t)2 * slice_len + 1 + big) * sizeof(unsigned);
+  if (lds > 150 * 1024 || (long long)B * 2 * kCsrSlices > 0x7fffffffLL) return PP_ENOTSUP;
+  static pp::DeviceFlags lds_ok;
+  const hipError_t e = pp::allow_big_lds(nmdist_bwd_csr_kernel<true>, 152 * 1024, lds_ok);
+  if (e != hipSuccess) return (int)e;
+  nmdist_bwd_csr_kernel<true><<<dim3((unsigned)(B * 2 * kCsrSlices)), dim3(1024), lds, (hipStream_t)stream>>>(
+      xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, N, M, slice_len);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
 }

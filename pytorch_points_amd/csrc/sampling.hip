@@ -6,7 +6,7 @@
 namespace pp {  // scatter.hip
 size_t ssa_workspace_bytes(int B, long long P, int R, int Nd, bool weighted);
 int ssa_run(const float* src, const int* dst, const float* weight, float* out, int B, int C,
-            long long P, int R, int Nd, long long src_bstride, void* workspace, hipStream_t s);
+            long long P, int R, int Nd, long long src_bstride, void* workspace, hipStream_t s, bool ordered);
 }  // namespace pp
 
 namespace {
@@ -1493,7 +1493,7 @@ extern "C" int pp_group_points_grad_ws_f32(const float* grad_out, const int* idx
   if (B > 0 && C > 0 && P > 0 && grad_out && idx && grad_points && N > 0 && P <= 4LL * N &&
       grad_out_batch_stride >= (long long)C * P && scatter_ok(B, C, P, 1, N, 0, workspace, workspace_bytes))
     return pp::ssa_run(grad_out, idx, nullptr, grad_points, B, C, P, 1, N, grad_out_batch_stride, workspace,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, false);
   return pp_group_points_grad_strided_f32(grad_out, idx, grad_points, B, C, N, npoint, nsample,
                                           grad_out_batch_stride, stream);
 }
@@ -1504,7 +1504,7 @@ extern "C" int pp_gather_backward_ws_f32(const float* grad_out, const int* idx, 
   if (B > 0 && C > 0 && M > 0 && N > 0 && grad_out && idx && grad_points &&
       scatter_ok(B, C, M, 1, N, 0, workspace, workspace_bytes))
     return pp::ssa_run(grad_out, idx, nullptr, grad_points, B, C, M, 1, N, (long long)C * M, workspace,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, false);
   return pp_gather_backward_f32(grad_out, idx, grad_points, B, C, N, M, stream);
 }
 
@@ -1518,6 +1518,52 @@ extern "C" int pp_three_interpolate_grad_ws_f32(const float* grad_out, const int
   if (!columns && B > 0 && C > 0 && N > 0 && M > 0 && grad_out && idx && weight && grad_points &&
       scatter_ok(B, C, 3LL * N, 3, M, 1, workspace, workspace_bytes))
     return pp::ssa_run(grad_out, idx, weight, grad_points, B, C, 3LL * N, 3, M, (long long)C * N, workspace,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, false);
   return pp_three_interpolate_grad_f32(grad_out, idx, weight, grad_points, B, C, N, M, stream);
+}
+
+// ---- ORDERED scatter-add backwards (deterministic mode) ------------------------------------------------
+// The sorted-triples form of scatter.hip with every destination's terms added in ascending source order: no
+// atomics on floating-point data, results identical from run to run and identical, bit for bit, to a
+// sequential loop in the order of the reference's launch (the CPU oracle).  Selected by the Python / C++ host
+// side when torch.are_deterministic_algorithms_enabled().  PP_ENOTSUP when the problem does not fit the form
+// (more than 20480 destinations per batch element, workspace too small): there is no deterministic substitute.
+static bool ordered_ok(int B, long long P, int R, int Nd, int weighted, const void* ws, size_t bytes) {
+  const size_t need = pp::ssa_workspace_bytes(B, P, R, Nd, weighted != 0);
+  return ws && need != 0 && bytes >= need;
+}
+
+extern "C" int pp_group_points_grad_ordered_f32(const float* grad_out, const int* idx, float* grad_points, int B,
+                                                int C, int N, int npoint, int nsample,
+                                                long long grad_out_batch_stride, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+  if (B < 0 || C < 0 || N < 0 || npoint < 0 || nsample < 0) return PP_EINVAL;
+  const long long P = (long long)npoint * nsample;
+  if (B == 0 || C == 0 || N == 0 || P == 0) return PP_OK;
+  if (!grad_out || !idx || !grad_points || grad_out_batch_stride < (long long)C * P) return PP_EINVAL;
+  if (!ordered_ok(B, P, 1, N, 0, workspace, workspace_bytes)) return PP_ENOTSUP;
+  return pp::ssa_run(grad_out, idx, nullptr, grad_points, B, C, P, 1, N, grad_out_batch_stride, workspace,
+                     (hipStream_t)stream, true);
+}
+
+extern "C" int pp_gather_backward_ordered_f32(const float* grad_out, const int* idx, float* grad_points, int B,
+                                              int C, int N, int M, void* workspace, size_t workspace_bytes,
+                                              void* stream) {
+  if (B < 0 || C < 0 || N < 0 || M < 0) return PP_EINVAL;
+  if (B == 0 || C == 0 || N == 0 || M == 0) return PP_OK;
+  if (!grad_out || !idx || !grad_points) return PP_EINVAL;
+  if (!ordered_ok(B, M, 1, N, 0, workspace, workspace_bytes)) return PP_ENOTSUP;
+  return pp::ssa_run(grad_out, idx, nullptr, grad_points, B, C, M, 1, N, (long long)C * M, workspace,
+                     (hipStream_t)stream, true);
+}
+
+extern "C" int pp_three_interpolate_grad_ordered_f32(const float* grad_out, const int* idx, const float* weight,
+                                                     float* grad_points, int B, int C, int N, int M,
+                                                     void* workspace, size_t workspace_bytes, void* stream) {
+  if (B < 0 || C < 0 || N < 0 || M < 0) return PP_EINVAL;
+  if (B == 0 || C == 0 || N == 0 || M == 0) return PP_OK;
+  if (!grad_out || !idx || !weight || !grad_points) return PP_EINVAL;
+  if (!ordered_ok(B, 3LL * N, 3, M, 1, workspace, workspace_bytes)) return PP_ENOTSUP;
+  return pp::ssa_run(grad_out, idx, weight, grad_points, B, C, 3LL * N, 3, M, (long long)C * N, workspace,
+                     (hipStream_t)stream, true);
 }

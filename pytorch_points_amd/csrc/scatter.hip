@@ -11,7 +11,12 @@
 // it stages 64 KiB of its source row in LDS, and thread t -- which exclusively owns destinations
 // [t*npt, (t+1)*npt) -- walks its contiguous slice of the sorted triples, reading the staged value
 // and accumulating into its own LDS slots with plain read-modify-writes.  The summation order
-// within a destination is unspecified, as it is with the reference's atomics.
+// within a destination is unspecified, as it is with the reference's atomics -- unless the ORDERED form
+// is asked for (pp_*_ordered_f32, selected by torch.use_deterministic_algorithms): the build kernel then
+// also sorts the triples of every (chunk, destination) group by source position, so that a destination
+// receives its terms in ascending source order.  That is the order in which a sequential loop over the
+// reference's launch (the CPU oracle) adds them: results are reproducible bit for bit from run to run AND
+// equal to the oracle's.
 #include "pp_common.h"
 
 namespace {
@@ -21,6 +26,10 @@ constexpr int kSsaMaxChunk = 16384;  // source elements staged per pass (chosen 
                                      // values + triples + accumulators fit the LDS)
 constexpr int kSsaSrcBits = 14;      // log2(kSsaMaxChunk)
 constexpr int kSsaMaxDst = 20480;    // destinations per batch element: accumulators live in LDS
+// a sorted triple: destination << 16 | source in chunk << 2 | triple of that source (R <= 3): the low 16
+// bits order the triples of one destination by source position
+constexpr int kSsaDstShift = 16;
+__device__ __forceinline__ unsigned ssa_src(unsigned e) { return (e >> 2) & ((1u << kSsaSrcBits) - 1u); }
 
 struct SsaLayout {
   size_t entries, weights, offsets, total;
@@ -40,7 +49,7 @@ __global__ __launch_bounds__(kSsaThreads) void ssa_build_kernel(const int* __res
                                                                 const float* __restrict__ weight,
                                                                 unsigned char* __restrict__ ws, int B,
                                                                 long long P, int R, int Nd, int nchunks,
-                                                                int S) {
+                                                                int S, int ordered) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // [Nd + Nd/32] skewed
   __shared__ unsigned s_wave[16];
   const int b = blockIdx.x / nchunks, q = blockIdx.x - b * nchunks;
@@ -72,6 +81,7 @@ __global__ __launch_bounds__(kSsaThreads) void ssa_build_kernel(const int* __res
   __syncthreads();
   unsigned run = incl - sum;
   for (int w = 0; w < (t >> 6); ++w) run += s_wave[w];
+  const unsigned first = run;
   offs[t] = run;  // first triple of thread t's destinations in this chunk
   if (t == kSsaThreads - 1) offs[kSsaThreads] = (unsigned)(p1 - p0);
   for (int c = c0; c < c1; ++c) {
@@ -83,9 +93,32 @@ __global__ __launch_bounds__(kSsaThreads) void ssa_build_kernel(const int* __res
   for (long long p = p0 + t; p < p1; p += kSsaThreads) {
     const int dd = d[p];
     const unsigned pos = atomicAdd(&s_cnt[sk(dd)], 1u);
-    const unsigned src_local = (unsigned)((p - p0) / R);
-    entries[pos] = ((unsigned)dd << kSsaSrcBits) | src_local;
+    const unsigned rel = (unsigned)(p - p0);
+    const unsigned src_local = rel / (unsigned)R;
+    entries[pos] = ((unsigned)dd << kSsaDstShift) | (src_local << 2) | (rel - src_local * (unsigned)R);
     if (win) wout[pos] = win[p];
+  }
+  if (!ordered) return;
+  // ORDERED: the cursors handed the positions inside a (chunk, destination) group out in arrival order;
+  // the owner of the destination sorts the group by source position (insertion sort: the groups are short)
+  __threadfence_block();
+  __syncthreads();
+  unsigned g0 = first;
+  for (int c = c0; c < c1; ++c) {
+    const unsigned g1 = s_cnt[sk(c)];  // the cursor now stands at the group's end
+    for (unsigned i = g0 + 1; i < g1; ++i) {
+      const unsigned e = entries[i];
+      const float w = wout ? wout[i] : 0.0f;
+      unsigned j = i;
+      while (j > g0 && (entries[j - 1] & 0xffffu) > (e & 0xffffu)) {
+        entries[j] = entries[j - 1];
+        if (wout) wout[j] = wout[j - 1];
+        --j;
+      }
+      entries[j] = e;
+      if (wout) wout[j] = w;
+    }
+    g0 = g1;
   }
 }
 
@@ -161,17 +194,17 @@ __global__ __launch_bounds__(kSsaThreads) void ssa_apply_kernel(const float* __r
       for (int u = 0; u < 4; ++u) ent[u] = s_ent[e + u];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        v[u] = s_val[ent[u] & ((1u << kSsaSrcBits) - 1u)];
+        v[u] = s_val[ssa_src(ent[u])];
         if (WEIGHTED) v[u] *= s_w[e + u];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s_acc[ent[u] >> kSsaSrcBits] += v[u];  // this thread is their only writer
+      for (int u = 0; u < 4; ++u) s_acc[ent[u] >> kSsaDstShift] += v[u];  // this thread is their only writer
     }
     for (; e < e1; ++e) {
       const unsigned en = s_ent[e];
-      float v = s_val[en & ((1u << kSsaSrcBits) - 1u)];
+      float v = s_val[ssa_src(en)];
       if (WEIGHTED) v *= s_w[e];
-      s_acc[en >> kSsaSrcBits] += v;
+      s_acc[en >> kSsaDstShift] += v;
     }
   }
   __syncthreads();
@@ -195,7 +228,7 @@ static int ssa_chunk(int R, int Nd, bool weighted) {
 
 // bytes of scratch for a segmented scatter-add of P triples per batch element (0: not applicable)
 size_t ssa_workspace_bytes(int B, long long P, int R, int Nd, bool weighted) {
-  if (B <= 0 || P <= 0 || Nd <= 0 || Nd > kSsaMaxDst || P % R != 0) return 0;
+  if (B <= 0 || P <= 0 || Nd <= 0 || Nd > kSsaMaxDst || P % R != 0 || R > 3) return 0;
   const int S = ssa_chunk(R, Nd, weighted);
   if (S == 0) return 0;
   const long long Ps = P / R;
@@ -206,7 +239,7 @@ size_t ssa_workspace_bytes(int B, long long P, int R, int Nd, bool weighted) {
 
 // out[b,c,dst[b,p]] += (weight ? weight[b,p] : 1) * src[b*src_bstride + c*(P/R) + p/R]
 int ssa_run(const float* src, const int* dst, const float* weight, float* out, int B, int C,
-            long long P, int R, int Nd, long long src_bstride, void* workspace, hipStream_t s) {
+            long long P, int R, int Nd, long long src_bstride, void* workspace, hipStream_t s, bool ordered) {
   const long long Ps = P / R;
   const int S = ssa_chunk(R, Nd, weight != nullptr);
   const int nchunks = (int)((Ps + S - 1) / S);
@@ -219,7 +252,7 @@ int ssa_run(const float* src, const int* dst, const float* weight, float* out, i
   if (e != hipSuccess) return (int)e;
   unsigned char* ws = (unsigned char*)workspace;
   ssa_build_kernel<<<dim3((unsigned)(B * nchunks)), dim3(kSsaThreads), (size_t)(Nd + Nd / 32 + 1) * sizeof(unsigned), s>>>(
-      dst, weight, ws, B, P, R, Nd, nchunks, S);
+      dst, weight, ws, B, P, R, Nd, nchunks, S, ordered ? 1 : 0);
   PP_RETURN_IF_LAUNCH_FAILED();
   const size_t lds = 4 * ((size_t)S + (size_t)S * R * (weight ? 2 : 1) + (size_t)Nd);
   const unsigned blocks = (unsigned)(8 * ((B + 7) / 8) * C);

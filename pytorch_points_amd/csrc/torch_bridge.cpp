@@ -83,10 +83,23 @@ variable_list chamfer_backward(AutogradContext* ctx, const variable_list& grads)
   Tensor out1 = torch::empty_like(xyz1), out2 = torch::empty_like(xyz2);  // fully overwritten by the kernel
   const c10::DeviceGuard guard(xyz1.device());
   const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(xyz1.device().index()).stream();
+  const int B = (int)xyz1.size(0), N = (int)xyz1.size(1), M = (int)xyz2.size(1), C = (int)xyz1.size(2);
+  if (at::globalContext().deterministicAlgorithms()) {
+    // the ordered form: ascending source order, no floating-point atomics (include/pp_hip.h)
+    const int code = pp_nmdistance_backward_ordered_f32(xyz1.data_ptr<float>(), xyz2.data_ptr<float>(),
+                                                        g1.data_ptr<float>(), g2.data_ptr<float>(), idx1.data_ptr<int>(),
+                                                        idx2.data_ptr<int>(), out1.data_ptr<float>(),
+                                                        out2.data_ptr<float>(), B, N, M, C, (void*)stream);
+    if (code == 0) return {out1, out2};
+    if (code != PP_ENOTSUP) check_code(code, "nmdistance_backward");
+    const char* msg = "pytorch_points_amd: nmdistance_backward has no deterministic implementation for this shape "
+                      "(torch.use_deterministic_algorithms(True) is set)";
+    TORCH_CHECK(at::globalContext().deterministicAlgorithmsWarnOnly(), msg);
+    TORCH_WARN(msg);
+  }
   check_code(pp_nmdistance_backward_f32(xyz1.data_ptr<float>(), xyz2.data_ptr<float>(), g1.data_ptr<float>(),
                                         g2.data_ptr<float>(), idx1.data_ptr<int>(), idx2.data_ptr<int>(),
-                                        out1.data_ptr<float>(), out2.data_ptr<float>(), (int)xyz1.size(0),
-                                        (int)xyz1.size(1), (int)xyz2.size(1), (int)xyz1.size(2), (void*)stream),
+                                        out1.data_ptr<float>(), out2.data_ptr<float>(), B, N, M, C, (void*)stream),
              "nmdistance_backward");
   return {out1, out2};
 }

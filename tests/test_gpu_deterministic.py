@@ -1,0 +1,200 @@
+"""Deterministic mode: with torch.use_deterministic_algorithms(True) the four
+scatter-add backward passes of the path -- Chamfer (K3), gather_points (K5), group_points (K9),
+three_interpolate (K12) -- take their ORDERED forms: every destination's terms are added in ascending source
+order with no floating-point atomics.  Two properties are tested:
+  * run twice on the same inputs at BASELINE config-2 / config-4 size: bitwise identical (torch.equal);
+  * equal, bit for bit, to the CPU oracle's sequential loops (the order of the reference's launches) --
+    a stronger statement than the 1e-5 the default (unordered) forms are held to.
+The reference itself is not reproducible here (global fp32 atomics: nmdistance_cuda.cu:180-181,
+sampling_cuda.cu:63,499-500, interpolate_gpu.cu:139-141)."""
+import contextlib
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pytorch_points_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def deterministic(warn_only=False):
+    before = torch.are_deterministic_algorithms_enabled()
+    before_warn = torch.is_deterministic_algorithms_warn_only_enabled()
+    torch.use_deterministic_algorithms(True, warn_only=warn_only)
+    try:
+        yield
+    finally:
+        torch.use_deterministic_algorithms(before, warn_only=before_warn)
+
+
+def _chamfer_grads(cuda, x1, x2, g1, g2, fn):
+    t1 = torch.from_numpy(x1).to(cuda).requires_grad_(True)
+    t2 = torch.from_numpy(x2).to(cuda).requires_grad_(True)
+    d1, d2, _, _ = fn(t1, t2)
+    torch.autograd.backward([d1, d2], [torch.from_numpy(g1).to(cuda), torch.from_numpy(g2).to(cuda)])
+    return t1.grad, t2.grad
+
+
+def test_chamfer_backward_is_reproducible_at_config_2(cuda):
+    from pytorch_points_amd.network import model_loss as ml
+    b, n = 32, 16384
+    x1, x2 = S.unit_sphere(0, b, n), S.unit_sphere(1, b, n)
+    g1 = S.normal(5, (b, n)) / (b * n)
+    g2 = S.normal(6, (b, n)) / (b * n)
+    with deterministic():
+        for fn in (ml.nndistance, ml.NmDistanceFunction.apply):       # the C++ node and the Python class
+            a = _chamfer_grads(cuda, x1, x2, g1, g2, fn)
+            c = _chamfer_grads(cuda, x1, x2, g1, g2, fn)
+            assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    # and it is the same gradient as the default (unordered) form to its tolerance
+    d = _chamfer_grads(cuda, x1, x2, g1, g2, ml.nndistance)
+    assert torch.allclose(a[0], d[0], rtol=1e-5, atol=1e-12) and torch.allclose(a[1], d[1], rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("b,n,m,dup", [(2, 3000, 2500, False), (1, 4096, 4096, True), (3, 1000, 5000, False)])
+def test_chamfer_backward_ordered_equals_oracle_bitwise(cuda, b, n, m, dup):
+    from pytorch_points_amd.network import model_loss as ml
+    x1, x2 = S.unit_sphere(10, b, n), S.unit_sphere(11, b, m)
+    if dup:   # many points share a nearest neighbour: long lists, the order of the sum matters
+        x2[:, m // 8:] = x2[:, : m - m // 8][:, ::-1][:, : m - m // 8]
+        x2 = np.ascontiguousarray(np.repeat(x2[:, : m // 16], 16, axis=1))
+    g1, g2 = S.normal(12, (b, n)), S.normal(13, (b, m))
+    fwd = oracle.chamfer_forward(x1, x2)
+    e1, e2 = oracle.chamfer_backward(x1, x2, g1, g2, fwd[1], fwd[3])
+    with deterministic():
+        a1, a2 = _chamfer_grads(cuda, x1, x2, g1, g2, ml.nndistance)
+    assert np.array_equal(a1.cpu().numpy(), e1) and np.array_equal(a2.cpu().numpy(), e2)
+
+
+def test_labeled_chamfer_backward_ordered_equals_oracle_bitwise(cuda):
+    from pytorch_points_amd.network import model_loss as ml
+    b, n, m = 2, 2048, 3000
+    x1, x2 = S.unit_sphere(14, b, n), S.unit_sphere(15, b, m)
+    l1 = (S.uniform01(16, (b, n)) * 4).astype(np.int64).reshape(b, n)
+    l2 = (S.uniform01(17, (b, m)) * 3).astype(np.int64).reshape(b, m)       # label 3 has no partner: idx -1
+    g1, g2 = S.normal(18, (b, n)), S.normal(19, (b, m))
+    fwd = oracle.labeled_chamfer_forward(x1, x2, l1.astype(np.float32), l2.astype(np.float32))
+    e1, e2 = oracle.chamfer_backward(x1, x2, g1, g2, fwd[1], fwd[3])
+    with deterministic():
+        t1 = torch.from_numpy(x1).to(cuda).requires_grad_(True)
+        t2 = torch.from_numpy(x2).to(cuda).requires_grad_(True)
+        d1, d2, i1, _ = ml.labeled_nndistance(t1, t2, torch.from_numpy(l1).to(cuda), torch.from_numpy(l2).to(cuda))
+        assert int((i1 < 0).sum()) > 0
+        torch.autograd.backward([d1, d2], [torch.from_numpy(g1).to(cuda), torch.from_numpy(g2).to(cuda)])
+    assert np.array_equal(t1.grad.cpu().numpy(), e1) and np.array_equal(t2.grad.cpu().numpy(), e2)
+
+
+def test_chamfer_backward_without_an_ordered_form_raises_or_warns(cuda):
+    from pytorch_points_amd.network import model_loss as ml
+    x1 = torch.from_numpy(S.unit_sphere(20, 1, 40000)).to(cuda).requires_grad_(True)   # beyond the LDS lists
+    x2 = torch.from_numpy(S.unit_sphere(21, 1, 4096)).to(cuda).requires_grad_(True)
+    with deterministic():
+        with pytest.raises(RuntimeError, match="deterministic"):
+            ml.nndistance(x1, x2)[0].sum().backward()
+    with deterministic(warn_only=True):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ml.nndistance(x1, x2)[0].sum().backward()
+        assert any("deterministic" in str(x.message) for x in w) and x1.grad is not None
+
+
+def _ball_idx(cuda, b, n, npoint, ns, seed):
+    from pytorch_points_amd.network.operations import ball_query
+    x = torch.from_numpy(S.unit_sphere(seed, b, n)).to(cuda)
+    return ball_query(0.1, ns, x, x[:, :: n // npoint].contiguous())
+
+
+def test_group_points_grad_is_reproducible_at_config_4(cuda):
+    from pytorch_points_amd._ext import sampling
+    b, c, n, npoint, ns = 32, 128, 16384, 4096, 64
+    idx = _ball_idx(cuda, b, n, npoint, ns, 30)
+    g = torch.randn(b, c, npoint, ns, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
+    with deterministic():
+        a = sampling.group_points_grad(g, idx, n)
+        d = sampling.group_points_grad(g, idx, n)
+    assert torch.equal(a, d)
+    ref = sampling.group_points_grad(g, idx, n)          # default form: same sums to its tolerance
+    assert torch.allclose(a, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_scatter_backwards_ordered_equal_oracle_bitwise(cuda):
+    from pytorch_points_amd._ext import sampling
+    b, c, n, npoint, ns = 2, 5, 3000, 300, 16
+    idx = _ball_idx(cuda, b, n, npoint, ns, 31)
+    g = S.normal(32, (b, c, npoint, ns))
+    with deterministic():
+        got = sampling.group_points_grad(torch.from_numpy(g).to(cuda), idx, n)
+    assert np.array_equal(got.cpu().numpy(), oracle.group_points_grad(g, idx.cpu().numpy(), n))
+    # gather_points backward, with repeated indices
+    m = 4000
+    gi = (S.uniform01(33, (b, m)) * n * 0.1).astype(np.int32).reshape(b, m)
+    go = S.normal(34, (b, c, m))
+    gp = torch.zeros(b, c, n, device=cuda)
+    with deterministic():
+        sampling.gather_backward(b, c, n, m, torch.from_numpy(go).to(cuda), torch.from_numpy(gi).to(cuda), gp)
+        gp2 = torch.zeros(b, c, n, device=cuda)
+        sampling.gather_backward(b, c, n, m, torch.from_numpy(go).to(cuda), torch.from_numpy(gi).to(cuda), gp2)
+    assert torch.equal(gp, gp2)
+    assert np.array_equal(gp.cpu().numpy(), oracle.gather_backward(go, gi, n))
+    # three_interpolate backward
+    nn_, mm = 5000, 700
+    ti = (S.uniform01(35, (b, nn_, 3)) * mm).astype(np.int32).reshape(b, nn_, 3)
+    ti[:, ::7, 1] = ti[:, ::7, 0]                      # one source feeding a destination twice
+    tw = S.uniform01(36, (b, nn_, 3)).astype(np.float32).reshape(b, nn_, 3)
+    tg = S.normal(37, (b, c, nn_))
+    out = torch.zeros(b, c, mm, device=cuda)
+    with deterministic():
+        sampling.three_interpolate_grad_wrapper(b, c, nn_, mm, torch.from_numpy(tg).to(cuda), torch.from_numpy(ti).to(cuda),
+                                                torch.from_numpy(tw).to(cuda), out)
+    assert np.array_equal(out.cpu().numpy(), oracle.three_interpolate_grad(tg, ti, tw, mm))
+
+
+def test_three_interpolate_and_gather_backward_reproducible_at_size(cuda):
+    from pytorch_points_amd._ext import sampling
+    b, c, n, m = 32, 128, 16384, 4096
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    idx = torch.randint(0, m, (b, n, 3), device=cuda, generator=gen, dtype=torch.int32)
+    w = torch.rand(b, n, 3, device=cuda, generator=gen)
+    g = torch.randn(b, c, n, device=cuda, generator=gen)
+    res = []
+    with deterministic():
+        for _ in range(2):
+            out = torch.zeros(b, c, m, device=cuda)
+            sampling.three_interpolate_grad_wrapper(b, c, n, m, g, idx, w, out)
+            res.append(out)
+    assert torch.equal(res[0], res[1])
+    gi = torch.randint(0, n, (b, m), device=cuda, generator=gen, dtype=torch.int32)
+    go = torch.randn(b, c, m, device=cuda, generator=gen)
+    res = []
+    with deterministic():
+        for _ in range(2):
+            gp = torch.zeros(b, c, n, device=cuda)
+            sampling.gather_backward(b, c, n, m, go, gi, gp)
+            res.append(gp)
+    assert torch.equal(res[0], res[1])
+
+
+def test_autograd_wrappers_route_to_the_ordered_forms(cuda):
+    """gather_points / grouping_operation / three_interpolate through autograd, deterministic mode, twice."""
+    from pytorch_points_amd.network.operations import gather_points, grouping_operation
+    from pytorch_points_amd.network.pointnet2_utils import three_interpolate
+    b, c, n = 4, 16, 8192
+    gen = torch.Generator(device=cuda).manual_seed(9)
+    feats = torch.randn(b, c, n, device=cuda, generator=gen)
+    idx = _ball_idx(cuda, b, n, 1024, 32, 40)
+    gidx = torch.randint(0, n, (b, 2048), device=cuda, generator=gen, dtype=torch.int32)
+    tidx = torch.randint(0, n, (b, 3000, 3), device=cuda, generator=gen, dtype=torch.int32)
+    tw = torch.rand(b, 3000, 3, device=cuda, generator=gen)
+    outs = []
+    with deterministic():
+        for _ in range(2):
+            f = feats.clone().requires_grad_(True)
+            loss = (grouping_operation(f, idx) ** 2).sum() + gather_points(f, gidx).sum() * 3 + \
+                (three_interpolate(f, tidx, tw) ** 3).sum()
+            loss.backward()
+            outs.append(f.grad)
+    assert torch.equal(outs[0], outs[1])
