@@ -178,6 +178,11 @@ size_t pp_knn_workspace_bytes(int B, int N, int M, int K);
 int pp_knn_ws_f32(const float* p1, const float* p2, const int* lengths1, const int* lengths2, float* dist2,
                   int* idx, int B, int N, int M, int K, void* workspace, size_t workspace_bytes,
                   void* stream);
+/* The same operator for ANY point dimension D (1..512) and K up to 128 -- the reference's feature-space
+ * searches, network/layers.py:52,99 (DenseEdgeConv: D = channel count, K = k + 1).  p1 (B,N,D), p2 (B,M,D).
+ * Squared distance = the sequential chain d = fma(t_c, t_c, d), c = 0..D-1; ties to the lower index. */
+int pp_knn_nd_f32(const float* p1, const float* p2, const int* lengths1, const int* lengths2, float* dist2,
+                  int* idx, int B, int N, int M, int D, int K, void* stream);
 
 /* Replaces sampling.three_interpolate_wrapper(b,c,m,n,points,idx,weight,out)
  *   (_ext/sampling.cpp:175-188 -> _ext/interpolate_gpu.cu:77-117).

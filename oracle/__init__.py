@@ -198,12 +198,13 @@ def three_nn(unknown, known):
 
 
 def knn(p1, p2, K, lengths1=None, lengths2=None):
-    """K nearest neighbours of p1 (B,N,3) in p2 (B,M,3) -> dist2 (B,N,K) f32 ascending, idx (B,N,K) i32;
-    ties to the lower index; padding (0, 0)"""
+    """K nearest neighbours of p1 (B,N,D) in p2 (B,M,D) -> dist2 (B,N,K) f32 ascending, idx (B,N,K) i32;
+    squared distance = sequential fma chain over the D dimensions; ties to the lower index; padding (0, 0)"""
     p1, q1 = _f(p1)
     p2, q2 = _f(p2)
-    b, n, _ = p1.shape
+    b, n, dim = p1.shape
     m = p2.shape[1]
+    assert p2.shape[2] == dim
     d2 = np.zeros((b, n, K), np.float32)
     idx = np.zeros((b, n, K), np.int32)
     l1 = l2 = None
@@ -214,7 +215,7 @@ def knn(p1, p2, K, lengths1=None, lengths2=None):
     if lengths2 is not None:
         a2 = np.ascontiguousarray(lengths2, np.int32)
         l2 = a2.ctypes.data_as(ctypes.c_void_p)
-    lib().oracle_knn(q1, q2, l1, l2, _p(d2), _p(idx), b, n, m, int(K))
+    lib().oracle_knn_nd(q1, q2, l1, l2, _p(d2), _p(idx), b, n, m, int(dim), int(K))
     return d2, idx
 
 

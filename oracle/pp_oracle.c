@@ -444,8 +444,8 @@ void oracle_three_nn(const float* unknown, const float* known, float* dist2, int
  * contraction = distc above); ties resolved to the lower index (pytorch3d leaves them unspecified);
  * slots beyond the valid points, and rows beyond lengths1, hold (0, 0).
  * ------------------------------------------------------------------------------------------- */
-void oracle_knn(const float* p1, const float* p2, const int* len1, const int* len2, float* dist, int* idx,
-                int b, int n, int m, int K) {
+void oracle_knn_nd(const float* p1, const float* p2, const int* len1, const int* len2, float* dist, int* idx,
+                   int b, int n, int m, int D, int K) {
 #pragma omp parallel for collapse(2) schedule(static)
   for (int i = 0; i < b; ++i)
     for (int j = 0; j < n; ++j) {
@@ -455,10 +455,10 @@ void oracle_knn(const float* p1, const float* p2, const int* len1, const int* le
       const int m2 = len2 ? (len2[i] < 0 ? 0 : (len2[i] > m ? m : len2[i])) : m;
       for (int k = 0; k < K; ++k) { od[k] = 0.0f; oi[k] = 0; }
       if (j >= n1) continue;
-      const float* q = p1 + ((size_t)i * n + j) * 3;
+      const float* q = p1 + ((size_t)i * n + j) * D;
       int have = 0;
       for (int k = 0; k < m2; ++k) {
-        const float d = distc(p2 + ((size_t)i * m + k) * 3, q, 3);
+        const float d = distc(p2 + ((size_t)i * m + k) * D, q, D);
         if (d != d) continue; /* NaN never enters */
         /* insertion into the ascending list; strict <: the earlier index stays ahead among equals */
         int pos = have < K ? have : K;
@@ -473,6 +473,11 @@ void oracle_knn(const float* p1, const float* p2, const int* len1, const int* le
       const int valid = m2 < K ? m2 : K;
       for (int k = have; k < valid; ++k) { od[k] = INFINITY; oi[k] = 0; }
     }
+}
+
+void oracle_knn(const float* p1, const float* p2, const int* len1, const int* len2, float* dist, int* idx,
+                int b, int n, int m, int K) {
+  oracle_knn_nd(p1, p2, len1, len2, dist, idx, b, n, m, 3, K);
 }
 
 /* K11  three_interpolate_kernel_fast, interpolate_gpu.cu:77-97 */

@@ -39,6 +39,7 @@ SIGNATURES = {
     "pp_shard_pack_f32": [_P, _P, _P, _P, _P, ctypes.c_longlong, ctypes.c_longlong, _I, _P],
     "pp_shard_unpack_f32": [_P, _I, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _I, _P, _P, _P, _P, _P],
     "pp_knn_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_knn_nd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "pp_knn_workspace_bytes": [_I, _I, _I, _I],
     "pp_knn_ws_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_three_nn_workspace_bytes": [_I, _I, _I],

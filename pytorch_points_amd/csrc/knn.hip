@@ -96,6 +96,119 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
   knn_store<KT>(L, od, oi, K, m2);
 }
 
+// Any point dimension D and any K up to 128 (the reference's DenseEdgeConv searches in FEATURE space:
+// network/layers.py:52,99, D = channel count, K = k + 1).  One wave per 64 queries, a lane per query.  The
+// queries' coordinates sit transposed in LDS ([D/4][64][4]: a lane reads four of its own dimensions with one
+// conflict-free ds_read_b128); reference points are wave-uniform (scalar loads), eight at a time, each with its
+// own accumulator, so the distance is the SEQUENTIAL fma chain over the dimensions -- d = fma(t_c, t_c, d),
+// c = 0 .. D-1, the order pytorch3d's kernels and oracle.knn use -- and the neighbour order is bit-exact.
+// Padding dimensions (D up to the next multiple of 8) are zeros on both sides: fma(0, 0, d) == d.
+template <int KT>
+__global__ __launch_bounds__(256) void knn_nd_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                     const int* __restrict__ len1, const int* __restrict__ len2,
+                                                     float* __restrict__ dist, int* __restrict__ idx, int N, int M,
+                                                     int D, int K, int tiles_per_b) {
+  // [Dp / 4][64][4] query coordinates, then one wave's K-list in transit: [KT][64] distances, [KT][64] indices
+  extern __shared__ __attribute__((aligned(16))) float s_q[];
+  const int b = blockIdx.x / tiles_per_b;
+  const int tile = blockIdx.x - b * tiles_per_b;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = pp::wave_id_uniform();
+  const int n = tile * 64 + lane;
+  const int n1 = len1 ? min(max(len1[b], 0), N) : N;
+  const int m2 = len2 ? min(max(len2[b], 0), M) : M;
+  const int Dp = (D + 7) & ~7;
+  float* s_ld = s_q + (size_t)Dp * 64;
+  int* s_li = reinterpret_cast<int*>(s_ld + KT * 64);
+  // stage the tile's queries (coalesced over the tile's 64 * D contiguous floats)
+  for (int e = t; e < 64 * Dp; e += 256) s_q[e] = 0.0f;
+  __syncthreads();
+  const int rows = min(64, N - tile * 64);
+  const float* __restrict__ qbase = p1 + ((size_t)b * N + (size_t)tile * 64) * D;
+  for (int e = t; e < rows * D; e += 256) {
+    const int q = e / D, d = e - q * D;
+    s_q[(d >> 2) * 256 + q * 4 + (d & 3)] = qbase[e];
+  }
+  __syncthreads();
+  const float* __restrict__ r = p2 + (size_t)b * M * D;
+  const pp::f4* __restrict__ sq = reinterpret_cast<const pp::f4*>(s_q) + lane;  // + 64 per group of four dimensions
+  KList<KT> L;
+  L.clear();
+  // the four waves share the tile's 64 queries and take a quarter of the reference cloud each (groups of eight)
+  const int groups = (m2 + 7) / 8;
+  const int g0 = (int)(((long long)groups * wave) / 4), g1 = (int)(((long long)groups * (wave + 1)) / 4);
+  const int Dfull = D & ~7;
+  for (int k0 = 8 * g0; k0 < 8 * g1; k0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
+    const float* rp[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) rp[u] = r + (size_t)min(k0 + u, m2 - 1) * D;  // wave-uniform
+    for (int db = 0; db < Dfull; db += 8) {
+      const pp::f4 qa = sq[(db >> 2) * 64], qb = sq[((db >> 2) + 1) * 64];
+      const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float tt = rp[u][db + c] - qv[c];
+          acc[u] = __builtin_fmaf(tt, tt, acc[u]);
+        }
+      }
+    }
+    if (Dfull < D) {  // last, partial block of dimensions
+      const pp::f4 qa = sq[(Dfull >> 2) * 64], qb = sq[((Dfull >> 2) + 1) * 64];
+      const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (Dfull + c < D) {  // wave-uniform
+            const float tt = rp[u][Dfull + c] - qv[c];
+            acc[u] = __builtin_fmaf(tt, tt, acc[u]);
+          }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + u < m2) {  // wave-uniform
+        if (__any(L.beats_last(acc[u], k0 + u))) L.insert(acc[u], k0 + u);
+      }
+  }
+  // merge: waves 1..3 hand their lists to wave 0 through LDS, one after the other (one list's worth of LDS:
+  // occupancy); the (distance, index) order does not depend on who inserts first
+  float* od = dist + ((size_t)b * N + min(n, N - 1)) * K;
+  int* oi = idx + ((size_t)b * N + min(n, N - 1)) * K;
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        s_ld[j * 64 + lane] = L.d[j];
+        s_li[j * 64 + lane] = L.i[j];
+      }
+    }
+    __syncthreads();
+    if (wave == 0)
+      for (int j = 0; j < KT; ++j) {
+        const float d = s_ld[j * 64 + lane];
+        const int i = s_li[j * 64 + lane];
+        if (!__any(L.beats_last(d, i))) break;  // the list is ascending: nothing further of it can enter either
+        L.insert(d, i);
+      }
+    __syncthreads();
+  }
+  if (wave > 0 || n >= N) return;
+  if (n >= n1) {  // a padded query row
+    for (int j = 0; j < K; ++j) {
+      od[j] = 0.0f;
+      oi[j] = 0;
+    }
+    return;
+  }
+  knn_store<KT>(L, od, oi, K, m2);
+}
+
 struct KnLayout {
   size_t sets, cell_start, sorted, qsorted, total;
 };
@@ -286,4 +399,37 @@ extern "C" int pp_knn_ws_f32(const float* p1, const float* p2, const int* length
   const KnLayout L = kn_layout(B, N, M);
   return knn_scan_dispatch(p1, p2, nullptr, nullptr, dist2, idx, B, N, M, K,
                            reinterpret_cast<const GridSet*>(ws + L.sets), s);
+}
+
+// pytorch3d.ops.knn_points for any point dimension D (1 <= D <= 512) and 1 <= K <= 128: brute force with the
+// sequential distance chain (knn_nd_kernel).  D == 3 with K <= 32 is better served by pp_knn_ws_f32.
+extern "C" int pp_knn_nd_f32(const float* p1, const float* p2, const int* lengths1, const int* lengths2, float* dist2,
+                             int* idx, int B, int N, int M, int D, int K, void* stream) {
+  if (B < 0 || N < 0 || M < 0 || D < 1 || D > 512 || K < 1 || K > 128) return PP_EINVAL;
+  if (B == 0 || N == 0) return PP_OK;
+  if (!p1 || !dist2 || !idx || (M > 0 && !p2)) return PP_EINVAL;
+  const int tiles = (N + 63) / 64;
+  const long long blocks = (long long)B * tiles;
+  if (blocks > 0x7fffffffLL) return PP_EINVAL;
+  const size_t lds_q = (size_t)((D + 7) & ~7) * 64 * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define PP_KNN_ND(KT)                                                                                          \
+  do {                                                                                                         \
+    static pp::DeviceFlags ok;                                                                                 \
+    const size_t lds = lds_q + (size_t)KT * 64 * 8;                                                        \
+    if (lds > 160 * 1024) return PP_EINVAL;                                                                    \
+    const hipError_t e = pp::allow_big_lds(knn_nd_kernel<KT>, 160 * 1024, ok);                                 \
+    if (e != hipSuccess) return (int)e;                                                                        \
+    knn_nd_kernel<KT><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(p1, p2, lengths1, lengths2, dist2, idx, N, M, \
+                                                                     D, K, tiles);                             \
+  } while (0)
+  if (K <= 4) PP_KNN_ND(4);
+  else if (K <= 8) PP_KNN_ND(8);
+  else if (K <= 16) PP_KNN_ND(16);
+  else if (K <= 32) PP_KNN_ND(32);
+  else if (K <= 64) PP_KNN_ND(64);
+  else PP_KNN_ND(128);
+#undef PP_KNN_ND
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
 }

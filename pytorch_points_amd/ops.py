@@ -6,9 +6,11 @@ layers.py:52,99,115), so that those modules can run without the un-vendored depe
     dists, idx, nn = knn_points(p1, p2, K=8, return_nn=True)
 
 dists (N, P1, K): squared distances, ascending; idx (N, P1, K) int64; nn (N, P1, K, D) or None.
-Differences from pytorch3d, all documented: D must be 3 (HIP kernels; the reference only ever passes
-3-D points), 1 <= K <= 32, ties go to the lower index (pytorch3d leaves them unspecified),
-``version`` is accepted and ignored, ``return_sorted=False`` still returns sorted neighbours.
+Any point dimension D up to 512 and any K up to 128: 3-D clouds with K <= 32 go through the exact grid search
+(csrc/knn.hip: knn_grid_kernel), everything else -- the reference's feature-space searches, layers.py:52,99
+(DenseEdgeConv: D = channel count, K = k + 1) -- through the brute force with the sequential distance chain
+(knn_nd_kernel).  Differences from pytorch3d, all documented: ties go to the lower index (pytorch3d leaves
+them unspecified), ``version`` is accepted and ignored, ``return_sorted=False`` still returns sorted neighbours.
 Parity with pytorch3d itself is unpinned (it is absent from the reference tree and this image); the
 operator is tested against a brute-force restatement of its published contract (oracle.knn).
 """
@@ -27,10 +29,17 @@ def _knn_forward(p1, p2, lengths1, lengths2, K):
     _lib.require_float(("p1", p1), ("p2", p2))
     if p1.dim() != 3 or p2.dim() != 3 or p1.size(0) != p2.size(0):
         raise ValueError("p1 and p2 must be (N, P1, D) and (N, P2, D)")
-    if p1.size(2) != 3 or p2.size(2) != 3:
-        raise NotImplementedError("knn_points: only D = 3 is implemented (HIP kernels)")
-    if not 1 <= K <= 32:
-        raise NotImplementedError("knn_points: 1 <= K <= 32")
+    dim = p1.size(2)
+    if p2.size(2) != dim:
+        raise ValueError("p1 and p2 must have the same point dimension")
+    if not 1 <= dim <= 512:
+        raise NotImplementedError("knn_points: 1 <= D <= 512")
+    if not 1 <= K <= 128:
+        raise NotImplementedError("knn_points: 1 <= K <= 128")
+    if not (dim == 3 and K <= 32):
+        kt = next(v for v in (4, 8, 16, 32, 64, 128) if K <= v)
+        if ((dim + 7) // 8 * 8) * 256 + kt * 512 > 160 * 1024:   # staged queries + one K-list in transit (LDS)
+            raise NotImplementedError("knn_points: D = %d with K = %d does not fit the LDS of the brute-force kernel" % (dim, K))
     p1 = p1.contiguous()
     p2 = p2.contiguous()
     b, n, _ = p1.shape
@@ -47,12 +56,17 @@ def _knn_forward(p1, p2, lengths1, lengths2, K):
     dist = torch.empty(b, n, K, dtype=torch.float32, device=dev)
     idx = torch.empty(b, n, K, dtype=torch.int32, device=dev)
     with _lib.on_device(dev) as stream:
-        nbytes = int(_lib.lib().pp_knn_workspace_bytes(b, n, m, K))
-        ws = _named_workspace(dev, "knn", nbytes)
-        _lib.check(_lib.lib().pp_knn_ws_f32(
-            _lib.ptr(p1), _lib.ptr(p2), _lib.ptr(l1) if l1 is not None else None,
-            _lib.ptr(l2) if l2 is not None else None, _lib.ptr(dist), _lib.ptr(idx), b, n, m, K,
-            _lib.ptr(ws) if ws is not None else None, nbytes, stream), "knn_points")
+        lp1, lp2 = (_lib.ptr(l1) if l1 is not None else None), (_lib.ptr(l2) if l2 is not None else None)
+        if dim == 3 and K <= 32:
+            nbytes = int(_lib.lib().pp_knn_workspace_bytes(b, n, m, K))
+            ws = _named_workspace(dev, "knn", nbytes)
+            _lib.check(_lib.lib().pp_knn_ws_f32(
+                _lib.ptr(p1), _lib.ptr(p2), lp1, lp2, _lib.ptr(dist), _lib.ptr(idx), b, n, m, K,
+                _lib.ptr(ws) if ws is not None else None, nbytes, stream), "knn_points")
+        else:
+            _lib.check(_lib.lib().pp_knn_nd_f32(
+                _lib.ptr(p1), _lib.ptr(p2), lp1, lp2, _lib.ptr(dist), _lib.ptr(idx), b, n, m, dim, K, stream),
+                "knn_points")
     return dist, idx
 
 
@@ -88,11 +102,12 @@ class _KnnFunction(torch.autograd.Function):
         m = p2.size(1)
         mask = _valid_mask(idx, ctx.lengths[0], ctx.lengths[1], m)
         g = (grad_dist * mask).unsqueeze(-1) * 2.0                                   # (b, n, k, 1)
-        nb = torch.gather(p2.unsqueeze(1).expand(-1, n, -1, -1), 2, idx.unsqueeze(-1).expand(-1, -1, -1, 3))
-        diff = g * (p1.unsqueeze(2) - nb)                                            # (b, n, k, 3)
+        dim = p1.size(2)
+        nb = torch.gather(p2.unsqueeze(1).expand(-1, n, -1, -1), 2, idx.unsqueeze(-1).expand(-1, -1, -1, dim))
+        diff = g * (p1.unsqueeze(2) - nb)                                            # (b, n, k, D)
         grad_p1 = diff.sum(2)
         grad_p2 = torch.zeros_like(p2)
-        grad_p2.scatter_add_(1, idx.reshape(b, n * k, 1).expand(-1, -1, 3), -diff.reshape(b, n * k, 3))
+        grad_p2.scatter_add_(1, idx.reshape(b, n * k, 1).expand(-1, -1, dim), -diff.reshape(b, n * k, dim))
         return grad_p1, grad_p2, None, None, None
 
 
@@ -110,7 +125,7 @@ def knn_gather(x, idx, lengths=None):
 
 
 def knn_points(p1, p2, lengths1=None, lengths2=None, K=1, version=-1, return_nn=False, return_sorted=True):
-    """pytorch3d.ops.knn_points for 3-D points on the GPU (see the module docstring)."""
+    """pytorch3d.ops.knn_points on the GPU, any point dimension (see the module docstring)."""
     dist, idx = _KnnFunction.apply(p1, p2, lengths1, lengths2, int(K))
     nn = knn_gather(p2, idx, lengths2) if return_nn else None
     return _KNN(dists=dist, idx=idx, knn=nn)

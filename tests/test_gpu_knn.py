@@ -108,3 +108,43 @@ def test_knn_golden_fixture(cuda, knn_path):
     g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "knn_b2_n600_m500_k8.npz")))
     out = knn_points(_t(g["p1"], cuda), _t(g["p2"], cuda), K=int(g["K"]))
     assert np.array_equal(out.idx.cpu().numpy(), g["idx"]) and np.array_equal(out.dists.cpu().numpy(), g["dist2"])
+
+
+@pytest.mark.parametrize("b,n,m,dim,K", [(2, 1024, 1024, 24, 17), (1, 2048, 2048, 64, 17), (2, 700, 1300, 128, 17),
+                                         (1, 512, 600, 5, 9), (1, 300, 257, 130, 33), (2, 256, 512, 3, 48),
+                                         (1, 200, 1000, 16, 128), (1, 64, 40, 7, 64)])
+def test_knn_any_dimension_and_large_k(cuda, b, n, m, dim, K):
+    """Feature-space searches (reference network/layers.py:52,99: D = channel count, K = k + 1 = 17) and K > 32:
+    indices and squared distances bit-exact against the generalised oracle (sequential fma chain over D)."""
+    from pytorch_points_amd.ops import knn_points
+    p1 = S.normal(95, (b, n, dim))
+    p2 = S.normal(96, (b, m, dim))
+    p2[:, m // 2:m // 2 + 20] = p2[:, :20]            # exact ties: the lower index first
+    p1[:, :3] = p2[:, 4:7]                            # zero distances
+    out = knn_points(_t(p1, cuda), _t(p2, cuda), K=K, return_nn=True)
+    e_d, e_i = oracle.knn(p1, p2, K)
+    assert np.array_equal(out.idx.cpu().numpy(), e_i) and np.array_equal(out.dists.cpu().numpy(), e_d)
+    assert out.knn.shape == (b, n, K, dim)
+    if K <= m:
+        assert torch.equal(out.knn[0, 10, K - 1], _t(p2, cuda)[0, int(e_i[0, 10, K - 1])])
+
+
+def test_knn_feature_space_gradients_and_ragged(cuda):
+    from pytorch_points_amd.ops import knn_points
+    b, n, m, dim, K = 2, 200, 150, 12, 5
+    p1 = _t(S.normal(97, (b, n, dim)), cuda).requires_grad_(True)
+    p2 = _t(S.normal(98, (b, m, dim)), cuda).requires_grad_(True)
+    l2 = torch.tensor([150, 40])
+    out = knn_points(p1, p2, lengths2=l2, K=K)
+    e_d, e_i = oracle.knn(p1.detach().cpu().numpy(), p2.detach().cpu().numpy(), K, None, l2.numpy().astype(np.int32))
+    assert np.array_equal(out.idx.cpu().numpy(), e_i) and np.array_equal(out.dists.detach().cpu().numpy(), e_d)
+    w = _t(S.normal(99, (b, n, K)), cuda)
+    (out.dists * w).sum().backward()
+    q1 = p1.detach().double().requires_grad_(True)
+    q2 = p2.detach().double().requires_grad_(True)
+    nb = torch.gather(q2.unsqueeze(1).expand(-1, n, -1, -1), 2, out.idx.unsqueeze(-1).expand(-1, -1, -1, dim))
+    (((q1.unsqueeze(2) - nb) ** 2).sum(-1) * w.double()).sum().backward()
+    assert torch.allclose(p1.grad.double(), q1.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(p2.grad.double(), q2.grad, rtol=1e-4, atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        knn_points(p1, p2, K=129)
