@@ -38,13 +38,36 @@ def is_stale():
 def build(force=False, verbose=False):
     """Compile csrc/*.hip -> libpp_hip.so and csrc/torch_bridge.cpp -> _pp_torch.so.  No-op when up to date."""
     if force or is_stale():
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, *HIPCC_FLAGS, "-I" + INCLUDE, "-I" + CSRC, *sources(), "-o", LIB]
+        _build_library(force, verbose)
+    build_bridge(force=force, verbose=verbose)
+    return LIB
+
+
+def _build_library(force, verbose):
+    """one hipcc -c per source, in parallel, into build/ (objects are reused while their source and the headers
+    are older), then one link"""
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            jobs.append([hipcc, *flags, "-I" + INCLUDE, "-I" + CSRC, "-c", src, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
-    build_bridge(force=force, verbose=verbose)
-    return LIB
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, (os.cpu_count() or 2)))) as pool:
+        list(pool.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
 
 
 def bridge_is_stale():

@@ -316,3 +316,27 @@ def test_native_autograd_nodes_equal_the_python_functions(cuda):
         ml.nndistance(x1.double(), x2.double())
     with pytest.raises(RuntimeError, match="disagree"):
         ml.nndistance(x1, torch.zeros(2, 4, 3, device=cuda))
+
+
+@pytest.mark.parametrize("shape", [(2, 1000, 777, 1), (2, 1024, 3000, 2), (1, 2049, 513, 4), (1, 700, 1300, 5),
+                                   (2, 999, 1024, 6), (1, 515, 2100, 7), (1, 4096, 300, 8), (1, 600, 900, 9),
+                                   (2, 1000, 1000, 12), (1, 257, 1025, 16)])
+@pytest.mark.parametrize("variant", [0, 9])
+def test_forward_other_point_dimensions_tiled_and_plain(cuda, shape, variant):
+    """C != 3 (the reference's kernel is generic in c, nmdistance_cuda.cu:31-35): the tiled kernel (variant 0:
+    registers x scalar loads x min3 groups, as for C = 3) and the one-lane-per-query kernel (variant 9), clouds
+    with duplicated points (ties -> lowest index) and sizes that are not multiples of the group: bit-exact."""
+    from pytorch_points_amd import _lib
+    b, n, m, c = shape
+    x1, x2 = _clouds(b, n, m, c, dup=True)
+    exp = oracle.chamfer_forward(x1, x2)
+    setter = _lib.lib().pp_debug_set_nmdistance_variant
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(variant)
+    try:
+        got = _run(cuda, x1, x2)
+    finally:
+        setter(0)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
