@@ -15,26 +15,55 @@
 //     assignment (one subtraction, one multiplication, one truncation) can misplace a point by
 //     <= 1e-5 h; both are covered by stopping only if  best < bound^2 * 0.999  (strict).
 //     Then no unexamined point can have a computed distance <= best, i.e. none can win or tie;
-//   * a query that cannot stop at rho = 2 (far from the cloud) is finished inside the search kernel by a
-//     scan of the whole cloud -- by its wave, or, when a wave has many such queries, by every lane for its
-//     own query with the brute-force kernel's inner loop; so is every query of a set whose grid is useless
-//     (non-finite coordinates, almost all points in one cell).  Two launches per forward, no list.
+//   * clouds that are not evenly sampled surfaces (everything below stays inside the two launches):
+//       - a cell holding more than kCrowd points (clusters, several scales) carries a grid of its own
+//         (grid_common.h: SubGrid); queries whose block touches one search it through that grid;
+//       - a wave in which many queries are open after the 2x2x2 block (thin regions) runs the cubes of radius
+//         1 and 2 a lane per query, otherwise the whole wave serves them one by one;
+//       - a query that cannot stop at rho = 2 (far from the reference cloud: clusters at different places,
+//         disjoint clouds, the tail of a Gaussian) joins a group of such queries of its wave that lie close
+//         together; the wave stages the cell rows the group can need -- bounded by the best candidate its
+//         members know -- through LDS and every lane walks them for its own query (wave_group_search);
+//       - labeled searches and non-finite queries keep the older forms of the last step (larger cubes by
+//         the whole wave, the occupied cells or the whole cloud a lane per query); so does every query of a
+//         set whose grid is useless (non-finite coordinates).  Two launches per forward, no list.
 #include <mutex>
 
 #include "grid_common.h"
 
 #ifdef PP_QUERY_PROBE
-// diagnostic build only (tools/query_probe.py): 100 MHz clock at the phase boundaries of a few workgroups
+// diagnostic build only (tools/query_probe.py): 100 MHz clock at the phase boundaries of a few workgroups, and
+// what every wave spent in each phase (10 ns units; the first kQWaves waves of the launch)
+constexpr int kQWaves = 1 << 17;
 __device__ unsigned long long g_qphase[8][16];
+__device__ unsigned g_qwave[kQWaves][10];
+__device__ unsigned long long g_qgroup[8];  // group search: calls, groups, blind groups, candidates staged, max candidates of one call, rows visited
 extern "C" int pp_debug_read_query_phases(void* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qphase), sizeof(g_qphase));
 }
+extern "C" int pp_debug_read_query_group_stats(void* out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qgroup), sizeof(g_qgroup));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_qgroup), z, sizeof(z));
+  }
+  return rc;
+}
+extern "C" int pp_debug_read_query_wave_phases(void* out) {  // kQWaves x 10 unsigned
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qwave), sizeof(g_qwave));
+}
+#define PP_QPHASE_DECL unsigned long long pp_prev = wall_clock64()
 #define PP_QPHASE(n)                                                                     \
   do {                                                                                   \
+    const unsigned long long pp_now = wall_clock64();                                    \
+    const unsigned pp_w = blockIdx.x * 4u + (threadIdx.x >> 6);                          \
+    if ((threadIdx.x & 63) == 0 && pp_w < (unsigned)kQWaves) g_qwave[pp_w][n] = (unsigned)(pp_now - pp_prev); \
+    pp_prev = pp_now;                                                                    \
     if (threadIdx.x == 0 && (blockIdx.x & 511) == 0 && (blockIdx.x >> 9) < 8)            \
-      g_qphase[blockIdx.x >> 9][n] = wall_clock64();                                     \
+      g_qphase[blockIdx.x >> 9][n] = pp_now;                                             \
   } while (0)
 #else
+#define PP_QPHASE_DECL
 #define PP_QPHASE(n)
 #endif
 
@@ -52,9 +81,16 @@ constexpr float kBoundSlack = 0.999f;
 //   [0, 64*S)                      GridSet[S]
 //   [.., +4*(kGridCells+1)*S)      unsigned cell_start[S][kGridCells+1]
 //   [.., +16*T)                    float4 sorted[T]   (x, y, z, original index bits)
-//   [.., +4*T)                     float slab[T]      labels in sorted order (labeled Chamfer only)
+//   [.., +4*(2*T + 2*S))           unsigned sub_start[...]   second level: cell tables of the crowded cells,
+//                                  the table of the cell whose points start at `start` of set s at 2*(set offset + start) + 2*s
+//   [.., +32*(T/kCrowd + 2*S))     SubGrid sub_desc[...]     their descriptors (grid_common.h)
+//   [.., +16*T)                    float4 sorted2[T]  spare copy the refinement sorts through
+//   [.., +16*S, +4*(kGridCells+4)*S)   occ_count[S][4], occ_list[S][4][kGridCells/4+1]: the occupied cells of every
+//                                  set, slab by slab (what a query far from the cloud walks instead of the cloud)
+//   [.., +4*T, +4*T)               float slab[T], slab2[T]   labels in sorted order + spare (labeled Chamfer only)
+// (the second-level arrays are only touched for sets that have crowded cells: never at config 2)
 struct Layout {
-  size_t sets, cell_start, sorted, slab, total;
+  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, occ_count, occ_list, slab, slab2, total;
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
   Layout L;
@@ -62,9 +98,24 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   L.sets = 0;
   L.cell_start = L.sets + ((64 * S + 255) / 256) * 256;
   L.sorted = L.cell_start + ((4 * (size_t)(kGridCells + 1) * S + 255) / 256) * 256;
-  L.slab = L.sorted + 16 * T;
-  L.total = L.slab + (labeled ? 4 * T : 0);
+  L.sub_start = L.sorted + 16 * T;
+  L.sub_desc = L.sub_start + ((4 * (2 * T + 2 * S) + 255) / 256) * 256;
+  L.sorted2 = L.sub_desc + ((32 * (T / pp::kCrowd + 2 * S) + 255) / 256) * 256;
+  L.occ_count = L.sorted2 + 16 * T;
+  L.occ_list = L.occ_count + ((16 * S + 255) / 256) * 256;
+  L.slab = L.occ_list + ((4 * (size_t)(kGridCells + 4) * S + 255) / 256) * 256;
+  L.slab2 = L.slab + (labeled ? 4 * T : 0);
+  L.total = L.slab2 + (labeled ? 4 * T : 0);
   return L;
+}
+// second-level arrays of set (b, dir): first table entry / first descriptor
+__host__ __device__ inline size_t set_sub_start_offset(int b, int dir, int N, int M) {
+  const size_t po = (size_t)b * ((size_t)N + M) + (dir ? (size_t)M : 0);  // = set_point_offset
+  return 2 * po + 2 * (size_t)(2 * b + dir);
+}
+__host__ __device__ inline size_t set_sub_desc_offset(int b, int dir, int N, int M) {
+  const size_t po = (size_t)b * ((size_t)N + M) + (dir ? (size_t)M : 0);
+  return po / pp::kCrowd + 2 * (size_t)(2 * b + dir);
 }
 // set s = 2*b + dir; dir 0: queries = cloud 1 (N), references = cloud 2 (M)
 __host__ __device__ inline size_t set_point_offset(int b, int dir, int N, int M) {
@@ -92,12 +143,17 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   const bool labeled = label1 != nullptr;
   const Layout L = make_layout(B, N, M, labeled);
   const float* __restrict__ lab = labeled ? (dir ? label1 : label2) + (size_t)b * nr : nullptr;
-  pp::grid_build_set<false, VEC>(ref, nr, reinterpret_cast<GridSet*>(ws + L.sets) + set,
-                     reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1),
-                     reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M),
-                     nullptr, s_cnt, lab,
-                     labeled ? reinterpret_cast<float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr,
-                     slab, pp::kBuildSlabs);
+  pp::grid_build_set_refined<VEC>(
+      ref, nr, reinterpret_cast<GridSet*>(ws + L.sets) + set,
+      reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1),
+      reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M), s_cnt, lab,
+      labeled ? reinterpret_cast<float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr, slab, pp::kBuildSlabs,
+      reinterpret_cast<unsigned*>(ws + L.sub_start) + set_sub_start_offset(b, dir, N, M),
+      reinterpret_cast<pp::SubGrid*>(ws + L.sub_desc) + set_sub_desc_offset(b, dir, N, M),
+      reinterpret_cast<pp::f4*>(ws + L.sorted2) + set_point_offset(b, dir, N, M),
+      labeled ? reinterpret_cast<float*>(ws + L.slab2) + set_point_offset(b, dir, N, M) : nullptr,
+      reinterpret_cast<unsigned*>(ws + L.occ_list) + (size_t)set * (kGridCells + 4),
+      reinterpret_cast<unsigned*>(ws + L.occ_count) + (size_t)set * 4);
 }
 
 // Stages B and C (cubes of Chebyshev radius 1 and 2 around the query's cell) for the queries stage A left
@@ -209,6 +265,58 @@ __device__ __forceinline__ bool wide_stages_wave(float qx, float qy, float qz, f
   return resolved;
 }
 
+// The same for a query the cube of radius 2 left open, when its wave has only a few such queries: cubes of radius
+// 4, then 8 (the rows of a cube taken 32 at a time), until a cube settles it or covers the grid; a query that is
+// still open then (returns false) is far from everything and joins the lane-per-query pass.  Cost ~ rows of the cube + points inside it: a query in a thin part of the cloud
+// (the tail of a Gaussian) stops after a few hundred candidates instead of scanning the cloud.
+template <bool LAB>
+__device__ __forceinline__ bool far_stages_wave(float qx, float qy, float qz, float ql, const GridSet& g,
+                                                const unsigned* __restrict__ cell_start,
+                                                const pp::f4* __restrict__ sorted, const float* __restrict__ slab,
+                                                float& best, int& bidx) {
+  const int lane = threadIdx.x & 63;
+  const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
+  const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
+  const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
+  const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
+              fz = (qz - g.minz) * g.invh - (float)cz;
+  unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, no index)
+  for (int rho = 4;; rho *= 2) {
+    const int y0 = max(cy - rho, 0), y1 = min(cy + rho, g.gy - 1), z0 = max(cz - rho, 0), z1 = min(cz + rho, g.gz - 1);
+    const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.gx - 1);
+    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    for (int base = 0; base < nrows; base += 32) {
+      const int r = base + lane;
+      const bool ok = lane < 32 && r < nrows;
+      const int z = z0 + (ok ? r / ny : 0), y = y0 + (ok ? r % ny : 0);
+      const int c = pp::cell_linear(0, y, z, g.gx, g.gy);
+      unsigned rs = 0, re = 0;
+      if (ok) {
+        rs = cell_start[c + x0];
+        re = cell_start[c + x1 + 1];
+      }
+      key = wave_scan_rows<LAB>(min(32, nrows - base), rs, re, sorted, slab, qx, qy, qz, ql, key);
+    }
+    const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
+    auto axis = [&](float f, int c, int gdim) {
+      const float lo = c - rho >= 1 ? (float)rho + f : __builtin_inff();
+      const float hi = c + rho <= gdim - 2 ? (float)(rho + 1) - f : __builtin_inff();
+      return fminf(lo, hi);
+    };
+    const float reach = g.h * fminf(axis(fx, cx, g.gx), fminf(axis(fy, cy, g.gy), axis(fz, cz, g.gz)));
+    const float kbest = __uint_as_float((unsigned)(key >> 32));
+    if (all || kbest < reach * reach * kBoundSlack) break;
+    if (rho >= 8) return false;  // far from everything: the lane-per-query pass over the cells / the cloud is cheaper
+  }
+  best = __uint_as_float((unsigned)(key >> 32));
+  bidx = (int)(unsigned)key;
+  if (!(best < __builtin_inff())) {  // nothing below +inf (non-finite query, or no point with the label)
+    best = LAB ? 0.0f : __builtin_inff();
+    bidx = LAB ? -1 : 0;
+  }
+  return true;
+}
+
 // Group k of a lane's stage-A sequence (see grid_query_wave_kernel): four points of the row it falls in,
 // read from global memory (waves whose region does not fit their LDS slice).
 // Everything per-row arrives BY VALUE: selects between variables captured by reference in a lambda come
@@ -239,46 +347,122 @@ __device__ __forceinline__ void stage_a_fetch(unsigned k, unsigned T1, unsigned 
 // LDS pointers carry their address space (a generic pointer would make the loads flat)
 typedef const pp::f4 __attribute__((address_space(3))) * lds_f4_ptr;
 typedef const float __attribute__((address_space(3))) * lds_f_ptr;
+typedef pp::f4 __attribute__((address_space(3))) * lds_f4_wptr;
 
 // helpers of the search kernels' in-kernel fallbacks (no brute-force list, no third launch)
 constexpr int kStageLayers = 8;
+constexpr int kLaneCubeMaxGroups = 48;  // groups of four points a lane walks per four rows of a cube before it gives up
+constexpr int kSubMaxRho = 2;  // widest cube of sub-cells a lane examines inside a crowded cell
+constexpr int kGroupBatch = 256;  // candidates per LDS batch of wave_group_search (<= the smallest per-wave slice)
+constexpr int kLaneStageMin = 6;  // open lanes of a wave from which the cubes are searched a lane per query
 
-// One wave, one query: the whole sorted cloud, 64 candidates per step.  Returns the (distance, index) key;
-// the brute force's result for degenerate inputs (no candidate with a distance below +inf: index 0, or -1 / 0
-// for a labeled query) is restored by finish_key.
+// distance (in cells) from a query at position f inside cell c to the nearer face of its 2-cell block along one
+// axis that has grid beyond it (s = -1: the block is cells c-1, c; +1: c, c+1; beyond the grid there is nothing)
+__device__ __forceinline__ float block_reach(float f, int s, int c, int gdim) {
+  const float lo = s < 0 ? (c >= 1 ? f + 1.0f : __builtin_inff()) : (c >= 1 ? f : __builtin_inff());
+  const float hi = s < 0 ? (c + 1 <= gdim - 1 ? 1.0f - f : __builtin_inff())
+                         : (c + 1 <= gdim - 1 ? 2.0f - f : __builtin_inff());
+  return fminf(lo, hi);
+}
+
+// One candidate in the exact (distance, index) order (bitwise operators: no exec-mask branches).
 template <bool LAB>
-__device__ __forceinline__ unsigned long long wave_scan_cloud(const pp::f4* __restrict__ sorted,
-                                                              const float* __restrict__ slab, int nr, float qx,
-                                                              float qy, float qz, float ql) {
-  const int lane = threadIdx.x & 63;
-  unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;
-  for (int c0 = 0; c0 < nr; c0 += 64) {
-    const int c = c0 + lane;
-    if (c < nr) {
-      const pp::f4 p = sorted[c];
-      const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
-      const unsigned long long cand =
-          ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
-      const bool ok = !LAB || slab[c] == ql;
-      key = (ok && cand < key) ? cand : key;
-    }
-  }
+__device__ __forceinline__ void take_candidate(const pp::f4& p, float pl, float qx, float qy, float qz, float ql,
+                                               float& best, int& bidx) {
+  const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
+  const int id = __float_as_int(p.w);
+  const bool take = (!LAB || pl == ql) & ((d < best) | ((d == best) & (id < bidx)));
+  best = take ? d : best;
+  bidx = take ? id : bidx;
+}
+
+// A query the cubes around its cell could not settle (far from the cloud, or in a gap of it): instead of the
+// whole cloud it walks the OCCUPIED CELLS (the build's compact list; wave-uniform, scalar loads), one lane per
+// query.  Pass 1 finds the cell with the smallest lower bound on the distance (the cell's cube; a cell on the
+// grid's boundary also holds the points clamped into it, so its cube is open on that side) and examines its
+// points; pass 2 examines every other cell whose bound does not already exceed the best distance.  Exact: every
+// point lies in some occupied cell, and a skipped cell cannot hold a point as close as the best one (the bound
+// is compared with slack for its own rounding; equal distances are examined, so ties still go to the lowest
+// index).  ~14 VALU per occupied cell and pass instead of ~8 per point of the cloud.
+// Points [cs, ce) of the sorted cloud for one lane, four loads in flight (a lane walking alone pays the full
+// latency of every load it waits for; the last batch repeats the range's last point, which is harmless).
+template <bool LAB>
+__device__ __forceinline__ void walk_range(unsigned cs, unsigned ce, const pp::f4* __restrict__ sorted,
+                                           const float* __restrict__ slab, float qx, float qy, float qz, float ql,
+                                           float& best, int& bidx) {
+  for (unsigned i = cs; i < ce; i += 4) {
+    pp::f4 p[4];
+    float pl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    key = o < key ? o : key;
+    for (int u = 0; u < 4; ++u) {
+      const unsigned e = min(i + (unsigned)u, ce - 1);
+      p[u] = sorted[e];
+      if (LAB) pl[u] = slab[e];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) take_candidate<LAB>(p[u], pl[u], qx, qy, qz, ql, best, bidx);
   }
-  return key;
 }
 
 template <bool LAB>
-__device__ __forceinline__ void finish_key(unsigned long long key, float& best, int& bidx) {
-  best = __uint_as_float((unsigned)(key >> 32));
-  bidx = (int)(unsigned)key;
-  if (!(best < __builtin_inff())) {  // nothing below +inf (non-finite input, or no point with the label)
-    best = LAB ? 0.0f : __builtin_inff();
-    bidx = LAB ? -1 : 0;
+__device__ __forceinline__ void lane_sparse_search(const GridSet g, const unsigned* __restrict__ cell_start,
+                                                   const pp::f4* __restrict__ sorted, const float* __restrict__ slab,
+                                                   const unsigned* __restrict__ occ_list,
+                                                   const unsigned* __restrict__ occ_count, float qx, float qy, float qz,
+                                                   float ql, float& best, int& bidx) {
+  const float inf = __builtin_inff();
+  auto axis_gap = [&](float q, float mn, int c, int gdim) {  // distance from q to cell c's slab along one axis
+    const float lo = c == 0 ? -inf : mn + (float)c * g.h, hi = c == gdim - 1 ? inf : mn + (float)(c + 1) * g.h;
+    // (minus 1e-4 h: a point may sit in the neighbouring cell by the rounding of its cell coordinate, and the
+    //  faces themselves are rounded)
+    return fmaxf(fmaxf(lo - q, q - hi) - 1.0e-4f * g.h, 0.0f);
+  };
+  auto bound_of = [&](unsigned lin) {  // lin wave-uniform
+    const int cz = (int)(lin / (unsigned)(g.gx * g.gy));
+    const int rem = (int)lin - cz * g.gx * g.gy;
+    const int cy = rem / g.gx, cx = rem - cy * g.gx;
+    const float dx = axis_gap(qx, g.minx, cx, g.gx), dy = axis_gap(qy, g.miny, cy, g.gy), dz = axis_gap(qz, g.minz, cz, g.gz);
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * 0.9999f;
+  };
+  auto walk = [&](unsigned lin) {  // per-lane cell
+    const unsigned cs = cell_start[lin], ce = cell_start[lin + 1];
+    unsigned i = cs;
+    for (; i + 4 <= ce; i += 4) {
+      pp::f4 p[4];
+      float pl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p[u] = sorted[i + u];
+        if (LAB) pl[u] = slab[i + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) take_candidate<LAB>(p[u], pl[u], qx, qy, qz, ql, best, bidx);
+    }
+    for (; i < ce; ++i) take_candidate<LAB>(sorted[i], LAB ? slab[i] : 0.0f, qx, qy, qz, ql, best, bidx);
+  };
+  best = inf;
+  bidx = 0x7fffffff;
+  float lb_min = inf;
+  unsigned first = 0xffffffffu;
+  for (int sl = 0; sl < pp::kBuildSlabs; ++sl) {
+    const unsigned cnt = occ_count[sl];
+    const unsigned* __restrict__ ol = occ_list + (size_t)sl * (kGridCells / pp::kBuildSlabs + 1);
+    for (unsigned k = 0; k < cnt; ++k) {
+      const unsigned lin = ol[k];
+      const float lb = bound_of(lin);
+      const bool lt = lb < lb_min;
+      lb_min = lt ? lb : lb_min;
+      first = lt ? lin : first;
+    }
+  }
+  if (first != 0xffffffffu) walk(first);
+  for (int sl = 0; sl < pp::kBuildSlabs; ++sl) {
+    const unsigned cnt = occ_count[sl];
+    const unsigned* __restrict__ ol = occ_list + (size_t)sl * (kGridCells / pp::kBuildSlabs + 1);
+    for (unsigned k = 0; k < cnt; ++k) {
+      const unsigned lin = ol[k];
+      if (bound_of(lin) <= best && lin != first) walk(lin);
+    }
   }
 }
 
@@ -336,6 +520,364 @@ __device__ __forceinline__ void lane_scan_cloud(const float* __restrict__ ref, c
 // copies the spans into its own slice of LDS and walks them from there.  No workgroup barrier anywhere: the
 // four waves of a workgroup are independent, 28-32 of them share a CU, and the chain of dependent loads of
 // one (query -> span bounds -> span copy) is covered by the others.
+// The search inside a crowded cell's own grid (grid_common.h: SubGrid), one lane: first the 2x2x2 block of
+// sub-cells nearest to the query (clamped into the sub-grid exactly as a query is clamped into the top-level
+// grid), then cubes of Chebyshev radius 1, 2, ... around its sub-cell, until the best distance found so far
+// (anywhere) lies below what the examined part guarantees for the rest OF THIS CELL, or the cube covers the
+// sub-grid.  Returns that guarantee (+inf when the whole cell has been examined): the cell settles itself, so
+// that only the top-level block's own reach is left to decide whether the query is done.
+template <bool LAB>
+__device__ __forceinline__ float sub_cell_search(const pp::SubGrid sg, const unsigned* __restrict__ tbl,
+                                                 const pp::f4* __restrict__ sorted, const float* __restrict__ slab,
+                                                 float qx, float qy, float qz, float ql, float& best, int& bidx) {
+  const int cx = cell_coord(qx, sg.minx, sg.invh, sg.gx);
+  const int cy = cell_coord(qy, sg.miny, sg.invh, sg.gy);
+  const int cz = cell_coord(qz, sg.minz, sg.invh, sg.gz);
+  const float fx = (qx - sg.minx) * sg.invh - (float)cx, fy = (qy - sg.miny) * sg.invh - (float)cy,
+              fz = (qz - sg.minz) * sg.invh - (float)cz;
+  auto walk_box = [&](int x0, int x1, int y0, int y1, int z0, int z1) {
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        const int base = (z * sg.gy + y) * sg.gx;
+        const unsigned rs = tbl[base + x0], re = tbl[base + x1 + 1];
+        walk_range<LAB>(rs, re, sorted, slab, qx, qy, qz, ql, best, bidx);
+      }
+  };
+  {
+    const int sx = fx < 0.5f ? -1 : 1, sy = fy < 0.5f ? -1 : 1, sz = fz < 0.5f ? -1 : 1;
+    walk_box(max(min(cx, cx + sx), 0), min(max(cx, cx + sx), sg.gx - 1), max(min(cy, cy + sy), 0),
+             min(max(cy, cy + sy), sg.gy - 1), max(min(cz, cz + sz), 0), min(max(cz, cz + sz), sg.gz - 1));
+    const float reach = sg.h * fminf(block_reach(fx, sx, cx, sg.gx), fminf(block_reach(fy, sy, cy, sg.gy), block_reach(fz, sz, cz, sg.gz)));
+    if (best < reach * reach * kBoundSlack) return reach;
+  }
+  for (int rho = 1;; ++rho) {
+    const int x0 = max(cx - rho, 0), x1 = min(cx + rho, sg.gx - 1), y0 = max(cy - rho, 0), y1 = min(cy + rho, sg.gy - 1),
+              z0 = max(cz - rho, 0), z1 = min(cz + rho, sg.gz - 1);
+    walk_box(x0, x1, y0, y1, z0, z1);
+    auto axis = [&](float f, int c, int gdim) {
+      const float lo = c - rho >= 1 ? (float)rho + f : __builtin_inff();
+      const float hi = c + rho <= gdim - 2 ? (float)(rho + 1) - f : __builtin_inff();
+      return fminf(lo, hi);
+    };
+    const float reach = sg.h * fminf(axis(fx, cx, sg.gx), fminf(axis(fy, cy, sg.gy), axis(fz, cz, sg.gz)));
+    if (!(reach < __builtin_inff()) || best < reach * reach * kBoundSlack) return reach;
+    // a query outside the cell's points (it sits in a neighbouring cell) would widen the cube sub-cell by sub-cell
+    // up to the whole sub-grid, one lane's loads at a time: leave it to the stages of the whole wave
+    if (rho >= kSubMaxRho) return reach;
+  }
+}
+
+// Second-level search for one lane whose 2x2x2 block touches crowded cells: the block's cells one by one, an
+// ordinary cell point by point, a crowded one through its own grid.  Returns the threshold below which the best
+// distance settles the query.  Out of line: it runs for clustered data only, and inlined it costs the search
+// kernel 16 VGPRs (a wave per SIMD) on the evenly sampled surfaces that never call it.
+// (results BY VALUE: a reference argument of a function that is not inlined lives in scratch memory, and the
+// caller then stores to it on its main path)
+struct Found {
+  float best;
+  int bidx;
+  float aux;  // lane_cube_search: 1 settled, 0 not, 2 gave up; refined_block_search: the threshold it reached
+};
+template <bool LAB>
+__device__ __attribute__((noinline)) Found refined_block_search(
+    const GridSet g, const unsigned* __restrict__ cell_start, const pp::f4* __restrict__ sorted,
+    const float* __restrict__ slab, const unsigned* __restrict__ sub_start, const pp::SubGrid* __restrict__ sub_desc,
+    float qx, float qy, float qz, float ql, int cx, int cy, int cz, int sx, int sy, int sz, float reach) {
+  const int x0 = max(min(cx, cx + sx), 0), x1 = min(max(cx, cx + sx), g.gx - 1);
+  float bound = reach;
+  float bb = __builtin_inff();
+  int bi = 0x7fffffff;
+  for (int e = 0; e < 8; ++e) {
+    const int z = cz + (e >> 2) * sz, y = cy + ((e >> 1) & 1) * sy;
+    if (z < 0 || z >= g.gz || y < 0 || y >= g.gy || ((e & 1) && x1 == x0)) continue;
+    const int lin = pp::cell_linear((e & 1) ? x1 : x0, y, z, g.gx, g.gy);
+    const unsigned cs = cell_start[lin], ce = cell_start[lin + 1];
+    if (ce - cs <= (unsigned)pp::kCrowd) {
+      walk_range<LAB>(cs, ce, sorted, slab, qx, qy, qz, ql, bb, bi);
+    } else {
+      bound = fminf(bound, sub_cell_search<LAB>(sub_desc[(cs + pp::kCrowd - 1) / pp::kCrowd], sub_start + 2 * (size_t)cs,
+                                                sorted, slab, qx, qy, qz, ql, bb, bi));
+    }
+  }
+  Found o;
+  o.best = bb;
+  o.bidx = bi;
+  o.aux = bound * bound * kBoundSlack;
+  return o;
+}
+
+// The queries a wave could not settle inside the cube of radius 2 (far from the reference cloud: disjoint clouds,
+// clusters at different places, the tail of a Gaussian), served by the WHOLE wave, group by group.  A group is the
+// open queries within r of one of them (the seed), r = a quarter of the distance the seed's neighbour can be at (its
+// best so far; if it has seen no candidate yet, the nearest of one sample point per cell row).  Every member then
+// has a neighbour within U = min(largest best-so-far of the group, (that distance + sqrt(3) r)^2), so what the
+// group can need lies in the cell rows within sqrt(U) of its bounding box, and in each row between the cells
+// that the rest of the budget allows along x.  Those row pieces are laid end to end and staged through the wave's slice
+// of LDS, 256 points at a time; every lane walks every staged point (LDS broadcast) keeping its own exact
+// (distance, index) minimum -- brute force restricted to the rows that can matter.  Extra candidates are
+// harmless, so no lane is masked.  Unlabeled searches, finite queries only.
+__device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, const unsigned* __restrict__ cell_start,
+                                                             const pp::f4* __restrict__ sorted, float qx, float qy,
+                                                             float qz, float best, int bidx, unsigned open_lo,
+                                                             unsigned open_hi, lds_f4_wptr lw) {
+  const lds_f4_ptr lr = (lds_f4_ptr)lw;
+  const int lane = threadIdx.x & 63;
+  const float inf = __builtin_inff();
+  unsigned long long open = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)open_hi) << 32) |
+                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)open_lo);
+  auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+  const float slack = 1.0e-4f * g.h;  // (cell faces and cell coordinates are rounded: see lane_sparse_search)
+  // distance from the interval [blo, bhi] to the slab of cell c along one axis (rim cells hold the outliers: they
+  // extend to infinity)
+  auto axis_gap = [&](float blo, float bhi, float mn, int c, int gdim) {
+    const float lo = c == 0 ? -inf : mn + (float)c * g.h, hi = c == gdim - 1 ? inf : mn + (float)(c + 1) * g.h;
+    return fmaxf(fmaxf(lo - bhi, blo - hi) - slack, 0.0f);
+  };
+#ifdef PP_QUERY_PROBE
+  unsigned long long pp_ngroups = 0, pp_nblind = 0, pp_ncand = 0, pp_nrows = 0;
+#endif
+  while (open) {
+    const int seed = (int)__builtin_ctzll(open);
+    const float sx = rl(qx, seed), sy = rl(qy, seed), sz = rl(qz, seed);
+    float us = rl(best, seed);
+    // wave-uniform: the seed has seen no candidate yet, or only one picked up by accident far outside its cubes
+    const bool blind = !(us < 16.0f * g.h * g.h);
+    if (blind) {
+      // one sample per non-empty cell row -- the first point at or after the seed's cell along x, else the row's last
+      // point -- four chunks of rows in flight; the nearest sample bounds the seed's neighbour
+      const int nall = g.gy * g.gz;
+      const int cxs = cell_coord(sx, g.minx, g.invh, g.gx);
+      float u1 = inf;
+      for (int r0 = 0; r0 < nall; r0 += 256) {
+        unsigned rs[4], rm[4], re[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = r0 + u * 64 + lane;
+          const bool ok = r < nall;
+          const int base = (ok ? r : 0) * g.gx;
+          rs[u] = cell_start[base];
+          rm[u] = cell_start[base + cxs];
+          re[u] = ok ? cell_start[base + g.gx] : rs[u];
+        }
+        pp::f4 smp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) smp[u] = sorted[re[u] > rs[u] ? min(rm[u], re[u] - 1) : 0u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float d = pp::chamfer_d3(smp[u].x, smp[u].y, smp[u].z, sx, sy, sz);
+          u1 = (re[u] > rs[u] && d < u1) ? d : u1;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) u1 = fminf(u1, __shfl_xor(u1, off));
+      us = fminf(us, u1 * 1.0001f);
+    }
+    // The seed takes along the open queries within r of it, r = a quarter of the distance of its candidate.  Where
+    // the seed knew a candidate: at least two cells, and only queries whose own candidate is no more than twice as
+    // far (the group's bound is the largest of them).  Where it did not (the bound is the sample's, a crude one):
+    // any open query within r -- it has a neighbour within that distance + sqrt(3) r through the seed.
+#ifdef PP_QUERY_PROBE
+    ++pp_ngroups;
+    pp_nblind += blind ? 1 : 0;
+#endif
+    const float ds = sqrtf(us);
+    const float r = blind ? 0.25f * ds : fmaxf(2.0f * g.h, 0.25f * ds);
+    const float via = ds + 1.7321f * r;
+    const bool member = (((open >> lane) & 1ull) != 0ull && (blind || best <= 4.0f * us) &&
+                         !(fmaxf(fabsf(qx - sx), fmaxf(fabsf(qy - sy), fabsf(qz - sz))) > r)) ||
+                        lane == seed;
+    open &= ~__ballot(member);
+    float v[6] = {member ? -qx : -inf, member ? -qy : -inf, member ? -qz : -inf,
+                  member ? qx : -inf,  member ? qy : -inf,  member ? qz : -inf};
+    pp::wave_reduce6_dpp<false, 6>(v);
+    const float blx = -rl(v[0], 63), bly = -rl(v[1], 63), blz = -rl(v[2], 63);
+    const float bhx = rl(v[3], 63), bhy = rl(v[4], 63), bhz = rl(v[5], 63);
+    // every member has a neighbour within its own best so far (the seed: within us)
+    float ub = member ? (lane == seed ? us : (blind ? fminf(best, via * via) : best)) : 0.0f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ub = fmaxf(ub, __shfl_xor(ub, off));
+    const float U = ub * 1.0001f;
+    // the rows within sqrt(U) of the box (cell coordinates are monotonic in the coordinate: exact)
+    const bool bounded = U < inf;
+    const float R = bounded ? sqrtf(U) * 1.0001f + slack : 0.0f;
+    const int y0 = bounded ? cell_coord(bly - R, g.miny, g.invh, g.gy) : 0;
+    const int y1 = bounded ? cell_coord(bhy + R, g.miny, g.invh, g.gy) : g.gy - 1;
+    const int z0 = bounded ? cell_coord(blz - R, g.minz, g.invh, g.gz) : 0;
+    const int z1 = bounded ? cell_coord(bhz + R, g.minz, g.invh, g.gz) : g.gz - 1;
+    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    const float inv_ny = 1.0f / (float)ny;
+#ifdef PP_QUERY_PROBE
+    pp_nrows += (unsigned long long)nrows;
+#endif
+    for (int r0 = 0; r0 < nrows; r0 += 64) {  // wave-uniform
+      const int rr = r0 + lane;
+      // (rr < 2^11, ny < 2^6: the rounded product is the exact quotient)
+      const int dz = (int)(((float)rr + 0.5f) * inv_ny);
+      const int cz = z0 + dz, cy = y0 + (rr - dz * ny);
+      unsigned cs = 0u, len = 0u;
+      if (rr < nrows) {
+        const float gy_ = axis_gap(bly, bhy, g.miny, cy, g.gy), gz_ = axis_gap(blz, bhz, g.minz, cz, g.gz);
+        const float rem = U - __builtin_fmaf(gz_, gz_, gy_ * gy_) * 0.9999f;  // budget left along x (+inf if unbounded)
+        if (rem >= 0.0f) {
+          const float rx = bounded ? sqrtf(rem) * 1.0001f + slack : 0.0f;
+          const int x0 = bounded ? cell_coord(blx - rx, g.minx, g.invh, g.gx) : 0;
+          const int x1 = bounded ? cell_coord(bhx + rx, g.minx, g.invh, g.gx) : g.gx - 1;
+          const int base = pp::cell_linear(0, cy, cz, g.gx, g.gy);
+          cs = cell_start[base + x0];
+          len = cell_start[base + x1 + 1] - cs;
+        }
+      }
+      if (__ballot(len != 0u) == 0ull) continue;  // wave-uniform: nothing in these rows
+      unsigned incl = len;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+      const unsigned excl = incl - len;
+      const unsigned shift = cs - excl;  // candidate c of this lane's row sits at sorted[c + shift]
+#ifdef PP_QUERY_PROBE
+      pp_ncand += total;
+#endif
+      for (unsigned t0 = 0; t0 < total; t0 += kGroupBatch) {  // wave-uniform
+        // kGroupBatch candidates into the wave's slice of LDS: a lane per candidate, its row found by bisection over
+        // the lanes' offsets (the last lane whose first candidate is <= c; empty rows are passed over because the
+        // row after them starts at the same offset)
+        pp::f4 pt[kGroupBatch / 64];
+#pragma unroll
+        for (int u = 0; u < kGroupBatch / 64; ++u) {
+          const unsigned c = min(t0 + (unsigned)(u * 64 + lane), total - 1);  // (the tail repeats the last candidate)
+          int lo = 0, hi = 63;
+#pragma unroll
+          for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi + 1) >> 1;
+            const bool ge = (unsigned)__shfl((int)excl, mid) <= c;
+            lo = ge ? mid : lo;
+            hi = ge ? hi : mid - 1;
+          }
+          pt[u] = sorted[c + (unsigned)__shfl((int)shift, lo)];
+        }
+#pragma unroll
+        for (int u = 0; u < kGroupBatch / 64; ++u) lw[u * 64 + lane] = pt[u];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned n = min((unsigned)kGroupBatch, (total - t0 + 3u) & ~3u);
+        for (unsigned i = 0; i < n; i += 4) {  // every lane, every candidate (uniform address: LDS broadcast)
+          pp::f4 q4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) q4[u] = lr[i + u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) take_candidate<false>(q4[u], 0.0f, qx, qy, qz, 0.0f, best, bidx);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+#ifdef PP_QUERY_PROBE
+  if (lane == 0) {
+    atomicAdd(&g_qgroup[0], 1ull);
+    atomicAdd(&g_qgroup[1], pp_ngroups);
+    atomicAdd(&g_qgroup[2], pp_nblind);
+    atomicAdd(&g_qgroup[3], pp_ncand);
+    atomicMax(&g_qgroup[4], pp_ncand);
+    atomicAdd(&g_qgroup[5], pp_nrows);
+    atomicMax(&g_qgroup[6], pp_ngroups);
+  }
+#endif
+  Found o;
+  o.best = best;
+  o.bidx = bidx;
+  o.aux = 0.0f;
+  return o;
+}
+
+// A cube of Chebyshev radius rho around the query's cell, a LANE per query (waves in which many lanes are open
+// after stage A: the thin parts of a cloud, the sparse scale of a two-scale cloud): the cube's (2 rho + 1)^2 rows
+// four at a time, each four as one sequence of groups like stage A, candidates from global memory in the exact
+// (distance, index) order.  Returns whether the cube settles the lane's query; (best, bidx) carry on.
+struct RowSpan {
+  unsigned s, e;
+};
+__device__ __forceinline__ RowSpan cube_row(int r, int nrows, int side, int rho, int cy, int cz, int x0, int x1,
+                                            bool active, const GridSet& g, const unsigned* __restrict__ cell_start) {
+  const int z = cz - rho + r / side, y = cy - rho + r % side;
+  const bool ok = active && r < nrows && z >= 0 && z < g.gz && y >= 0 && y < g.gy;
+  const int c = pp::cell_linear(0, min(max(y, 0), g.gy - 1), min(max(z, 0), g.gz - 1), g.gx, g.gy);
+  RowSpan o;
+  o.s = ok ? cell_start[c + x0] : 0u;
+  o.e = ok ? cell_start[c + x1 + 1] : 0u;
+  return o;
+}
+
+template <bool LAB>
+__device__ __attribute__((noinline)) Found lane_cube_search(const GridSet g, const unsigned* __restrict__ cell_start,
+                                                            const pp::f4* __restrict__ sorted,
+                                                            const float* __restrict__ slab, float qx, float qy, float qz,
+                                                            float ql, int rho, bool active, float best_in, int bidx_in) {
+  const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
+  const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
+  const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
+  const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
+              fz = (qz - g.minz) * g.invh - (float)cz;
+  const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.gx - 1);
+  const int side = 2 * rho + 1, nrows = side * side;
+  float best = best_in;
+  int bidx = bidx_in;
+  bool gave_up = false;
+  for (int r0 = 0; r0 < nrows; r0 += 4) {  // wave-uniform
+    const RowSpan a0 = cube_row(r0, nrows, side, rho, cy, cz, x0, x1, active, g, cell_start);
+    const RowSpan a1 = cube_row(r0 + 1, nrows, side, rho, cy, cz, x0, x1, active, g, cell_start);
+    const RowSpan a2 = cube_row(r0 + 2, nrows, side, rho, cy, cz, x0, x1, active, g, cell_start);
+    const RowSpan a3 = cube_row(r0 + 3, nrows, side, rho, cy, cz, x0, x1, active, g, cell_start);
+    unsigned t0 = (a0.e - a0.s + 3) >> 2, t1 = (a1.e - a1.s + 3) >> 2, t2 = (a2.e - a2.s + 3) >> 2,
+             t3 = (a3.e - a3.s + 3) >> 2;
+    // a lane whose rows run through a crowded cell would keep the whole wave waiting on its loads, one lane's
+    // worth at a time: it gives up and is served by the whole wave afterwards
+    if (t0 + t1 + t2 + t3 > (unsigned)kLaneCubeMaxGroups) {
+      gave_up = true;
+      t0 = t1 = t2 = t3 = 0u;
+    }
+    const unsigned T1 = t0, T2 = T1 + t1, T3 = T2 + t2, T4 = T3 + t3;
+    const unsigned adj0 = a0.s, adj1 = a1.s - 4 * T1, adj2 = a2.s - 4 * T2, adj3 = a3.s - 4 * T3;
+    const unsigned last0 = a0.e - 1, last1 = a1.e - 1, last2 = a2.e - 1, last3 = a3.e - 1;
+    pp::f4 pa[4], pb[4];
+    float la[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    stage_a_fetch<LAB>(0, T1, T2, T3, T4, adj0, adj1, adj2, adj3, last0, last1, last2, last3, sorted, slab, pa, la);
+    for (unsigned k = 0; __any(k < T4); k += 2) {
+      stage_a_fetch<LAB>(k + 1, T1, T2, T3, T4, adj0, adj1, adj2, adj3, last0, last1, last2, last3, sorted, slab, pb, lb);
+      if (k < T4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) take_candidate<LAB>(pa[u], la[u], qx, qy, qz, ql, best, bidx);
+      }
+      stage_a_fetch<LAB>(k + 2, T1, T2, T3, T4, adj0, adj1, adj2, adj3, last0, last1, last2, last3, sorted, slab, pa, la);
+      if (k + 1 < T4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) take_candidate<LAB>(pb[u], lb[u], qx, qy, qz, ql, best, bidx);
+      }
+    }
+  }
+  auto axis = [&](float f, int c, int gdim) {
+    const float lo = c - rho >= 1 ? (float)rho + f : __builtin_inff();
+    const float hi = c + rho <= gdim - 2 ? (float)(rho + 1) - f : __builtin_inff();
+    return fminf(lo, hi);
+  };
+  const float reach = g.h * fminf(axis(fx, cx, g.gx), fminf(axis(fy, cy, g.gy), axis(fz, cz, g.gz)));
+  const bool all = cz - rho <= 0 && cz + rho >= g.gz - 1 && cy - rho <= 0 && cy + rho >= g.gy - 1 && cx - rho <= 0 &&
+                   cx + rho >= g.gx - 1;
+  const bool settled = all ? (LAB || bidx != 0x7fffffff) : (best < reach * reach * kBoundSlack);
+  Found o;
+  o.best = active ? best : best_in;
+  o.bidx = active ? bidx : bidx_in;
+  if (LAB && active && settled && !gave_up && bidx == 0x7fffffff) {  // whole grid examined, nobody carries this label
+    o.best = 0.0f;                                         // (ref nmdistance_cuda.cu:110-113)
+    o.bidx = -1;
+  }
+  o.aux = gave_up ? 2.0f : ((settled && active) ? 1.0f : 0.0f);  // (candidates seen before giving up stay valid)
+  return o;
+}
+
 // first staged position of group k of a lane's sequence (by value: see stage_a_fetch)
 __device__ __forceinline__ unsigned stage_first(unsigned k, unsigned T1, unsigned T2, unsigned T3, unsigned T4,
                                                 unsigned adj0, unsigned adj1, unsigned adj2, unsigned adj3) {
@@ -352,7 +894,7 @@ __device__ __forceinline__ float min2(float a, float b) {
 }
 
 template <bool LAB, int CAPW>
-__global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __restrict__ xyz1,
+__global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __restrict__ xyz1,
                                                               const float* __restrict__ xyz2,
                                                               float* __restrict__ dist1, int* __restrict__ idx1,
                                                               float* __restrict__ dist2, int* __restrict__ idx2,
@@ -362,6 +904,7 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
                                                               const float* __restrict__ label2) {
   const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
   if (V >= total) return;
+  PP_QPHASE_DECL;
   PP_QPHASE(0);
   const int per_b = tiles1 + tiles2;
   const int b = V / per_b;
@@ -412,6 +955,12 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
       reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
   const float* __restrict__ slab =
       LAB ? reinterpret_cast<const float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr;
+  // second level (sets with cells of more than kCrowd points: dense clusters, several scales): see below
+  const bool refined_set = pp::grid_refined(g);
+  const unsigned* __restrict__ sub_start =
+      reinterpret_cast<const unsigned*>(ws + L.sub_start) + set_sub_start_offset(b, dir, N, M);
+  const pp::SubGrid* __restrict__ sub_desc =
+      reinterpret_cast<const pp::SubGrid*>(ws + L.sub_desc) + set_sub_desc_offset(b, dir, N, M);
 
   // (+4: a group of four is read from any staged position without clamping; the tail repeats a real point)
   __shared__ pp::f4 s_pts[4][CAPW + 4];
@@ -431,6 +980,7 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
   const int y0 = max(min(cy, cy + sy), 0), y1 = min(max(cy, cy + sy), g.gy - 1);
   const int z0 = max(min(cz, cz + sz), 0), z1 = min(max(cz, cz + sz), g.gz - 1);
   unsigned rs0, rs1, rs2, rs3, re0, re1, re2, re3;
+  bool crowd = false;  // some cell of the block holds more than kCrowd points (it then has a grid of its own)
   {
     // (named scalars, not arrays: hipcc turns a select between array elements into an indexed load from
     // scratch memory)
@@ -445,6 +995,7 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
       __builtin_memcpy(&v, cell_start + c + x0, sizeof(v));
       s_out = ok ? v.x : 0u;
       e_out = ok ? (x1 > x0 ? v.z : v.y) : 0u;
+      crowd = crowd | (ok & ((v.y - v.x > (unsigned)pp::kCrowd) | ((x1 > x0) & (v.z - v.y > (unsigned)pp::kCrowd))));
     };
     row_range(0, 0, rs0, re0);
     row_range(0, 1, rs1, re1);
@@ -455,14 +1006,16 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
   // beyond it (beyond the grid there are no points).  Lower face: 1 + f cells away when the block includes
   // cell c-1, f when it starts at c; upper face: 1 - f or 2 - f.  Never below h/2.  The query is settled if
   // its best distance is below reach^2 * kBoundSlack (strict).
-  auto reach1 = [](float f, int s, int c, int gdim) {
-    const float lo = s < 0 ? (c >= 1 ? f + 1.0f : __builtin_inff()) : (c >= 1 ? f : __builtin_inff());
-    const float hi = s < 0 ? (c + 1 <= gdim - 1 ? 1.0f - f : __builtin_inff())
-                           : (c + 1 <= gdim - 1 ? 2.0f - f : __builtin_inff());
-    return fminf(lo, hi);
-  };
-  const float reach = g.h * fminf(reach1(fx, sx, cx, g.gx), fminf(reach1(fy, sy, cy, g.gy), reach1(fz, sz, cz, g.gz)));
-  const float thr = reach * reach * kBoundSlack;
+  const float reach = g.h * fminf(block_reach(fx, sx, cx, g.gx), fminf(block_reach(fy, sy, cy, g.gy), block_reach(fz, sz, cz, g.gz)));
+  float thr = reach * reach * kBoundSlack;
+  // Lanes whose block touches a crowded cell do not take part in the staged walk: their candidates are the
+  // sub-cells near the query, found through the crowded cells' own grids further down.  (refined_set is
+  // wave-uniform and false for every set of an evenly sampled surface: config 2 pays one scalar branch.)
+  const bool deferred = refined_set && crowd;
+  if (deferred) {
+    re0 = rs0; re1 = rs1; re2 = rs2; re3 = rs3;
+  }
+  const bool none_normal = refined_set && !__any(!deferred);
   PP_QPHASE(1);
 
   // ---- the wave's region: its z-layers and the row range in each (cell coordinates are < 2^24: exact as floats)
@@ -470,12 +1023,12 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
   auto lane63 = [](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); };
   int Lz, nz;
   {
-    float v[6] = {-(float)z0, (float)z1, ninf, ninf, ninf, ninf};
+    float v[6] = {deferred ? ninf : -(float)z0, deferred ? ninf : (float)z1, ninf, ninf, ninf, ninf};
     pp::wave_reduce6_dpp<false, 6>(v);
-    Lz = -(int)lane63(v[0]);
-    nz = (int)lane63(v[1]) - Lz + 1;
+    Lz = none_normal ? 0 : -(int)lane63(v[0]);
+    nz = none_normal ? 1 : (int)lane63(v[1]) - Lz + 1;
   }
-  bool staged = nz <= kStageLayers;
+  bool staged = nz <= kStageLayers && !none_normal;
   unsigned n_staged = 0, delta = 0, offv = 0;  // lanes 0..7: the layer's (global start - LDS start), LDS start
   if (staged) {
     int ya = 1, yb = 0;  // lane l < nz: row range of layer Lz + l
@@ -484,7 +1037,7 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int z = Lz + base + i;
-        const bool m = z0 == z || z1 == z;
+        const bool m = (z0 == z || z1 == z) && !deferred;
         v[2 * i] = m ? -(float)y0 : ninf;
         v[2 * i + 1] = m ? (float)y1 : ninf;
       }
@@ -520,9 +1073,9 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
   const lds_f_ptr llab = (lds_f_ptr)(&s_lab[wave][0]);
   if (staged) {
     // every lane's rows live in its two layers: global position -> LDS position
-    const unsigned dA = __shfl(delta, cz - Lz);
+    const unsigned dA = __shfl(delta, deferred ? 0 : cz - Lz);
     const int zb = cz + sz;
-    const unsigned dB = __shfl(delta, (zb >= 0 && zb < g.gz) ? zb - Lz : 0);
+    const unsigned dB = __shfl(delta, (!deferred && zb >= 0 && zb < g.gz) ? zb - Lz : 0);
     rs0 -= dA; re0 -= dA; rs1 -= dA; re1 -= dA;
     rs2 -= dB; re2 -= dB; rs3 -= dB; re3 -= dB;
     // copy layer by layer: everything but the lane offset is wave-uniform (a span's last piece may be partial)
@@ -662,14 +1215,55 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
     }
   }
   PP_QPHASE(4);
+  if (refined_set && __any(deferred)) {  // wave-uniform
+    // ---- second level: the block's cells one by one; a crowded cell through its own grid ---------------------
+    if (deferred) {
+      const Found f = refined_block_search<LAB>(g, cell_start, sorted, slab, sub_start, sub_desc, qx, qy, qz, ql, cx, cy,
+                                                cz, sx, sy, sz, reach);
+      best = f.best;
+      bidx = f.bidx;
+      thr = f.aux;
+    }
+  }
+  PP_QPHASE(5);
   const bool resolved = best < thr;
   if (resolved && valid) {
     od[j] = best;
     oi[j] = bidx;
   }
-  // ---- what stage A left: wide stages by the whole wave; then the whole cloud ---------------------------
-  unsigned long long pending = __ballot(!resolved && valid);
-  unsigned long long open = 0ull;  // lanes whose query the cube of radius 2 could not settle
+  // ---- what stage A left.  Many lanes of the wave (thin regions, the sparse scale of a two-scale cloud): the
+  // cubes of radius 1 and 2 a lane per query.  (Lanes next to a crowded cell stay with the whole-wave stages:
+  // a cube around them holds thousands of points.)
+  bool pend = !resolved && valid;
+  bool open_lane = false;
+  if (__builtin_popcountll(__ballot(pend && !deferred)) >= kLaneStageMin) {
+    const bool mine = pend && !deferred;
+    Found f = lane_cube_search<LAB>(g, cell_start, sorted, slab, qx, qy, qz, ql, 1, mine, best, bidx);
+    best = f.best;
+    bidx = f.bidx;
+    if (f.aux == 1.0f) {
+      od[j] = best;
+      oi[j] = bidx;
+      pend = false;
+    }
+    const bool mine2 = pend && !deferred && f.aux != 2.0f;
+    if (__builtin_popcountll(__ballot(mine2)) >= kLaneStageMin) {
+      f = lane_cube_search<LAB>(g, cell_start, sorted, slab, qx, qy, qz, ql, 2, mine2, best, bidx);
+      best = f.best;
+      bidx = f.bidx;
+      if (f.aux == 1.0f) {
+        od[j] = best;
+        oi[j] = bidx;
+        pend = false;
+      }
+      open_lane = pend && mine2 && f.aux == 0.0f;  // radius 2 examined in full and not enough
+      pend = pend && !open_lane;
+    }
+  }
+  PP_QPHASE(6);
+  // ---- few lanes: wide stages by the whole wave; then the whole cloud ---------------------------------------
+  unsigned long long pending = __ballot(pend);
+  unsigned long long open = __ballot(open_lane);  // lanes whose query the cube of radius 2 could not settle
   while (pending) {
     const int l = (int)__builtin_ctzll(pending);
     pending &= pending - 1;
@@ -690,39 +1284,67 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(const float* __res
       open |= 1ull << l;
     }
   }
-  PP_QPHASE(5);
-  if (open) {  // wave-uniform
-    if (__builtin_popcountll(open) >= 12) {
-      // many: one pass of the wave over the cloud serves them all, a lane per query
-      float sb;
-      int si;
-      lane_scan_cloud<LAB>(ref_raw, rlab_raw, nr, qx, qy, qz, ql, sb, si);
-      if ((open >> lane) & 1ull) {
-        od[j] = sb;
-        oi[j] = si;
+  PP_QPHASE(7);
+  if (!LAB && open) {  // wave-uniform
+    const bool finite = __builtin_isfinite(qx) && __builtin_isfinite(qy) && __builtin_isfinite(qz);
+    const unsigned long long todo = open & __ballot(finite);
+    if (todo) {
+      const Found f = wave_group_search(g, cell_start, sorted, qx, qy, qz, best, bidx, (unsigned)todo,
+                                        (unsigned)(todo >> 32), (lds_f4_wptr)(&s_pts[wave][0]));
+      if ((todo >> lane) & 1ull) {
+        od[j] = f.best;
+        oi[j] = f.bidx;
       }
-    } else {
-      while (open) {
-        const int l = (int)__builtin_ctzll(open);
-        open &= open - 1;
-        const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
-        const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), l));
-        const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), l));
-        const float wl = LAB ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ql), l)) : 0.0f;
-        const int wj = __builtin_amdgcn_readlane(j, l);
-        const unsigned long long key = wave_scan_cloud<LAB>(sorted, slab, nr, wx, wy, wz, wl);
-        float wbest;
-        int widx;
-        finish_key<LAB>(key, wbest, widx);
+      open &= ~todo;
+    }
+  }
+  PP_QPHASE(8);
+  if (open && __builtin_popcountll(open) < 12) {  // few: one after the other by the whole wave, larger cubes
+    unsigned long long still = 0ull;
+    while (open) {
+      const int l = (int)__builtin_ctzll(open);
+      open &= open - 1;
+      const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
+      const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), l));
+      const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), l));
+      const float wl = LAB ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ql), l)) : 0.0f;
+      const int wj = __builtin_amdgcn_readlane(j, l);
+      float wbest;
+      int widx;
+      if (far_stages_wave<LAB>(wx, wy, wz, wl, g, cell_start, sorted, slab, wbest, widx)) {
         if (lane == 0) {
           od[wj] = wbest;
           oi[wj] = widx;
         }
+      } else {
+        still |= 1ull << l;
       }
     }
+    open = still;
   }
-  PP_QPHASE(6);
-  PP_QPHASE(7);
+  if (open) {  // wave-uniform
+    // many, or far from everything (clouds apart, a thin region): one pass of the wave serves them all, a lane
+    // per query -- over the occupied cells where those are few (clustered data), else over the cloud
+    const unsigned* __restrict__ occ_count = reinterpret_cast<const unsigned*>(ws + L.occ_count) + (size_t)set * 4;
+    const unsigned* __restrict__ occ_list = reinterpret_cast<const unsigned*>(ws + L.occ_list) + (size_t)set * (kGridCells + 4);
+    const unsigned o0 = occ_count[0], o1 = occ_count[1], o2 = occ_count[2], o3 = occ_count[3];
+    float sb;
+    int si;
+    if (o0 != 0xffffffffu && (unsigned long long)o0 + o1 + o2 + o3 <= (unsigned long long)nr / 10) {
+      lane_sparse_search<LAB>(g, cell_start, sorted, slab, occ_list, occ_count, qx, qy, qz, ql, sb, si);
+      if (!(sb < __builtin_inff())) {  // nothing below +inf (non-finite query, or no point with the label)
+        sb = LAB ? 0.0f : __builtin_inff();
+        si = LAB ? -1 : 0;
+      }
+    } else {
+      lane_scan_cloud<LAB>(ref_raw, rlab_raw, nr, qx, qy, qz, ql, sb, si);
+    }
+    if ((open >> lane) & 1ull) {
+      od[j] = sb;
+      oi[j] = si;
+    }
+  }
+  PP_QPHASE(9);
 }
 
 }  // namespace

@@ -21,14 +21,39 @@ struct GridSet {  // one per (batch, direction); written by the build kernel
   int gx, gy, gz;
   int useless;             // 1: degenerate data (non-finite / zero extent): no grid at all
   int pad[3];              // pad[0]: free for the caller (ball_query / three_nn: "the grid path serves this set")
-  int crowd[kBuildSlabs];  // crowd[s] = 1: slab s found a cell holding a large share of the points
+  int crowd[kBuildSlabs];  // crowd[s] = 1: slab s found a cell too crowded to be of use; 2: it refined its crowded
+                           // cells into sub-grids (REFINE builds: see SubGrid)
 };
 static_assert(sizeof(GridSet) == 64, "");
 
 // the grid is not worth using (or does not exist): send the set's queries to the brute force
 __device__ __forceinline__ bool grid_useless(const GridSet& g) {
-  return (g.useless | g.crowd[0] | g.crowd[1] | g.crowd[2] | g.crowd[3]) != 0;
+  return g.useless != 0 || g.crowd[0] == 1 || g.crowd[1] == 1 || g.crowd[2] == 1 || g.crowd[3] == 1;
 }
+// some cells of the grid hold more than kCrowd points and carry a second-level grid
+__device__ __forceinline__ bool grid_refined(const GridSet& g) {
+  return g.crowd[0] == 2 || g.crowd[1] == 2 || g.crowd[2] == 2 || g.crowd[3] == 2;
+}
+
+// Second level (REFINE builds, chamfer_grid.hip): a cell holding more than kCrowd points -- dense clusters,
+// clouds with several scales, the core of a Gaussian -- is sorted once more, in place, into a grid of its own
+// over the bounding box of ITS points, sized by its population (about four points per sub-cell if the points
+// filled the box; at most kSubMaxCells cells).  A cell is "crowded" exactly when it holds more than kCrowd
+// points: the searches read that off the cell table they load anyway.  The sub-grid of the crowded cell whose
+// points start at `start` in the sorted cloud is described by desc[(start + kCrowd - 1) / kCrowd] (a range of
+// more than kCrowd consecutive positions contains exactly one such slot first) and its table of cell starts
+// (absolute positions in the sorted cloud, cells + 1 entries) begins at sub_start[2 * start].
+constexpr int kCrowd = 128;
+constexpr int kSubMaxAxis = 26;
+constexpr int kSubMaxCells = 16384;
+constexpr int kSubWaveCells = 1536;  // sub-cells of a crowded cell refined by one wave (its slice of the build's LDS)
+constexpr int kBuildSlabCrowdMax = 1024;  // crowded cells one slab can refine
+struct SubGrid {
+  float minx, miny, minz, h, invh;
+  int gx, gy, gz;
+};
+static_assert(sizeof(SubGrid) == 32, "");
+__host__ __device__ inline size_t sub_desc_slots(size_t npoints) { return npoints / kCrowd + 2; }
 
 __device__ __forceinline__ int cell_coord(float p, float mn, float invh, int g) {
   const float f = (p - mn) * invh;
@@ -83,13 +108,197 @@ __device__ __forceinline__ int morton3(int x, int y, int z) {
 // [s*ncell/nslab, (s+1)*ncell/nslab) -- it reads the whole cloud (L2), counts and scatters the points
 // of its own cells only, and learns where its range starts in `sorted` by counting the points of the
 // cells below.  Nothing is exchanged between the workgroups; the LDS counters shrink by nslab.
-template <bool MORTON, bool VEC>
+// The second level of a REFINE build (see grid_build_set_impl): the crowded cells of one slab, listed in
+// s_clist[ncrowd] as (start, count), each sorted in place into its own grid.  NOT inlined: the build kernel of an
+// evenly sampled cloud never gets here, and inlined this code costs it registers (148 bytes of scratch per lane).
+__device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sorted, f4* __restrict__ sorted2,
+                                                            float* __restrict__ sorted_payload,
+                                                            float* __restrict__ payload2,
+                                                            unsigned* __restrict__ sub_start,
+                                                            SubGrid* __restrict__ sub_desc, unsigned* s_cnt,
+                                                            unsigned* s_part, float* s_box,
+                                                            const unsigned (*s_clist)[2], unsigned ncrowd) {
+  const int t = threadIdx.x;
+  {
+    {
+      // The whole dynamic LDS is free now: one counter per sub-cell.  Small crowded cells (the usual kind: tens
+      // to hundreds per set in clustered data) are refined by ONE WAVE each, sixteen at a time, with no workgroup
+      // barrier (a wave's slice of the LDS holds kSubWaveCells counters); a cell too large for that is refined by
+      // the whole workgroup.  Either way: streamed, register-light passes over the cell's points (they sit in
+      // L2) -- bounding box, count, scatter into the spare copy `sorted2`, copy back.
+      const int lane = t & 63, wave = t >> 6;
+      constexpr unsigned kWaveMaxPoints = 2048;
+      auto sub_geometry = [&](const float (&bmn)[6], unsigned n, int max_cells) {
+        SubGrid sg;
+        sg.minx = -bmn[0]; sg.miny = -bmn[1]; sg.minz = -bmn[2];
+        const float sex = bmn[3] - sg.minx, sey = bmn[4] - sg.miny, sez = bmn[5] - sg.minz;
+        const float semax = fmaxf(sex, fmaxf(sey, sez));
+        int g2 = (int)cbrtf((float)n);  // ~ one point per sub-cell if the points filled their box (they never do)
+        g2 = g2 < 2 ? 2 : (g2 > kSubMaxAxis - 1 ? kSubMaxAxis - 1 : g2);
+        sg.h = semax / (float)g2;
+        if (!(sg.h > 0.0f) || !__builtin_isfinite(sg.h)) sg.h = 1.0f;  // identical points: one sub-cell
+        sg.invh = 1.0f / sg.h;
+        auto cells2 = [&](float e) {
+          const int c = (int)(e * sg.invh) + 1;
+          return c < 1 ? 1 : (c > kSubMaxAxis ? kSubMaxAxis : c);
+        };
+        sg.gx = cells2(sex); sg.gy = cells2(sey); sg.gz = cells2(sez);
+        // (cells + 1 table entries must fit sub_start[2 start .. 2 (start + n)), the counters their LDS slice)
+        while ((long long)sg.gx * sg.gy * sg.gz > min((long long)max_cells, 2LL * n - 1)) {
+          if (sg.gx >= sg.gy && sg.gx >= sg.gz) --sg.gx; else if (sg.gy >= sg.gz) --sg.gy; else --sg.gz;
+        }
+        return sg;
+      };
+      auto cell2 = [](const SubGrid& sg, const f4& p) {
+        return cell_linear(cell_coord(p.x, sg.minx, sg.invh, sg.gx), cell_coord(p.y, sg.miny, sg.invh, sg.gy),
+                           cell_coord(p.z, sg.minz, sg.invh, sg.gz), sg.gx, sg.gy);
+      };
+      auto wave_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+      };
+      // ---- one wave per small crowded cell ----
+      {
+        unsigned* s_sub = s_cnt + (size_t)wave * kSubWaveCells;
+        for (unsigned ci = wave; ci < ncrowd; ci += kBuildThreads / 64) {  // wave-uniform
+          const unsigned start = s_clist[ci][0], n = s_clist[ci][1];
+          if (n > kWaveMaxPoints) continue;
+          float bmn[6] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(),
+                          -__builtin_inff()};  // max of (-x, -y, -z, x, y, z)
+          for (unsigned k = lane; k < n; k += 64) {
+            const f4 q = sorted[start + k];
+            bmn[0] = fmaxf(bmn[0], -q.x); bmn[1] = fmaxf(bmn[1], -q.y); bmn[2] = fmaxf(bmn[2], -q.z);
+            bmn[3] = fmaxf(bmn[3], q.x); bmn[4] = fmaxf(bmn[4], q.y); bmn[5] = fmaxf(bmn[5], q.z);
+          }
+          wave_reduce6_dpp<false, 6>(bmn);
+#pragma unroll
+          for (int e = 0; e < 6; ++e) bmn[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmn[e]), 63));
+          const SubGrid sg = sub_geometry(bmn, n, kSubWaveCells);
+          const int total2 = sg.gx * sg.gy * sg.gz;
+          for (int c = lane; c < total2; c += 64) s_sub[c] = 0u;
+          wave_sync();
+          for (unsigned k = lane; k < n; k += 64) atomicAdd(&s_sub[cell2(sg, sorted[start + k])], 1u);
+          wave_sync();
+          {  // exclusive scan: lane l owns a contiguous run of counters
+            const int per2 = (total2 + 63) / 64;
+            const int d0 = min(total2, lane * per2), d1 = min(total2, d0 + per2);
+            unsigned sum2 = 0;
+            for (int c = d0; c < d1; ++c) sum2 += s_sub[c];
+            unsigned incl2 = sum2;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+              const unsigned o = __shfl_up(incl2, off);
+              if (lane >= off) incl2 += o;
+            }
+            unsigned run2 = start + incl2 - sum2;
+            unsigned* __restrict__ tbl = sub_start + 2 * (size_t)start;
+            for (int c = d0; c < d1; ++c) {
+              const unsigned v = s_sub[c];
+              s_sub[c] = run2;  // sub-cell start (absolute position): table entry and scatter cursor
+              tbl[c] = run2;
+              run2 += v;
+            }
+            if (lane == 0) tbl[total2] = start + n;
+          }
+          wave_sync();
+          for (unsigned k = lane; k < n; k += 64) {
+            const f4 q = sorted[start + k];
+            const unsigned pos = atomicAdd(&s_sub[cell2(sg, q)], 1u);
+            sorted2[pos] = q;
+            if (sorted_payload) payload2[pos] = sorted_payload[start + k];
+          }
+          wave_sync();
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          for (unsigned k = lane; k < n; k += 64) {  // back into place (coalesced)
+            sorted[start + k] = sorted2[start + k];
+            if (sorted_payload) sorted_payload[start + k] = payload2[start + k];
+          }
+          if (lane == 0) sub_desc[(start + kCrowd - 1) / kCrowd] = sg;
+        }
+      }
+      __syncthreads();
+      // ---- the whole workgroup for a large crowded cell ----
+      unsigned* s_sub = s_cnt;
+      for (unsigned ci = 0; ci < ncrowd; ++ci) {
+        const unsigned start = s_clist[ci][0], n = s_clist[ci][1];
+        if (n <= kWaveMaxPoints) continue;
+        float bmn[6] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(),
+                        -__builtin_inff()};
+        for (unsigned k = t; k < n; k += kBuildThreads) {
+          const f4 q = sorted[start + k];
+          bmn[0] = fmaxf(bmn[0], -q.x); bmn[1] = fmaxf(bmn[1], -q.y); bmn[2] = fmaxf(bmn[2], -q.z);
+          bmn[3] = fmaxf(bmn[3], q.x); bmn[4] = fmaxf(bmn[4], q.y); bmn[5] = fmaxf(bmn[5], q.z);
+        }
+        wave_reduce6_dpp<false, 6>(bmn);
+        __syncthreads();  // s_box / s_sub of the previous cell are no longer read
+        if ((t & 63) == 63)
+#pragma unroll
+          for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + e] = bmn[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 6; ++e) bmn[e] = s_box[(t & 15) * 16 + e];
+        wave_reduce6_dpp<false, 4>(bmn);
+#pragma unroll
+        for (int e = 0; e < 6; ++e) bmn[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmn[e]), 15));
+        const SubGrid sg = sub_geometry(bmn, n, kSubMaxCells);
+        const int total2 = sg.gx * sg.gy * sg.gz;
+        for (int c = t; c < total2; c += kBuildThreads) s_sub[c] = 0u;
+        __syncthreads();
+        for (unsigned k = t; k < n; k += kBuildThreads) atomicAdd(&s_sub[cell2(sg, sorted[start + k])], 1u);
+        __syncthreads();
+        {  // exclusive scan of the total2 counters (contiguous runs per thread, as above)
+          const int per2 = (total2 + kBuildThreads - 1) / kBuildThreads;
+          const int d0 = min(total2, t * per2), d1 = min(total2, d0 + per2);
+          unsigned sum2 = 0;
+          for (int c = d0; c < d1; ++c) sum2 += s_sub[c];
+          unsigned incl2 = sum2;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned o = __shfl_up(incl2, off);
+            if ((t & 63) >= off) incl2 += o;
+          }
+          if ((t & 63) == 63) s_part[t >> 6] = incl2;
+          __syncthreads();
+          unsigned run2 = start + incl2 - sum2;
+          for (int w = 0; w < (t >> 6); ++w) run2 += s_part[w];
+          unsigned* __restrict__ tbl = sub_start + 2 * (size_t)start;
+          for (int c = d0; c < d1; ++c) {
+            const unsigned v = s_sub[c];
+            s_sub[c] = run2;
+            tbl[c] = run2;
+            run2 += v;
+          }
+          if (t == 0) tbl[total2] = start + n;
+        }
+        __syncthreads();
+        for (unsigned k = t; k < n; k += kBuildThreads) {
+          const f4 q = sorted[start + k];
+          const unsigned pos = atomicAdd(&s_sub[cell2(sg, q)], 1u);
+          sorted2[pos] = q;
+          if (sorted_payload) payload2[pos] = sorted_payload[start + k];
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (unsigned k = t; k < n; k += kBuildThreads) {  // back into place (coalesced)
+          sorted[start + k] = sorted2[start + k];
+          if (sorted_payload) sorted_payload[start + k] = payload2[start + k];
+        }
+        if (t == 0) sub_desc[(start + kCrowd - 1) / kCrowd] = sg;
+      }
+    }
+  }
+}
+
+template <bool MORTON, bool VEC, bool REFINE>
 __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ ref, int nr, GridSet* gs,
                                                unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
                                                int* __restrict__ inv, unsigned* s_cnt,
                                                const float* __restrict__ payload,
                                                float* __restrict__ sorted_payload, int slab,
-                                               int nslab) {
+                                               int nslab, unsigned* __restrict__ sub_start,
+                                               SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
+                                               float* __restrict__ payload2, unsigned* __restrict__ occ_list,
+                                               unsigned* __restrict__ occ_count) {
   __shared__ unsigned s_part[kBuildThreads];
   __shared__ unsigned s_crowd;
   __shared__ float s_box[(kBuildThreads / 64) * 16];
@@ -287,10 +496,14 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     // cell index is computed once.  A round that ends in "coarsen" (rare for surfaces) recounts.
     __shared__ unsigned s_occ[kGridCells / 32];
     __shared__ unsigned s_nocc;
-    for (int round = 0; round < 4; ++round) {
+    constexpr int kRounds = 4;
+    bool stale = false;  // the resolution changed after the last count
+    for (int round = 0; round < kRounds; ++round) {
+      stale = false;
       const int nc = gx * gy * gz;
       const int lo = (int)((long long)nc * slab / nslab), nl = (int)((long long)nc * (slab + 1) / nslab) - lo;
-      for (int wd = t; wd < (nc + 31) / 32; wd += kBuildThreads) s_occ[wd] = 0;
+      const int nwords = (nc + 31) / 32;
+      for (int wd = t; wd < nwords; wd += kBuildThreads) s_occ[wd] = 0;
       for (int c = t; c < nl; c += kBuildThreads) s_cnt[sk(c)] = 0;
       if (t == 0) s_nocc = 0;
       __syncthreads();
@@ -321,7 +534,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       }
       __syncthreads();
       unsigned mine = 0;
-      for (int wd = t; wd < (nc + 31) / 32; wd += kBuildThreads) mine += __builtin_popcount(s_occ[wd]);
+      for (int wd = t; wd < nwords; wd += kBuildThreads) mine += __builtin_popcount(s_occ[wd]);
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
       if ((t & 63) == 0 && mine) atomicAdd(&s_nocc, mine);
@@ -332,8 +545,10 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       if ((float)nr >= 2.5f * (float)nocc || gmax <= 4) break;
       // coarsen by ~1/sqrt(2) per round: x2.8 points per cell for a volume, x2 for a surface
       set_resolution(max(4, (int)((float)gmax * 0.7071f)));
+      stale = true;
     }
-    counted = true;
+    // (a cloud still too fine after the last round is counted again below, at the resolution it ended with)
+    counted = !stale;
   }
   PP_PHASE(4);
   const int ncell = MORTON ? kGridCells : gx * gy * gz;
@@ -348,6 +563,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   const bool place = MORTON || !degenerate;
   if (!counted) {  // Morton mode (and degenerate sets, which only need empty counters)
     for (int c = t; c < nloc; c += kBuildThreads) s_cnt[sk(c)] = 0;
+    below = 0;
     __syncthreads();
     if (place)
       for (int ch = 0; ch < nchunks; ++ch) {
@@ -374,8 +590,10 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     mx = max(mx, s_cnt[sk(c)]);
   }
   // a cell holding so many points (> 256 + N/32) that walking it lane by lane costs more than the
-  // brute-force kernel's share of the cloud (flag cleared before the first barrier, read after the last)
-  if ((float)mx > 256.0f + (float)nr * (1.0f / 32.0f)) s_crowd = 1u;
+  // brute-force kernel's share of the cloud (flag cleared before the first barrier, read after the last).
+  // REFINE builds give every cell above kCrowd points a grid of its own instead (below).
+  if (!REFINE && (float)mx > 256.0f + (float)nr * (1.0f / 32.0f)) s_crowd = 1u;
+  if (REFINE && place && sub_start && sub_desc && mx > (unsigned)kCrowd) atomicOr(&s_crowd, 2u);  // (read after barriers)
   // exclusive scan of the 1024 per-thread sums: inclusive scan inside each wave (shuffles), then
   // the 16 wave totals; the points below this slab (summed the same way) are the starting offset
   unsigned incl = sum, bsum = below;
@@ -395,10 +613,38 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     if (w < (t >> 6)) wave_base += s_part[w];
   }
   unsigned run = wave_base + incl - sum;
+  unsigned occ_mask = 0;          // which of this thread's cells hold points (per <= 32 cells per thread)
   for (int c = c0; c < c1; ++c) {
     const unsigned v = s_cnt[sk(c)];
+    occ_mask |= (v != 0u ? 1u : 0u) << ((c - c0) & 31);
     s_cnt[sk(c)] = run;  // cell start; becomes the scatter cursor below
     run += v;
+  }
+  if constexpr (REFINE && !MORTON) {
+    // the slab's OCCUPIED cells as a compact list (any order): what a query far from the cloud walks instead of
+    // the whole cloud (chamfer_grid.hip: lane_sparse_search).  One LDS atomic per wave reserves the slots.
+    if (occ_list && per <= 32) {
+      __shared__ unsigned s_nocc_list;
+      if (t == 0) s_nocc_list = 0u;
+      __syncthreads();
+      const unsigned mine = (unsigned)__builtin_popcount(occ_mask);
+      unsigned incl_o = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(incl_o, off);
+        if ((t & 63) >= off) incl_o += o;
+      }
+      unsigned wbase = 0;
+      if ((t & 63) == 63) wbase = atomicAdd(&s_nocc_list, incl_o);
+      wbase = __shfl(wbase, 63);
+      unsigned at = wbase + incl_o - mine;
+      unsigned* __restrict__ ol = occ_list + (size_t)slab * (kGridCells / kBuildSlabs + 1);
+      for (unsigned mm = occ_mask; mm; mm &= mm - 1u) ol[at++] = (unsigned)(cell_lo + c0 + __builtin_ctz(mm));
+      __syncthreads();
+      if (t == 0) occ_count[slab] = s_nocc_list;
+    } else if (occ_count && t == 0) {
+      occ_count[slab] = 0xffffffffu;  // no list (grids beyond 32 cells per thread: not built by the Chamfer path)
+    }
   }
   __syncthreads();
   PP_PHASE(7);
@@ -442,8 +688,42 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       }
     }
   PP_PHASE(9);
+  bool refined = false;
+  if constexpr (REFINE && !MORTON) {
+    // ---- second level: every cell of this slab with more than kCrowd points gets its own grid --------------
+    __shared__ unsigned s_ncrowd;
+    __shared__ unsigned s_clist[kBuildSlabCrowdMax][2];  // (start, count) of this slab's crowded cells
+    __syncthreads();
+    if ((s_crowd & 2u) != 0u) {  // uniform: some cell of this slab is crowded (never at config 2: nothing below runs)
+      if (t == 0) s_ncrowd = 0u;
+      __threadfence_block();  // the scatter's stores are read back below
+      __syncthreads();
+      {
+        unsigned prev = c0 < c1 ? cell_start[cell_lo + c0] : 0u;  // start of this thread's first cell (table written above)
+        for (int c = c0; c < c1; ++c) {
+          const unsigned end = s_cnt[sk(c)];  // the cursor stands at the cell's end after the scatter
+          const unsigned cnt = end - prev;
+          if (cnt > (unsigned)kCrowd) {
+            const unsigned at = atomicAdd(&s_ncrowd, 1u);
+            if (at < (unsigned)kBuildSlabCrowdMax) {
+              s_clist[at][0] = prev;
+              s_clist[at][1] = cnt;
+            } else {
+              atomicOr(&s_crowd, 1u);  // more crowded cells than the list holds: the set goes to the brute force
+            }
+          }
+          prev = end;
+        }
+      }
+      __syncthreads();
+      const unsigned ncrowd = min(s_ncrowd, (unsigned)kBuildSlabCrowdMax);
+      refined = ncrowd > 0;
+      grid_refine_cells(sorted, sorted2, sorted_payload, payload2, sub_start, sub_desc, s_cnt, s_part, s_box, s_clist,
+                        ncrowd);
+    }
+  }
   if (t == 0) {
-    gs->crowd[slab] = (!degenerate && s_crowd != 0u) ? 1 : 0;
+    gs->crowd[slab] = degenerate ? 0 : ((s_crowd & 1u) != 0u ? 1 : (refined ? 2 : 0));
     if (slab == 0) {
       gs->minx = mnx; gs->miny = mny; gs->minz = mnz; gs->h = h; gs->invh = invh;
       gs->gx = gx; gs->gy = gy; gs->gz = gz;
@@ -465,7 +745,25 @@ __device__ __forceinline__ void grid_build_set(const float* __restrict__ ref, in
                                                const float* __restrict__ payload = nullptr,
                                                float* __restrict__ sorted_payload = nullptr, int slab = 0,
                                                int nslab = 1) {
-  grid_build_set_impl<MORTON, VEC>(ref, nr, gs, cell_start, sorted, inv, s_cnt, payload, sorted_payload, slab, nslab);
+  grid_build_set_impl<MORTON, VEC, false>(ref, nr, gs, cell_start, sorted, inv, s_cnt, payload, sorted_payload, slab,
+                                          nslab, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+// the same with the second level: crowded cells refined into sub-grids (sub_start: 2 * nr + 2 entries of this
+// set, sub_desc: sub_desc_slots(nr) descriptors of this set; sorted2 / payload2: spare copies as large as
+// sorted / sorted_payload, addressed like them; occ_list: kBuildSlabs * (kGridCells / kBuildSlabs + 1) cell ids of
+// this set, occ_count: kBuildSlabs counts -- the occupied cells, slab by slab)
+template <bool VEC>
+__device__ __forceinline__ void grid_build_set_refined(const float* __restrict__ ref, int nr, GridSet* gs,
+                                                       unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
+                                                       unsigned* s_cnt, const float* __restrict__ payload,
+                                                       float* __restrict__ sorted_payload, int slab, int nslab,
+                                                       unsigned* __restrict__ sub_start,
+                                                       SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
+                                                       float* __restrict__ payload2, unsigned* __restrict__ occ_list,
+                                                       unsigned* __restrict__ occ_count) {
+  grid_build_set_impl<false, VEC, true>(ref, nr, gs, cell_start, sorted, nullptr, s_cnt, payload, sorted_payload, slab,
+                                        nslab, sub_start, sub_desc, sorted2, payload2, occ_list, occ_count);
 }
 
 // every batch element's cloud (base + b * n * 3 floats) is 16-byte aligned

@@ -64,6 +64,22 @@ def _cases():
     c["integer_lattice_ties"] = (lattice + np.float32(0.5), lattice.copy())   # 8-way exact ties
     mixed = np.concatenate([_u(23, (1, n // 2, 3)) * np.float32(1e-3), _u(24, (1, n // 2, 3)) * np.float32(50)], 1)
     c["two_scales"] = (mixed, _u(25, (1, n, 3)) * np.float32(50))
+    # round 2: the paths for clouds that are not evenly sampled surfaces (crowded cells with their own grids, lane
+    # cubes, the group search of far queries)
+    c["gaussian"] = (S.normal(26, (2, n, 3)), S.normal(27, (2, n, 3)))
+    cen = _u(28, (1, 8, 3)) * np.float32(2)
+    same = (np.repeat(cen, n // 8, 1) + S.normal(29, (1, n, 3)) * np.float32(0.02)).astype(np.float32)
+    same2 = (np.repeat(cen, n // 8, 1) + S.normal(30, (1, n, 3)) * np.float32(0.02)).astype(np.float32)
+    c["blobs_same_places"] = (same, same2)                # crowded cells on both sides: second-level grids
+    other = (np.repeat(_u(31, (1, 8, 3)) * np.float32(2), n // 8, 1) + S.normal(32, (1, n, 3)) * np.float32(0.02))
+    c["blobs_other_places"] = (same, other.astype(np.float32))   # every query far from the references: groups
+    half = _u(33, (1, n, 3)).copy()
+    half[0, : n // 2] *= np.float32(1e-2)
+    half2 = _u(34, (1, n, 3)).copy()
+    half2[0, : n // 2] *= np.float32(1e-2)
+    c["half_dense_half_sparse"] = (half, half2)
+    c["sparse_volume_vs_surface"] = (_u(35, (1, n, 3)) * np.float32(2) - np.float32(1), S.unit_sphere(36, 1, n))
+    c["dense_blob_vs_far_uniform"] = (half, _u(37, (1, n, 3)) + np.float32(3))
     return c
 
 
@@ -92,6 +108,19 @@ def test_grid_search_full_size_c2(cuda):
     e = oracle.chamfer_forward(x1[:2], x2[:2])
     for u, v in zip(a, e):
         assert np.array_equal(u[:2], v)
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "blobs8", "two_scales", "shapenet_like"])
+def test_grid_search_full_size_other_distributions(cuda, kind):
+    """The distributions of bench.py's other_distributions_fwd_ms at config-2 cloud size: grid == brute force,
+    and two runs of the grid path agree (no order dependence in the in-kernel fallbacks)."""
+    import bench
+    x1, x2 = bench._distribution(kind, 0, 2, 16384), bench._distribution(kind, 1, 2, 16384)
+    a = _run(cuda, x1, x2, 2)
+    a2 = _run(cuda, x1, x2, 2)
+    b = _run(cuda, x1, x2, 1)
+    for u, v, w in zip(a, a2, b):
+        assert np.array_equal(u, v) and np.array_equal(u, w)
 
 
 def test_grid_workspace_reused_across_shapes(cuda):
@@ -125,7 +154,8 @@ def _labels(seed, shape, nlabels):
 
 @pytest.mark.parametrize("labels", ["four", "one_missing", "all_same", "mostly_unique", "disjoint"])
 @pytest.mark.parametrize("name", ["sphere", "sphere_ragged", "cube_volume", "tight_blobs_vs_uniform", "duplicates",
-                                  "all_identical_refs", "huge_offset", "integer_lattice_ties", "outliers"])
+                                  "all_identical_refs", "huge_offset", "integer_lattice_ties", "outliers", "gaussian",
+                                  "blobs_same_places", "blobs_other_places", "half_dense_half_sparse"])
 def test_labeled_grid_search_equals_oracle(cuda, name, labels):
     """labeled Chamfer through the grid (the label filter inside the staged search, the labeled list
     fallback, idx -1 / dist 0 for queries without a partner) == oracle, bit for bit"""

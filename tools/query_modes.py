@@ -52,5 +52,16 @@ for kind in kinds:
         res[mode] = run(lambda: losses.nmdistance_forward(x1, x2, d1, d2, i1, i2))
         outs[mode] = (d1, d2, i1, i2)
     setq(0)
+    setq(0)
+    tk = L.pp_debug_set_nmdistance_kernel_timing; tk.argtypes = [ctypes.c_int]; tk.restype = None
+    rd = L.pp_debug_nmdistance_kernel_ms; rd.argtypes = [ctypes.POINTER(ctypes.c_float)] * 2; rd.restype = ctypes.c_int
+    tk(1)
+    bms, sms = [], []
+    for _ in range(5):
+        losses.nmdistance_forward(x1, x2, d1, d2, i1, i2)
+        a_, b_ = ctypes.c_float(0), ctypes.c_float(0)
+        rd(ctypes.byref(a_), ctypes.byref(b_)); bms.append(a_.value); sms.append(b_.value)
+    tk(0)
+    print("               build %.3f ms, search %.3f ms" % (np.mean(bms[1:]), np.mean(sms[1:])))
     same = all(all(torch.equal(a, b) for a, b in zip(outs[m], outs[384])) for m in (320, 512))
     print("%-14s fwd ms: cap 384 %.4f | 320 %.4f | 512 %.4f | identical %s" % (kind, res[384], res[320], res[512], same), flush=True)
