@@ -85,12 +85,10 @@ constexpr float kBoundSlack = 0.999f;
 //                                  the table of the cell whose points start at `start` of set s at 2*(set offset + start) + 2*s
 //   [.., +32*(T/kCrowd + 2*S))     SubGrid sub_desc[...]     their descriptors (grid_common.h)
 //   [.., +16*T)                    float4 sorted2[T]  spare copy the refinement sorts through
-//   [.., +16*S, +4*(kGridCells+4)*S)   occ_count[S][4], occ_list[S][4][kGridCells/4+1]: the occupied cells of every
-//                                  set, slab by slab (what a query far from the cloud walks instead of the cloud)
 //   [.., +4*T, +4*T)               float slab[T], slab2[T]   labels in sorted order + spare (labeled Chamfer only)
 // (the second-level arrays are only touched for sets that have crowded cells: never at config 2)
 struct Layout {
-  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, occ_count, occ_list, slab, slab2, total;
+  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, total;
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
   Layout L;
@@ -101,9 +99,7 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   L.sub_start = L.sorted + 16 * T;
   L.sub_desc = L.sub_start + ((4 * (2 * T + 2 * S) + 255) / 256) * 256;
   L.sorted2 = L.sub_desc + ((32 * (T / pp::kCrowd + 2 * S) + 255) / 256) * 256;
-  L.occ_count = L.sorted2 + 16 * T;
-  L.occ_list = L.occ_count + ((16 * S + 255) / 256) * 256;
-  L.slab = L.occ_list + ((4 * (size_t)(kGridCells + 4) * S + 255) / 256) * 256;
+  L.slab = L.sorted2 + 16 * T;
   L.slab2 = L.slab + (labeled ? 4 * T : 0);
   L.total = L.slab2 + (labeled ? 4 * T : 0);
   return L;
@@ -151,9 +147,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
       reinterpret_cast<unsigned*>(ws + L.sub_start) + set_sub_start_offset(b, dir, N, M),
       reinterpret_cast<pp::SubGrid*>(ws + L.sub_desc) + set_sub_desc_offset(b, dir, N, M),
       reinterpret_cast<pp::f4*>(ws + L.sorted2) + set_point_offset(b, dir, N, M),
-      labeled ? reinterpret_cast<float*>(ws + L.slab2) + set_point_offset(b, dir, N, M) : nullptr,
-      reinterpret_cast<unsigned*>(ws + L.occ_list) + (size_t)set * (kGridCells + 4),
-      reinterpret_cast<unsigned*>(ws + L.occ_count) + (size_t)set * 4);
+      labeled ? reinterpret_cast<float*>(ws + L.slab2) + set_point_offset(b, dir, N, M) : nullptr);
 }
 
 // Stages B and C (cubes of Chebyshev radius 1 and 2 around the query's cell) for the queries stage A left
@@ -265,58 +259,6 @@ __device__ __forceinline__ bool wide_stages_wave(float qx, float qy, float qz, f
   return resolved;
 }
 
-// The same for a query the cube of radius 2 left open, when its wave has only a few such queries: cubes of radius
-// 4, then 8 (the rows of a cube taken 32 at a time), until a cube settles it or covers the grid; a query that is
-// still open then (returns false) is far from everything and joins the lane-per-query pass.  Cost ~ rows of the cube + points inside it: a query in a thin part of the cloud
-// (the tail of a Gaussian) stops after a few hundred candidates instead of scanning the cloud.
-template <bool LAB>
-__device__ __forceinline__ bool far_stages_wave(float qx, float qy, float qz, float ql, const GridSet& g,
-                                                const unsigned* __restrict__ cell_start,
-                                                const pp::f4* __restrict__ sorted, const float* __restrict__ slab,
-                                                float& best, int& bidx) {
-  const int lane = threadIdx.x & 63;
-  const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
-  const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
-  const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
-  const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
-              fz = (qz - g.minz) * g.invh - (float)cz;
-  unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, no index)
-  for (int rho = 4;; rho *= 2) {
-    const int y0 = max(cy - rho, 0), y1 = min(cy + rho, g.gy - 1), z0 = max(cz - rho, 0), z1 = min(cz + rho, g.gz - 1);
-    const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.gx - 1);
-    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
-    for (int base = 0; base < nrows; base += 32) {
-      const int r = base + lane;
-      const bool ok = lane < 32 && r < nrows;
-      const int z = z0 + (ok ? r / ny : 0), y = y0 + (ok ? r % ny : 0);
-      const int c = pp::cell_linear(0, y, z, g.gx, g.gy);
-      unsigned rs = 0, re = 0;
-      if (ok) {
-        rs = cell_start[c + x0];
-        re = cell_start[c + x1 + 1];
-      }
-      key = wave_scan_rows<LAB>(min(32, nrows - base), rs, re, sorted, slab, qx, qy, qz, ql, key);
-    }
-    const bool all = z0 == 0 && z1 == g.gz - 1 && y0 == 0 && y1 == g.gy - 1 && x0 == 0 && x1 == g.gx - 1;
-    auto axis = [&](float f, int c, int gdim) {
-      const float lo = c - rho >= 1 ? (float)rho + f : __builtin_inff();
-      const float hi = c + rho <= gdim - 2 ? (float)(rho + 1) - f : __builtin_inff();
-      return fminf(lo, hi);
-    };
-    const float reach = g.h * fminf(axis(fx, cx, g.gx), fminf(axis(fy, cy, g.gy), axis(fz, cz, g.gz)));
-    const float kbest = __uint_as_float((unsigned)(key >> 32));
-    if (all || kbest < reach * reach * kBoundSlack) break;
-    if (rho >= 8) return false;  // far from everything: the lane-per-query pass over the cells / the cloud is cheaper
-  }
-  best = __uint_as_float((unsigned)(key >> 32));
-  bidx = (int)(unsigned)key;
-  if (!(best < __builtin_inff())) {  // nothing below +inf (non-finite query, or no point with the label)
-    best = LAB ? 0.0f : __builtin_inff();
-    bidx = LAB ? -1 : 0;
-  }
-  return true;
-}
-
 // Group k of a lane's stage-A sequence (see grid_query_wave_kernel): four points of the row it falls in,
 // read from global memory (waves whose region does not fit their LDS slice).
 // Everything per-row arrives BY VALUE: selects between variables captured by reference in a lambda come
@@ -348,6 +290,7 @@ __device__ __forceinline__ void stage_a_fetch(unsigned k, unsigned T1, unsigned 
 typedef const pp::f4 __attribute__((address_space(3))) * lds_f4_ptr;
 typedef const float __attribute__((address_space(3))) * lds_f_ptr;
 typedef pp::f4 __attribute__((address_space(3))) * lds_f4_wptr;
+typedef float __attribute__((address_space(3))) * lds_f_wptr;
 
 // helpers of the search kernels' in-kernel fallbacks (no brute-force list, no third launch)
 constexpr int kStageLayers = 8;
@@ -401,68 +344,6 @@ __device__ __forceinline__ void walk_range(unsigned cs, unsigned ce, const pp::f
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) take_candidate<LAB>(p[u], pl[u], qx, qy, qz, ql, best, bidx);
-  }
-}
-
-template <bool LAB>
-__device__ __forceinline__ void lane_sparse_search(const GridSet g, const unsigned* __restrict__ cell_start,
-                                                   const pp::f4* __restrict__ sorted, const float* __restrict__ slab,
-                                                   const unsigned* __restrict__ occ_list,
-                                                   const unsigned* __restrict__ occ_count, float qx, float qy, float qz,
-                                                   float ql, float& best, int& bidx) {
-  const float inf = __builtin_inff();
-  auto axis_gap = [&](float q, float mn, int c, int gdim) {  // distance from q to cell c's slab along one axis
-    const float lo = c == 0 ? -inf : mn + (float)c * g.h, hi = c == gdim - 1 ? inf : mn + (float)(c + 1) * g.h;
-    // (minus 1e-4 h: a point may sit in the neighbouring cell by the rounding of its cell coordinate, and the
-    //  faces themselves are rounded)
-    return fmaxf(fmaxf(lo - q, q - hi) - 1.0e-4f * g.h, 0.0f);
-  };
-  auto bound_of = [&](unsigned lin) {  // lin wave-uniform
-    const int cz = (int)(lin / (unsigned)(g.gx * g.gy));
-    const int rem = (int)lin - cz * g.gx * g.gy;
-    const int cy = rem / g.gx, cx = rem - cy * g.gx;
-    const float dx = axis_gap(qx, g.minx, cx, g.gx), dy = axis_gap(qy, g.miny, cy, g.gy), dz = axis_gap(qz, g.minz, cz, g.gz);
-    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)) * 0.9999f;
-  };
-  auto walk = [&](unsigned lin) {  // per-lane cell
-    const unsigned cs = cell_start[lin], ce = cell_start[lin + 1];
-    unsigned i = cs;
-    for (; i + 4 <= ce; i += 4) {
-      pp::f4 p[4];
-      float pl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        p[u] = sorted[i + u];
-        if (LAB) pl[u] = slab[i + u];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) take_candidate<LAB>(p[u], pl[u], qx, qy, qz, ql, best, bidx);
-    }
-    for (; i < ce; ++i) take_candidate<LAB>(sorted[i], LAB ? slab[i] : 0.0f, qx, qy, qz, ql, best, bidx);
-  };
-  best = inf;
-  bidx = 0x7fffffff;
-  float lb_min = inf;
-  unsigned first = 0xffffffffu;
-  for (int sl = 0; sl < pp::kBuildSlabs; ++sl) {
-    const unsigned cnt = occ_count[sl];
-    const unsigned* __restrict__ ol = occ_list + (size_t)sl * (kGridCells / pp::kBuildSlabs + 1);
-    for (unsigned k = 0; k < cnt; ++k) {
-      const unsigned lin = ol[k];
-      const float lb = bound_of(lin);
-      const bool lt = lb < lb_min;
-      lb_min = lt ? lb : lb_min;
-      first = lt ? lin : first;
-    }
-  }
-  if (first != 0xffffffffu) walk(first);
-  for (int sl = 0; sl < pp::kBuildSlabs; ++sl) {
-    const unsigned cnt = occ_count[sl];
-    const unsigned* __restrict__ ol = occ_list + (size_t)sl * (kGridCells / pp::kBuildSlabs + 1);
-    for (unsigned k = 0; k < cnt; ++k) {
-      const unsigned lin = ol[k];
-      if (bound_of(lin) <= best && lin != first) walk(lin);
-    }
   }
 }
 
@@ -615,18 +496,25 @@ __device__ __attribute__((noinline)) Found refined_block_search(
 // that the rest of the budget allows along x.  Those row pieces are laid end to end and staged through the wave's slice
 // of LDS, 256 points at a time; every lane walks every staged point (LDS broadcast) keeping its own exact
 // (distance, index) minimum -- brute force restricted to the rows that can matter.  Extra candidates are
-// harmless, so no lane is masked.  Unlabeled searches, finite queries only.
+// harmless, so no lane is masked.  Finite queries only.  Labeled searches: a candidate counts for a query of the
+// same label only, so a seed without a candidate samples points of its own label and takes along queries of its
+// label only (a label nobody carries ends in one scan of the whole cloud, which settles every open query).
+template <bool LAB>
 __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, const unsigned* __restrict__ cell_start,
-                                                             const pp::f4* __restrict__ sorted, float qx, float qy,
-                                                             float qz, float best, int bidx, unsigned open_lo,
-                                                             unsigned open_hi, lds_f4_wptr lw) {
+                                                             const pp::f4* __restrict__ sorted,
+                                                             const float* __restrict__ slab, float qx, float qy,
+                                                             float qz, float ql, float best, int bidx, unsigned open_lo,
+                                                             unsigned open_hi, lds_f4_wptr lw, lds_f_wptr lwl) {
   const lds_f4_ptr lr = (lds_f4_ptr)lw;
+  const lds_f_ptr lrl = (lds_f_ptr)lwl;
   const int lane = threadIdx.x & 63;
   const float inf = __builtin_inff();
   unsigned long long open = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)open_hi) << 32) |
                             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)open_lo);
   auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
-  const float slack = 1.0e-4f * g.h;  // (cell faces and cell coordinates are rounded: see lane_sparse_search)
+  // (a point may sit in the neighbouring cell by the rounding of its cell coordinate, and the faces themselves
+  //  are rounded: every gap is shortened by this much)
+  const float slack = 1.0e-4f * g.h;
   // distance from the interval [blo, bhi] to the slab of cell c along one axis (rim cells hold the outliers: they
   // extend to infinity)
   auto axis_gap = [&](float blo, float bhi, float mn, int c, int gdim) {
@@ -639,6 +527,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
   while (open) {
     const int seed = (int)__builtin_ctzll(open);
     const float sx = rl(qx, seed), sy = rl(qy, seed), sz = rl(qz, seed);
+    const float sl = LAB ? rl(ql, seed) : 0.0f;
     float us = rl(best, seed);
     // wave-uniform: the seed has seen no candidate yet, or only one picked up by accident far outside its cubes
     const bool blind = !(us < 16.0f * g.h * g.h);
@@ -660,12 +549,17 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
           re[u] = ok ? cell_start[base + g.gx] : rs[u];
         }
         pp::f4 smp[4];
+        float sml[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) smp[u] = sorted[re[u] > rs[u] ? min(rm[u], re[u] - 1) : 0u];
+        for (int u = 0; u < 4; ++u) {
+          const unsigned at = re[u] > rs[u] ? min(rm[u], re[u] - 1) : 0u;
+          smp[u] = sorted[at];
+          if (LAB) sml[u] = slab[at];
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float d = pp::chamfer_d3(smp[u].x, smp[u].y, smp[u].z, sx, sy, sz);
-          u1 = (re[u] > rs[u] && d < u1) ? d : u1;
+          u1 = (re[u] > rs[u] && (!LAB || sml[u] == sl) && d < u1) ? d : u1;
         }
       }
 #pragma unroll
@@ -683,7 +577,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     const float ds = sqrtf(us);
     const float r = blind ? 0.25f * ds : fmaxf(2.0f * g.h, 0.25f * ds);
     const float via = ds + 1.7321f * r;
-    const bool member = (((open >> lane) & 1ull) != 0ull && (blind || best <= 4.0f * us) &&
+    const bool member = (((open >> lane) & 1ull) != 0ull && (blind ? (!LAB || ql == sl) : best <= 4.0f * us) &&
                          !(fmaxf(fabsf(qx - sx), fmaxf(fabsf(qy - sy), fabsf(qz - sz))) > r)) ||
                         lane == seed;
     open &= ~__ballot(member);
@@ -745,6 +639,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         // the lanes' offsets (the last lane whose first candidate is <= c; empty rows are passed over because the
         // row after them starts at the same offset)
         pp::f4 pt[kGroupBatch / 64];
+        float ptl[kGroupBatch / 64];
 #pragma unroll
         for (int u = 0; u < kGroupBatch / 64; ++u) {
           const unsigned c = min(t0 + (unsigned)(u * 64 + lane), total - 1);  // (the tail repeats the last candidate)
@@ -756,19 +651,28 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
             lo = ge ? mid : lo;
             hi = ge ? hi : mid - 1;
           }
-          pt[u] = sorted[c + (unsigned)__shfl((int)shift, lo)];
+          const unsigned at = c + (unsigned)__shfl((int)shift, lo);
+          pt[u] = sorted[at];
+          ptl[u] = LAB ? slab[at] : 0.0f;
         }
 #pragma unroll
-        for (int u = 0; u < kGroupBatch / 64; ++u) lw[u * 64 + lane] = pt[u];
+        for (int u = 0; u < kGroupBatch / 64; ++u) {
+          lw[u * 64 + lane] = pt[u];
+          if (LAB) lwl[u * 64 + lane] = ptl[u];
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const unsigned n = min((unsigned)kGroupBatch, (total - t0 + 3u) & ~3u);
         for (unsigned i = 0; i < n; i += 4) {  // every lane, every candidate (uniform address: LDS broadcast)
           pp::f4 q4[4];
+          float l4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-          for (int u = 0; u < 4; ++u) q4[u] = lr[i + u];
+          for (int u = 0; u < 4; ++u) {
+            q4[u] = lr[i + u];
+            if (LAB) l4[u] = lrl[i + u];
+          }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) take_candidate<false>(q4[u], 0.0f, qx, qy, qz, 0.0f, best, bidx);
+          for (int u = 0; u < 4; ++u) take_candidate<LAB>(q4[u], l4[u], qx, qy, qz, ql, best, bidx);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -922,8 +826,6 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
   const pp::f4* __restrict__ qsorted =
       reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir ^ 1, N, M);
   const bool g_useless = pp::grid_useless(g), gp_useless = pp::grid_useless(gp);
-  const float* __restrict__ ref_raw = (dir ? xyz1 : xyz2) + (size_t)b * nr * 3;
-  const float* __restrict__ rlab_raw = LAB ? (dir ? label1 : label2) + (size_t)b * nr : nullptr;
   float* __restrict__ od = (dir ? dist2 : dist1) + (size_t)b * nq;
   int* __restrict__ oi = (dir ? idx2 : idx1) + (size_t)b * nq;
   float qx, qy, qz, ql = 0.0f;
@@ -942,7 +844,8 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
   if (g_useless) {  // no grid for this set (non-finite or zero-extent data, crowded cells): every pair
     float best;
     int bidx;
-    lane_scan_cloud<LAB>(ref_raw, rlab_raw, nr, qx, qy, qz, ql, best, bidx);
+    lane_scan_cloud<LAB>((dir ? xyz1 : xyz2) + (size_t)b * nr * 3, LAB ? (dir ? label1 : label2) + (size_t)b * nr : nullptr,
+                         nr, qx, qy, qz, ql, best, bidx);
     if (valid) {
       od[j] = best;
       oi[j] = bidx;
@@ -1285,60 +1188,27 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
     }
   }
   PP_QPHASE(7);
-  if (!LAB && open) {  // wave-uniform
+  if (open) {  // wave-uniform: far from everything the cubes hold -- group by group, the whole wave (see above)
     const bool finite = __builtin_isfinite(qx) && __builtin_isfinite(qy) && __builtin_isfinite(qz);
     const unsigned long long todo = open & __ballot(finite);
     if (todo) {
-      const Found f = wave_group_search(g, cell_start, sorted, qx, qy, qz, best, bidx, (unsigned)todo,
-                                        (unsigned)(todo >> 32), (lds_f4_wptr)(&s_pts[wave][0]));
+      const Found f = wave_group_search<LAB>(g, cell_start, sorted, slab, qx, qy, qz, ql, best, bidx, (unsigned)todo,
+                                             (unsigned)(todo >> 32), (lds_f4_wptr)(&s_pts[wave][0]),
+                                             (lds_f_wptr)(&s_lab[wave][0]));
       if ((todo >> lane) & 1ull) {
-        od[j] = f.best;
-        oi[j] = f.bidx;
+        const bool none = f.bidx == 0x7fffffff;  // (labeled: nobody carries this label -- ref nmdistance_cuda.cu:110-113)
+        od[j] = (LAB && none) ? 0.0f : f.best;
+        oi[j] = none ? (LAB ? -1 : 0) : f.bidx;
       }
       open &= ~todo;
     }
   }
   PP_QPHASE(8);
-  if (open && __builtin_popcountll(open) < 12) {  // few: one after the other by the whole wave, larger cubes
-    unsigned long long still = 0ull;
-    while (open) {
-      const int l = (int)__builtin_ctzll(open);
-      open &= open - 1;
-      const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
-      const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), l));
-      const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), l));
-      const float wl = LAB ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ql), l)) : 0.0f;
-      const int wj = __builtin_amdgcn_readlane(j, l);
-      float wbest;
-      int widx;
-      if (far_stages_wave<LAB>(wx, wy, wz, wl, g, cell_start, sorted, slab, wbest, widx)) {
-        if (lane == 0) {
-          od[wj] = wbest;
-          oi[wj] = widx;
-        }
-      } else {
-        still |= 1ull << l;
-      }
-    }
-    open = still;
-  }
-  if (open) {  // wave-uniform
-    // many, or far from everything (clouds apart, a thin region): one pass of the wave serves them all, a lane
-    // per query -- over the occupied cells where those are few (clustered data), else over the cloud
-    const unsigned* __restrict__ occ_count = reinterpret_cast<const unsigned*>(ws + L.occ_count) + (size_t)set * 4;
-    const unsigned* __restrict__ occ_list = reinterpret_cast<const unsigned*>(ws + L.occ_list) + (size_t)set * (kGridCells + 4);
-    const unsigned o0 = occ_count[0], o1 = occ_count[1], o2 = occ_count[2], o3 = occ_count[3];
+  if (open) {  // non-finite queries: every pair, as the brute force orders them
     float sb;
     int si;
-    if (o0 != 0xffffffffu && (unsigned long long)o0 + o1 + o2 + o3 <= (unsigned long long)nr / 10) {
-      lane_sparse_search<LAB>(g, cell_start, sorted, slab, occ_list, occ_count, qx, qy, qz, ql, sb, si);
-      if (!(sb < __builtin_inff())) {  // nothing below +inf (non-finite query, or no point with the label)
-        sb = LAB ? 0.0f : __builtin_inff();
-        si = LAB ? -1 : 0;
-      }
-    } else {
-      lane_scan_cloud<LAB>(ref_raw, rlab_raw, nr, qx, qy, qz, ql, sb, si);
-    }
+    lane_scan_cloud<LAB>((dir ? xyz1 : xyz2) + (size_t)b * nr * 3, LAB ? (dir ? label1 : label2) + (size_t)b * nr : nullptr,
+                         nr, qx, qy, qz, ql, sb, si);
     if ((open >> lane) & 1ull) {
       od[j] = sb;
       oi[j] = si;

@@ -297,8 +297,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
                                                float* __restrict__ sorted_payload, int slab,
                                                int nslab, unsigned* __restrict__ sub_start,
                                                SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
-                                               float* __restrict__ payload2, unsigned* __restrict__ occ_list,
-                                               unsigned* __restrict__ occ_count) {
+                                               float* __restrict__ payload2) {
   __shared__ unsigned s_part[kBuildThreads];
   __shared__ unsigned s_crowd;
   __shared__ float s_box[(kBuildThreads / 64) * 16];
@@ -613,38 +612,10 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     if (w < (t >> 6)) wave_base += s_part[w];
   }
   unsigned run = wave_base + incl - sum;
-  unsigned occ_mask = 0;          // which of this thread's cells hold points (per <= 32 cells per thread)
   for (int c = c0; c < c1; ++c) {
     const unsigned v = s_cnt[sk(c)];
-    occ_mask |= (v != 0u ? 1u : 0u) << ((c - c0) & 31);
     s_cnt[sk(c)] = run;  // cell start; becomes the scatter cursor below
     run += v;
-  }
-  if constexpr (REFINE && !MORTON) {
-    // the slab's OCCUPIED cells as a compact list (any order): what a query far from the cloud walks instead of
-    // the whole cloud (chamfer_grid.hip: lane_sparse_search).  One LDS atomic per wave reserves the slots.
-    if (occ_list && per <= 32) {
-      __shared__ unsigned s_nocc_list;
-      if (t == 0) s_nocc_list = 0u;
-      __syncthreads();
-      const unsigned mine = (unsigned)__builtin_popcount(occ_mask);
-      unsigned incl_o = mine;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned o = __shfl_up(incl_o, off);
-        if ((t & 63) >= off) incl_o += o;
-      }
-      unsigned wbase = 0;
-      if ((t & 63) == 63) wbase = atomicAdd(&s_nocc_list, incl_o);
-      wbase = __shfl(wbase, 63);
-      unsigned at = wbase + incl_o - mine;
-      unsigned* __restrict__ ol = occ_list + (size_t)slab * (kGridCells / kBuildSlabs + 1);
-      for (unsigned mm = occ_mask; mm; mm &= mm - 1u) ol[at++] = (unsigned)(cell_lo + c0 + __builtin_ctz(mm));
-      __syncthreads();
-      if (t == 0) occ_count[slab] = s_nocc_list;
-    } else if (occ_count && t == 0) {
-      occ_count[slab] = 0xffffffffu;  // no list (grids beyond 32 cells per thread: not built by the Chamfer path)
-    }
   }
   __syncthreads();
   PP_PHASE(7);
@@ -746,13 +717,12 @@ __device__ __forceinline__ void grid_build_set(const float* __restrict__ ref, in
                                                float* __restrict__ sorted_payload = nullptr, int slab = 0,
                                                int nslab = 1) {
   grid_build_set_impl<MORTON, VEC, false>(ref, nr, gs, cell_start, sorted, inv, s_cnt, payload, sorted_payload, slab,
-                                          nslab, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                                          nslab, nullptr, nullptr, nullptr, nullptr);
 }
 
 // the same with the second level: crowded cells refined into sub-grids (sub_start: 2 * nr + 2 entries of this
 // set, sub_desc: sub_desc_slots(nr) descriptors of this set; sorted2 / payload2: spare copies as large as
-// sorted / sorted_payload, addressed like them; occ_list: kBuildSlabs * (kGridCells / kBuildSlabs + 1) cell ids of
-// this set, occ_count: kBuildSlabs counts -- the occupied cells, slab by slab)
+// sorted / sorted_payload, addressed like them)
 template <bool VEC>
 __device__ __forceinline__ void grid_build_set_refined(const float* __restrict__ ref, int nr, GridSet* gs,
                                                        unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
@@ -760,10 +730,9 @@ __device__ __forceinline__ void grid_build_set_refined(const float* __restrict__
                                                        float* __restrict__ sorted_payload, int slab, int nslab,
                                                        unsigned* __restrict__ sub_start,
                                                        SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
-                                                       float* __restrict__ payload2, unsigned* __restrict__ occ_list,
-                                                       unsigned* __restrict__ occ_count) {
+                                                       float* __restrict__ payload2) {
   grid_build_set_impl<false, VEC, true>(ref, nr, gs, cell_start, sorted, nullptr, s_cnt, payload, sorted_payload, slab,
-                                        nslab, sub_start, sub_desc, sorted2, payload2, occ_list, occ_count);
+                                        nslab, sub_start, sub_desc, sorted2, payload2);
 }
 
 // every batch element's cloud (base + b * n * 3 floats) is 16-byte aligned
