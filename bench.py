@@ -453,7 +453,7 @@ def bench_chamfer(args, dist, world, rank, device):
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
             # rocprofv3 --pmc FETCH_SIZE (x2: 16-byte loads count half on gfx950) + WRITE_SIZE of this kernel
             # per launch (profiles/r2/pmc_summary.txt)
-            "traffic": 32.2e6 if c2 else None,
+            "traffic": 33.2e6 if c2 else None,
             "kernel_ms": search_ms, "build_kernel_ms": build_ms,
             "note": "SURVEY.md §8(d): algorithmic forward bytes (%.0f) / the search kernel's average duration, HIP events "
                     "on the launch stream around that kernel (pp_hip_debug.h), %d forwards after the timed region. The "

@@ -909,8 +909,7 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
   // beyond it (beyond the grid there are no points).  Lower face: 1 + f cells away when the block includes
   // cell c-1, f when it starts at c; upper face: 1 - f or 2 - f.  Never below h/2.  The query is settled if
   // its best distance is below reach^2 * kBoundSlack (strict).
-  const float reach = g.h * fminf(block_reach(fx, sx, cx, g.gx), fminf(block_reach(fy, sy, cy, g.gy), block_reach(fz, sz, cz, g.gz)));
-  float thr = reach * reach * kBoundSlack;
+  // (computed after the walk, from the query again: the cell coordinates need not live through it)
   // Lanes whose block touches a crowded cell do not take part in the staged walk: their candidates are the
   // sub-cells near the query, found through the crowded cells' own grids further down.  (refined_set is
   // wave-uniform and false for every set of an evenly sampled surface: config 2 pays one scalar branch.)
@@ -1118,11 +1117,27 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
     }
   }
   PP_QPHASE(4);
+  float reach;
+  int cx2, cy2, cz2, sx2, sy2, sz2;
+  {
+    float ax = qx, ay = qy, az = qz;
+    asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));  // (opaque copies: nothing below is merged with the values above)
+    cx2 = cell_coord(ax, g.minx, g.invh, g.gx);
+    cy2 = cell_coord(ay, g.miny, g.invh, g.gy);
+    cz2 = cell_coord(az, g.minz, g.invh, g.gz);
+    const float fx2 = (ax - g.minx) * g.invh - (float)cx2, fy2 = (ay - g.miny) * g.invh - (float)cy2,
+                fz2 = (az - g.minz) * g.invh - (float)cz2;
+    sx2 = fx2 < 0.5f ? -1 : 1;
+    sy2 = fy2 < 0.5f ? -1 : 1;
+    sz2 = fz2 < 0.5f ? -1 : 1;
+    reach = g.h * fminf(block_reach(fx2, sx2, cx2, g.gx), fminf(block_reach(fy2, sy2, cy2, g.gy), block_reach(fz2, sz2, cz2, g.gz)));
+  }
+  float thr = reach * reach * kBoundSlack;
   if (refined_set && __any(deferred)) {  // wave-uniform
     // ---- second level: the block's cells one by one; a crowded cell through its own grid ---------------------
     if (deferred) {
-      const Found f = refined_block_search<LAB>(g, cell_start, sorted, slab, sub_start, sub_desc, qx, qy, qz, ql, cx, cy,
-                                                cz, sx, sy, sz, reach);
+      const Found f = refined_block_search<LAB>(g, cell_start, sorted, slab, sub_start, sub_desc, qx, qy, qz, ql, cx2, cy2,
+                                                cz2, sx2, sy2, sz2, reach);
       best = f.best;
       bidx = f.bidx;
       thr = f.aux;
