@@ -884,27 +884,37 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
   const int z0 = max(min(cz, cz + sz), 0), z1 = min(max(cz, cz + sz), g.gz - 1);
   unsigned rs0, rs1, rs2, rs3, re0, re1, re2, re3;
   bool crowd = false;  // some cell of the block holds more than kCrowd points (it then has a grid of its own)
+  // The bounds of the block's four rows (y, z): a row is one or two cells wide, its two bounds are at most two
+  // entries apart, so ONE 12-byte load fetches both (the entry after a set's table is the next set's or the
+  // sorted cloud: valid memory).  The loads are only ISSUED here; their values are first touched after the wave's
+  // region has been worked out (below), whose own loads then travel at the same time instead of one round trip later.
+  typedef unsigned u3 __attribute__((ext_vector_type(3)));
+  u3 rv0, rv1, rv2, rv3;
   {
-    // (named scalars, not arrays: hipcc turns a select between array elements into an indexed load from
-    // scratch memory)
-    auto row_range = [&](int a, int bq, unsigned& s_out, unsigned& e_out) {
+    auto row_issue = [&](int a, int bq, u3& v) {
       const int z = cz + a * sz, y = cy + bq * sy;
-      const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
       const int c = pp::cell_linear(0, min(max(y, 0), g.gy - 1), min(max(z, 0), g.gz - 1), g.gx, g.gy);
-      // the row is one or two cells wide: its two bounds are at most two entries apart, so ONE 12-byte load
-      // fetches both (the entry after a set's table is the next set's or the sorted cloud: valid memory)
-      typedef unsigned u3 __attribute__((ext_vector_type(3)));
-      u3 v;
       __builtin_memcpy(&v, cell_start + c + x0, sizeof(v));
-      s_out = ok ? v.x : 0u;
-      e_out = ok ? (x1 > x0 ? v.z : v.y) : 0u;
-      crowd = crowd | (ok & ((v.y - v.x > (unsigned)pp::kCrowd) | ((x1 > x0) & (v.z - v.y > (unsigned)pp::kCrowd))));
     };
-    row_range(0, 0, rs0, re0);
-    row_range(0, 1, rs1, re1);
-    row_range(1, 0, rs2, re2);
-    row_range(1, 1, rs3, re3);
+    row_issue(0, 0, rv0);
+    row_issue(0, 1, rv1);
+    row_issue(1, 0, rv2);
+    row_issue(1, 1, rv3);
   }
+  // (named scalars, not arrays: hipcc turns a select between array elements into an indexed load from scratch)
+  auto row_finish = [&](int a, int bq, const u3 v, unsigned& s_out, unsigned& e_out) {
+    const int z = cz + a * sz, y = cy + bq * sy;
+    const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
+    s_out = ok ? v.x : 0u;
+    e_out = ok ? (x1 > x0 ? v.z : v.y) : 0u;
+    crowd = crowd | (ok & ((v.y - v.x > (unsigned)pp::kCrowd) | ((x1 > x0) & (v.z - v.y > (unsigned)pp::kCrowd))));
+  };
+  auto rows_finish = [&]() {
+    row_finish(0, 0, rv0, rs0, re0);
+    row_finish(0, 1, rv1, rs1, re1);
+    row_finish(1, 0, rv2, rs2, re2);
+    row_finish(1, 1, rv3, rs3, re3);
+  };
   // What the block guarantees for THIS query: along each axis the nearer face of the block that has grid
   // beyond it (beyond the grid there are no points).  Lower face: 1 + f cells away when the block includes
   // cell c-1, f when it starts at c; upper face: 1 - f or 2 - f.  Never below h/2.  The query is settled if
@@ -913,62 +923,73 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
   // Lanes whose block touches a crowded cell do not take part in the staged walk: their candidates are the
   // sub-cells near the query, found through the crowded cells' own grids further down.  (refined_set is
   // wave-uniform and false for every set of an evenly sampled surface: config 2 pays one scalar branch.)
-  const bool deferred = refined_set && crowd;
-  if (deferred) {
-    re0 = rs0; re1 = rs1; re2 = rs2; re3 = rs3;
-  }
-  const bool none_normal = refined_set && !__any(!deferred);
   PP_QPHASE(1);
-
-  // ---- the wave's region: its z-layers and the row range in each (cell coordinates are < 2^24: exact as floats)
   const float ninf = -__builtin_inff();
   auto lane63 = [](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); };
   int Lz, nz;
-  {
-    float v[6] = {deferred ? ninf : -(float)z0, deferred ? ninf : (float)z1, ninf, ninf, ninf, ninf};
-    pp::wave_reduce6_dpp<false, 6>(v);
-    Lz = none_normal ? 0 : -(int)lane63(v[0]);
-    nz = none_normal ? 1 : (int)lane63(v[1]) - Lz + 1;
-  }
-  bool staged = nz <= kStageLayers && !none_normal;
+  bool staged;
   unsigned n_staged = 0, delta = 0, offv = 0;  // lanes 0..7: the layer's (global start - LDS start), LDS start
-  if (staged) {
-    int ya = 1, yb = 0;  // lane l < nz: row range of layer Lz + l
-    for (int base = 0; base < nz; base += 3) {  // wave-uniform
-      float v[6];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int z = Lz + base + i;
-        const bool m = (z0 == z || z1 == z) && !deferred;
-        v[2 * i] = m ? -(float)y0 : ninf;
-        v[2 * i + 1] = m ? (float)y1 : ninf;
-      }
+  // (a function of its two flags, instantiated twice: for sets without crowded cells -- every evenly sampled
+  // surface -- both are constants and the region does not depend on the row bounds at all)
+  auto region = [&](const bool dfr, const bool nonorm) {
+    // ---- the wave's region: its z-layers and the row range in each (cell coordinates are < 2^24: exact as floats)
+    {
+      float v[6] = {dfr ? ninf : -(float)z0, dfr ? ninf : (float)z1, ninf, ninf, ninf, ninf};
       pp::wave_reduce6_dpp<false, 6>(v);
+      Lz = nonorm ? 0 : -(int)lane63(v[0]);
+      nz = nonorm ? 1 : (int)lane63(v[1]) - Lz + 1;
+    }
+    staged = nz <= kStageLayers && !nonorm;
+    if (staged) {
+      int ya = 1, yb = 0;  // lane l < nz: row range of layer Lz + l
+      for (int base = 0; base < nz; base += 3) {  // wave-uniform
+        float v[6];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float a = lane63(v[2 * i]), bmax = lane63(v[2 * i + 1]);
-        if (lane == base + i && bmax >= 0.0f) {
-          ya = -(int)a;
-          yb = (int)bmax;
+        for (int i = 0; i < 3; ++i) {
+          const int z = Lz + base + i;
+          const bool m = (z0 == z || z1 == z) && !dfr;
+          v[2 * i] = m ? -(float)y0 : ninf;
+          v[2 * i + 1] = m ? (float)y1 : ninf;
+        }
+        pp::wave_reduce6_dpp<false, 6>(v);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float a = lane63(v[2 * i]), bmax = lane63(v[2 * i + 1]);
+          if (lane == base + i && bmax >= 0.0f) {
+            ya = -(int)a;
+            yb = (int)bmax;
+          }
         }
       }
-    }
-    unsigned gs = 0, ge = 0;
-    if (lane < nz && ya <= yb) {
-      gs = cell_start[pp::cell_linear(0, ya, Lz + lane, g.gx, g.gy)];
-      ge = cell_start[pp::cell_linear(0, yb, Lz + lane, g.gx, g.gy) + g.gx];
-    }
-    const unsigned len = ge - gs;
-    unsigned incl = len;
+      unsigned gs = 0, ge = 0;
+      if (lane < nz && ya <= yb) {
+        gs = cell_start[pp::cell_linear(0, ya, Lz + lane, g.gx, g.gy)];
+        ge = cell_start[pp::cell_linear(0, yb, Lz + lane, g.gx, g.gy) + g.gx];
+      }
+      const unsigned len = ge - gs;
+      unsigned incl = len;
 #pragma unroll
-    for (int off = 1; off < kStageLayers; off <<= 1) {
-      const unsigned o = __shfl_up(incl, off);
-      if (lane >= off) incl += o;
+      for (int off = 1; off < kStageLayers; off <<= 1) {
+        const unsigned o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      offv = incl - len;
+      delta = gs - offv;
+      n_staged = (unsigned)__builtin_amdgcn_readlane((int)incl, kStageLayers - 1);
+      staged = n_staged <= (unsigned)CAPW;
     }
-    offv = incl - len;
-    delta = gs - offv;
-    n_staged = (unsigned)__builtin_amdgcn_readlane((int)incl, kStageLayers - 1);
-    staged = n_staged <= (unsigned)CAPW;
+  };
+  bool deferred = false;
+  if (!refined_set) {  // wave-uniform
+    region(false, false);
+    rows_finish();
+  } else {
+    rows_finish();
+    deferred = crowd;
+    if (deferred) {
+      re0 = rs0; re1 = rs1; re2 = rs2; re3 = rs3;
+    }
+    region(deferred, !__any(!deferred));
   }
   PP_QPHASE(2);
   const lds_f4_ptr lpts = (lds_f4_ptr)(&s_pts[wave][0]);
