@@ -42,9 +42,15 @@ def _cloud(rng, b, n, kind):
         x = (rng.integers(0, 12, (b, n, 3)) / 4).astype(np.float32)
     elif kind == 4:   # thin slab far from the origin
         x = rng.random((b, n, 3), dtype=np.float32) * np.array([3, 3, 1e-3], np.float32) + np.float32(300.0)
-    else:             # one far outlier stretches the bounding box
+    elif kind == 5:   # one far outlier stretches the bounding box
         x = rng.random((b, n, 3), dtype=np.float32)
         x[:, 0] = 1e3
+    elif kind == 6:   # Gaussian cloud: dense core, thin tails (far queries, group search)
+        x = rng.standard_normal((b, n, 3)).astype(np.float32) * np.float32(rng.choice([0.1, 1.0, 30.0]))
+    else:             # two scales: a share of the points in a tiny corner of the box (crowded cells, second-level grids)
+        x = rng.random((b, n, 3), dtype=np.float32)
+        k = int(n * rng.choice([0.1, 0.5, 0.9]))
+        x[:, :k] *= np.float32(rng.choice([1e-2, 1e-3]))
     return np.ascontiguousarray(x, np.float32)
 
 
@@ -55,12 +61,12 @@ def _sizes(rng):
     return b, n, m
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(100))
 def test_fuzz_chamfer_and_labeled(cuda, search_mode, seed):
     from pytorch_points_amd.network.model_loss import nndistance, labeled_nndistance
     rng = np.random.default_rng(1000 + seed)
     b, n, m = _sizes(rng)
-    k1, k2 = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+    k1, k2 = int(rng.integers(0, 8)), int(rng.integers(0, 8))
     x1, x2 = _cloud(rng, b, n, k1), _cloud(rng, b, m, k2)
     if seed % 3 == 0:
         x2 = x2 + x1.mean(1, keepdims=True) - x2.mean(1, keepdims=True)   # overlapping clouds
@@ -83,9 +89,9 @@ def test_fuzz_ball_query(cuda, search_mode, seed):
     from pytorch_points_amd._ext import sampling
     rng = np.random.default_rng(2000 + seed)
     b, m, n = _sizes(rng)                      # m centres, n points
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 8))
     x = _cloud(rng, b, n, kind)
-    c = x[:, rng.integers(0, n, m)] if seed % 2 else _cloud(rng, b, m, int(rng.integers(0, 6)))
+    c = x[:, rng.integers(0, n, m)] if seed % 2 else _cloud(rng, b, m, int(rng.integers(0, 8)))
     c = np.ascontiguousarray(c + (rng.standard_normal(c.shape) * 1e-3).astype(np.float32))
     ext = float(np.ptp(x.reshape(-1, 3), 0).max()) or 1.0
     r = float(rng.choice([1e-4, 0.01, 0.05, 0.2, 1.5])) * min(ext, 3.0)
@@ -101,7 +107,7 @@ def test_fuzz_three_nn_and_knn(cuda, seed):
     from pytorch_points_amd.ops import knn_points
     rng = np.random.default_rng(3000 + seed)
     b, n, m = _sizes(rng)
-    u, k = _cloud(rng, b, n, int(rng.integers(0, 6))), _cloud(rng, b, m, int(rng.integers(0, 6)))
+    u, k = _cloud(rng, b, n, int(rng.integers(0, 8))), _cloud(rng, b, m, int(rng.integers(0, 8)))
     d2 = torch.empty(b, n, 3, device=cuda)
     idx = torch.empty(b, n, 3, dtype=torch.int32, device=cuda)
     sampling.three_nn_wrapper(b, n, m, torch.from_numpy(u).to(cuda), torch.from_numpy(k).to(cuda), d2, idx)
