@@ -297,6 +297,7 @@ constexpr int kStageLayers = 8;
 constexpr int kLaneCubeMaxGroups = 48;  // groups of four points a lane walks per four rows of a cube before it gives up
 constexpr int kSubMaxRho = 2;  // widest cube of sub-cells a lane examines inside a crowded cell
 constexpr int kGroupBatch = 256;  // candidates per LDS batch of wave_group_search (<= the smallest per-wave slice)
+constexpr int kSerialMax = 24;  // open lanes of a wave from which the whole-wave cubes are skipped for the group search
 constexpr int kLaneStageMin = 6;  // open lanes of a wave from which the cubes are searched a lane per query
 
 // distance (in cells) from a query at position f inside cell c to the nearer face of its 2-cell block along one
@@ -1203,6 +1204,12 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
   // ---- few lanes: wide stages by the whole wave; then the whole cloud ---------------------------------------
   unsigned long long pending = __ballot(pend);
   unsigned long long open = __ballot(open_lane);  // lanes whose query the cube of radius 2 could not settle
+  if (__builtin_popcountll(pending) >= kSerialMax) {
+    // many (next to crowded cells, typically: every one of them would scan those cells by itself, ~ 0.8 wave
+    // instructions per candidate and query against ~ 13 per candidate for all of them in the group search)
+    open |= pending;
+    pending = 0ull;
+  }
   while (pending) {
     const int l = (int)__builtin_ctzll(pending);
     pending &= pending - 1;

@@ -303,7 +303,7 @@ def test_native_autograd_nodes_equal_the_python_functions(cuda):
                 if k < 4:
                     assert torch.equal(a, c)
                 else:   # gradients: same terms, summation order of the default backward is not fixed (1e-5)
-                    assert torch.allclose(a, c, rtol=1e-5, atol=1e-9)
+                    assert torch.allclose(a, c, rtol=1e-5, atol=1e-6)   # (sums of terms of either sign: absolute floor)
     # a missing upstream gradient (only dist1 used) counts as zero in both
     x1 = torch.from_numpy(S.unit_sphere(74, 1, 64)).to(cuda).requires_grad_(True)
     x2 = torch.from_numpy(S.unit_sphere(75, 1, 80)).to(cuda).requires_grad_(True)
