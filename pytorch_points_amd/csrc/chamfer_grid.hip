@@ -664,7 +664,16 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const unsigned n = min((unsigned)kGroupBatch, (total - t0 + 3u) & ~3u);
-        for (unsigned i = 0; i < n; i += 4) {  // every lane, every candidate (uniform address: LDS broadcast)
+        // Every lane, every candidate (uniform address: LDS broadcast), trimmed for VALU issue like the staged walk of
+        // stage A: per group of four only the running minimum (v_min3 + v_min) and the group that last lowered it;
+        // the winner's index is recovered from that group afterwards (it is still in the slice).  A distance EQUAL to
+        // the running minimum (duplicates, lattices, or the candidate the lane already holds) cannot be ordered that
+        // way: the wave then repeats the batch with the exact (distance, index) comparison.
+        const float best0 = best;
+        const int bidx0 = bidx;
+        unsigned gi = 0xffffffffu;
+        bool tie = false;
+        for (unsigned i = 0; i < n; i += 4) {
           pp::f4 q4[4];
           float l4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -672,8 +681,43 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
             q4[u] = lr[i + u];
             if (LAB) l4[u] = lrl[i + u];
           }
+          float d[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) take_candidate<LAB>(q4[u], l4[u], qx, qy, qz, ql, best, bidx);
+          for (int u = 0; u < 4; ++u) {
+            d[u] = pp::chamfer_d3(q4[u].x, q4[u].y, q4[u].z, qx, qy, qz);
+            if (LAB) d[u] = l4[u] == ql ? d[u] : inf;
+          }
+          const float gmin = fminf(pp::min3(d[0], d[1], d[2]), d[3]);
+          tie = tie | ((gmin == best) & (gmin < inf));
+          const bool lt = gmin < best;
+          gi = lt ? i : gi;
+          best = lt ? gmin : best;
+        }
+        if (__any(tie)) {  // exact redo of the batch (rare)
+          best = best0;
+          bidx = bidx0;
+          for (unsigned i = 0; i < n; i += 4) {
+            pp::f4 q4[4];
+            float l4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              q4[u] = lr[i + u];
+              if (LAB) l4[u] = lrl[i + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take_candidate<LAB>(q4[u], l4[u], qx, qy, qz, ql, best, bidx);
+          }
+        } else if (gi != 0xffffffffu) {  // the winner is in group gi: lowest index among its minima
+          int cand = 0x7fffffff;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const pp::f4 q = lr[gi + u];
+            float du = pp::chamfer_d3(q.x, q.y, q.z, qx, qy, qz);
+            if (LAB) du = lrl[gi + u] == ql ? du : inf;
+            const int id = __float_as_int(q.w);
+            cand = ((du == best) & (id < cand)) ? id : cand;
+          }
+          bidx = cand;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
