@@ -634,11 +634,18 @@ def main():
         a4 = copy.copy(args)
         a4.steps, a4.warmup, a4.with_backward = 10, 3, True
         out["ball_group"] = _short(bench_ball_group(a4, None, 1, 0, device))
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, which is flushed at
+    # exit -- after Python's print -- unless it is flushed here first
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
