@@ -149,6 +149,34 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
         }
         return sg;
       };
+      // The box the sub-grid is laid over: the bounding box of the cell's points, unless a few stragglers stretch it
+      // (a dense blob plus a handful of points of the sparse scale in the same cell) -- then the box within 3.5
+      // sigma of the mean, the stragglers landing in the rim sub-cells (cell_coord clamps; every bound of the
+      // searches is stated through that monotone coordinate, exactly as at the top level).  sm: sums of (p - c) and
+      // (p - c)^2 per axis, c the centre of the bounding box.
+      auto trim_box = [&](float (&bmn)[6], const float (&sm)[6], unsigned n) {
+        const float inv_n = 1.0f / (float)n;
+        float lo[3] = {-bmn[0], -bmn[1], -bmn[2]}, hi[3] = {bmn[3], bmn[4], bmn[5]};
+        const float ext0 = fmaxf(hi[0] - lo[0], fmaxf(hi[1] - lo[1], hi[2] - lo[2]));
+        float tl[3], th[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float c = 0.5f * (lo[a] + hi[a]);
+          const float m = sm[a] * inv_n;
+          const float var = fmaxf(sm[3 + a] * inv_n - m * m, 0.0f);
+          const float sd = sqrtf(var);
+          tl[a] = fmaxf(lo[a], c + m - 3.5f * sd);
+          th[a] = fminf(hi[a], c + m + 3.5f * sd);
+        }
+        const float ext1 = fmaxf(th[0] - tl[0], fmaxf(th[1] - tl[1], th[2] - tl[2]));
+        if (ext1 > 0.0f && ext1 < 0.75f * ext0) {  // (NaN moments compare false: the bounding box stays)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            bmn[a] = -tl[a];
+            bmn[3 + a] = th[a];
+          }
+        }
+      };
       auto cell2 = [](const SubGrid& sg, const f4& p) {
         return cell_linear(cell_coord(p.x, sg.minx, sg.invh, sg.gx), cell_coord(p.y, sg.miny, sg.invh, sg.gy),
                            cell_coord(p.z, sg.minz, sg.invh, sg.gz), sg.gx, sg.gy);
@@ -173,6 +201,20 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
           wave_reduce6_dpp<false, 6>(bmn);
 #pragma unroll
           for (int e = 0; e < 6; ++e) bmn[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmn[e]), 63));
+          {
+            const float c0 = 0.5f * (bmn[3] - bmn[0]), c1 = 0.5f * (bmn[4] - bmn[1]), c2 = 0.5f * (bmn[5] - bmn[2]);
+            float sm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            for (unsigned k = lane; k < n; k += 64) {
+              const f4 q = sorted[start + k];
+              const float dx = q.x - c0, dy = q.y - c1, dz = q.z - c2;
+              sm[0] += dx; sm[1] += dy; sm[2] += dz;
+              sm[3] = __builtin_fmaf(dx, dx, sm[3]); sm[4] = __builtin_fmaf(dy, dy, sm[4]); sm[5] = __builtin_fmaf(dz, dz, sm[5]);
+            }
+            wave_reduce6_dpp<true, 6>(sm);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) sm[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm[e]), 63));
+            trim_box(bmn, sm, n);
+          }
           const SubGrid sg = sub_geometry(bmn, n, kSubWaveCells);
           const int total2 = sg.gx * sg.gy * sg.gz;
           for (int c = lane; c < total2; c += 64) s_sub[c] = 0u;
@@ -240,6 +282,28 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
         wave_reduce6_dpp<false, 4>(bmn);
 #pragma unroll
         for (int e = 0; e < 6; ++e) bmn[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmn[e]), 15));
+        {
+          const float c0 = 0.5f * (bmn[3] - bmn[0]), c1 = 0.5f * (bmn[4] - bmn[1]), c2 = 0.5f * (bmn[5] - bmn[2]);
+          float sm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+          for (unsigned k = t; k < n; k += kBuildThreads) {
+            const f4 q = sorted[start + k];
+            const float dx = q.x - c0, dy = q.y - c1, dz = q.z - c2;
+            sm[0] += dx; sm[1] += dy; sm[2] += dz;
+            sm[3] = __builtin_fmaf(dx, dx, sm[3]); sm[4] = __builtin_fmaf(dy, dy, sm[4]); sm[5] = __builtin_fmaf(dz, dz, sm[5]);
+          }
+          wave_reduce6_dpp<true, 6>(sm);
+          __syncthreads();  // s_box: the bounding-box partials have been read
+          if ((t & 63) == 63)
+#pragma unroll
+            for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + e] = sm[e];
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < 6; ++e) sm[e] = s_box[(t & 15) * 16 + e];
+          wave_reduce6_dpp<true, 4>(sm);
+#pragma unroll
+          for (int e = 0; e < 6; ++e) sm[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm[e]), 15));
+          trim_box(bmn, sm, n);
+        }
         const SubGrid sg = sub_geometry(bmn, n, kSubMaxCells);
         const int total2 = sg.gx * sg.gy * sg.gz;
         for (int c = t; c < total2; c += kBuildThreads) s_sub[c] = 0u;
