@@ -710,7 +710,11 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_lds64_kernel(
 #pragma unroll
     for (int u = 0; u < KO; ++u) {
       const int jc = j2[u] >= 0 ? j2[u] : 0;
-      ox[u] = xo[3 * (size_t)jc]; oy[u] = xo[3 * (size_t)jc + 1]; oz[u] = xo[3 * (size_t)jc + 2];
+      // (one 12-byte load per neighbour instead of three scattered 4-byte ones: a third of the L1 requests)
+      typedef float f3 __attribute__((ext_vector_type(3)));
+      f3 v;
+      __builtin_memcpy(&v, xo + 3 * (size_t)jc, sizeof(v));
+      ox[u] = v.x; oy[u] = v.y; oz[u] = v.z;
     }
 #pragma unroll
     for (int u = 0; u < KO; ++u) {
