@@ -599,7 +599,7 @@ def bench_ball_group(args, dist, world, rank, device):
             "ball_query_ms": bq_ms, "group_points_ms": gp_ms, "group_points_grad_ms": gpg_ms,
             "query_and_group_fused_ms": qg_fused_ms, "query_and_group_composed_ms": qg_unfused_ms,
             "ball_query_pairs_per_s": float(B) * npoint * N / (bq_ms * 1e-3),
-            "roofline": {"bound": "hbm", "kernel": "group_points_dma_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "group_points_dma1_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          # PMC passes (profiles/r1/pmc_summary.txt): WRITE_SIZE 4096 MB exact, FETCH_SIZE
                          # 144 MB x2 (16-B loads read 1/2 on gfx950) = 288 MB
