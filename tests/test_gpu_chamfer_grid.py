@@ -123,6 +123,18 @@ def test_grid_search_full_size_other_distributions(cuda, kind):
         assert np.array_equal(u, v) and np.array_equal(u, w)
 
 
+@pytest.mark.parametrize("kind,n,m", [("two_scales", 40000, 40000), ("blobs8", 40000, 25000), ("gaussian", 100000, 70000)])
+def test_grid_search_large_clustered_clouds(cuda, kind, n, m):
+    """clouds beyond one build chunk (16384 points per workgroup pass) with crowded cells: the second-level grids
+    built from the multi-chunk path, the group search over long rows; grid == brute force"""
+    import bench
+    x1, x2 = bench._distribution(kind, 0, 1, n), bench._distribution(kind, 1, 1, m)
+    a = _run(cuda, x1, x2, 2)
+    b = _run(cuda, x1, x2, 1)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+
+
 def test_grid_workspace_reused_across_shapes(cuda):
     for n, m in [(4096, 2048), (2048, 8192), (3000, 3000)]:
         x1, x2 = S.unit_sphere(n, 2, n), S.unit_sphere(m + 1, 2, m)

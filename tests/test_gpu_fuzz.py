@@ -1,6 +1,8 @@
 """Randomised shapes and point distributions for every search operator (Chamfer, labeled Chamfer,
 ball_query, three_nn, knn) against the CPU oracle, bit for bit.  Seeds are fixed: a failure names the
 case.  Sizes straddle the thresholds at which the operators switch between scan and grid kernels."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -61,7 +63,7 @@ def _sizes(rng):
     return b, n, m
 
 
-@pytest.mark.parametrize("seed", range(100))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PP_FUZZ_SEEDS", "100"))))   # PP_FUZZ_SEEDS=1000 for a long run
 def test_fuzz_chamfer_and_labeled(cuda, search_mode, seed):
     from pytorch_points_amd.network.model_loss import nndistance, labeled_nndistance
     rng = np.random.default_rng(1000 + seed)

@@ -7,7 +7,8 @@ from pytorch_points_amd._ext import losses
 dev = torch.device("cuda:0")
 L = _lib.lib()
 mode = L.pp_debug_set_nmdistance_search; mode.argtypes = [ctypes.c_int]; mode.restype = None
-B, N = int(sys.argv[1]) if len(sys.argv) > 1 else 2, 16384
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 for kind in ("gaussian", "blobs8", "two_scales", "shapenet_like"):
     x1 = torch.from_numpy(bench._distribution(kind, 0, B, N)).to(dev); x2 = torch.from_numpy(bench._distribution(kind, 1, B, N)).to(dev)
     outs = []
