@@ -9,6 +9,8 @@ here is "gathered shards == the unsharded result, bitwise".
 
 FPS stays single-GPU (replicas only): its cost is a serial chain, not capacity.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -109,6 +111,7 @@ class PackedShardGather:
                      for _ in range(depth)]
         self.inflight = [None] * depth
         self.turn = 0
+        self._nccl = dist.get_backend(group) == "nccl"   # (asked once: the launch path is host-bound at config 2)
         # GPU buffers: the gathered bytes are unpacked (indices widened to int32, rank-major global batch) on
         # a SIDE stream right behind the collective, into per-slot outputs allocated once -- at 8 ranks that
         # is ~110 MiB of traffic per step that the stream issuing the searches never executes; it only waits
@@ -150,7 +153,7 @@ class PackedShardGather:
             v[1].copy_(d2.detach().reshape(-1))
             v[2].copy_(i1.reshape(-1))            # int32 -> int16 keeps the low 16 bits
             v[3].copy_(i2.reshape(-1))
-        if dist.get_backend(self.group) == "nccl":
+        if self._nccl:
             work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
         else:                                 # gloo (CPU tests)
             work = dist.all_gather(list(self.recv[slot].unbind(0)), self.send[slot], group=self.group,
@@ -182,13 +185,19 @@ class PackedShardGather:
                               torch.empty(w * b, self.n, dtype=torch.int32, device=dev),
                               torch.empty(w * b, self.m, dtype=torch.int32, device=dev))
         d1, d2, i1, i2 = self.out[slot]
-        with torch.cuda.stream(self.side):
+        # (set_stream twice instead of the `with torch.cuda.stream(...)` context manager, and the side stream's raw
+        #  handle straight to the C ABI: the exchange costs the issuing thread ~60 us per step, every piece counts)
+        prev = torch.cuda.current_stream(dev)
+        torch.cuda.set_stream(self.side)
+        try:
             work.wait()   # RCCL: the side stream waits for the collective (no host block); gloo: the host does
-            with _lib.on_device(dev) as stream:   # the current stream is the side stream here
-                _lib.check(_lib.lib().pp_shard_unpack_f32(
-                    _lib.ptr(r), w, self.nbytes_padded, b * self.n, b * self.m, 1 if self.compact else 0,
-                    _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2), stream), "shard_unpack")
+            _lib.check(_lib.lib().pp_shard_unpack_f32(
+                _lib.ptr(r), w, self.nbytes_padded, b * self.n, b * self.m, 1 if self.compact else 0,
+                _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2), ctypes.c_void_p(self.side.cuda_stream)),
+                "shard_unpack")
             self.done[slot].record(self.side)
+        finally:
+            torch.cuda.set_stream(prev)
 
     def wait(self, slot):
         """Blocks the current stream (not the host, on RCCL) until the gather of ``slot`` is done and unpacked,
