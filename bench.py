@@ -342,6 +342,13 @@ def bench_chamfer(args, dist, world, rank, device):
         maybe_exchange(d1, d2, i1, i2)
 
     # ---- the timed region: the autograd operator (eager) unless another issue mode is asked for ---------------
+    # The backward runs on the CALLING thread (torch.autograd.set_multithreading_enabled(False), a public switch):
+    # by default the engine hands every backward to its per-device worker thread and blocks on it, which costs this
+    # step ~50 us of host time (tools/host_probe2.py: 82 against 32 us per eager step) -- more than the kernels
+    # leave idle, so the default is host-bound and follows the box's other tenants.  The default-engine number is
+    # reported beside it as launch_modes_ms_per_step["eager_engine_threads"].
+    engine_threads_default = torch.autograd.is_multithreading_enabled()
+    torch.autograd.set_multithreading_enabled(False)
     want = "eager" if args.launch == "all" else args.launch
     if want == "graph" and gstep is None:
         want = "eager"
@@ -355,6 +362,9 @@ def bench_chamfer(args, dist, world, rank, device):
         modes["ext"] = run_timed(ext_step, 5, n_cal) / n_cal * 1e3
         if gstep is not None:
             modes["graph"] = run_timed(graph_step, 5, n_cal) / n_cal * 1e3
+        torch.autograd.set_multithreading_enabled(True)
+        modes["eager_engine_threads"] = run_timed(eager_step, 5, n_cal) / n_cal * 1e3
+        torch.autograd.set_multithreading_enabled(False)
     compute_ms = exchange_ms = None
     if dist is not None:
         # the two legs by themselves: the same steps without the exchange, and the exchange with nothing beside it
@@ -416,7 +426,9 @@ def bench_chamfer(args, dist, world, rank, device):
     c2 = (B, N, M) == (32, 16384, 16384)
     launch_text = {
         "eager": "torch.autograd.Function operator (nndistance forward, autograd backward), one Python call each: "
-                 "what a user of the drop-in API runs",
+                 "what a user of the drop-in API runs, with torch.autograd.set_multithreading_enabled(False) (the "
+                 "backward on the calling thread; 'eager_engine_threads' is the same with the engine's default worker "
+                 "thread, which is host-bound)",
         "ext": "two calls per step of the extension-module API (_ext.losses.nmdistance_forward / _backward) on "
                "static buffers: plain stream launches, same kernels as the autograd operator",
         "graph": "hipGraph replay of the step's launches (same kernels as the eager operator)"}
@@ -503,6 +515,7 @@ def bench_chamfer(args, dist, world, rank, device):
         out["other_distributions_fwd_ms"] = od
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the CPU leg runs at N=1 only
         out["cpu_baseline"] = cpu_baseline_chamfer(N, C)
+    torch.autograd.set_multithreading_enabled(engine_threads_default)
     return out
 
 
