@@ -159,11 +159,17 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
 // the smallest (distance bits, index) key it has seen -- for non-negative non-NaN distances the order
 // of the packed key is the order of "d < best || (d == best && id < bidx)", and a NaN distance (bits
 // above +inf) is never taken, as in the lane-per-query form -- and one wave-wide minimum ends a stage.
-template <bool LAB>
+// PIPE = false: one step of 64 candidates per round; a scan of more than kScanInline candidates (rows through a
+// crowded cell) is not started -- `skipped` -- and left to the pipelined form.
+// PIPE = true (serve_long_scans): four steps per round, their loads issued together: with one dependent load per step
+// a scan of thousands of candidates costs its length in memory round trips.
+constexpr unsigned kScanInline = 512;
+template <bool LAB, bool PIPE>
 __device__ __forceinline__ unsigned long long wave_scan_rows(int nrows, unsigned rs, unsigned re,
                                                              const pp::f4* __restrict__ sorted,
                                                              const float* __restrict__ slab, float qx, float qy,
-                                                             float qz, float ql, unsigned long long key) {
+                                                             float qz, float ql, unsigned long long key,
+                                                             bool& skipped) {
   const int lane = threadIdx.x & 63;
   const unsigned len = lane < nrows ? re - rs : 0u;
   unsigned incl = len;  // nrows <= 32: five steps
@@ -175,21 +181,57 @@ __device__ __forceinline__ unsigned long long wave_scan_rows(int nrows, unsigned
   const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
   const unsigned excl = incl - len;
   const unsigned shift = rs - excl;  // candidate c of row r sits at sorted[c + shift_r]
-  for (unsigned c0 = 0; c0 < total; c0 += 64) {
-    const unsigned c = c0 + lane;
-    unsigned add = 0;
-    for (int r = 0; r < nrows; ++r) {  // the last row whose first candidate is <= c (empty rows are overridden)
-      const unsigned ex = (unsigned)__builtin_amdgcn_readlane((int)excl, r);
-      const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)shift, r);
-      add = c >= ex ? sh : add;
+  if (!PIPE && total > kScanInline) {  // wave-uniform
+    skipped = true;
+    return key;
+  }
+  if constexpr (!PIPE) {
+    for (unsigned c0 = 0; c0 < total; c0 += 64) {
+      const unsigned c = c0 + lane;
+      unsigned add = 0;
+      for (int r = 0; r < nrows; ++r) {  // the last row whose first candidate is <= c (empty rows are overridden)
+        const unsigned ex = (unsigned)__builtin_amdgcn_readlane((int)excl, r);
+        const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)shift, r);
+        add = c >= ex ? sh : add;
+      }
+      if (c < total) {
+        const pp::f4 p = sorted[c + add];
+        const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
+        const unsigned long long cand =
+            ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+        const bool ok = !LAB || slab[c + add] == ql;
+        key = (ok && cand < key) ? cand : key;
+      }
     }
-    if (c < total) {
-      const pp::f4 p = sorted[c + add];
-      const float d = pp::chamfer_d3(p.x, p.y, p.z, qx, qy, qz);
-      const unsigned long long cand =
-          ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
-      const bool ok = !LAB || slab[c + add] == ql;
-      key = (ok && cand < key) ? cand : key;
+  } else {
+    for (unsigned c0 = 0; c0 < total; c0 += 256) {  // (a step past the end repeats the last candidate: harmless)
+      unsigned at[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned c = min(c0 + (unsigned)(u * 64 + lane), total - 1);
+        unsigned add = 0;
+        for (int r = 0; r < nrows; ++r) {
+          const unsigned ex = (unsigned)__builtin_amdgcn_readlane((int)excl, r);
+          const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)shift, r);
+          add = c >= ex ? sh : add;
+        }
+        at[u] = c + add;
+      }
+      pp::f4 p[4];
+      float pl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p[u] = sorted[at[u]];
+        if (LAB) pl[u] = slab[at[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+        const unsigned long long cand =
+            ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w);
+        const bool ok = !LAB || pl[u] == ql;
+        key = (ok && cand < key) ? cand : key;
+      }
     }
   }
   // wave-wide minimum
@@ -205,11 +247,11 @@ __device__ __forceinline__ unsigned long long wave_scan_rows(int nrows, unsigned
 // The wide stages for one query, executed by a whole wave (every lane active, all arguments wave-uniform):
 // cube of Chebyshev radius 1 around the query's cell, then 2.  Returns whether the query is settled;
 // (best, bidx) is the nearest examined candidate ((0, -1) for a labeled query whose label nobody carries).
-template <bool LAB>
+template <bool LAB, bool PIPE>
 __device__ __forceinline__ bool wide_stages_wave(float qx, float qy, float qz, float ql, const GridSet& g,
                                                  const unsigned* __restrict__ cell_start,
                                                  const pp::f4* __restrict__ sorted, const float* __restrict__ slab,
-                                                 float& best, int& bidx) {
+                                                 float& best, int& bidx, bool& skipped) {
   const int lane = threadIdx.x & 63;
   const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
   const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
@@ -242,7 +284,8 @@ __device__ __forceinline__ bool wide_stages_wave(float qx, float qy, float qz, f
       rs = cell_start[c + x0];
       re = cell_start[c + x1 + 1];
     }
-    key = wave_scan_rows<LAB>(side * side, rs, re, sorted, slab, qx, qy, qz, ql, key);
+    key = wave_scan_rows<LAB, PIPE>(side * side, rs, re, sorted, slab, qx, qy, qz, ql, key, skipped);
+    if (skipped) break;  // (PIPE = false only) a long scan: the whole query goes to serve_long_scans
     const float kbest = __uint_as_float((unsigned)(key >> 32));
     const int kidx = (int)(unsigned)key;
     const bool all = cz - rho <= 0 && cz + rho >= g.gz - 1 && cy - rho <= 0 && cy + rho >= g.gy - 1 &&
@@ -460,6 +503,101 @@ struct Found {
   int bidx;
   float aux;  // lane_cube_search: 1 settled, 0 not, 2 gave up; refined_block_search: the threshold it reached
 };
+// The whole-wave cubes for the queries whose scans are long (rows through crowded cells), one after the other, with
+// the pipelined scan.  Out of line; never called for evenly sampled surfaces.  (The grid's descriptor by POINTER:
+// by value it would occupy sixteen of the registers a callee may use without saving them.)
+struct OpenMask {
+  unsigned lo, hi;
+};
+template <bool LAB>
+__device__ __attribute__((noinline)) OpenMask serve_long_scans(const GridSet* __restrict__ gp,
+                                                               const unsigned* __restrict__ cell_start,
+                                                               const pp::f4* __restrict__ sorted,
+                                                               const float* __restrict__ slab, float* __restrict__ od,
+                                                               int* __restrict__ oi, float qx, float qy, float qz,
+                                                               float ql, int j, unsigned todo_lo, unsigned todo_hi) {
+  const GridSet g = *gp;
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)todo_hi) << 32) |
+                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)todo_lo);
+  unsigned long long open = 0ull;
+  while (todo) {
+    const int l = (int)__builtin_ctzll(todo);
+    todo &= todo - 1;
+    const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
+    const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), l));
+    const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), l));
+    const float wl = LAB ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ql), l)) : 0.0f;
+    const int wj = __builtin_amdgcn_readlane(j, l);
+    float wbest;
+    int widx;
+    bool skipped = false;
+    if (wide_stages_wave<LAB, true>(wx, wy, wz, wl, g, cell_start, sorted, slab, wbest, widx, skipped)) {
+      if (lane == 0) {
+        od[wj] = wbest;
+        oi[wj] = widx;
+      }
+    } else {
+      open |= 1ull << l;
+    }
+  }
+  OpenMask o;
+  o.lo = (unsigned)open;
+  o.hi = (unsigned)(open >> 32);
+  return o;
+}
+
+// The queries of a wave left for the whole-wave cubes, one after the other (out of line: one call per wave that has
+// any -- one in five at config 2 -- so the cubes' code and registers are not the search kernel's).  Short scans are
+// done here; a query whose cubes run through crowded cells goes on to serve_long_scans.  Writes the results of the
+// queries it settles; returns the mask of those the cube of radius 2 left open.
+template <bool LAB>
+__device__ __attribute__((noinline)) OpenMask serve_pending(const GridSet* __restrict__ gp,
+                                                            const unsigned* __restrict__ cell_start,
+                                                            const pp::f4* __restrict__ sorted,
+                                                            const float* __restrict__ slab, float* __restrict__ od,
+                                                            int* __restrict__ oi, float qx, float qy, float qz, float ql,
+                                                            int j, unsigned pending_lo, unsigned pending_hi) {
+  const GridSet g = *gp;
+  const int lane = threadIdx.x & 63;
+  unsigned long long pending = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)pending_hi) << 32) |
+                               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)pending_lo);
+  unsigned long long open = 0ull, longscan = 0ull;
+  while (pending) {
+    const int l = (int)__builtin_ctzll(pending);
+    pending &= pending - 1;
+    const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
+    const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), l));
+    const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), l));
+    const float wl = LAB ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ql), l)) : 0.0f;
+    const int wj = __builtin_amdgcn_readlane(j, l);
+    float wbest;
+    int widx;
+    bool skipped = false;
+    const bool settled = wide_stages_wave<LAB, false>(wx, wy, wz, wl, g, cell_start, sorted, slab, wbest, widx, skipped);
+    if (skipped) {
+      longscan |= 1ull << l;
+    } else if (settled) {
+      if (lane == 0) {
+        od[wj] = wbest;
+        oi[wj] = widx;
+      }
+    } else {
+      open |= 1ull << l;
+    }
+  }
+  if (longscan) {  // wave-uniform: cubes through crowded cells (never on an evenly sampled surface)
+    const OpenMask om = serve_long_scans<LAB>(gp, cell_start, sorted, slab, od, oi, qx, qy, qz, ql, j, (unsigned)longscan,
+                                              (unsigned)(longscan >> 32));
+    open |= ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.hi) << 32) |
+            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.lo);
+  }
+  OpenMask o;
+  o.lo = (unsigned)open;
+  o.hi = (unsigned)(open >> 32);
+  return o;
+}
+
 template <bool LAB>
 __device__ __attribute__((noinline)) Found refined_block_search(
     const GridSet g, const unsigned* __restrict__ cell_start, const pp::f4* __restrict__ sorted,
@@ -1254,25 +1392,11 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
     open |= pending;
     pending = 0ull;
   }
-  while (pending) {
-    const int l = (int)__builtin_ctzll(pending);
-    pending &= pending - 1;
-    const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
-    const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), l));
-    const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), l));
-    const float wl = LAB ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ql), l)) : 0.0f;
-    const int wj = __builtin_amdgcn_readlane(j, l);
-    float wbest;
-    int widx;
-    const bool settled = wide_stages_wave<LAB>(wx, wy, wz, wl, g, cell_start, sorted, slab, wbest, widx);
-    if (settled) {
-      if (lane == 0) {
-        od[wj] = wbest;
-        oi[wj] = widx;
-      }
-    } else {
-      open |= 1ull << l;
-    }
+  if (pending) {  // wave-uniform
+    const OpenMask om = serve_pending<LAB>(reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted, slab, od,
+                                           oi, qx, qy, qz, ql, j, (unsigned)pending, (unsigned)(pending >> 32));
+    open |= ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.hi) << 32) |
+            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.lo);
   }
   PP_QPHASE(7);
   if (open) {  // wave-uniform: far from everything the cubes hold -- group by group, the whole wave (see above)
