@@ -270,9 +270,7 @@ __device__ __forceinline__ bool wide_stages_wave(float qx, float qy, float qz, f
   };
   unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, no index)
   bool resolved = false;
-#pragma unroll
-  for (int rho = 1; rho <= 2; ++rho) {  // cube of radius 1, then 2 (re-examining cells is harmless)
-    if (resolved) break;
+  auto stage = [&](const int rho) {  // cube of radius rho (re-examining cells is harmless)
     const int side = 2 * rho + 1;
     const int x0 = max(cx - rho, 0), x1 = min(cx + rho, g.gx - 1);
     // lane r < side*side fetches the range of row (cz - rho + r / side, cy - rho + r % side)
@@ -285,13 +283,22 @@ __device__ __forceinline__ bool wide_stages_wave(float qx, float qy, float qz, f
       re = cell_start[c + x1 + 1];
     }
     key = wave_scan_rows<LAB, PIPE>(side * side, rs, re, sorted, slab, qx, qy, qz, ql, key, skipped);
-    if (skipped) break;  // (PIPE = false only) a long scan: the whole query goes to serve_long_scans
+    if (skipped) return;  // (PIPE = false only) a long scan: the whole query goes to serve_long_scans
     const float kbest = __uint_as_float((unsigned)(key >> 32));
     const int kidx = (int)(unsigned)key;
     const bool all = cz - rho <= 0 && cz + rho >= g.gz - 1 && cy - rho <= 0 && cy + rho >= g.gy - 1 &&
                      cx - rho <= 0 && cx + rho >= g.gx - 1;
     const float reach = g.h * reach_cube(rho);
     resolved = all ? (LAB || kidx != 0x7fffffff) : (kbest < reach * reach * kBoundSlack);
+  };
+  if constexpr (PIPE) {  // the two radii as constants: the row search of the long scans is unrolled
+    stage(1);
+    if (!resolved && !skipped) stage(2);
+  } else {
+    // one body for both radii (the short scans live in a leaf function that must stay within the registers a callee
+    // need not save: serve_pending)
+#pragma nounroll
+    for (int rho = 1; rho <= 2 && !resolved && !skipped; ++rho) stage(rho);
   }
   best = __uint_as_float((unsigned)(key >> 32));
   bidx = (int)(unsigned)key;
@@ -507,7 +514,8 @@ struct Found {
 // the pipelined scan.  Out of line; never called for evenly sampled surfaces.  (The grid's descriptor by POINTER:
 // by value it would occupy sixteen of the registers a callee may use without saving them.)
 struct OpenMask {
-  unsigned lo, hi;
+  unsigned lo, hi;      // queries the cube of radius 2 left open
+  unsigned llo, lhi;    // serve_pending: queries whose scans are long (for serve_long_scans)
 };
 template <bool LAB>
 __device__ __attribute__((noinline)) OpenMask serve_long_scans(const GridSet* __restrict__ gp,
@@ -544,13 +552,14 @@ __device__ __attribute__((noinline)) OpenMask serve_long_scans(const GridSet* __
   OpenMask o;
   o.lo = (unsigned)open;
   o.hi = (unsigned)(open >> 32);
+  o.llo = o.lhi = 0u;
   return o;
 }
 
 // The queries of a wave left for the whole-wave cubes, one after the other (out of line: one call per wave that has
 // any -- one in five at config 2 -- so the cubes' code and registers are not the search kernel's).  Short scans are
-// done here; a query whose cubes run through crowded cells goes on to serve_long_scans.  Writes the results of the
-// queries it settles; returns the mask of those the cube of radius 2 left open.
+// done here; a query whose cubes run through crowded cells is reported back for serve_long_scans.  Writes the results
+// of the queries it settles; returns the masks of those the cube of radius 2 left open and of the long scans.
 template <bool LAB>
 __device__ __attribute__((noinline)) OpenMask serve_pending(const GridSet* __restrict__ gp,
                                                             const unsigned* __restrict__ cell_start,
@@ -586,15 +595,13 @@ __device__ __attribute__((noinline)) OpenMask serve_pending(const GridSet* __res
       open |= 1ull << l;
     }
   }
-  if (longscan) {  // wave-uniform: cubes through crowded cells (never on an evenly sampled surface)
-    const OpenMask om = serve_long_scans<LAB>(gp, cell_start, sorted, slab, od, oi, qx, qy, qz, ql, j, (unsigned)longscan,
-                                              (unsigned)(longscan >> 32));
-    open |= ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.hi) << 32) |
-            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.lo);
-  }
+  // (a LEAF: values that had to live across a call in here would sit in registers the function must save and
+  //  restore -- 18 MB of scratch traffic per launch at config 2 when it called serve_long_scans itself)
   OpenMask o;
   o.lo = (unsigned)open;
   o.hi = (unsigned)(open >> 32);
+  o.llo = (unsigned)longscan;
+  o.lhi = (unsigned)(longscan >> 32);
   return o;
 }
 
@@ -1397,6 +1404,15 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
                                            oi, qx, qy, qz, ql, j, (unsigned)pending, (unsigned)(pending >> 32));
     open |= ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.hi) << 32) |
             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.lo);
+    const unsigned long long longscan = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.lhi) << 32) |
+                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.llo);
+    if (longscan) {  // wave-uniform: cubes through crowded cells (never on an evenly sampled surface)
+      const OpenMask ol = serve_long_scans<LAB>(reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted,
+                                                slab, od, oi, qx, qy, qz, ql, j, (unsigned)longscan,
+                                                (unsigned)(longscan >> 32));
+      open |= ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ol.hi) << 32) |
+              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ol.lo);
+    }
   }
   PP_QPHASE(7);
   if (open) {  // wave-uniform: far from everything the cubes hold -- group by group, the whole wave (see above)
