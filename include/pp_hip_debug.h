@@ -19,8 +19,11 @@ extern "C" {
 void pp_debug_set_nmdistance_search(int mode);
 /* brute-force kernel variant (Q queries per lane, G points per group, packed / prefetch forms; chamfer.hip) */
 void pp_debug_set_nmdistance_variant(int variant);
-/* grid search: staged points per wave of the search kernel (0 = 384; 320, 512) */
+/* grid search, wave-private form of the search kernel: staged points per wave (320, 384, 512; selecting one also
+ * selects that form; 0 = the default, the tile form) */
 void pp_debug_set_nmdistance_stage_cap(int points);
+/* grid search, tile form: queries per workgroup (0 = 512; 256, 768); -1 = the wave-private form */
+void pp_debug_set_nmdistance_tile(int queries);
 /* labeled Chamfer brute force: 1 = the one-lane-per-query kernel */
 void pp_debug_set_labeled_variant(int variant);
 /* Chamfer backward: 1 LDS doubles, 2 CSR lists, 3 LDS fp32 columns, 4 global atomics, 5 deterministic */

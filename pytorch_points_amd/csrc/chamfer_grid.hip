@@ -56,7 +56,7 @@ extern "C" int pp_debug_read_query_wave_phases(void* out) {  // kQWaves x 10 uns
 #define PP_QPHASE(n)                                                                     \
   do {                                                                                   \
     const unsigned long long pp_now = wall_clock64();                                    \
-    const unsigned pp_w = blockIdx.x * 4u + (threadIdx.x >> 6);                          \
+    const unsigned pp_w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                          \
     if ((threadIdx.x & 63) == 0 && pp_w < (unsigned)kQWaves) g_qwave[pp_w][n] = (unsigned)(pp_now - pp_prev); \
     pp_prev = pp_now;                                                                    \
     if (threadIdx.x == 0 && (blockIdx.x & 511) == 0 && (blockIdx.x >> 9) < 8)            \
@@ -987,8 +987,13 @@ __device__ __forceinline__ float min2(float a, float b) {
   return r;
 }
 
-template <bool LAB, int CAPW>
-__global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __restrict__ xyz1,
+// TQ = 0: the form above (256-thread workgroups of four independent waves, a wave-private region of CAPW points).
+// TQ > 0 (round 3, the default): a workgroup is a TILE of TQ consecutive queries; it stages the WHOLE z-layers of
+// the reference grid that its queries' blocks touch -- one contiguous piece of the sorted cloud, found with one
+// min / max reduction and two scalar loads instead of a per-wave region of row ranges per layer -- into ONE LDS
+// image of CAPW points shared by its waves (two workgroup barriers).  Everything after the copy is the same code.
+template <bool LAB, int CAPW, int TQ>
+__global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6) void grid_query_wave_kernel(const float* __restrict__ xyz1,
                                                               const float* __restrict__ xyz2,
                                                               float* __restrict__ dist1, int* __restrict__ idx1,
                                                               float* __restrict__ dist2, int* __restrict__ idx2,
@@ -1000,6 +1005,8 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
   if (V >= total) return;
   PP_QPHASE_DECL;
   PP_QPHASE(0);
+  constexpr int kT = TQ ? TQ : 256;  // threads = queries per workgroup
+  constexpr int kW = kT / 64;
   const int per_b = tiles1 + tiles2;
   const int b = V / per_b;
   const int r = V - b * per_b;
@@ -1007,8 +1014,8 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
   const int tile = dir ? r - tiles1 : r;
   const int nq = dir ? M : N, nr = dir ? N : M;
   const int t = threadIdx.x, lane = t & 63;
-  const bool valid = tile * 256 + t < nq;
-  const int jj = valid ? tile * 256 + t : nq - 1;
+  const bool valid = tile * kT + t < nq;
+  const int jj = valid ? tile * kT + t : nq - 1;
   const int set = 2 * b + dir;
   const Layout L = make_layout(B, N, M, LAB);
   const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[set];
@@ -1056,9 +1063,13 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
       reinterpret_cast<const pp::SubGrid*>(ws + L.sub_desc) + set_sub_desc_offset(b, dir, N, M);
 
   // (+4: a group of four is read from any staged position without clamping; the tail repeats a real point)
-  __shared__ pp::f4 s_pts[4][CAPW + 4];
-  __shared__ float s_lab[4][LAB ? CAPW + 4 : 1];
+  constexpr int kSlices = TQ ? 1 : 4;
+  __shared__ pp::f4 s_pts[kSlices][CAPW + 4];
+  __shared__ float s_lab[kSlices][LAB ? CAPW + 4 : 1];
+  __shared__ float s_zr[TQ ? 2 * kW : 1];  // tile mode: every wave's (-lowest, highest) layer
+  static_assert(!TQ || CAPW + 4 >= kW * kGroupBatch, "the group search takes a slice of the image per wave");
   const int wave = pp::wave_id_uniform();
+  const int slice = TQ ? 0 : wave;
 
   // Stage A: the 2x2x2 block of cells nearest to q' (own cell + the neighbour on the side of the cell q' lies
   // in, per axis).  A point outside that block is beyond the far face of q''s cell along some axis (>= h/2
@@ -1169,9 +1180,36 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
       staged = n_staged <= (unsigned)CAPW;
     }
   };
+  // Tile mode: the layers the workgroup's blocks touch, [Lz, Lz + nz), are one contiguous piece of the sorted cloud
+  // (cells are z-major): `tbase` = its first point.  Every lane's rows lie inside it by construction.
+  unsigned tbase = 0;
+  auto region_tile = [&](const bool dfr) {
+    float v[6] = {dfr ? ninf : -(float)z0, dfr ? ninf : (float)z1, ninf, ninf, ninf, ninf};
+    pp::wave_reduce6_dpp<false, 6>(v);
+    if (lane == 63) {
+      s_zr[2 * wave] = v[0];
+      s_zr[2 * wave + 1] = v[1];
+    }
+    __syncthreads();
+    float w[6] = {lane < kW ? s_zr[2 * (lane < kW ? lane : 0)] : ninf, lane < kW ? s_zr[2 * (lane < kW ? lane : 0) + 1] : ninf,
+                  ninf, ninf, ninf, ninf};
+    pp::wave_reduce6_dpp<false, 4>(w);  // kW <= 16 values in lanes 0..15: lane 15 holds the result
+    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[0]), 15));
+    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[1]), 15));
+    staged = hi >= 0.0f;  // (no lane takes part: nothing to stage)
+    Lz = staged ? -(int)lo : 0;
+    nz = staged ? (int)hi - Lz + 1 : 0;
+    if (staged) {
+      const int c0 = __builtin_amdgcn_readfirstlane(Lz * g.gy * g.gx);
+      const int c1 = __builtin_amdgcn_readfirstlane((Lz + nz) * g.gy * g.gx);
+      tbase = cell_start[c0];
+      n_staged = cell_start[c1] - tbase;
+      staged = n_staged <= (unsigned)CAPW;
+    }
+  };
   bool deferred = false;
   if (!refined_set) {  // wave-uniform
-    region(false, false);
+    if constexpr (TQ != 0) region_tile(false); else region(false, false);
     rows_finish();
   } else {
     rows_finish();
@@ -1179,12 +1217,38 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
     if (deferred) {
       re0 = rs0; re1 = rs1; re2 = rs2; re3 = rs3;
     }
-    region(deferred, !__any(!deferred));
+    if constexpr (TQ != 0) region_tile(deferred); else region(deferred, !__any(!deferred));
   }
   PP_QPHASE(2);
-  const lds_f4_ptr lpts = (lds_f4_ptr)(&s_pts[wave][0]);
-  const lds_f_ptr llab = (lds_f_ptr)(&s_lab[wave][0]);
-  if (staged) {
+  const lds_f4_ptr lpts = (lds_f4_ptr)(&s_pts[slice][0]);
+  const lds_f_ptr llab = (lds_f_ptr)(&s_lab[slice][0]);
+  if constexpr (TQ != 0) {
+    if (staged) {  // workgroup-uniform
+      rs0 -= tbase; re0 -= tbase; rs1 -= tbase; re1 -= tbase;
+      rs2 -= tbase; re2 -= tbase; rs3 -= tbase; re3 -= tbase;
+      for (unsigned p0 = 0; p0 < n_staged; p0 += 4 * kT) {
+        pp::f4 v[4];
+        float vl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned p = min(p0 + (unsigned)(u * kT + t), n_staged - 1);  // (duplicates store the same value)
+          v[u] = sorted[p + tbase];
+          if (LAB) vl[u] = slab[p + tbase];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned p = min(p0 + (unsigned)(u * kT + t), n_staged - 1);
+          (&s_pts[0][0])[p] = v[u];
+          if (LAB) (&s_lab[0][0])[p] = vl[u];
+        }
+      }
+      if (n_staged > 0 && t < 4) {  // the padding repeats the last point (a real candidate)
+        (&s_pts[0][0])[n_staged + t] = sorted[tbase + n_staged - 1];
+        if (LAB) (&s_lab[0][0])[n_staged + t] = slab[tbase + n_staged - 1];
+      }
+    }
+    __syncthreads();
+  } else if (staged) {
     // every lane's rows live in its two layers: global position -> LDS position
     const unsigned dA = __shfl(delta, deferred ? 0 : cz - Lz);
     const int zb = cz + sz;
@@ -1415,13 +1479,15 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
     }
   }
   PP_QPHASE(7);
+  if constexpr (TQ != 0) __syncthreads();  // every wave has left the image: the group search takes it over, a slice per wave
   if (open) {  // wave-uniform: far from everything the cubes hold -- group by group, the whole wave (see above)
     const bool finite = __builtin_isfinite(qx) && __builtin_isfinite(qy) && __builtin_isfinite(qz);
     const unsigned long long todo = open & __ballot(finite);
     if (todo) {
       const Found f = wave_group_search<LAB>(g, cell_start, sorted, slab, qx, qy, qz, ql, best, bidx, (unsigned)todo,
-                                             (unsigned)(todo >> 32), (lds_f4_wptr)(&s_pts[wave][0]),
-                                             (lds_f_wptr)(&s_lab[wave][0]));
+                                             (unsigned)(todo >> 32),
+                                             (lds_f4_wptr)(TQ ? &s_pts[0][wave * kGroupBatch] : &s_pts[slice][0]),
+                                             (lds_f_wptr)(TQ ? &s_lab[0][LAB ? wave * kGroupBatch : 0] : &s_lab[slice][0]));
       if ((todo >> lane) & 1ull) {
         const bool none = f.bidx == 0x7fffffff;  // (labeled: nobody carries this label -- ref nmdistance_cuda.cu:110-113)
         od[j] = (LAB && none) ? 0.0f : f.best;
@@ -1450,9 +1516,13 @@ __global__ __launch_bounds__(256, 6) void grid_query_wave_kernel(const float* __
 // launches); 1 = brute force; 2 = grid wherever it is structurally possible (tests)
 static pp::Knob g_grid_mode;
 extern "C" void pp_debug_set_nmdistance_search(int v) { g_grid_mode.set(v); }
-// LDS points per wave of the search kernel: 0 = default (384); 320 / 512 for comparison
+// LDS points per wave of the wave-private form of the search kernel (320 / 384 / 512); selecting one also selects that
+// form.  0 = default: the tile form below.
 static pp::Knob g_stage_cap;
 extern "C" void pp_debug_set_nmdistance_stage_cap(int v) { g_stage_cap.set(v); }
+// queries per workgroup of the tile form: 0 = default (512); 256, 512, 768; -1 = the wave-private form (CAPW 384)
+static pp::Knob g_tile;
+extern "C" void pp_debug_set_nmdistance_tile(int v) { g_tile.set(v); }
 
 // Per-kernel timing of the grid forward (bench.py's roofline of the dominant kernel): when switched on, HIP
 // events are recorded on the launch stream before the build, between the two kernels and after the search;
@@ -1515,17 +1585,28 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
       xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr);
   PP_RETURN_IF_LAUNCH_FAILED();
   if (timing) record_timing_event(1, s);
-  const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
+  const int cap = g_stage_cap, tile = g_tile;
+  const bool wave_form = cap == 320 || cap == 384 || cap == 512 || tile == -1;
+  const int tq = wave_form ? 256 : (tile == 256 || tile == 768 ? tile : 512);
+  const int tiles1 = (N + tq - 1) / tq, tiles2 = (M + tq - 1) / tq;
   const long long blocks = (long long)B * (tiles1 + tiles2);
   if (blocks > 0x7fffffffLL) return PP_EINVAL;
   const int per_xcd = (int)((blocks + 7) / 8);
-#define PP_LAUNCH_W(CAP_)                                                                                  \
-  grid_query_wave_kernel<LAB, CAP_><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(                       \
+#define PP_LAUNCH_W(CAP_, TQ_)                                                                             \
+  grid_query_wave_kernel<LAB, CAP_, TQ_><<<dim3((unsigned)(per_xcd * 8)), dim3(TQ_ ? TQ_ : 256), 0, s>>>(      \
       xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2)
-  switch (g_stage_cap) {
-    case 320: PP_LAUNCH_W(320); break;
-    case 512: PP_LAUNCH_W(512); break;
-    default: PP_LAUNCH_W(384); break;
+  if (wave_form) {
+    switch (cap) {
+      case 320: PP_LAUNCH_W(320, 0); break;
+      case 512: PP_LAUNCH_W(512, 0); break;
+      default: PP_LAUNCH_W(384, 0); break;
+    }
+  } else {
+    switch (tq) {
+      case 256: PP_LAUNCH_W(1532, 256); break;
+      case 768: PP_LAUNCH_W(3068, 768); break;
+      default: PP_LAUNCH_W(2556, 512); break;
+    }
   }
 #undef PP_LAUNCH_W
   PP_RETURN_IF_LAUNCH_FAILED();

@@ -1,4 +1,4 @@
-"""python tools/fwd_loop.py QUERY_MODE [kind] [iters]: nndistance forward at config 2 in a loop (for rocprofv3)"""
+"""python tools/fwd_loop.py TILE_MODE (pp_debug_set_nmdistance_tile) [kind] [iters]: nndistance forward at config 2 in a loop (for rocprofv3)"""
 import ctypes, sys, numpy as np, torch
 sys.path.insert(0, ".")
 from pytorch_points_amd import _lib, synthetic as S
@@ -8,7 +8,7 @@ B, N = 32, 16384
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 L = _lib.lib()
-setq = L.pp_debug_set_nmdistance_stage_cap; setq.argtypes = [ctypes.c_int]; setq.restype = None
+setq = L.pp_debug_set_nmdistance_tile; setq.argtypes = [ctypes.c_int]; setq.restype = None
 setq(mode)
 x1 = torch.from_numpy(S.unit_sphere(0, B, N)).to(dev); x2 = torch.from_numpy(S.unit_sphere(1, B, N)).to(dev)
 d1 = torch.empty(B, N, device=dev); d2 = torch.empty(B, N, device=dev)

@@ -1,13 +1,14 @@
 """Phase clocks of grid_query_wave_kernel (p0 rows, p1 region, p2 copy, p3 stage A, p4 second level, p5 lane cubes,
-p6 whole-wave cubes, p7 group search, p8 the rest) (a -DPP_QUERY_PROBE build of the library, made by this script into
-/tmp; the shipped library carries no stamps).  python tools/query_probe.py [mode ...]"""
+p6 whole-wave cubes, p7 group search, p8 the rest) (a -DPP_QUERY_PROBE build of the library,
+tools/libpp_hip_probe.so; the shipped library carries no stamps).  python tools/query_probe.py [tile mode ...]
+(modes: pp_debug_set_nmdistance_tile: -1 wave-private form, 256 / 512 / 768 queries per tile)"""
 import ctypes, os, subprocess, sys, numpy as np, torch
 sys.path.insert(0, ".")
 from pytorch_points_amd import _build
-lib = "/tmp/libpp_hip_probe.so"
-cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), *_build.HIPCC_FLAGS, "-DPP_QUERY_PROBE", "-I" + _build.INCLUDE, "-I" + _build.CSRC,
-       *_build.sources(), "-o", lib]
-subprocess.run(cmd, check=True)
+# built in the container with tools/build_probe_lib.sh (hipcc takes minutes for the whole library: not on the GPU box)
+lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpp_hip_probe.so")
+if not os.path.exists(lib):
+    subprocess.run(["bash", os.path.join(os.path.dirname(os.path.abspath(__file__)), "build_probe_lib.sh")], check=True)
 _build.LIB = lib
 _build.is_stale = lambda: False
 from pytorch_points_amd import _lib, synthetic as S
@@ -15,7 +16,7 @@ from pytorch_points_amd._ext import losses
 L = _lib.lib()
 dev = torch.device("cuda:0")
 B, N = 32, 16384
-setq = L.pp_debug_set_nmdistance_stage_cap; setq.argtypes = [ctypes.c_int]; setq.restype = None
+setq = L.pp_debug_set_nmdistance_tile; setq.argtypes = [ctypes.c_int]; setq.restype = None
 rd = L.pp_debug_read_query_phases; rd.argtypes = [ctypes.c_void_p]; rd.restype = ctypes.c_int
 import bench
 kind = os.environ.get("PP_PROBE_KIND", "sphere")
@@ -25,7 +26,7 @@ else:
     x1 = torch.from_numpy(bench._distribution(kind, 0, B, N)).to(dev); x2 = torch.from_numpy(bench._distribution(kind, 1, B, N)).to(dev)
 d1 = torch.empty(B, N, device=dev); d2 = torch.empty(B, N, device=dev)
 i1 = torch.empty(B, N, dtype=torch.int32, device=dev); i2 = torch.empty(B, N, dtype=torch.int32, device=dev)
-for mode in [int(a) for a in sys.argv[1:]] or [384]:
+for mode in [int(a) for a in sys.argv[1:]] or [0]:
     setq(mode)
     for _ in range(5):
         losses.nmdistance_forward(x1, x2, d1, d2, i1, i2)
@@ -42,7 +43,7 @@ for mode in [int(a) for a in sys.argv[1:]] or [384]:
     assert rdw(wv.ctypes.data) == 0
     nw = min(1 << 17, ((B * ((N + 255) // 256) * 2 + 7) // 8) * 8 * 4)
     wv = wv[:nw, 1:].astype(np.float64) / 100.0
-    print("   per wave, us:  " + " ".join("p%d mean %.1f max %.1f@wg%d |" % (k, wv[:, k].mean(), wv[:, k].max(), wv[:, k].argmax() // 4) for k in range(9)))
+    print("   per wave, us:  " + " ".join("p%d mean %.1f max %.1f@wave%d |" % (k, wv[:, k].mean(), wv[:, k].max(), wv[:, k].argmax()) for k in range(9)))
     gs = np.zeros(8, np.uint64)
     rdg = L.pp_debug_read_query_group_stats; rdg.argtypes = [ctypes.c_void_p, ctypes.c_int]; rdg.restype = ctypes.c_int
     assert rdg(gs.ctypes.data, 1) == 0
@@ -50,9 +51,10 @@ for mode in [int(a) for a in sys.argv[1:]] or [384]:
     tot = wv.sum(1)
     print("   wave total: mean %.1f  p99 %.1f  max %.1f us; waves over 4x the mean: %d" % (tot.mean(), np.percentile(tot, 99), tot.max(), int((tot > 4 * tot.mean()).sum())))
     print("mode %d: fwd %.1f us" % (mode, a.elapsed_time(b) / 20 * 1e3))
+    ph = ph[ph[:, 0] > 0]
     t0 = ph[:, 0].min()
     print("   kernel end (last stamped wg) +%.1f us" % ((int(ph[:, 9].max()) - int(t0)) / 100.0))
-    for w in range(8):
+    for w in range(len(ph)):
         d = (ph[w, 1:10].astype(np.int64) - ph[w, 0:9].astype(np.int64)) / 100.0
         print("   wg %4d start +%.2f us: " % (w * 512, (int(ph[w, 0]) - int(t0)) / 100.0) + " ".join("p%d %.2f" % (k, v) for k, v in enumerate(d)) +
               "  total %.2f" % ((int(ph[w, 9]) - int(ph[w, 0])) / 100.0))
