@@ -87,8 +87,10 @@ constexpr float kBoundSlack = 0.999f;
 //   [.., +16*T)                    float4 sorted2[T]  spare copy the refinement sorts through
 //   [.., +4*T, +4*T)               float slab[T], slab2[T]   labels in sorted order + spare (labeled Chamfer only)
 // (the second-level arrays are only touched for sets that have crowded cells: never at config 2)
+//   [.., +4 * S * kBuildSlabs * 2 * chunks)  int tile_z[S][kBuildSlabs][chunks][2]   chunk table (grid_common.h: kChunk)
 struct Layout {
-  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, total;
+  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, tile_z, total;
+  int chunks;  // chunk-table entries per set and slab (0: sets too large for the table)
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
   Layout L;
@@ -101,7 +103,10 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   L.sorted2 = L.sub_desc + ((32 * (T / pp::kCrowd + 2 * S) + 255) / 256) * 256;
   L.slab = L.sorted2 + 16 * T;
   L.slab2 = L.slab + (labeled ? 4 * T : 0);
-  L.total = L.slab2 + (labeled ? 4 * T : 0);
+  L.tile_z = ((L.slab2 + (labeled ? 4 * T : 0) + 255) / 256) * 256;
+  const int chq = ((N > M ? N : M) + pp::kChunk - 1) / pp::kChunk;
+  L.chunks = chq <= pp::kChunkMax ? chq : 0;
+  L.total = L.tile_z + 4 * S * pp::kBuildSlabs * 2 * (size_t)L.chunks;
   return L;
 }
 // second-level arrays of set (b, dir): first table entry / first descriptor
@@ -147,7 +152,8 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
       reinterpret_cast<unsigned*>(ws + L.sub_start) + set_sub_start_offset(b, dir, N, M),
       reinterpret_cast<pp::SubGrid*>(ws + L.sub_desc) + set_sub_desc_offset(b, dir, N, M),
       reinterpret_cast<pp::f4*>(ws + L.sorted2) + set_point_offset(b, dir, N, M),
-      labeled ? reinterpret_cast<float*>(ws + L.slab2) + set_point_offset(b, dir, N, M) : nullptr);
+      labeled ? reinterpret_cast<float*>(ws + L.slab2) + set_point_offset(b, dir, N, M) : nullptr,
+      L.chunks ? reinterpret_cast<int*>(ws + L.tile_z) + (size_t)set * pp::kBuildSlabs * 2 * L.chunks : nullptr, L.chunks);
 }
 
 // Stages B and C (cubes of Chebyshev radius 1 and 2 around the query's cell) for the queries stage A left
@@ -987,6 +993,32 @@ __device__ __forceinline__ float min2(float a, float b) {
   return r;
 }
 
+// byte position in the tile's image of group k of a lane's sequence (lean front; everything by value)
+__device__ __forceinline__ unsigned lean_group_pos(unsigned k, unsigned T1, unsigned T2, unsigned T3, unsigned a0,
+                                                   unsigned a1, unsigned a2, unsigned a3, unsigned endb) {
+  const unsigned a = k < T1 ? a0 : (k < T2 ? a1 : (k < T3 ? a2 : a3));
+  return min(a + (k << 6), endb);
+}
+
+// Two wave-wide max reductions at once, in place, through DPP (see pp::wave_reduce6_dpp; two interleaved chains need
+// one more wait state between dependent DPP operations).  ROWS: only inside every row of 16 lanes (lane 15 of a row
+// holds that row's result); otherwise lane 63 holds the wave's.  Every lane must be active.
+#define PP_DPP2_STEP(CTRL) \
+  "v_max_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+template <bool ROWS>
+__device__ __forceinline__ void wave_max2_dpp(float& a, float& b) {
+  if constexpr (ROWS)
+    asm volatile("s_nop 1\n\t" PP_DPP2_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") PP_DPP2_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     PP_DPP2_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") PP_DPP2_STEP("row_shr:8 row_mask:0xf bank_mask:0xf") "s_nop 0"
+                 : "+v"(a), "+v"(b));
+  else
+    asm volatile("s_nop 1\n\t" PP_DPP2_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") PP_DPP2_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+                     PP_DPP2_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") PP_DPP2_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+                         PP_DPP2_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") PP_DPP2_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
+                 : "+v"(a), "+v"(b));
+}
+typedef const char __attribute__((address_space(3))) * lds_c_ptr;
+
 // TQ = 0: the form above (256-thread workgroups of four independent waves, a wave-private region of CAPW points).
 // TQ > 0 (round 3, the default): a workgroup is a TILE of TQ consecutive queries; it stages the WHOLE z-layers of
 // the reference grid that its queries' blocks touch -- one contiguous piece of the sorted cloud, found with one
@@ -1067,10 +1099,192 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
   __shared__ pp::f4 s_pts[kSlices][CAPW + 4];
   __shared__ float s_lab[kSlices][LAB ? CAPW + 4 : 1];
   __shared__ float s_zr[TQ ? 2 * kW : 1];  // tile mode: every wave's (-lowest, highest) layer
+  __shared__ unsigned s_left;              // tile mode: waves that have finished with the image (see the group search)
+  if (TQ != 0 && t == 0) s_left = 0u;      // (ordered before every use by the first workgroup barrier)
   static_assert(!TQ || CAPW + 4 >= kW * kGroupBatch, "the group search takes a slice of the image per wave");
   const int wave = pp::wave_id_uniform();
   const int slice = TQ ? 0 : wave;
 
+  bool deferred = false;
+  float best = __builtin_inff();
+  int bidx = 0x7fffffff;
+  float thr = 0.0f;
+  bool lean_done = false;
+  if constexpr (TQ != 0 && !LAB) {
+    // (uniform over the set) no crowded cells on either side, and the query cloud's chunk table exists: every evenly
+    // sampled cloud of up to 65536 points
+    if (!refined_set && !gp_useless && !pp::grid_refined(gp) && gp.pad[1] == 1 && L.chunks > 0) {
+      // ---- the lean front (round 3): the same search as the general front below, for the case that decides the
+      // benchmark -- a tile of an unlabeled set without second-level grids -- written for VALU issue and for a short
+      // chain of dependent loads: the layers the tile can touch come from the QUERY cloud's chunk table (two scalar
+      // loads per build slab and chunk: no reduction over the tile, no barrier before the image is ordered), the image
+      // is copied while the lanes' own queries and row bounds are still on their way, and ONE barrier separates the
+      // copy from the walk; one chain of cell arithmetic (no second pass for the reach), 32-bit offsets from
+      // wave-uniform bases, a walk that tracks the byte position of the winning group.
+      const float inf = __builtin_inff();
+      const int gx1 = __builtin_amdgcn_readfirstlane(g.gx - 1), gy1 = __builtin_amdgcn_readfirstlane(g.gy - 1),
+                gz1 = __builtin_amdgcn_readfirstlane(g.gz - 1);
+      // the tile's z range (world coordinates) -> the layers of the reference grid its blocks can touch: a block holds
+      // the query's layer and one neighbour, and pp::cell_coord is monotone in z
+      int Lz, Hz;
+      {
+        const int* __restrict__ tzq = reinterpret_cast<const int*>(ws + L.tile_z) + (size_t)(set ^ 1) * pp::kBuildSlabs * 2 * L.chunks;
+        const int c0 = tile * (kT / pp::kChunk), cend = min(c0 + kT / pp::kChunk, (nq + pp::kChunk - 1) / pp::kChunk);
+        int kmin = 0x7fffffff, kmax = (int)0x80000000;
+        for (int sl = 0; sl < pp::kBuildSlabs; ++sl)
+          for (int c = c0; c < cend; ++c) {  // (uniform addresses: scalar loads)
+            kmin = min(kmin, tzq[(sl * L.chunks + c) * 2]);
+            kmax = max(kmax, tzq[(sl * L.chunks + c) * 2 + 1]);
+          }
+        Lz = max(__builtin_amdgcn_readfirstlane(cell_coord(pp::zkey_inv(kmin), g.minz, g.invh, g.gz)) - 1, 0);
+        Hz = min(__builtin_amdgcn_readfirstlane(cell_coord(pp::zkey_inv(kmax), g.minz, g.invh, g.gz)) + 1, gz1);
+      }
+      const unsigned layer = (unsigned)g.gx * (unsigned)g.gy;
+      const unsigned tb0 = cell_start[__builtin_amdgcn_readfirstlane((int)((unsigned)Lz * layer))];
+      const unsigned ns = cell_start[__builtin_amdgcn_readfirstlane((int)((unsigned)(Hz + 1) * layer))] - tb0;
+      if (ns > 0u && ns <= (unsigned)CAPW) {  // workgroup-uniform (else: the general front, which walks global memory)
+        // the image: [tb0, tb0 + ns) of the sorted cloud; the first pieces are ordered here, before anything waits
+        const pp::f4* __restrict__ src = sorted + tb0;
+        pp::f4 cpy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cpy[u] = src[min((unsigned)(u * kT + t), ns - 1)];  // (duplicates store the same value)
+        const float px = (qx - g.minx) * g.invh, py = (qy - g.miny) * g.invh, pz = (qz - g.minz) * g.invh;  // in cells
+        int cx, cy, cz;  // the query's cell (pp::cell_coord's arithmetic)
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cx) : "v"((int)px), "s"(gx1));
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cy) : "v"((int)py), "s"(gy1));
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cz) : "v"((int)pz), "s"(gz1));
+        // the 2x2x2 block: cells l, l + 1 per axis (the neighbour on the side of the cell the query lies in), clamped
+        const int lx = px - (float)cx < 0.5f ? cx - 1 : cx, ly = py - (float)cy < 0.5f ? cy - 1 : cy,
+                  lz = pz - (float)cz < 0.5f ? cz - 1 : cz;
+        const int x0 = max(lx, 0), x1 = min(lx + 1, gx1), y0 = max(ly, 0), y1 = min(ly + 1, gy1), z0 = max(lz, 0),
+                  z1 = min(lz + 1, gz1);
+        // What the block guarantees: along each axis the distance to the nearer face of the block that has grid beyond
+        // it (lower face at coordinate l, cells below it exist iff l >= 1; upper face at l + 2, cells above iff
+        // l + 2 <= cells - 1); beyond the grid there is nothing, the rim cells hold what was clamped into them.
+        auto face = [&](float p, int l, int g1) {
+          const float lo = l >= 1 ? p - (float)l : inf;
+          const float hi = l + 1 < g1 ? (float)(l + 2) - p : inf;
+          return fminf(lo, hi);
+        };
+        const float reach = g.h * fminf(face(px, lx, gx1), fminf(face(py, ly, gy1), face(pz, lz, gz1)));
+        // the bounds of the block's four rows (y, z): one 12-byte load each (see the general front)
+        typedef unsigned u3 __attribute__((ext_vector_type(3)));
+        u3 r00, r01, r10, r11;
+        {
+          const unsigned gx4 = (unsigned)g.gx << 2, x04 = (unsigned)x0 << 2;
+          auto row_off = [&](int z, int y) {  // byte offset of entry (x0, y, z): every factor fits 24 bits
+            unsigned o;
+            asm("v_mad_u32_u24 %0, %1, %2, %3\n\tv_mad_u32_u24 %0, %0, %4, %5" : "=&v"(o) : "v"(z), "s"(g.gy), "v"(y), "s"(gx4), "v"(x04));
+            return o;
+          };
+          const char* __restrict__ tb = reinterpret_cast<const char*>(cell_start);
+          __builtin_memcpy(&r00, tb + row_off(z0, y0), 12);
+          __builtin_memcpy(&r01, tb + row_off(z0, y1), 12);
+          __builtin_memcpy(&r10, tb + row_off(z1, y0), 12);
+          __builtin_memcpy(&r11, tb + row_off(z1, y1), 12);
+        }
+        PP_QPHASE(1);
+        {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) (&s_pts[0][0])[min((unsigned)(u * kT + t), ns - 1)] = cpy[u];
+          for (unsigned p0 = 4 * kT; p0 < ns; p0 += 4 * kT) {  // (images of more than 4 kT points: none at CAPW <= 4 kT)
+            pp::f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = src[min(p0 + (unsigned)(u * kT + t), ns - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) (&s_pts[0][0])[min(p0 + (unsigned)(u * kT + t), ns - 1)] = v[u];
+          }
+          // the padding: four points that can never be taken (their distance is NaN); lanes whose rows are finished, and
+          // groups that run past the end of the image, land here
+          if (t < 4) {
+            const float qn = __builtin_nanf("");
+            const pp::f4 nanp = {qn, qn, qn, __int_as_float(0x7fffffff)};
+            (&s_pts[0][0])[ns + t] = nanp;
+          }
+        }
+        // rows -> byte positions in the image
+        const bool wide = x1 > x0;
+        const bool va0 = lz >= 0, va1 = lz < gz1, vb0 = ly >= 0, vb1 = ly < gy1;  // the row's layer / line exists
+        const unsigned s0 = r00.x, e0 = (va0 & vb0) ? (wide ? r00.z : r00.y) : s0;
+        const unsigned s1 = r01.x, e1 = (va0 & vb1) ? (wide ? r01.z : r01.y) : s1;
+        const unsigned s2 = r10.x, e2 = (va1 & vb0) ? (wide ? r10.z : r10.y) : s2;
+        const unsigned s3 = r11.x, e3 = (va1 & vb1) ? (wide ? r11.z : r11.y) : s3;
+        const unsigned t0 = (e0 - s0 + 3) >> 2, t1 = (e1 - s1 + 3) >> 2, t2 = (e2 - s2 + 3) >> 2, t3 = (e3 - s3 + 3) >> 2;
+        const unsigned T1 = t0, T2 = T1 + t1, T3 = T2 + t2, T4 = T3 + t3;
+        // group k of the lane's sequence starts at byte a_r + 64 k of the image, r the row k falls in
+        const unsigned a0 = (s0 - tb0) << 4, a1 = ((s1 - tb0) << 4) - (T1 << 6), a2 = ((s2 - tb0) << 4) - (T2 << 6),
+                       a3 = ((s3 - tb0) << 4) - (T3 << 6);
+        const unsigned endb = ns << 4;  // the padding
+        const int kmax = (int)pp::wave_reduce_dpp<false>((float)T4);
+        PP_QPHASE(2);
+        __syncthreads();
+        PP_QPHASE(3);
+        const lds_c_ptr lb = (lds_c_ptr)(&s_pts[0][0]);
+        // (by value, through a function: selects between variables a lambda captures by reference come out of hipcc as
+        //  indexed loads from a pointer table in scratch memory)
+        auto pos_of = [=](unsigned k) { return lean_group_pos(k, T1, T2, T3, a0, a1, a2, a3, endb); };
+        pp::f4 pa[4], pb[4];
+        auto fetch4 = [&](unsigned pos, pp::f4 (&p)[4]) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) p[u] = *(lds_f4_ptr)(lb + pos + 16 * u);
+        };
+        unsigned gpos = endb;  // byte position of the group that holds the winner
+        unsigned long long tie = 0ull;  // lanes that saw a distance equal to their running minimum in a later group
+        auto track = [&](unsigned pos, const pp::f4 (&p)[4]) {
+          float d[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) d[u] = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+          const float gmin = min2(pp::min3(d[0], d[1], d[2]), d[3]);
+          const bool lt = gmin < best;
+          tie |= __ballot(gmin == best);
+          gpos = lt ? pos : gpos;
+          best = lt ? gmin : best;
+        };
+        unsigned pcur = pos_of(0), pnext;
+        fetch4(pcur, pa);
+        for (int k = 0; k < kmax; k += 2) {
+          pnext = pos_of(k + 1);
+          fetch4(pnext, pb);
+          track(pcur, pa);
+          pcur = pos_of(k + 2);
+          fetch4(pcur, pa);
+          track(pnext, pb);
+        }
+        if (tie) {  // an exact tie across groups (duplicated points, lattices): the walk again in the exact order
+          best = inf;
+          auto examine = [&](const pp::f4 (&p)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+              const int id = __float_as_int(p[u].w);
+              const bool take = (d < best) | ((d == best) & (id < bidx));
+              best = take ? d : best;
+              bidx = take ? id : bidx;
+            }
+          };
+          fetch4(pos_of(0), pa);
+          for (int k = 0; k < kmax; k += 2) {
+            fetch4(pos_of(k + 1), pb);
+            examine(pa);
+            fetch4(pos_of(k + 2), pa);
+            examine(pb);
+          }
+        } else {  // the winner is in the group at gpos: lowest index among its minima
+          fetch4(gpos, pa);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float d = pp::chamfer_d3(pa[u].x, pa[u].y, pa[u].z, qx, qy, qz);
+            const int id = __float_as_int(pa[u].w);
+            bidx = ((d == best) & (id < bidx)) ? id : bidx;
+          }
+        }
+        thr = reach * reach * kBoundSlack;
+        lean_done = true;
+        PP_QPHASE(4);
+      }
+    }
+  }
+  if (!lean_done) {  // ---- the general front: labeled searches, sets with crowded cells, the wave-private form, tiles that do not fit
   // Stage A: the 2x2x2 block of cells nearest to q' (own cell + the neighbour on the side of the cell q' lies
   // in, per axis).  A point outside that block is beyond the far face of q''s cell along some axis (>= h/2
   // away) or beyond the neighbour (>= h away).  The block is four rows (y, z) of one or two cells (x0..x1).
@@ -1207,7 +1421,7 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
       staged = n_staged <= (unsigned)CAPW;
     }
   };
-  bool deferred = false;
+  deferred = false;
   if (!refined_set) {  // wave-uniform
     if constexpr (TQ != 0) region_tile(false); else region(false, false);
     rows_finish();
@@ -1297,8 +1511,8 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
   // T_r <= k < T_{r+1} (T = running sums).  k is wave-uniform, so the wave runs max over lanes of the TOTAL
   // group count instead of the sum over rows of the per-row maxima, and the loads of group k + 1 are in
   // flight while group k is evaluated.
-  float best = __builtin_inff();
-  int bidx = 0x7fffffff;
+  best = __builtin_inff();
+  bidx = 0x7fffffff;
   {
     const unsigned t0 = (re0 - rs0 + 3) >> 2, t1 = (re1 - rs1 + 3) >> 2, t2 = (re2 - rs2 + 3) >> 2,
                    t3 = (re3 - rs3 + 3) >> 2;
@@ -1407,7 +1621,7 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
     sz2 = fz2 < 0.5f ? -1 : 1;
     reach = g.h * fminf(block_reach(fx2, sx2, cx2, g.gx), fminf(block_reach(fy2, sy2, cy2, g.gy), block_reach(fz2, sz2, cz2, g.gz)));
   }
-  float thr = reach * reach * kBoundSlack;
+  thr = reach * reach * kBoundSlack;
   if (refined_set && __any(deferred)) {  // wave-uniform
     // ---- second level: the block's cells one by one; a crowded cell through its own grid ---------------------
     if (deferred) {
@@ -1417,6 +1631,11 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
       bidx = f.bidx;
       thr = f.aux;
     }
+  }
+  }  // (the general front)
+  if constexpr (TQ != 0) {  // this wave reads the image no more
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(&s_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   PP_QPHASE(5);
   const bool resolved = best < thr;
@@ -1479,8 +1698,13 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
     }
   }
   PP_QPHASE(7);
-  if constexpr (TQ != 0) __syncthreads();  // every wave has left the image: the group search takes it over, a slice per wave
   if (open) {  // wave-uniform: far from everything the cubes hold -- group by group, the whole wave (see above)
+    if constexpr (TQ != 0) {
+      // the group search stages its candidates through a slice of the image: wait until every wave of the workgroup has
+      // finished its walk (a count in LDS, not a barrier: waves with nothing left to do must not wait for the slow ones)
+      while (__hip_atomic_load(&s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)kW) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     const bool finite = __builtin_isfinite(qx) && __builtin_isfinite(qy) && __builtin_isfinite(qz);
     const unsigned long long todo = open & __ballot(finite);
     if (todo) {
@@ -1605,7 +1829,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
     switch (tq) {
       case 256: PP_LAUNCH_W(1532, 256); break;
       case 768: PP_LAUNCH_W(3068, 768); break;
-      default: PP_LAUNCH_W(2556, 512); break;
+      default: PP_LAUNCH_W(3068, 512); break;
     }
   }
 #undef PP_LAUNCH_W

@@ -16,11 +16,30 @@ constexpr int kBuildThreads = 1024;
 
 constexpr int kBuildSlabs = 4;  // workgroups that share the build of one set (each owns a range of cells)
 
+// Chunk table (Chamfer's tile search): for every kChunk consecutive points of the sorted cloud, the lowest and the
+// highest z coordinate among them, as order-preserving integers (zkey), one (min, max) pair per chunk AND per build
+// slab -- a slab records the points it scatters; pairs of chunks it does not touch stay (+inf, -inf) -- so that the
+// slabs need not meet: tile_z[(slab * chunks + chunk) * 2 + {0, 1}].  Lets a tile of queries find the z-layers of the
+// OTHER cloud's grid it can touch from two scalar loads, before its queries have arrived.
+constexpr int kChunk = 256;
+constexpr int kChunkMax = 256;  // chunks per set the build can track (sets of up to 65536 points)
+__host__ __device__ inline int zkey(float z) {  // monotone in z for every non-NaN float
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int o = __float_as_int(z);
+#else
+  int o;
+  __builtin_memcpy(&o, &z, 4);
+#endif
+  return o ^ ((o >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float zkey_inv(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+
 struct GridSet {  // one per (batch, direction); written by the build kernel
   float minx, miny, minz, h, invh;
   int gx, gy, gz;
   int useless;             // 1: degenerate data (non-finite / zero extent): no grid at all
-  int pad[3];              // pad[0]: free for the caller (ball_query / three_nn: "the grid path serves this set")
+  int pad[3];              // pad[0]: free for the caller (ball_query / three_nn: "the grid path serves this set");
+                           // pad[1]: 1 = the set's chunk table (tile_z) has been written
   int crowd[kBuildSlabs];  // crowd[s] = 1: slab s found a cell too crowded to be of use; 2: it refined its crowded
                            // cells into sub-grids (REFINE builds: see SubGrid)
 };
@@ -361,13 +380,20 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
                                                float* __restrict__ sorted_payload, int slab,
                                                int nslab, unsigned* __restrict__ sub_start,
                                                SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
-                                               float* __restrict__ payload2) {
+                                               float* __restrict__ payload2, int* __restrict__ tile_z = nullptr,
+                                               int tz_chunks = 0) {
   __shared__ unsigned s_part[kBuildThreads];
+  __shared__ int s_tz[REFINE ? 2 * kChunkMax : 2];  // chunk table of this slab: (min, max) z keys
+  const int nchunkq = (nr + kChunk - 1) / kChunk;
+  const bool track_z = REFINE && tile_z != nullptr && nchunkq <= tz_chunks && tz_chunks <= kChunkMax;  // (uniform)
   __shared__ unsigned s_crowd;
   __shared__ float s_box[(kBuildThreads / 64) * 16];
   static_assert(kBuildThreads / 64 == 16, "the bounding-box reduction assumes 16 waves");
   const int t = threadIdx.x;
   if (t == 0) s_crowd = 0u;
+  if constexpr (REFINE) {
+    if (track_z && t < 2 * kChunkMax) s_tz[t] = (t & 1) ? zkey(-__builtin_inff()) : zkey(__builtin_inff());
+  }
 
   // A thread keeps KP points in registers (one chunk = 1024*KP points; a single chunk covers
   // 16384 points, so the three passes read the cloud from memory once).  Loads are unconditional
@@ -717,11 +743,26 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
             const int k = kidx(ch * kBuildThreads * KP, i0 + i);
             f4 v = {px[i0 + i], py[i0 + i], pz[i0 + i], __int_as_float(k)};
             sorted[pos[i]] = v;
+            if constexpr (REFINE) {
+              if (track_z) {
+                const int zk = zkey(pz[i0 + i]);
+                atomicMin(&s_tz[2 * (pos[i] / kChunk)], zk);
+                atomicMax(&s_tz[2 * (pos[i] / kChunk) + 1], zk);
+              }
+            }
             if (inv) inv[k] = (int)pos[i];
             if (sorted_payload) sorted_payload[pos[i]] = payload[k];  // one float per point, carried along
           }
       }
     }
+  if constexpr (REFINE) {
+    if (track_z) {  // (the refinement below permutes points inside a cell only: a cell's points keep their chunk's range
+                    //  up to the cell's own extent -- it re-sorts a cell in place, so a chunk may receive points of the
+                    //  same cell from a neighbouring chunk; sets with crowded cells do not use the table, see the search)
+      __syncthreads();
+      for (int c = t; c < 2 * nchunkq; c += kBuildThreads) tile_z[(size_t)slab * 2 * tz_chunks + c] = s_tz[c];
+    }
+  }
   PP_PHASE(9);
   bool refined = false;
   if constexpr (REFINE && !MORTON) {
@@ -764,6 +805,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       gs->gx = gx; gs->gy = gy; gs->gz = gz;
       gs->useless = degenerate ? 1 : 0;
       for (int i = 0; i < 3; ++i) gs->pad[i] = 0;
+      if (REFINE && track_z && place) gs->pad[1] = 1;
       for (int i = nslab; i < kBuildSlabs; ++i) gs->crowd[i] = 0;
     }
   }
@@ -794,9 +836,10 @@ __device__ __forceinline__ void grid_build_set_refined(const float* __restrict__
                                                        float* __restrict__ sorted_payload, int slab, int nslab,
                                                        unsigned* __restrict__ sub_start,
                                                        SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
-                                                       float* __restrict__ payload2) {
+                                                       float* __restrict__ payload2, int* __restrict__ tile_z = nullptr,
+                                                       int tz_chunks = 0) {
   grid_build_set_impl<false, VEC, true>(ref, nr, gs, cell_start, sorted, nullptr, s_cnt, payload, sorted_payload, slab,
-                                        nslab, sub_start, sub_desc, sorted2, payload2);
+                                        nslab, sub_start, sub_desc, sorted2, payload2, tile_z, tz_chunks);
 }
 
 // every batch element's cloud (base + b * n * 3 floats) is 16-byte aligned
