@@ -22,7 +22,7 @@ void pp_debug_set_nmdistance_variant(int variant);
 /* grid search, wave-private form of the search kernel: staged points per wave (320, 384, 512; selecting one also
  * selects that form; 0 = the default, the tile form) */
 void pp_debug_set_nmdistance_stage_cap(int points);
-/* grid search, tile form: queries per workgroup (0 = 512; 256, 768); -1 = the wave-private form */
+/* grid search, unlabeled: queries per workgroup of the stage-A kernel (0 = 512; 256, 1024); -1 = no stage-A kernel */
 void pp_debug_set_nmdistance_tile(int queries);
 /* labeled Chamfer brute force: 1 = the one-lane-per-query kernel */
 void pp_debug_set_labeled_variant(int variant);
@@ -31,6 +31,11 @@ void pp_debug_set_nmdistance_backward_variant(int variant);
 /* per-kernel HIP-event timing of the grid forward (build, search), read back after the call */
 void pp_debug_set_nmdistance_kernel_timing(int on);
 int pp_debug_nmdistance_kernel_ms(float* build_ms, float* search_ms);
+/* the same with the search's two launches apart (stage A by tiles, then what it left); stage_a_ms = 0 without a stage-A kernel */
+int pp_debug_nmdistance_kernel_ms3(float* build_ms, float* stage_a_ms, float* rest_ms);
+
+/* unlabeled grid forward: queries its stage-A kernel left to the list kernel, per direction (2 B values; synchronises) */
+int pp_debug_nmdistance_pending(const void* workspace, int B, int N, int M, unsigned* totals);
 
 void pp_debug_set_fps_v1(int on); /* 1 = one workgroup per batch element instead of the CU cluster */
 void pp_debug_set_gather_variant(int variant);

@@ -28,6 +28,7 @@
 //         the whole wave, the occupied cells or the whole cloud a lane per query); so does every query of a
 //         set whose grid is useless (non-finite coordinates).  Two launches per forward, no list.
 #include <mutex>
+#include <vector>
 
 #include "grid_common.h"
 
@@ -88,8 +89,12 @@ constexpr float kBoundSlack = 0.999f;
 //   [.., +4*T, +4*T)               float slab[T], slab2[T]   labels in sorted order + spare (labeled Chamfer only)
 // (the second-level arrays are only touched for sets that have crowded cells: never at config 2)
 //   [.., +4 * S * kBuildSlabs * 2 * chunks)  int tile_z[S][kBuildSlabs][chunks][2]   chunk table (grid_common.h: kChunk)
+//   [.., +4 * S * kLayerWords)     unsigned layers[S][kLayerWords]   layer table + pending counter (grid_common.h)
+//   [.., +4*T)                     int pend[T]        unlabeled searches: the queries stage A left (positions in the query
+//                                  cloud's sorted order), 64 slots per wave of the stage-A kernel
+//   [.., +4*(T/64 + S + 1))        unsigned pend_cnt[...]   how many of a wave's 64 slots are filled
 struct Layout {
-  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, tile_z, total;
+  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, tile_z, layers, pend, pend_cnt, total;
   int chunks;  // chunk-table entries per set and slab (0: sets too large for the table)
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
@@ -104,9 +109,12 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   L.slab = L.sorted2 + 16 * T;
   L.slab2 = L.slab + (labeled ? 4 * T : 0);
   L.tile_z = ((L.slab2 + (labeled ? 4 * T : 0) + 255) / 256) * 256;
-  const int chq = ((N > M ? N : M) + pp::kChunk - 1) / pp::kChunk;
-  L.chunks = chq <= pp::kChunkMax ? chq : 0;
-  L.total = L.tile_z + 4 * S * pp::kBuildSlabs * 2 * (size_t)L.chunks;
+  const int chq = (((N > M ? N : M) + pp::kChunk - 1) / pp::kChunk + 3) & ~3;  // (a tile reads up to four chunks' pairs)
+  L.chunks = (!labeled && chq <= pp::kChunkMax) ? chq : 0;
+  L.layers = ((L.tile_z + 4 * S * pp::kBuildSlabs * 2 * (size_t)L.chunks + 255) / 256) * 256;
+  L.pend = L.layers + (L.chunks ? ((4 * S * pp::kLayerWords + 255) / 256) * 256 : 0);
+  L.pend_cnt = L.pend + (L.chunks ? 4 * T : 0);
+  L.total = L.pend_cnt + (L.chunks ? ((4 * (T / 64 + S + 1) + 255) / 256) * 256 : 0);
   return L;
 }
 // second-level arrays of set (b, dir): first table entry / first descriptor
@@ -117,6 +125,11 @@ __host__ __device__ inline size_t set_sub_start_offset(int b, int dir, int N, in
 __host__ __device__ inline size_t set_sub_desc_offset(int b, int dir, int N, int M) {
   const size_t po = (size_t)b * ((size_t)N + M) + (dir ? (size_t)M : 0);
   return po / pp::kCrowd + 2 * (size_t)(2 * b + dir);
+}
+// the pending list of the queries of (b, dir) -- they are the points of set (b, dir ^ 1) -- and its per-wave counts
+__host__ __device__ inline size_t pend_count_offset(int b, int dir, int N, int M) {
+  const size_t po = (size_t)b * ((size_t)N + M) + (dir ? 0 : (size_t)M);  // = set_point_offset(b, dir ^ 1)
+  return po / 64 + (size_t)(2 * b + (dir ^ 1));
 }
 // set s = 2*b + dir; dir 0: queries = cloud 1 (N), references = cloud 2 (M)
 __host__ __device__ inline size_t set_point_offset(int b, int dir, int N, int M) {
@@ -153,7 +166,8 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
       reinterpret_cast<pp::SubGrid*>(ws + L.sub_desc) + set_sub_desc_offset(b, dir, N, M),
       reinterpret_cast<pp::f4*>(ws + L.sorted2) + set_point_offset(b, dir, N, M),
       labeled ? reinterpret_cast<float*>(ws + L.slab2) + set_point_offset(b, dir, N, M) : nullptr,
-      L.chunks ? reinterpret_cast<int*>(ws + L.tile_z) + (size_t)set * pp::kBuildSlabs * 2 * L.chunks : nullptr, L.chunks);
+      L.chunks ? reinterpret_cast<int*>(ws + L.tile_z) + (size_t)set * pp::kBuildSlabs * 2 * L.chunks : nullptr, L.chunks,
+      L.chunks ? reinterpret_cast<unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords : nullptr);
 }
 
 // Stages B and C (cubes of Chebyshev radius 1 and 2 around the query's cell) for the queries stage A left
@@ -993,63 +1007,25 @@ __device__ __forceinline__ float min2(float a, float b) {
   return r;
 }
 
-// byte position in the tile's image of group k of a lane's sequence (lean front; everything by value)
-__device__ __forceinline__ unsigned lean_group_pos(unsigned k, unsigned T1, unsigned T2, unsigned T3, unsigned a0,
-                                                   unsigned a1, unsigned a2, unsigned a3, unsigned endb) {
-  const unsigned a = k < T1 ? a0 : (k < T2 ? a1 : (k < T3 ? a2 : a3));
-  return min(a + (k << 6), endb);
-}
-
-// Two wave-wide max reductions at once, in place, through DPP (see pp::wave_reduce6_dpp; two interleaved chains need
-// one more wait state between dependent DPP operations).  ROWS: only inside every row of 16 lanes (lane 15 of a row
-// holds that row's result); otherwise lane 63 holds the wave's.  Every lane must be active.
-#define PP_DPP2_STEP(CTRL) \
-  "v_max_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
-template <bool ROWS>
-__device__ __forceinline__ void wave_max2_dpp(float& a, float& b) {
-  if constexpr (ROWS)
-    asm volatile("s_nop 1\n\t" PP_DPP2_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") PP_DPP2_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-                     PP_DPP2_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") PP_DPP2_STEP("row_shr:8 row_mask:0xf bank_mask:0xf") "s_nop 0"
-                 : "+v"(a), "+v"(b));
-  else
-    asm volatile("s_nop 1\n\t" PP_DPP2_STEP("row_shr:1 row_mask:0xf bank_mask:0xf") PP_DPP2_STEP("row_shr:2 row_mask:0xf bank_mask:0xf")
-                     PP_DPP2_STEP("row_shr:4 row_mask:0xf bank_mask:0xf") PP_DPP2_STEP("row_shr:8 row_mask:0xf bank_mask:0xf")
-                         PP_DPP2_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") PP_DPP2_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 0"
-                 : "+v"(a), "+v"(b));
-}
-typedef const char __attribute__((address_space(3))) * lds_c_ptr;
-
-// TQ = 0: the form above (256-thread workgroups of four independent waves, a wave-private region of CAPW points).
-// TQ > 0 (round 3, the default): a workgroup is a TILE of TQ consecutive queries; it stages the WHOLE z-layers of
-// the reference grid that its queries' blocks touch -- one contiguous piece of the sorted cloud, found with one
-// min / max reduction and two scalar loads instead of a per-wave region of row ranges per layer -- into ONE LDS
-// image of CAPW points shared by its waves (two workgroup barriers).  Everything after the copy is the same code.
-template <bool LAB, int CAPW, int TQ>
-__global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6) void grid_query_wave_kernel(const float* __restrict__ xyz1,
-                                                              const float* __restrict__ xyz2,
-                                                              float* __restrict__ dist1, int* __restrict__ idx1,
-                                                              float* __restrict__ dist2, int* __restrict__ idx2,
-                                                              unsigned char* __restrict__ ws, int B, int N, int M,
-                                                              int tiles1, int tiles2, int total, int per_xcd,
-                                                              const float* __restrict__ label1,
-                                                              const float* __restrict__ label2) {
-  const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
-  if (V >= total) return;
+// The search of (up to) 64 queries by one wave, one lane per query: stage A, then whatever stage A leaves (see the
+// top of the file).  `jj` = the lane's query as a position in the sorted query cloud (in the cloud itself when that
+// cloud has no grid), `valid` = the lane has a query; s_pts_w / s_lab_w = the wave's private slice of LDS (CAPW + 4
+// points / labels).  skip_a (wave-uniform): stage A has been run for every one of these queries already (the stage-A
+// kernel) and settled none of them -- go straight to the stages after it.
+template <bool LAB, int CAPW>
+__device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                               float* __restrict__ dist1, int* __restrict__ idx1,
+                                               float* __restrict__ dist2, int* __restrict__ idx2,
+                                               unsigned char* __restrict__ ws, int B, int N, int M,
+                                               const float* __restrict__ label1, const float* __restrict__ label2,
+                                               const Layout& L, const int b, const int dir, const int jj,
+                                               const bool valid, const bool skip_a, lds_f4_wptr s_pts_w,
+                                               lds_f_wptr s_lab_w) {
   PP_QPHASE_DECL;
   PP_QPHASE(0);
-  constexpr int kT = TQ ? TQ : 256;  // threads = queries per workgroup
-  constexpr int kW = kT / 64;
-  const int per_b = tiles1 + tiles2;
-  const int b = V / per_b;
-  const int r = V - b * per_b;
-  const int dir = r >= tiles1 ? 1 : 0;
-  const int tile = dir ? r - tiles1 : r;
-  const int nq = dir ? M : N, nr = dir ? N : M;
-  const int t = threadIdx.x, lane = t & 63;
-  const bool valid = tile * kT + t < nq;
-  const int jj = valid ? tile * kT + t : nq - 1;
+  const int lane = threadIdx.x & 63;
   const int set = 2 * b + dir;
-  const Layout L = make_layout(B, N, M, LAB);
+  const int nq = dir ? M : N, nr = dir ? N : M;
   const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[set];
   const GridSet gp = reinterpret_cast<const GridSet*>(ws + L.sets)[set ^ 1];
   const pp::f4* __restrict__ qsorted =
@@ -1095,196 +1071,12 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
       reinterpret_cast<const pp::SubGrid*>(ws + L.sub_desc) + set_sub_desc_offset(b, dir, N, M);
 
   // (+4: a group of four is read from any staged position without clamping; the tail repeats a real point)
-  constexpr int kSlices = TQ ? 1 : 4;
-  __shared__ pp::f4 s_pts[kSlices][CAPW + 4];
-  __shared__ float s_lab[kSlices][LAB ? CAPW + 4 : 1];
-  __shared__ float s_zr[TQ ? 2 * kW : 1];  // tile mode: every wave's (-lowest, highest) layer
-  __shared__ unsigned s_left;              // tile mode: waves that have finished with the image (see the group search)
-  if (TQ != 0 && t == 0) s_left = 0u;      // (ordered before every use by the first workgroup barrier)
-  static_assert(!TQ || CAPW + 4 >= kW * kGroupBatch, "the group search takes a slice of the image per wave");
-  const int wave = pp::wave_id_uniform();
-  const int slice = TQ ? 0 : wave;
 
   bool deferred = false;
   float best = __builtin_inff();
   int bidx = 0x7fffffff;
-  float thr = 0.0f;
-  bool lean_done = false;
-  if constexpr (TQ != 0 && !LAB) {
-    // (uniform over the set) no crowded cells on either side, and the query cloud's chunk table exists: every evenly
-    // sampled cloud of up to 65536 points
-    if (!refined_set && !gp_useless && !pp::grid_refined(gp) && gp.pad[1] == 1 && L.chunks > 0) {
-      // ---- the lean front (round 3): the same search as the general front below, for the case that decides the
-      // benchmark -- a tile of an unlabeled set without second-level grids -- written for VALU issue and for a short
-      // chain of dependent loads: the layers the tile can touch come from the QUERY cloud's chunk table (two scalar
-      // loads per build slab and chunk: no reduction over the tile, no barrier before the image is ordered), the image
-      // is copied while the lanes' own queries and row bounds are still on their way, and ONE barrier separates the
-      // copy from the walk; one chain of cell arithmetic (no second pass for the reach), 32-bit offsets from
-      // wave-uniform bases, a walk that tracks the byte position of the winning group.
-      const float inf = __builtin_inff();
-      const int gx1 = __builtin_amdgcn_readfirstlane(g.gx - 1), gy1 = __builtin_amdgcn_readfirstlane(g.gy - 1),
-                gz1 = __builtin_amdgcn_readfirstlane(g.gz - 1);
-      // the tile's z range (world coordinates) -> the layers of the reference grid its blocks can touch: a block holds
-      // the query's layer and one neighbour, and pp::cell_coord is monotone in z
-      int Lz, Hz;
-      {
-        const int* __restrict__ tzq = reinterpret_cast<const int*>(ws + L.tile_z) + (size_t)(set ^ 1) * pp::kBuildSlabs * 2 * L.chunks;
-        const int c0 = tile * (kT / pp::kChunk), cend = min(c0 + kT / pp::kChunk, (nq + pp::kChunk - 1) / pp::kChunk);
-        int kmin = 0x7fffffff, kmax = (int)0x80000000;
-        for (int sl = 0; sl < pp::kBuildSlabs; ++sl)
-          for (int c = c0; c < cend; ++c) {  // (uniform addresses: scalar loads)
-            kmin = min(kmin, tzq[(sl * L.chunks + c) * 2]);
-            kmax = max(kmax, tzq[(sl * L.chunks + c) * 2 + 1]);
-          }
-        Lz = max(__builtin_amdgcn_readfirstlane(cell_coord(pp::zkey_inv(kmin), g.minz, g.invh, g.gz)) - 1, 0);
-        Hz = min(__builtin_amdgcn_readfirstlane(cell_coord(pp::zkey_inv(kmax), g.minz, g.invh, g.gz)) + 1, gz1);
-      }
-      const unsigned layer = (unsigned)g.gx * (unsigned)g.gy;
-      const unsigned tb0 = cell_start[__builtin_amdgcn_readfirstlane((int)((unsigned)Lz * layer))];
-      const unsigned ns = cell_start[__builtin_amdgcn_readfirstlane((int)((unsigned)(Hz + 1) * layer))] - tb0;
-      if (ns > 0u && ns <= (unsigned)CAPW) {  // workgroup-uniform (else: the general front, which walks global memory)
-        // the image: [tb0, tb0 + ns) of the sorted cloud; the first pieces are ordered here, before anything waits
-        const pp::f4* __restrict__ src = sorted + tb0;
-        pp::f4 cpy[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) cpy[u] = src[min((unsigned)(u * kT + t), ns - 1)];  // (duplicates store the same value)
-        const float px = (qx - g.minx) * g.invh, py = (qy - g.miny) * g.invh, pz = (qz - g.minz) * g.invh;  // in cells
-        int cx, cy, cz;  // the query's cell (pp::cell_coord's arithmetic)
-        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cx) : "v"((int)px), "s"(gx1));
-        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cy) : "v"((int)py), "s"(gy1));
-        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cz) : "v"((int)pz), "s"(gz1));
-        // the 2x2x2 block: cells l, l + 1 per axis (the neighbour on the side of the cell the query lies in), clamped
-        const int lx = px - (float)cx < 0.5f ? cx - 1 : cx, ly = py - (float)cy < 0.5f ? cy - 1 : cy,
-                  lz = pz - (float)cz < 0.5f ? cz - 1 : cz;
-        const int x0 = max(lx, 0), x1 = min(lx + 1, gx1), y0 = max(ly, 0), y1 = min(ly + 1, gy1), z0 = max(lz, 0),
-                  z1 = min(lz + 1, gz1);
-        // What the block guarantees: along each axis the distance to the nearer face of the block that has grid beyond
-        // it (lower face at coordinate l, cells below it exist iff l >= 1; upper face at l + 2, cells above iff
-        // l + 2 <= cells - 1); beyond the grid there is nothing, the rim cells hold what was clamped into them.
-        auto face = [&](float p, int l, int g1) {
-          const float lo = l >= 1 ? p - (float)l : inf;
-          const float hi = l + 1 < g1 ? (float)(l + 2) - p : inf;
-          return fminf(lo, hi);
-        };
-        const float reach = g.h * fminf(face(px, lx, gx1), fminf(face(py, ly, gy1), face(pz, lz, gz1)));
-        // the bounds of the block's four rows (y, z): one 12-byte load each (see the general front)
-        typedef unsigned u3 __attribute__((ext_vector_type(3)));
-        u3 r00, r01, r10, r11;
-        {
-          const unsigned gx4 = (unsigned)g.gx << 2, x04 = (unsigned)x0 << 2;
-          auto row_off = [&](int z, int y) {  // byte offset of entry (x0, y, z): every factor fits 24 bits
-            unsigned o;
-            asm("v_mad_u32_u24 %0, %1, %2, %3\n\tv_mad_u32_u24 %0, %0, %4, %5" : "=&v"(o) : "v"(z), "s"(g.gy), "v"(y), "s"(gx4), "v"(x04));
-            return o;
-          };
-          const char* __restrict__ tb = reinterpret_cast<const char*>(cell_start);
-          __builtin_memcpy(&r00, tb + row_off(z0, y0), 12);
-          __builtin_memcpy(&r01, tb + row_off(z0, y1), 12);
-          __builtin_memcpy(&r10, tb + row_off(z1, y0), 12);
-          __builtin_memcpy(&r11, tb + row_off(z1, y1), 12);
-        }
-        PP_QPHASE(1);
-        {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) (&s_pts[0][0])[min((unsigned)(u * kT + t), ns - 1)] = cpy[u];
-          for (unsigned p0 = 4 * kT; p0 < ns; p0 += 4 * kT) {  // (images of more than 4 kT points: none at CAPW <= 4 kT)
-            pp::f4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = src[min(p0 + (unsigned)(u * kT + t), ns - 1)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) (&s_pts[0][0])[min(p0 + (unsigned)(u * kT + t), ns - 1)] = v[u];
-          }
-          // the padding: four points that can never be taken (their distance is NaN); lanes whose rows are finished, and
-          // groups that run past the end of the image, land here
-          if (t < 4) {
-            const float qn = __builtin_nanf("");
-            const pp::f4 nanp = {qn, qn, qn, __int_as_float(0x7fffffff)};
-            (&s_pts[0][0])[ns + t] = nanp;
-          }
-        }
-        // rows -> byte positions in the image
-        const bool wide = x1 > x0;
-        const bool va0 = lz >= 0, va1 = lz < gz1, vb0 = ly >= 0, vb1 = ly < gy1;  // the row's layer / line exists
-        const unsigned s0 = r00.x, e0 = (va0 & vb0) ? (wide ? r00.z : r00.y) : s0;
-        const unsigned s1 = r01.x, e1 = (va0 & vb1) ? (wide ? r01.z : r01.y) : s1;
-        const unsigned s2 = r10.x, e2 = (va1 & vb0) ? (wide ? r10.z : r10.y) : s2;
-        const unsigned s3 = r11.x, e3 = (va1 & vb1) ? (wide ? r11.z : r11.y) : s3;
-        const unsigned t0 = (e0 - s0 + 3) >> 2, t1 = (e1 - s1 + 3) >> 2, t2 = (e2 - s2 + 3) >> 2, t3 = (e3 - s3 + 3) >> 2;
-        const unsigned T1 = t0, T2 = T1 + t1, T3 = T2 + t2, T4 = T3 + t3;
-        // group k of the lane's sequence starts at byte a_r + 64 k of the image, r the row k falls in
-        const unsigned a0 = (s0 - tb0) << 4, a1 = ((s1 - tb0) << 4) - (T1 << 6), a2 = ((s2 - tb0) << 4) - (T2 << 6),
-                       a3 = ((s3 - tb0) << 4) - (T3 << 6);
-        const unsigned endb = ns << 4;  // the padding
-        const int kmax = (int)pp::wave_reduce_dpp<false>((float)T4);
-        PP_QPHASE(2);
-        __syncthreads();
-        PP_QPHASE(3);
-        const lds_c_ptr lb = (lds_c_ptr)(&s_pts[0][0]);
-        // (by value, through a function: selects between variables a lambda captures by reference come out of hipcc as
-        //  indexed loads from a pointer table in scratch memory)
-        auto pos_of = [=](unsigned k) { return lean_group_pos(k, T1, T2, T3, a0, a1, a2, a3, endb); };
-        pp::f4 pa[4], pb[4];
-        auto fetch4 = [&](unsigned pos, pp::f4 (&p)[4]) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) p[u] = *(lds_f4_ptr)(lb + pos + 16 * u);
-        };
-        unsigned gpos = endb;  // byte position of the group that holds the winner
-        unsigned long long tie = 0ull;  // lanes that saw a distance equal to their running minimum in a later group
-        auto track = [&](unsigned pos, const pp::f4 (&p)[4]) {
-          float d[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) d[u] = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
-          const float gmin = min2(pp::min3(d[0], d[1], d[2]), d[3]);
-          const bool lt = gmin < best;
-          tie |= __ballot(gmin == best);
-          gpos = lt ? pos : gpos;
-          best = lt ? gmin : best;
-        };
-        unsigned pcur = pos_of(0), pnext;
-        fetch4(pcur, pa);
-        for (int k = 0; k < kmax; k += 2) {
-          pnext = pos_of(k + 1);
-          fetch4(pnext, pb);
-          track(pcur, pa);
-          pcur = pos_of(k + 2);
-          fetch4(pcur, pa);
-          track(pnext, pb);
-        }
-        if (tie) {  // an exact tie across groups (duplicated points, lattices): the walk again in the exact order
-          best = inf;
-          auto examine = [&](const pp::f4 (&p)[4]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
-              const int id = __float_as_int(p[u].w);
-              const bool take = (d < best) | ((d == best) & (id < bidx));
-              best = take ? d : best;
-              bidx = take ? id : bidx;
-            }
-          };
-          fetch4(pos_of(0), pa);
-          for (int k = 0; k < kmax; k += 2) {
-            fetch4(pos_of(k + 1), pb);
-            examine(pa);
-            fetch4(pos_of(k + 2), pa);
-            examine(pb);
-          }
-        } else {  // the winner is in the group at gpos: lowest index among its minima
-          fetch4(gpos, pa);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float d = pp::chamfer_d3(pa[u].x, pa[u].y, pa[u].z, qx, qy, qz);
-            const int id = __float_as_int(pa[u].w);
-            bidx = ((d == best) & (id < bidx)) ? id : bidx;
-          }
-        }
-        thr = reach * reach * kBoundSlack;
-        lean_done = true;
-        PP_QPHASE(4);
-      }
-    }
-  }
-  if (!lean_done) {  // ---- the general front: labeled searches, sets with crowded cells, the wave-private form, tiles that do not fit
+  float thr = 0.0f;  // (nothing settles below it: skip_a leaves every query to the stages after stage A)
+  if (!skip_a) {  // (wave-uniform)
   // Stage A: the 2x2x2 block of cells nearest to q' (own cell + the neighbour on the side of the cell q' lies
   // in, per axis).  A point outside that block is beyond the far face of q''s cell along some axis (>= h/2
   // away) or beyond the neighbour (>= h away).  The block is four rows (y, z) of one or two cells (x0..x1).
@@ -1394,36 +1186,9 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
       staged = n_staged <= (unsigned)CAPW;
     }
   };
-  // Tile mode: the layers the workgroup's blocks touch, [Lz, Lz + nz), are one contiguous piece of the sorted cloud
-  // (cells are z-major): `tbase` = its first point.  Every lane's rows lie inside it by construction.
-  unsigned tbase = 0;
-  auto region_tile = [&](const bool dfr) {
-    float v[6] = {dfr ? ninf : -(float)z0, dfr ? ninf : (float)z1, ninf, ninf, ninf, ninf};
-    pp::wave_reduce6_dpp<false, 6>(v);
-    if (lane == 63) {
-      s_zr[2 * wave] = v[0];
-      s_zr[2 * wave + 1] = v[1];
-    }
-    __syncthreads();
-    float w[6] = {lane < kW ? s_zr[2 * (lane < kW ? lane : 0)] : ninf, lane < kW ? s_zr[2 * (lane < kW ? lane : 0) + 1] : ninf,
-                  ninf, ninf, ninf, ninf};
-    pp::wave_reduce6_dpp<false, 4>(w);  // kW <= 16 values in lanes 0..15: lane 15 holds the result
-    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[0]), 15));
-    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[1]), 15));
-    staged = hi >= 0.0f;  // (no lane takes part: nothing to stage)
-    Lz = staged ? -(int)lo : 0;
-    nz = staged ? (int)hi - Lz + 1 : 0;
-    if (staged) {
-      const int c0 = __builtin_amdgcn_readfirstlane(Lz * g.gy * g.gx);
-      const int c1 = __builtin_amdgcn_readfirstlane((Lz + nz) * g.gy * g.gx);
-      tbase = cell_start[c0];
-      n_staged = cell_start[c1] - tbase;
-      staged = n_staged <= (unsigned)CAPW;
-    }
-  };
   deferred = false;
   if (!refined_set) {  // wave-uniform
-    if constexpr (TQ != 0) region_tile(false); else region(false, false);
+    region(false, false);
     rows_finish();
   } else {
     rows_finish();
@@ -1431,38 +1196,12 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
     if (deferred) {
       re0 = rs0; re1 = rs1; re2 = rs2; re3 = rs3;
     }
-    if constexpr (TQ != 0) region_tile(deferred); else region(deferred, !__any(!deferred));
+    region(deferred, !__any(!deferred));
   }
   PP_QPHASE(2);
-  const lds_f4_ptr lpts = (lds_f4_ptr)(&s_pts[slice][0]);
-  const lds_f_ptr llab = (lds_f_ptr)(&s_lab[slice][0]);
-  if constexpr (TQ != 0) {
-    if (staged) {  // workgroup-uniform
-      rs0 -= tbase; re0 -= tbase; rs1 -= tbase; re1 -= tbase;
-      rs2 -= tbase; re2 -= tbase; rs3 -= tbase; re3 -= tbase;
-      for (unsigned p0 = 0; p0 < n_staged; p0 += 4 * kT) {
-        pp::f4 v[4];
-        float vl[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned p = min(p0 + (unsigned)(u * kT + t), n_staged - 1);  // (duplicates store the same value)
-          v[u] = sorted[p + tbase];
-          if (LAB) vl[u] = slab[p + tbase];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned p = min(p0 + (unsigned)(u * kT + t), n_staged - 1);
-          (&s_pts[0][0])[p] = v[u];
-          if (LAB) (&s_lab[0][0])[p] = vl[u];
-        }
-      }
-      if (n_staged > 0 && t < 4) {  // the padding repeats the last point (a real candidate)
-        (&s_pts[0][0])[n_staged + t] = sorted[tbase + n_staged - 1];
-        if (LAB) (&s_lab[0][0])[n_staged + t] = slab[tbase + n_staged - 1];
-      }
-    }
-    __syncthreads();
-  } else if (staged) {
+  const lds_f4_ptr lpts = (lds_f4_ptr)s_pts_w;
+  const lds_f_ptr llab = (lds_f_ptr)s_lab_w;
+  if (staged) {
     // every lane's rows live in its two layers: global position -> LDS position
     const unsigned dA = __shfl(delta, deferred ? 0 : cz - Lz);
     const int zb = cz + sz;
@@ -1486,8 +1225,8 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const unsigned p = min(p0 + (unsigned)(u * 64 + lane), end - 1);
-          (&s_pts[wave][0])[p] = v[u];
-          if (LAB) (&s_lab[wave][0])[p] = vl[u];
+          s_pts_w[p] = v[u];
+          if (LAB) s_lab_w[p] = vl[u];
         }
       }
     }
@@ -1497,8 +1236,8 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
       const pp::f4 padv = lpts[n_staged - 1];
       const float padl = LAB ? llab[n_staged - 1] : 0.0f;
       if (lane < 4) {
-        (&s_pts[wave][0])[n_staged + lane] = padv;
-        if (LAB) (&s_lab[wave][0])[n_staged + lane] = padl;
+        s_pts_w[n_staged + lane] = padv;
+        if (LAB) s_lab_w[n_staged + lane] = padl;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1632,11 +1371,7 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
       thr = f.aux;
     }
   }
-  }  // (the general front)
-  if constexpr (TQ != 0) {  // this wave reads the image no more
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_fetch_add(&s_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
+  }  // (!skip_a)
   PP_QPHASE(5);
   const bool resolved = best < thr;
   if (resolved && valid) {
@@ -1699,19 +1434,12 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
   }
   PP_QPHASE(7);
   if (open) {  // wave-uniform: far from everything the cubes hold -- group by group, the whole wave (see above)
-    if constexpr (TQ != 0) {
-      // the group search stages its candidates through a slice of the image: wait until every wave of the workgroup has
-      // finished its walk (a count in LDS, not a barrier: waves with nothing left to do must not wait for the slow ones)
-      while (__hip_atomic_load(&s_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)kW) __builtin_amdgcn_s_sleep(2);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
     const bool finite = __builtin_isfinite(qx) && __builtin_isfinite(qy) && __builtin_isfinite(qz);
     const unsigned long long todo = open & __ballot(finite);
     if (todo) {
       const Found f = wave_group_search<LAB>(g, cell_start, sorted, slab, qx, qy, qz, ql, best, bidx, (unsigned)todo,
-                                             (unsigned)(todo >> 32),
-                                             (lds_f4_wptr)(TQ ? &s_pts[0][wave * kGroupBatch] : &s_pts[slice][0]),
-                                             (lds_f_wptr)(TQ ? &s_lab[0][LAB ? wave * kGroupBatch : 0] : &s_lab[slice][0]));
+                                             (unsigned)(todo >> 32), s_pts_w,
+                                             s_lab_w);
       if ((todo >> lane) & 1ull) {
         const bool none = f.bidx == 0x7fffffff;  // (labeled: nobody carries this label -- ref nmdistance_cuda.cu:110-113)
         od[j] = (LAB && none) ? 0.0f : f.best;
@@ -1734,17 +1462,453 @@ __global__ __launch_bounds__(TQ ? TQ : 256, LAB && TQ ? (TQ == 768 ? 3 : 4) : 6)
   PP_QPHASE(9);
 }
 
+// The whole search in one kernel (labeled searches; unlabeled ones when there is no stage-A kernel): 256-thread
+// workgroups of four independent waves, workgroup `tile` of (b, dir) takes queries [256 tile, 256 tile + 256).
+template <bool LAB, int CAPW>
+__global__ __launch_bounds__(256, LAB ? (CAPW > 384 ? 3 : 4) : (CAPW > 384 ? 4 : 6)) void grid_query_wave_kernel(
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1, int* __restrict__ idx1,
+    float* __restrict__ dist2, int* __restrict__ idx2, unsigned char* __restrict__ ws, int B, int N, int M, int tiles1,
+    int tiles2, int total, int per_xcd, const float* __restrict__ label1, const float* __restrict__ label2) {
+  const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
+  if (V >= total) return;
+  const int per_b = tiles1 + tiles2;
+  const int b = V / per_b;
+  const int r = V - b * per_b;
+  const int dir = r >= tiles1 ? 1 : 0;
+  const int tile = dir ? r - tiles1 : r;
+  const int nq = dir ? M : N;
+  const int t = threadIdx.x;
+  const Layout L = make_layout(B, N, M, LAB);
+  const bool valid = tile * 256 + t < nq;
+  const int jj = valid ? tile * 256 + t : nq - 1;
+  // (+4: a group of four is read from any staged position without clamping; the tail repeats a real point)
+  __shared__ pp::f4 s_pts[4][CAPW + 4];
+  __shared__ float s_lab[4][LAB ? CAPW + 4 : 1];
+  const int wave = pp::wave_id_uniform();
+  search_queries<LAB, CAPW>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, label1, label2, L, b, dir, jj, valid, false,
+                            (lds_f4_wptr)(&s_pts[wave][0]), (lds_f_wptr)(&s_lab[wave][0]));
+}
+
+// Round 3, unlabeled searches: what the stage-A kernel (below) left.  The pending list of a direction is 64 slots per
+// wave of that kernel plus a count per wave (no atomics there); here every WAVE works by itself: the direction's total
+// first (one scalar load -- on an evenly sampled surface 0.3 % of the queries are left, ~50 per direction, and most
+// waves leave at once), then, per piece of the list it takes, a prefix sum of the per-wave counts (in its own slice of
+// LDS, before the slice is used for points) that turns entry numbers into slots.  A direction's waves_per_set waves
+// share its list: few entries are spread one or two to a wave, so that each is served by a whole wave at once (what
+// costs there is a query's chain of dependent loads, not lanes); a long list -- clouds far from each other -- fills the
+// waves, 64 entries each, in the order of the sorted query cloud (neighbours stay together), piece after piece.
+// An entry carries bit 30 when stage A has been run for it (and failed): a wave of such entries skips stage A.
+constexpr int kPendTried = 1 << 30;
+template <int CAPW>
+__global__ __launch_bounds__(256, 6) void grid_query_list_kernel(const float* __restrict__ xyz1,
+                                                                  const float* __restrict__ xyz2,
+                                                                  float* __restrict__ dist1, int* __restrict__ idx1,
+                                                                  float* __restrict__ dist2, int* __restrict__ idx2,
+                                                                  unsigned char* __restrict__ ws, int B, int N, int M,
+                                                                  int waves_per_set, const Layout L) {
+  static_assert((CAPW + 4) * 16 >= 1024 * 4, "the prefix sums of up to 1024 counts use the wave's slice");
+  __shared__ pp::f4 s_pts[4][CAPW + 4];
+  const int wave = pp::wave_id_uniform();
+  const int lane = threadIdx.x & 63;
+  // a direction's list is served on the XCD that built its grids and wrote the list (the build's and the stage-A kernel's
+  // set -> XCD mapping: contiguous ranges of sets per XCD): its tables and points are in that L2 -- served from another
+  // XCD every one of a query's dependent loads went to the memory side (24 -> 1x us for the whole launch at config 2).
+  // Speed only: whatever the placement, the results are the same.
+  const int gw = pp::xcd_virtual_block((int)blockIdx.x, (int)(gridDim.x >> 3)) * 4 + wave;  // (the grid is a multiple of 8)
+  const int set = gw / waves_per_set, wi = gw - set * waves_per_set;
+  if (set >= 2 * B) return;
+  const int b = set >> 1, dir = set & 1;
+  const int nq = dir ? M : N;
+  const int nwq = (nq + 63) / 64;  // waves of the stage-A kernel in this direction (<= 1024)
+  const unsigned* __restrict__ pcnt = reinterpret_cast<const unsigned*>(ws + L.pend_cnt) + pend_count_offset(b, dir, N, M);
+  const int* __restrict__ plist = reinterpret_cast<const int*>(ws + L.pend) + set_point_offset(b, dir ^ 1, N, M);
+  unsigned __attribute__((address_space(3)))* pref = (unsigned __attribute__((address_space(3)))*)(&s_pts[wave][0]);
+  // Exclusive prefix sums of the per-wave counts into the wave's slice (lane l takes counts cpl l .. cpl l + cpl - 1,
+  // cpl = 4, 8 or 16 by the number of waves); returns the direction's total.  Redone for every piece: the search
+  // overwrites the slice.
+  // (loads unconditional, indices clamped, the count of loads a compile-time constant: a load inside an `if` is waited
+  //  for on the spot, one round trip each)
+  const int cpl = nwq <= 256 ? 4 : (nwq <= 512 ? 8 : 16);
+  auto scan_n = [&](auto cpl_c) -> unsigned {
+    constexpr int CPL = decltype(cpl_c)::value;
+    unsigned c[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) c[i] = pcnt[min(CPL * lane + i, nwq - 1)];
+    unsigned mine = 0;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      c[i] = CPL * lane + i < nwq ? c[i] : 0u;
+      mine += c[i];
+    }
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    unsigned run = incl - mine;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+      pref[CPL * lane + i] = run;
+      run += c[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+  };
+  auto scan_counts = [&]() -> unsigned {
+    if (cpl == 4) return scan_n(std::integral_constant<int, 4>{});
+    if (cpl == 8) return scan_n(std::integral_constant<int, 8>{});
+    return scan_n(std::integral_constant<int, 16>{});
+  };
+  const unsigned total = scan_counts();  // (on an evenly sampled surface ~1 % of the queries: most waves leave here or after one piece)
+  if (total == 0u) return;
+  const unsigned per_wave = min(64u, max(1u, (total + (unsigned)waves_per_set - 1) / (unsigned)waves_per_set));
+  // pieces of per_wave entries: the first waves_per_set are dealt out statically (wave wi takes piece wi: a short list
+  // costs no atomic), the rest from a counter, so that waves whose pieces are cheap take more of them
+  unsigned* __restrict__ cursor = reinterpret_cast<unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords + pp::kLayerCursor;
+  bool fresh = true;  // the slice holds the prefix sums
+  for (unsigned piece = (unsigned)wi; piece * per_wave < total;) {  // wave-uniform
+    const unsigned first = piece * per_wave;
+    if ((unsigned)waves_per_set * per_wave < total) {  // (uniform) a long list: fetch the next piece
+      unsigned nxt = 0;
+      if (lane == 0) nxt = atomicAdd(cursor, 1u);
+      piece = (unsigned)waves_per_set + (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
+    } else {
+      piece = 0xffffffffu / 64u;  // the static deal covers the list: this piece is the wave's only one
+    }
+    if (!fresh) scan_counts();
+    fresh = false;
+    const unsigned e = first + (unsigned)lane;
+    const bool valid = (unsigned)lane < per_wave && e < total;
+    const unsigned ec = valid ? e : min(first, total - 1);
+    int lo = 0, hi = nwq - 1;  // the last wave whose first entry is <= ec (waves without entries are passed over)
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+      const int mid = (lo + hi + 1) >> 1;
+      const bool ge = pref[mid] <= ec;
+      lo = ge ? mid : lo;
+      hi = ge ? hi : mid - 1;
+    }
+    const int entry = plist[lo * 64 + (int)(ec - pref[lo])];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // (the slice is the search's from here on)
+    const bool skip_a = __all(!valid || (entry & kPendTried) != 0);
+    search_queries<false, CAPW>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, nullptr, nullptr, L, b, dir,
+                                entry & ~kPendTried, valid, skip_a, (lds_f4_wptr)(&s_pts[wave][0]), (lds_f_wptr) nullptr);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Round 3: stage A as a kernel of its own (unlabeled searches; the kernel above, in LIST mode, then serves what it
+// leaves).  Why: inside one kernel the rare long tails -- a wave with leftover queries runs the whole-wave cubes for
+// microseconds -- held back the LDS of their whole workgroup, and the tails' registers (80) capped the occupancy of
+// the 99.7 % of the work that never needs them.  Here a workgroup is a TILE of TQ consecutive queries of the sorted
+// query cloud:
+//   * the z-layers of the reference grid its queries' 2x2x2 blocks can touch come from the QUERY cloud's chunk table
+//     (grid_common.h: kChunk; two scalar loads per build slab and chunk -- no reduction over the tile, nothing waits
+//     for the queries themselves); those layers are ONE contiguous piece of the sorted reference cloud (cells are
+//     z-major), copied into ONE LDS image of at most CAP points shared by the tile's waves, while the lanes' own
+//     queries and the bounds of their blocks' rows are still on their way; one workgroup barrier;
+//   * every lane walks the four rows of its block in the image -- one sequence of groups of four consecutive points,
+//     only the running minimum (v_min3) and the byte position of the group that last lowered it tracked; the winner's
+//     index is recovered from that group afterwards, an exact tie across groups repeats the walk in the exact
+//     (distance, index) order -- and is settled if its best distance is below what the block guarantees (reach);
+//   * settled queries store their result; the others are written to the wave's 64 slots of the pending list with the
+//     wave's count (no atomics).  A tile that cannot be served this way (sets with crowded cells, degenerate sets,
+//     images beyond CAP, no chunk table) leaves ALL its queries pending: same results either way.
+// Same candidates, same arithmetic (pp::chamfer_d3), same tie rule as the kernel above.
+__device__ __forceinline__ unsigned lean_group_pos(unsigned k, unsigned T1, unsigned T2, unsigned T3, unsigned a0,
+                                                   unsigned a1, unsigned a2, unsigned a3, unsigned endb) {
+  // byte position in the image of group k of a lane's sequence (everything by value: see stage_a_fetch)
+  const unsigned a = k < T1 ? a0 : (k < T2 ? a1 : (k < T3 ? a2 : a3));
+  return min(a + (k << 6), endb);
+}
+typedef const char __attribute__((address_space(3))) * lds_c_ptr;
+
+// (phase stamps of the stage-A kernel: off in a -DPP_PROBE_LIST_ONLY probe build, which clocks the list kernel alone)
+#if defined(PP_QUERY_PROBE) && !defined(PP_PROBE_LIST_ONLY)
+#define PP_APHASE(n) PP_QPHASE(n)
+#else
+#define PP_APHASE(n)
+#endif
+// What a tile's front needs from memory, ordered in ONE round trip and a tile AHEAD (the kernel is persistent: a
+// workgroup walks tile i while this is on its way for tile i + 1): lanes 0..47 of `meta` = the reference grid's
+// descriptor (16 words), the query grid's (16), the tile's chunk-table entries (<= 16 words for TQ <= 512; 32 at 1024:
+// meta2); `lay` = the reference grid's layer table (lane z: first point of layer z); `qq` = the lane's query.
+template <int TQ>
+struct StageAFront {
+  int live;             // the virtual tile exists (the grid is padded to a multiple of eight)
+  int b, dir, tile, jj;
+  bool valid;
+  unsigned meta, meta2, lay;
+  pp::f4 qq;
+};
+template <int TQ>
+__device__ __forceinline__ void stage_a_issue(StageAFront<TQ>& f, int it, int per_xcd, int total, int tiles1, int tiles2,
+                                              int N, int M, const unsigned char* __restrict__ ws, const Layout& L, int t,
+                                              int lane) {
+  const int V = pp::xcd_virtual_block(it, per_xcd);
+  f.live = V < total ? 1 : 0;
+  const int Vc = f.live ? V : 0;  // (a padding tile loads tile 0's front and does nothing with it)
+  const int per_b = tiles1 + tiles2;
+  f.b = Vc / per_b;
+  const int r = Vc - f.b * per_b;
+  f.dir = r >= tiles1 ? 1 : 0;
+  f.tile = f.dir ? r - tiles1 : r;
+  const int nq = f.dir ? M : N;
+  f.valid = f.live && f.tile * TQ + t < nq;
+  f.jj = f.valid ? f.tile * TQ + t : nq - 1;
+  const int set = 2 * f.b + f.dir;
+  constexpr int kTz = 8 * (TQ / pp::kChunk);  // chunk-table words of a tile
+  static_assert(pp::kBuildSlabs == 4 && kTz <= 32, "eight words per chunk");
+  const unsigned* __restrict__ gsets = reinterpret_cast<const unsigned*>(ws + L.sets);
+  const unsigned* __restrict__ tz = reinterpret_cast<const unsigned*>(ws + L.tile_z) +
+                                    ((size_t)(set ^ 1) * L.chunks + (size_t)f.tile * (TQ / pp::kChunk)) * 8;
+  const unsigned* __restrict__ src = lane < 16 ? gsets + 16 * (size_t)set + lane
+                                               : (lane < 32 ? gsets + 16 * (size_t)(set ^ 1) + (lane - 16)
+                                                            : tz + min(lane - 32, kTz - 1));
+  f.meta = *src;
+  f.meta2 = kTz > 16 ? tz[min(lane, kTz - 1)] : 0u;
+  f.lay = (reinterpret_cast<const unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords)[lane < pp::kLayerWords ? lane : 0];
+  const pp::f4* __restrict__ qsorted = reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(f.b, f.dir ^ 1, N, M);
+  // (an asm load: a plain one the compiler sinks to its first use, a round trip later; it is invisible to the compiler's
+  //  counting of loads in flight, so an explicit s_waitcnt vmcnt(0) precedes every use -- stage_a_kernel's loop top)
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(f.qq) : "v"((unsigned)f.jj << 4), "s"(qsorted) : "memory");
+}
+
+template <int TQ, int CAP, int WPE>
+__global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict__ dist1, int* __restrict__ idx1,
+                                                              float* __restrict__ dist2, int* __restrict__ idx2,
+                                                              unsigned char* __restrict__ ws, int B, int N, int M,
+                                                              int tiles1, int tiles2, int total, int per_xcd,
+                                                              const Layout L) {
+  static_assert(TQ % pp::kChunk == 0 && (CAP + 63) / 64 * 64 + 4 <= 4096 + 4, "");
+  // PERSISTENT: the launch is a few workgroups per CU (a multiple of eight, so that a workgroup's tiles stay on its
+  // XCD under the round-robin placement -- speed only); workgroup w takes the virtual tiles w, w + gridDim.x, ...
+  const int nvt = per_xcd * 8;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = pp::wave_id_uniform();
+  constexpr int kW = TQ / 64;
+  __shared__ pp::f4 s_img[(CAP + 63) / 64 * 64 + 4];  // (whole pieces of 64 points, then the padding)
+  PP_QPHASE_DECL;
+  StageAFront<TQ> nx;
+  stage_a_issue<TQ>(nx, (int)blockIdx.x, per_xcd, total, tiles1, tiles2, N, M, ws, L, t, lane);
+  for (int it = (int)blockIdx.x; it < nvt; it += (int)gridDim.x) {  // workgroup-uniform
+  PP_APHASE(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's front has landed (the asm load of the query too)
+  const StageAFront<TQ> f = nx;
+  if (it + (int)gridDim.x < nvt)  // the next tile's front goes out now and travels while this tile is walked
+    stage_a_issue<TQ>(nx, it + (int)gridDim.x, per_xcd, total, tiles1, tiles2, N, M, ws, L, t, lane);
+  const int b = f.b, dir = f.dir, tile = f.tile, jj = f.jj;
+  const bool valid = f.valid;
+  const int nq = dir ? M : N;
+  const int set = 2 * b + dir;
+  const pp::f4 qq = f.qq;
+  const unsigned lay = f.lay;
+  auto meta = [&](int l) { return __builtin_amdgcn_readlane((int)f.meta, l); };
+  int kmin = 0x7fffffff, kmax = (int)0x80000000;  // the tile's lowest / highest z (pp::zkey)
+  {
+    constexpr int kTz = 8 * (TQ / pp::kChunk);
+#pragma unroll
+    for (int w = 0; w < kTz; w += 2) {
+      const int lo = kTz > 16 ? __builtin_amdgcn_readlane((int)f.meta2, w) : meta(32 + w);
+      const int hi = kTz > 16 ? __builtin_amdgcn_readlane((int)f.meta2, w + 1) : meta(32 + w + 1);
+      kmin = min(kmin, lo);
+      kmax = max(kmax, hi);
+    }
+  }
+  int* __restrict__ plist = reinterpret_cast<int*>(ws + L.pend) + set_point_offset(b, dir ^ 1, N, M);
+  unsigned* __restrict__ pcnt = reinterpret_cast<unsigned*>(ws + L.pend_cnt) + pend_count_offset(b, dir, N, M);
+  bool pend = valid;  // (until settled)
+  int tried = 0;      // kPendTried once stage A has really been run for the tile
+  GridSet g;          // the reference grid (lanes 0..15 of meta: see the static_assert on GridSet's layout)
+  static_assert(sizeof(GridSet) == 64 && offsetof(GridSet, gx) == 20 && offsetof(GridSet, useless) == 32 &&
+                    offsetof(GridSet, pad) == 36 && offsetof(GridSet, crowd) == 48, "the words read below");
+  g.minx = __int_as_float(meta(0)); g.miny = __int_as_float(meta(1)); g.minz = __int_as_float(meta(2));
+  g.h = __int_as_float(meta(3)); g.invh = __int_as_float(meta(4));
+  g.gx = meta(5); g.gy = meta(6); g.gz = meta(7);
+  // (uniform over the set) grids without crowded cells on both sides (crowd: 1 useless, 2 second-level grids), no
+  // degenerate set, and the query cloud's chunk table exists; no short-circuits: nothing here is worth a branch
+  const bool lean_ok = (f.live != 0) & (meta(8) == 0) & ((meta(12) | meta(13) | meta(14) | meta(15)) == 0) & (meta(16 + 8) == 0) &
+                       ((meta(16 + 12) | meta(16 + 13) | meta(16 + 14) | meta(16 + 15)) == 0) & (meta(16 + 10) == 1);
+  if (lean_ok) {
+    const float qx = qq.x, qy = qq.y, qz = qq.z;
+    const unsigned* __restrict__ cell_start =
+        reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
+    const pp::f4* __restrict__ sorted = reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
+    const float inf = __builtin_inff();
+    const int gx1 = __builtin_amdgcn_readfirstlane(g.gx - 1), gy1 = __builtin_amdgcn_readfirstlane(g.gy - 1),
+              gz1 = __builtin_amdgcn_readfirstlane(g.gz - 1);
+    // the tile's z range (world coordinates) -> the layers of the reference grid its blocks can touch: a block holds
+    // the query's layer and one neighbour, and pp::cell_coord is monotone in z
+    const int Lz = max(__builtin_amdgcn_readfirstlane(cell_coord(pp::zkey_inv(kmin), g.minz, g.invh, g.gz)) - 1, 0);
+    const int Hz = min(__builtin_amdgcn_readfirstlane(cell_coord(pp::zkey_inv(kmax), g.minz, g.invh, g.gz)) + 1, gz1);
+    const unsigned tb0 = (unsigned)__builtin_amdgcn_readlane((int)lay, Lz);
+    const unsigned ns = (unsigned)__builtin_amdgcn_readlane((int)lay, Hz + 1) - tb0;
+    if (ns > 0u && ns <= (unsigned)CAP) {  // workgroup-uniform
+      // the image: [tb0, tb0 + ns) of the sorted cloud, by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write),
+      // in pieces of 64 points, wave w the pieces w, w + kW, ...; ordered here, before anything waits.  A piece's lanes
+      // beyond the image's end re-read its last point (the slots behind the end are the padding's, written below).
+      const pp::f4* __restrict__ src = sorted + tb0;
+      for (unsigned pc = (unsigned)wave; pc * 64u < ns; pc += (unsigned)kW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + min(pc * 64u + (unsigned)lane, ns - 1)),
+                                         (__attribute__((address_space(3))) void*)(&s_img[pc * 64u]), 16, 0, 0);
+      const float px = (qx - g.minx) * g.invh, py = (qy - g.miny) * g.invh, pz = (qz - g.minz) * g.invh;  // in cells
+      int cx, cy, cz;  // the query's cell (pp::cell_coord's arithmetic)
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cx) : "v"((int)px), "s"(gx1));
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cy) : "v"((int)py), "s"(gy1));
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cz) : "v"((int)pz), "s"(gz1));
+      // the 2x2x2 block: cells l, l + 1 per axis (the neighbour on the side of the cell the query lies in), clamped
+      const int lx = px - (float)cx < 0.5f ? cx - 1 : cx, ly = py - (float)cy < 0.5f ? cy - 1 : cy,
+                lz = pz - (float)cz < 0.5f ? cz - 1 : cz;
+      const int x0 = max(lx, 0), x1 = min(lx + 1, gx1), y0 = max(ly, 0), y1 = min(ly + 1, gy1), z0 = max(lz, 0),
+                z1 = min(lz + 1, gz1);
+      // What the block guarantees: along each axis the distance to the nearer face of the block that has grid beyond
+      // it (lower face at coordinate l, cells below it exist iff l >= 1; upper face at l + 2, cells above iff
+      // l + 2 <= cells - 1); beyond the grid there is nothing, the rim cells hold what was clamped into them.
+      auto face = [&](float p, int l, int g1) {
+        const float lo = l >= 1 ? p - (float)l : inf;
+        const float hi = l + 1 < g1 ? (float)(l + 2) - p : inf;
+        return fminf(lo, hi);
+      };
+      const float reach = g.h * fminf(face(px, lx, gx1), fminf(face(py, ly, gy1), face(pz, lz, gz1)));
+      // the bounds of the block's four rows (y, z): a row is one or two cells wide, its bounds at most two table
+      // entries apart: one 12-byte load each
+      typedef unsigned u3 __attribute__((ext_vector_type(3)));
+      u3 r00, r01, r10, r11;
+      {
+        const unsigned gx4 = (unsigned)g.gx << 2, x04 = (unsigned)x0 << 2;
+        auto row_off = [&](int z, int y) {  // byte offset of entry (x0, y, z): every factor fits 24 bits
+          unsigned o;
+          asm("v_mad_u32_u24 %0, %1, %2, %3\n\tv_mad_u32_u24 %0, %0, %4, %5" : "=&v"(o) : "v"(z), "s"(g.gy), "v"(y), "s"(gx4), "v"(x04));
+          return o;
+        };
+        const char* __restrict__ tb = reinterpret_cast<const char*>(cell_start);
+        __builtin_memcpy(&r00, tb + row_off(z0, y0), 12);
+        __builtin_memcpy(&r01, tb + row_off(z0, y1), 12);
+        __builtin_memcpy(&r10, tb + row_off(z1, y0), 12);
+        __builtin_memcpy(&r11, tb + row_off(z1, y1), 12);
+      }
+      PP_APHASE(1);
+      // rows -> byte positions in the image
+      const bool wide = x1 > x0;
+      const bool va0 = lz >= 0, va1 = lz < gz1, vb0 = ly >= 0, vb1 = ly < gy1;  // the row's layer / line exists
+      const unsigned s0 = r00.x, e0 = (va0 & vb0) ? (wide ? r00.z : r00.y) : s0;
+      const unsigned s1 = r01.x, e1 = (va0 & vb1) ? (wide ? r01.z : r01.y) : s1;
+      const unsigned s2 = r10.x, e2 = (va1 & vb0) ? (wide ? r10.z : r10.y) : s2;
+      const unsigned s3 = r11.x, e3 = (va1 & vb1) ? (wide ? r11.z : r11.y) : s3;
+      const unsigned t0 = (e0 - s0 + 3) >> 2, t1 = (e1 - s1 + 3) >> 2, t2 = (e2 - s2 + 3) >> 2, t3 = (e3 - s3 + 3) >> 2;
+      const unsigned T1 = t0, T2 = T1 + t1, T3 = T2 + t2, T4 = T3 + t3;
+      // group k of the lane's sequence starts at byte a_r + 64 k of the image, r the row k falls in
+      const unsigned a0 = (s0 - tb0) << 4, a1 = ((s1 - tb0) << 4) - (T1 << 6), a2 = ((s2 - tb0) << 4) - (T2 << 6),
+                     a3 = ((s3 - tb0) << 4) - (T3 << 6);
+      const unsigned endb = ns << 4;  // the padding
+      const int kmax = (int)pp::wave_reduce_dpp<false>((float)T4);
+      PP_APHASE(2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the image have landed
+      // the padding: four points that can never be taken (their distance is NaN); lanes whose rows are finished, and
+      // groups that run past the end of the image, land here.  Written by the wave that owns the piece the image ends
+      // in, after that piece has landed (its lanes beyond the end wrote the slots first).
+      if (wave == (int)((ns >> 6) % (unsigned)kW) && lane < 4) {
+        const float qn = __builtin_nanf("");
+        const pp::f4 nanp = {qn, qn, qn, __int_as_float(0x7fffffff)};
+        s_img[ns + lane] = nanp;
+      }
+      __syncthreads();
+      PP_APHASE(3);
+      const lds_c_ptr lb = (lds_c_ptr)(&s_img[0]);
+      auto pos_of = [=](unsigned k) { return lean_group_pos(k, T1, T2, T3, a0, a1, a2, a3, endb); };
+      pp::f4 pa[4], pb[4];
+      auto fetch4 = [&](unsigned pos, pp::f4 (&p)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = *(lds_f4_ptr)(lb + pos + 16 * u);
+      };
+      float best = inf;
+      int bidx = 0x7fffffff;
+      unsigned gpos = endb;           // byte position of the group that holds the winner
+      unsigned long long tie = 0ull;  // lanes that met a distance equal to their running minimum in a later group
+      auto track = [&](unsigned pos, const pp::f4 (&p)[4]) {
+        float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+        const float gmin = min2(pp::min3(d[0], d[1], d[2]), d[3]);
+        const bool lt = gmin < best;
+        tie |= __ballot(gmin == best);
+        gpos = lt ? pos : gpos;
+        best = lt ? gmin : best;
+      };
+      unsigned pcur = pos_of(0), pnext;
+      fetch4(pcur, pa);
+      for (int k = 0; k < kmax; k += 2) {
+        pnext = pos_of(k + 1);
+        fetch4(pnext, pb);
+        track(pcur, pa);
+        pcur = pos_of(k + 2);
+        fetch4(pcur, pa);
+        track(pnext, pb);
+      }
+      if (tie) {  // an exact tie across groups (duplicated points, lattices): the walk again in the exact order
+        best = inf;
+        auto examine = [&](const pp::f4 (&p)[4]) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+            const int id = __float_as_int(p[u].w);
+            const bool take = (d < best) | ((d == best) & (id < bidx));
+            best = take ? d : best;
+            bidx = take ? id : bidx;
+          }
+        };
+        fetch4(pos_of(0), pa);
+        for (int k = 0; k < kmax; k += 2) {
+          fetch4(pos_of(k + 1), pb);
+          examine(pa);
+          fetch4(pos_of(k + 2), pa);
+          examine(pb);
+        }
+      } else {  // the winner is in the group at gpos: lowest index among its minima
+        fetch4(gpos, pa);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float d = pp::chamfer_d3(pa[u].x, pa[u].y, pa[u].z, qx, qy, qz);
+          const int id = __float_as_int(pa[u].w);
+          bidx = ((d == best) & (id < bidx)) ? id : bidx;
+        }
+      }
+      PP_APHASE(4);
+      tried = kPendTried;
+      if (valid && best < reach * reach * kBoundSlack) {  // settled (strict; a NaN bound settles nothing)
+        const int j = __float_as_int(qq.w);
+        (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
+        (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
+        pend = false;
+      }
+    }
+  }
+  // what is left goes to the wave's slots of the pending list (in lane order: the order of the sorted cloud)
+  const unsigned long long pm = __ballot(pend);
+  const int wq = tile * (TQ / 64) + wave;  // this wave among the waves of the direction
+  if (f.live && wq * 64 < nq) {
+    if (pend) plist[wq * 64 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u))] = jj | tried;
+    if (lane == 0) pcnt[wq] = (unsigned)__builtin_popcountll(pm);  // (no atomics: the list kernel adds the counts up)
+  }
+  PP_APHASE(5);
+  __syncthreads();  // every wave has left the image: the next tile's may be written
+  }  // (tiles)
+}
+
 }  // namespace
 
 // 0 = automatic (grid when a workspace is given and the problem is large enough to pay for its two
 // launches); 1 = brute force; 2 = grid wherever it is structurally possible (tests)
 static pp::Knob g_grid_mode;
 extern "C" void pp_debug_set_nmdistance_search(int v) { g_grid_mode.set(v); }
-// LDS points per wave of the wave-private form of the search kernel (320 / 384 / 512); selecting one also selects that
-// form.  0 = default: the tile form below.
+// LDS points per wave of the whole-search kernel (grid_query_wave_kernel): 0 = default (384); 320 / 512 for comparison
 static pp::Knob g_stage_cap;
 extern "C" void pp_debug_set_nmdistance_stage_cap(int v) { g_stage_cap.set(v); }
-// queries per workgroup of the tile form: 0 = default (512); 256, 512, 768; -1 = the wave-private form (CAPW 384)
+// unlabeled searches: queries per workgroup of the stage-A kernel: 0 = default (512); 256, 512, 1024; -1 = no stage-A
+// kernel (round 2's two launches: the whole-search kernel serves every query)
 static pp::Knob g_tile;
 extern "C" void pp_debug_set_nmdistance_tile(int v) { g_tile.set(v); }
 
@@ -1754,23 +1918,59 @@ extern "C" void pp_debug_set_nmdistance_tile(int v) { g_tile.set(v); }
 // forward.  One set of events per process (a measurement aid for one stream at a time, not a product feature).
 static pp::Knob g_time_kernels;
 static std::mutex g_ev_mutex;
-static hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+static hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // before the build, after it, after stage A, after the search
 static bool g_ev_valid = false;
+static bool g_ev_two_stage = false;
 extern "C" void pp_debug_set_nmdistance_kernel_timing(int on) { g_time_kernels.set(on); }
 extern "C" int pp_debug_nmdistance_kernel_ms(float* build_ms, float* search_ms) {
   std::lock_guard<std::mutex> lock(g_ev_mutex);
   if (!g_ev_valid || !build_ms || !search_ms) return PP_EINVAL;
-  hipError_t e = hipEventSynchronize(g_ev[2]);
+  hipError_t e = hipEventSynchronize(g_ev[3]);
   if (e == hipSuccess) e = hipEventElapsedTime(build_ms, g_ev[0], g_ev[1]);
-  if (e == hipSuccess) e = hipEventElapsedTime(search_ms, g_ev[1], g_ev[2]);
+  if (e == hipSuccess) e = hipEventElapsedTime(search_ms, g_ev[1], g_ev[3]);
   return (int)e;
 }
-static void record_timing_event(int i, hipStream_t s) {
+// the search's two launches by themselves (unlabeled searches: the stage-A kernel, then the kernel that serves what it
+// left); stage_a_ms = 0 when the most recent forward had no stage-A kernel
+extern "C" int pp_debug_nmdistance_kernel_ms3(float* build_ms, float* stage_a_ms, float* rest_ms) {
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  if (!g_ev_valid || !build_ms || !stage_a_ms || !rest_ms) return PP_EINVAL;
+  hipError_t e = hipEventSynchronize(g_ev[3]);
+  if (e == hipSuccess) e = hipEventElapsedTime(build_ms, g_ev[0], g_ev[1]);
+  *stage_a_ms = 0.0f;
+  if (e == hipSuccess && g_ev_two_stage) e = hipEventElapsedTime(stage_a_ms, g_ev[1], g_ev[2]);
+  if (e == hipSuccess) e = hipEventElapsedTime(rest_ms, g_ev[g_ev_two_stage ? 2 : 1], g_ev[3]);
+  return (int)e;
+}
+static void record_timing_event(int i, hipStream_t s, bool two_stage = false) {
   std::lock_guard<std::mutex> lock(g_ev_mutex);
   if (!g_ev[0])
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 4; ++k)
       if (hipEventCreate(&g_ev[k]) != hipSuccess) return;
-  if (hipEventRecord(g_ev[i], s) == hipSuccess && i == 2) g_ev_valid = true;
+  if (hipEventRecord(g_ev[i], s) == hipSuccess && i == 3) {
+    g_ev_valid = true;
+    g_ev_two_stage = two_stage;
+  }
+}
+
+// queries the stage-A kernel of the most recent unlabeled forward on this workspace left to the list kernel, per
+// direction (2 B numbers; synchronises the device): what fraction of the search ran outside stage A
+extern "C" int pp_debug_nmdistance_pending(const void* workspace, int B, int N, int M, unsigned* totals) {
+  if (!workspace || !totals || B <= 0) return PP_EINVAL;
+  const Layout L = make_layout(B, N, M, false);
+  if (L.chunks == 0) return PP_EINVAL;
+  hipError_t e = hipDeviceSynchronize();
+  std::vector<unsigned> cnt;
+  for (int s = 0; s < 2 * B && e == hipSuccess; ++s) {
+    const int b = s >> 1, dir = s & 1, nwq = ((dir ? M : N) + 63) / 64;
+    cnt.resize((size_t)nwq);
+    e = hipMemcpy(cnt.data(), (const unsigned char*)workspace + L.pend_cnt + 4 * pend_count_offset(b, dir, N, M), 4 * (size_t)nwq,
+                  hipMemcpyDeviceToHost);
+    unsigned t = 0;
+    for (unsigned c : cnt) t += c;
+    totals[s] = t;
+  }
+  return (int)e;
 }
 
 static bool grid_applicable(int B, int N, int M, int C) {
@@ -1809,32 +2009,69 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
       xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr);
   PP_RETURN_IF_LAUNCH_FAILED();
   if (timing) record_timing_event(1, s);
-  const int cap = g_stage_cap, tile = g_tile;
-  const bool wave_form = cap == 320 || cap == 384 || cap == 512 || tile == -1;
-  const int tq = wave_form ? 256 : (tile == 256 || tile == 768 ? tile : 512);
-  const int tiles1 = (N + tq - 1) / tq, tiles2 = (M + tq - 1) / tq;
+  const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
   const long long blocks = (long long)B * (tiles1 + tiles2);
   if (blocks > 0x7fffffffLL) return PP_EINVAL;
   const int per_xcd = (int)((blocks + 7) / 8);
-#define PP_LAUNCH_W(CAP_, TQ_)                                                                             \
-  grid_query_wave_kernel<LAB, CAP_, TQ_><<<dim3((unsigned)(per_xcd * 8)), dim3(TQ_ ? TQ_ : 256), 0, s>>>(      \
-      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2)
-  if (wave_form) {
-    switch (cap) {
-      case 320: PP_LAUNCH_W(320, 0); break;
-      case 512: PP_LAUNCH_W(512, 0); break;
-      default: PP_LAUNCH_W(384, 0); break;
+  const int tile = g_tile;
+  const Layout lay = make_layout(B, N, M, LAB);
+  const bool two_stage = !LAB && tile != -1 && lay.chunks > 0;
+  if (two_stage) {  // stage A by tiles, then the whole-search kernel over what it left (LIST)
+    const int tq = tile == 256 || tile == 1024 || tile == 513 ? tile : 512;
+    const int tqq = tq == 513 ? 512 : tq;
+    const int ta1 = (N + tqq - 1) / tqq, ta2 = (M + tqq - 1) / tqq;
+    const long long ablocks = (long long)B * (ta1 + ta2);
+    const int aper = (int)((ablocks + 7) / 8);
+    // persistent: as many workgroups as stay resident (CUs x workgroups per CU by the image's size), a multiple of
+    // eight, at most one per tile; each walks the tiles w, w + grid, ... with the next tile's front loads in flight
+    static std::atomic<int> cus{0};
+    int ncu = cus.load(std::memory_order_relaxed);
+    if (ncu == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          ncu <= 0)
+        ncu = 256;
+      cus.store(ncu, std::memory_order_relaxed);
     }
-  } else {
+#define PP_LAUNCH_A(TQ_, CAP_, PER_CU_, WPE_)                                                                          \
+  do {                                                                                                          \
+    long long g_ = (long long)ncu * (PER_CU_);                                                                  \
+    g_ = (g_ < (long long)aper * 8 ? g_ : (long long)aper * 8);                                                 \
+    g_ = (g_ + 7) / 8 * 8;                                                                                      \
+    grid_stage_a_kernel<TQ_, CAP_, WPE_><<<dim3((unsigned)g_), dim3(TQ_), 0, s>>>(dist1, idx1, dist2, idx2, ws, B, N, M, ta1, \
+                                                                         ta2, (int)ablocks, aper, lay);         \
+  } while (0)
     switch (tq) {
-      case 256: PP_LAUNCH_W(1532, 256); break;
-      case 768: PP_LAUNCH_W(3068, 768); break;
-      default: PP_LAUNCH_W(3068, 512); break;
+      case 256: PP_LAUNCH_A(256, 2044, 4, 4); break;
+      case 1024: PP_LAUNCH_A(1024, 4032, 2, 8); break;
+      case 513: PP_LAUNCH_A(512, 3068, 2, 5); break;   // (512 at 96 registers: two workgroups per CU)
+      default: PP_LAUNCH_A(512, 3068, 3, 6); break;
+    }
+#undef PP_LAUNCH_A
+    PP_RETURN_IF_LAUNCH_FAILED();
+    if (timing) record_timing_event(2, s);
+  }
+#define PP_LAUNCH_W(CAP_)                                                                                  \
+  grid_query_wave_kernel<LAB, CAP_><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(                       \
+      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2)
+  if (two_stage) {
+    // what stage A left: waves_per_set waves per direction (about 8192 waves in all), every wave by itself
+    const int sets = 2 * B;
+    int wps = 8192 / sets;
+    wps = wps < 4 ? 4 : (wps > 256 ? 256 : wps);
+    const long long lwaves = (long long)sets * wps;
+    grid_query_list_kernel<384><<<dim3((unsigned)(((lwaves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2,
+                                                                                      ws, B, N, M, wps, lay);
+  } else {
+    switch (g_stage_cap) {
+      case 320: PP_LAUNCH_W(320); break;
+      case 512: PP_LAUNCH_W(512); break;
+      default: PP_LAUNCH_W(384); break;
     }
   }
 #undef PP_LAUNCH_W
   PP_RETURN_IF_LAUNCH_FAILED();
-  if (timing) record_timing_event(2, s);
+  if (timing) record_timing_event(3, s, two_stage);
   return PP_OK;
 }
 

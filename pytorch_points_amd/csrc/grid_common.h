@@ -19,8 +19,15 @@ constexpr int kBuildSlabs = 4;  // workgroups that share the build of one set (e
 // Chunk table (Chamfer's tile search): for every kChunk consecutive points of the sorted cloud, the lowest and the
 // highest z coordinate among them, as order-preserving integers (zkey), one (min, max) pair per chunk AND per build
 // slab -- a slab records the points it scatters; pairs of chunks it does not touch stay (+inf, -inf) -- so that the
-// slabs need not meet: tile_z[(slab * chunks + chunk) * 2 + {0, 1}].  Lets a tile of queries find the z-layers of the
+// slabs need not meet: tile_z[(chunk * slabs + slab) * 2 + {0, 1}] (a tile's chunks are one contiguous piece: one wide
+// scalar load), every one of the `chunks` pairs the caller allocated written.  Lets a tile of queries find the z-layers of the
 // OTHER cloud's grid it can touch from two scalar loads, before its queries have arrived.
+// Layer table (same consumer): layers[z] = position in the sorted cloud of the first point of z-layer z (z = 0 .. gz,
+// layers[gz] = the number of points) -- the cell table's entries z * gy * gx, gathered where one vector load fetches
+// them all; layers[kLayerPending] = a counter the build zeroes (the stage-A kernel counts the queries it leaves there).
+constexpr int kLayerWords = 40;
+constexpr int kLayerPending = 36;
+constexpr int kLayerCursor = 37;  // (zeroed by the build too) pieces of the pending list handed out so far: list kernel
 constexpr int kChunk = 256;
 constexpr int kChunkMax = 256;  // chunks per set the build can track (sets of up to 65536 points)
 __host__ __device__ inline int zkey(float z) {  // monotone in z for every non-NaN float
@@ -381,7 +388,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
                                                int nslab, unsigned* __restrict__ sub_start,
                                                SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
                                                float* __restrict__ payload2, int* __restrict__ tile_z = nullptr,
-                                               int tz_chunks = 0) {
+                                               int tz_chunks = 0, unsigned* __restrict__ layers = nullptr) {
   __shared__ unsigned s_part[kBuildThreads];
   __shared__ int s_tz[REFINE ? 2 * kChunkMax : 2];  // chunk table of this slab: (min, max) z keys
   const int nchunkq = (nr + kChunk - 1) / kChunk;
@@ -714,6 +721,16 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     for (int c = t; c < nloc; c += kBuildThreads) cell_start[cell_lo + c] = s_cnt[sk(c)];
     if (t == 0 && slab == nslab - 1) cell_start[ncell] = degenerate ? 0u : (unsigned)nr;
   }
+  if constexpr (REFINE) {
+    if (layers != nullptr) {  // the layer table: the entries of this slab's cells (read before the scatter moves the cursors)
+      if (t < gz) {
+        const int c = t * gy * gx - cell_lo;
+        if (c >= 0 && c < nloc) layers[t] = s_cnt[sk(c)];
+      }
+      if (t == gz && slab == nslab - 1) layers[gz] = degenerate ? 0u : (unsigned)nr;
+      if ((t == kLayerPending || t == kLayerCursor) && slab == 0) layers[t] = 0u;
+    }
+  }
   __syncthreads();
   PP_PHASE(8);
   if (place)
@@ -760,7 +777,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
                     //  up to the cell's own extent -- it re-sorts a cell in place, so a chunk may receive points of the
                     //  same cell from a neighbouring chunk; sets with crowded cells do not use the table, see the search)
       __syncthreads();
-      for (int c = t; c < 2 * nchunkq; c += kBuildThreads) tile_z[(size_t)slab * 2 * tz_chunks + c] = s_tz[c];
+      for (int c = t; c < 2 * tz_chunks; c += kBuildThreads) tile_z[((size_t)(c >> 1) * nslab + slab) * 2 + (c & 1)] = s_tz[c];
     }
   }
   PP_PHASE(9);
@@ -837,9 +854,9 @@ __device__ __forceinline__ void grid_build_set_refined(const float* __restrict__
                                                        unsigned* __restrict__ sub_start,
                                                        SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
                                                        float* __restrict__ payload2, int* __restrict__ tile_z = nullptr,
-                                                       int tz_chunks = 0) {
+                                                       int tz_chunks = 0, unsigned* __restrict__ layers = nullptr) {
   grid_build_set_impl<false, VEC, true>(ref, nr, gs, cell_start, sorted, nullptr, s_cnt, payload, sorted_payload, slab,
-                                        nslab, sub_start, sub_desc, sorted2, payload2, tile_z, tz_chunks);
+                                        nslab, sub_start, sub_desc, sorted2, payload2, tile_z, tz_chunks, layers);
 }
 
 // every batch element's cloud (base + b * n * 3 floats) is 16-byte aligned

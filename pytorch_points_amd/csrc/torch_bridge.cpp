@@ -11,13 +11,18 @@
 // PyTorch is plumbing here: tensors, the caching allocator, the current stream, autograd bookkeeping.  The
 // compute is libpp_hip.so (include/pp_hip.h), which this module links and which has no torch types in it.
 // Built in-tree by pytorch_points_amd/_build.py with g++ against the installed torch (ROCm build).
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>  // a ROCm build of torch names its HIP devices "cuda"
 #include <c10/core/DeviceGuard.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/extension.h>
+
+#include <hip/hip_runtime_api.h>
 
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "pp_hip.h"
 
@@ -183,6 +188,102 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> labeled_nndistance(const Tensor& xyz1
   return std::make_tuple(r[0], r[1], r[2], r[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The batch-sharded operator's one exchange per step (pytorch_points_amd/sharded.py: PackedShardGather), issued from
+// C++: pack the shard's (dist1 | dist2 | idx1 | idx2) into one buffer (pp_shard_pack_f32, on the
+// current stream), ONE all-gather of it over RCCL (c10d: ProcessGroup::_allgather_base), and -- on a side stream that
+// waits for the collective -- unpack the gathered bytes into the global-batch tensors (pp_shard_unpack_f32), all in one
+// call that never touches Python: issued from Python the same three steps cost the thread ~50 us per step, more than
+// the step's kernels leave idle.  Slots are double-buffered by the caller's `depth`; wait(slot) makes the CURRENT
+// stream (not the host) wait for the slot's unpack and returns its tensors, valid until the slot is launched again.
+struct PackedExchange {
+  c10::intrusive_ptr<c10d::ProcessGroup> pg;
+  int world, b, n, m, depth, compact;
+  int64_t nbytes_padded;
+  c10::Device dev;
+  std::vector<Tensor> send, recv;
+  std::vector<std::vector<Tensor>> out;
+  std::vector<hipEvent_t> done;
+  std::vector<bool> inflight;
+  c10::hip::HIPStreamMasqueradingAsCUDA side;
+  int turn = 0;
+
+  PackedExchange(const c10::intrusive_ptr<c10d::ProcessGroup>& group, int b_local, int n_, int m_, const c10::Device& device,
+                 int depth_)
+      : pg(group), world(group->getSize()), b(b_local), n(n_), m(m_), depth(depth_), dev(device),
+        side(c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, device.index())) {
+    TORCH_CHECK(device.is_cuda() && depth >= 1, "PackedExchange needs a GPU device and depth >= 1");
+    compact = std::max(n, m) <= 65535 ? 1 : 0;
+    const int64_t isz = compact ? 2 : 4;
+    const int64_t nbytes = (int64_t)4 * b * (n + m) + isz * b * (n + m);
+    nbytes_padded = (nbytes + 15) / 16 * 16;
+    const auto u8 = torch::TensorOptions().dtype(torch::kUInt8).device(device);
+    const auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(device);
+    const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(device);
+    const c10::DeviceGuard guard(device);
+    for (int k = 0; k < depth; ++k) {
+      send.push_back(torch::empty({nbytes_padded}, u8));
+      recv.push_back(torch::empty({(int64_t)world, nbytes_padded}, u8));
+      out.push_back({torch::empty({(int64_t)world * b, n}, f32), torch::empty({(int64_t)world * b, m}, f32),
+                     torch::empty({(int64_t)world * b, n}, i32), torch::empty({(int64_t)world * b, m}, i32)});
+      hipEvent_t ev;
+      TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+      done.push_back(ev);
+      inflight.push_back(false);
+    }
+  }
+  ~PackedExchange() {
+    for (hipEvent_t ev : done) (void)hipEventDestroy(ev);
+  }
+
+  void finish(int slot) {  // the current stream waits for the slot's unpack
+    if (!inflight[slot]) return;
+    const hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
+    TORCH_CHECK(hipStreamWaitEvent(cur, done[slot], 0) == hipSuccess, "hipStreamWaitEvent failed");
+    inflight[slot] = false;
+  }
+
+  int launch(const Tensor& d1_, const Tensor& d2_, const Tensor& i1_, const Tensor& i2_) {
+    const int slot = turn;
+    turn = (turn + 1) % depth;
+    finish(slot);  // the slot's buffers are about to be overwritten
+    const Tensor d1 = d1_.detach().contiguous(), d2 = d2_.detach().contiguous(), i1 = i1_.contiguous(), i2 = i2_.contiguous();
+    TORCH_CHECK(d1.numel() == (int64_t)b * n && d2.numel() == (int64_t)b * m && i1.numel() == d1.numel() &&
+                    i2.numel() == d2.numel() && d1.scalar_type() == torch::kFloat32 && i1.scalar_type() == torch::kInt32 &&
+                    d1.device() == dev,
+                "PackedExchange.launch: shard outputs of another shape, dtype or device");
+    const c10::DeviceGuard guard(dev);
+    const hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
+    check_code(pp_shard_pack_f32(d1.data_ptr<float>(), d2.data_ptr<float>(), i1.data_ptr<int>(), i2.data_ptr<int>(),
+                                 send[slot].data_ptr(), (long long)b * n, (long long)b * m, compact, (void*)cur),
+               "shard_pack");
+    // (the collective is ordered behind the pack by c10d: it syncs its own stream with the current one)
+    c10::intrusive_ptr<c10d::Work> work = pg->_allgather_base(recv[slot], send[slot]);
+    {
+      const c10::hip::HIPStreamGuardMasqueradingAsCUDA on_side(side);
+      work->wait();  // RCCL: the side stream waits for the collective's end, the host does not block
+      check_code(pp_shard_unpack_f32(recv[slot].data_ptr(), world, (long long)nbytes_padded, (long long)b * n,
+                                     (long long)b * m, compact, out[slot][0].data_ptr<float>(),
+                                     out[slot][1].data_ptr<float>(), out[slot][2].data_ptr<int>(),
+                                     out[slot][3].data_ptr<int>(), (void*)side.stream()),
+                 "shard_unpack");
+      TORCH_CHECK(hipEventRecord(done[slot], side.stream()) == hipSuccess, "hipEventRecord failed");
+    }
+    inflight[slot] = true;
+    return slot;
+  }
+
+  std::vector<Tensor> wait(int slot) {
+    TORCH_CHECK(slot >= 0 && slot < depth, "PackedExchange.wait: no such slot");
+    finish(slot);
+    return out[slot];
+  }
+
+  void drain() {
+    for (int k = 0; k < depth; ++k) finish(k);
+  }
+};
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -192,4 +293,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "labeled_nndistance(xyz1, xyz2, label1, label2) -> (dist1, dist2, idx1, idx2)");
   m.def("set_force_bruteforce", [](bool on) { g_force_brute = on; });
   m.def("library_version", []() { return std::string(pp_version()); });
+  pybind11::class_<PackedExchange>(m, "PackedExchange")
+      .def(pybind11::init<const c10::intrusive_ptr<c10d::ProcessGroup>&, int, int, int, const c10::Device&, int>())
+      .def("launch", &PackedExchange::launch, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def("wait", &PackedExchange::wait)
+      .def("drain", &PackedExchange::drain)
+      .def_readonly("compact", &PackedExchange::compact)
+      .def_readonly("nbytes_padded", &PackedExchange::nbytes_padded);
 }

@@ -11,6 +11,8 @@ FPS stays single-GPU (replicas only): its cost is a serial chain, not capacity.
 """
 import ctypes
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -121,6 +123,17 @@ class PackedShardGather:
             self.side = torch.cuda.Stream(device=self.send[0].device)
             self.done = [torch.cuda.Event() for _ in range(depth)]
             self.out = [None] * depth
+        # RCCL on GPU tensors: the whole exchange -- pack, all-gather, unpack on a side stream -- is ONE native call
+        # (csrc/torch_bridge.cpp: PackedExchange over c10d's ProcessGroup): issued from Python the three steps cost
+        # the thread ~50 us per step, more than a config-2 step's kernels leave idle.
+        # PP_SHARD_EXCHANGE=python keeps the Python path (comparison, debugging).
+        self._native = None
+        if self.on_gpu and self._nccl and os.environ.get("PP_SHARD_EXCHANGE", "native") != "python":
+            from . import _lib
+            pg = group if group is not None else dist.distributed_c10d._get_default_group()
+            self._native = _lib.bridge().PackedExchange(pg, self.b, self.n, self.m, torch.device(device), depth)
+            assert self._native.nbytes_padded == self.nbytes_padded and bool(self._native.compact) == self.compact
+            self.send = self.recv = None   # (the native object owns its buffers)
 
     def _views(self, buf):
         """(d1, d2, i1, i2) views of one rank's packed bytes (1-D uint8)"""
@@ -135,6 +148,8 @@ class PackedShardGather:
         return t.is_cuda
 
     def launch(self, d1, d2, i1, i2):
+        if self._native is not None:
+            return self._native.launch(d1, d2, i1, i2)
         slot = self.turn
         self.turn = (self.turn + 1) % len(self.send)
         if self.inflight[slot] is not None:   # the buffers of this slot are about to be overwritten
@@ -203,6 +218,8 @@ class PackedShardGather:
         """Blocks the current stream (not the host, on RCCL) until the gather of ``slot`` is done and unpacked,
         and returns (dist1, dist2, idx1, idx2) of the global batch in rank order.  On the GPU these are the
         slot's own buffers: valid until the slot is launched again (``depth`` launches later)."""
+        if self._native is not None:
+            return tuple(self._native.wait(slot))
         self._finish(slot)
         r = self.recv[slot]
         o = self.off
@@ -222,5 +239,7 @@ class PackedShardGather:
         return d1, d2, i1, i2
 
     def drain(self):
+        if self._native is not None:
+            return self._native.drain()
         for s in range(len(self.inflight)):
             self._finish(s)

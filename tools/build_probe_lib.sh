@@ -5,6 +5,6 @@ set -e
 cd "$(dirname "$0")/.."
 python -c "from pytorch_points_amd import _build; _build.build()"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fPIC -std=c++17 -Wall -Wno-unused-function \
-  -DPP_QUERY_PROBE -Iinclude -Ipytorch_points_amd/csrc -c pytorch_points_amd/csrc/chamfer_grid.hip -o /tmp/chamfer_grid_probe.o
+  -DPP_QUERY_PROBE $PP_PROBE_FLAGS -Iinclude -Ipytorch_points_amd/csrc -c pytorch_points_amd/csrc/chamfer_grid.hip -o /tmp/chamfer_grid_probe.o
 objs=$(ls pytorch_points_amd/build/*.o | grep -v chamfer_grid.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/chamfer_grid_probe.o -o tools/libpp_hip_probe.so

@@ -12,7 +12,7 @@ L = _lib.lib()
 sett = L.pp_debug_set_nmdistance_tile; sett.argtypes = [ctypes.c_int]; sett.restype = None
 sets = L.pp_debug_set_nmdistance_search; sets.argtypes = [ctypes.c_int]; sets.restype = None
 tk = L.pp_debug_set_nmdistance_kernel_timing; tk.argtypes = [ctypes.c_int]; tk.restype = None
-rd = L.pp_debug_nmdistance_kernel_ms; rd.argtypes = [ctypes.POINTER(ctypes.c_float)] * 2; rd.restype = ctypes.c_int
+rd = L.pp_debug_nmdistance_kernel_ms3; rd.argtypes = [ctypes.POINTER(ctypes.c_float)] * 3; rd.restype = ctypes.c_int
 def run(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -45,7 +45,7 @@ def clouds(kind, seed):
         if seed: x += 5.0
         return x
 kinds = sys.argv[1:] or ["sphere", "cube", "gaussian", "blobs8", "two_scales", "plane", "line", "shapenet_like", "disjoint"]
-modes = (-1, 256, 512, 768)
+modes = (-1, 512, 513, 1024)
 for kind in kinds:
     x1 = torch.from_numpy(np.ascontiguousarray(clouds(kind, 0))).to(dev); x2 = torch.from_numpy(np.ascontiguousarray(clouds(kind, 1))).to(dev)
     def outs():
@@ -62,14 +62,21 @@ for kind in kinds:
         o = outs()
         ms = run(lambda: losses.nmdistance_forward(x1, x2, *o))
         tk(1)
-        bms, sms = [], []
+        bms, sms, rms = [], [], []
         for _ in range(6):
             losses.nmdistance_forward(x1, x2, *o)
-            a_, b_ = ctypes.c_float(0), ctypes.c_float(0)
-            rd(ctypes.byref(a_), ctypes.byref(b_)); bms.append(a_.value); sms.append(b_.value)
+            a_, b_, c_ = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
+            rd(ctypes.byref(a_), ctypes.byref(b_), ctypes.byref(c_)); bms.append(a_.value); sms.append(b_.value); rms.append(c_.value)
         tk(0)
         same = all(torch.equal(a, b) for a, b in zip(o, ref))
+        pend = ""
+        if mode != -1:
+            tot = (ctypes.c_uint * (2 * B))()
+            wsb = _lib.cached_workspaces("nmdistance")[0]
+            fn = L.pp_debug_nmdistance_pending; fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]; fn.restype = ctypes.c_int
+            if fn(wsb.data_ptr(), B, N, N, tot) == 0:
+                pend = " left %.2f%%" % (100.0 * sum(tot) / (2.0 * B * N))
         ok = ok and same
-        line += " | %4d: fwd %.4f build %.4f search %.4f %s" % (mode, ms, np.mean(bms[1:]), np.mean(sms[1:]), "ok" if same else "MISMATCH")
+        line += " | %4d: fwd %.4f build %.4f stageA %.4f rest %.4f %s" % (mode, ms, np.mean(bms[1:]), np.mean(sms[1:]), np.mean(rms[1:]), ("ok" if same else "MISMATCH") + pend)
     sett(0)
     print(line, flush=True)
