@@ -165,13 +165,14 @@ def _knob(name):
 
 
 def _search_kernel_ms(fwd, n=40):
-    """Average duration of the forward's two kernels (grid build, search), HIP events recorded by the library
+    """Average duration of the forward's launches -- grid build, stage-A kernel (unlabeled searches), the kernel that
+    serves what stage A left (or the whole search where there is no stage-A kernel) -- HIP events recorded by the library
     on the launch stream around each launch (pp_debug_set_nmdistance_kernel_timing, include/pp_hip_debug.h)."""
     import ctypes
     from pytorch_points_amd import _lib
     L = _lib.lib()
-    read = L.pp_debug_nmdistance_kernel_ms
-    read.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    read = L.pp_debug_nmdistance_kernel_ms3
+    read.argtypes = [ctypes.POINTER(ctypes.c_float)] * 3
     read.restype = ctypes.c_int
     on = _knob("pp_debug_set_nmdistance_kernel_timing")
     on(1)
@@ -179,17 +180,18 @@ def _search_kernel_ms(fwd, n=40):
         for _ in range(3):
             fwd()
         torch.cuda.synchronize()
-        bs, ss = [], []
+        bs, aa, rr = [], [], []
         for _ in range(n):
             fwd()
-            bm, sm = ctypes.c_float(0), ctypes.c_float(0)
-            if read(ctypes.byref(bm), ctypes.byref(sm)) != 0:
-                return None, None
+            bm, am, rm = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
+            if read(ctypes.byref(bm), ctypes.byref(am), ctypes.byref(rm)) != 0:
+                return None, None, None
             bs.append(bm.value)
-            ss.append(sm.value)
+            aa.append(am.value)
+            rr.append(rm.value)
     finally:
         on(0)
-    return float(np.mean(bs)), float(np.mean(ss))
+    return float(np.mean(bs)), float(np.mean(aa)), float(np.mean(rr))
 
 
 def _distribution(kind, seed, B, N):
@@ -414,9 +416,10 @@ def bench_chamfer(args, dist, world, rank, device):
     torch.cuda.synchronize()
     fwd_ms = e0.elapsed_time(e1) / nf
     grid = args.search == "auto" and int(_lib.lib().pp_nmdistance_forward_workspace_bytes(B, N, M, C)) > 0
-    build_ms = search_ms = None
+    build_ms = stage_a_ms = rest_ms = search_ms = None
     if grid:
-        build_ms, search_ms = _search_kernel_ms(fwd_only)
+        build_ms, stage_a_ms, rest_ms = _search_kernel_ms(fwd_only)
+        search_ms = (stage_a_ms + rest_ms) if build_ms is not None else None
 
     # the same step with the search forced to the brute-force kernel (every pair evaluated)
     brute = None

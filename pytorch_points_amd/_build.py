@@ -70,11 +70,35 @@ def _build_library(force, verbose):
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
 
 
+BRIDGE_META = BRIDGE + ".meta"
+
+
+def _bridge_tag():
+    """what the bridge was compiled against: it links libtorch and the CPython ABI, so a module built for another
+    torch or Python (it travels with a snapshot of the tree) must be rebuilt, not imported"""
+    import sys
+    import sysconfig
+
+    import torch
+    return "torch=%s python=%s abi=%s" % (torch.__version__, sys.version.split()[0], sysconfig.get_config_var("SOABI"))
+
+
 def bridge_is_stale():
     if not os.path.exists(BRIDGE):
         return True
     t = os.path.getmtime(BRIDGE)
-    return any(os.path.getmtime(d) > t for d in (BRIDGE_SRC, os.path.join(INCLUDE, "pp_hip.h")))
+    if any(os.path.getmtime(d) > t for d in (BRIDGE_SRC, os.path.join(INCLUDE, "pp_hip.h"))):
+        return True
+    return bridge_abi_mismatch()
+
+
+def bridge_abi_mismatch():
+    """the module on disk was built against another torch / Python (or carries no tag): importing it would fail with
+    undefined symbols at best"""
+    try:
+        return open(BRIDGE_META).read().strip() != _bridge_tag()
+    except OSError:
+        return True
 
 
 def build_bridge(force=False, verbose=False):
@@ -96,6 +120,8 @@ def build_bridge(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    with open(BRIDGE_META, "w") as fh:
+        fh.write(_bridge_tag() + "\n")
     return BRIDGE
 
 

@@ -110,7 +110,15 @@ def bridge():
                 "pytorch_points_amd: %s not found. Build it with `python -m pytorch_points_amd._build` (g++ against "
                 "the installed torch)." % _build.BRIDGE)
         import importlib
-        mod = importlib.import_module("pytorch_points_amd._pp_torch")
+        if _build.bridge_abi_mismatch():   # (the tag only: file times do not survive a copy of the tree)
+            raise RuntimeError(
+                "pytorch_points_amd: %s was built for another torch / Python than this one (%s). Rebuild it with "
+                "`python -m pytorch_points_amd._build`." % (_build.BRIDGE, _build.BRIDGE_META))
+        try:
+            mod = importlib.import_module("pytorch_points_amd._pp_torch")
+        except ImportError as exc:
+            raise RuntimeError("pytorch_points_amd: %s does not load (%s). Rebuild it with `python -m "
+                               "pytorch_points_amd._build`." % (_build.BRIDGE, exc)) from exc
         mod.set_force_bruteforce(os.environ.get("PP_NMDISTANCE_SEARCH") == "bruteforce")
         _bridge = mod
     return _bridge

@@ -27,6 +27,7 @@
 //       - labeled searches and non-finite queries keep the older forms of the last step (larger cubes by
 //         the whole wave, the occupied cells or the whole cloud a lane per query); so does every query of a
 //         set whose grid is useless (non-finite coordinates).  Two launches per forward, no list.
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -1012,6 +1013,100 @@ __device__ __forceinline__ float min2(float a, float b) {
 // cloud has no grid), `valid` = the lane has a query; s_pts_w / s_lab_w = the wave's private slice of LDS (CAPW + 4
 // points / labels).  skip_a (wave-uniform): stage A has been run for every one of these queries already (the stage-A
 // kernel) and settled none of them -- go straight to the stages after it.
+// One query by the whole wave: the cube of Chebyshev radius 2 around its cell in ONE pass -- lane r < 25 fetches the
+// bounds of row r (one round trip), the rows are laid end to end, and every lane loads its share of the candidates with
+// all its loads in flight together (the next round trip); the smallest (distance bits, index) key of the wave is the
+// nearest examined point.  Returns true when that settles the query: the best distance lies below what the cube
+// guarantees (every unexamined point is beyond one of its faces that has grid beyond it), or the cube covers the grid.
+// False (nothing written) when the cube holds more than kCube2Max candidates or does not settle the query: the
+// caller's other stages take over.  Unlabeled searches, finite or not (a non-finite query settles nothing).
+// (Out of line, results by value, the grid by pointer: see serve_pending.)
+constexpr unsigned kCube2Max = 384;
+__device__ __attribute__((noinline)) Found wave_cube2_search(float qx, float qy, float qz, const GridSet* __restrict__ gp,
+                                                             const unsigned* __restrict__ cell_start,
+                                                             const pp::f4* __restrict__ sorted) {
+  const GridSet g = *gp;
+  Found out;
+  out.best = __builtin_inff();
+  out.bidx = 0x7fffffff;
+  out.aux = 0.0f;  // 1: settled
+  const int lane = threadIdx.x & 63;
+  const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
+  const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
+  const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
+  const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.gx - 1);
+  const int z = cz - 2 + lane / 5, y = cy - 2 + lane % 5;
+  const bool ok = lane < 25 && z >= 0 && z < g.gz && y >= 0 && y < g.gy;
+  const int c = pp::cell_linear(0, min(max(y, 0), g.gy - 1), min(max(z, 0), g.gz - 1), g.gx, g.gy);
+  unsigned rs = 0, re = 0;
+  if (ok) {
+    rs = cell_start[c + x0];
+    re = cell_start[c + x1 + 1];
+  }
+  const unsigned len = re - rs;
+  unsigned incl = len;
+#pragma unroll
+  for (int off = 1; off < 32; off <<= 1) {
+    const unsigned o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
+  if (total == 0u || total > kCube2Max) return out;  // (wave-uniform)
+  const unsigned excl = incl - len;
+  const unsigned shift = rs - excl;  // candidate k of row r sits at sorted[k + shift_r]
+  unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, no index)
+  constexpr int kU = kCube2Max / 64;
+  unsigned at[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const unsigned k = min((unsigned)(u * 64 + lane), total - 1);  // (the tail repeats the last candidate: harmless)
+    unsigned add = 0;
+    for (int r = 0; r < 25; ++r) {  // the last row whose first candidate is <= k (empty rows are overridden)
+      const unsigned ex = (unsigned)__builtin_amdgcn_readlane((int)excl, r);
+      const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)shift, r);
+      add = k >= ex ? sh : add;
+    }
+    at[u] = k + add;
+  }
+  pp::f4 p[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u)
+    if ((unsigned)(u * 64) < total) p[u] = sorted[at[u]];  // (wave-uniform conditions: the loads stay in flight together)
+#pragma unroll
+  for (int u = 0; u < kU; ++u)
+    if ((unsigned)(u * 64) < total) {
+      const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
+      const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w);
+      key = cand < key ? cand : key;  // (a NaN distance -- bits above +inf -- is never taken)
+    }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    key = o < key ? o : key;
+  }
+  out.best = __uint_as_float((unsigned)(key >> 32));
+  out.bidx = (int)(unsigned)key;
+  if (out.bidx == 0x7fffffff) return out;
+  const bool all = cz - 2 <= 0 && cz + 2 >= g.gz - 1 && cy - 2 <= 0 && cy + 2 >= g.gy - 1 && cx - 2 <= 0 && cx + 2 >= g.gx - 1;
+  const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
+              fz = (qz - g.minz) * g.invh - (float)cz;
+  auto axis = [&](float f, int cc, int gdim) {  // distance (cells) to the nearer face of the cube with grid beyond it
+    const float lo = cc - 2 >= 1 ? 2.0f + f : __builtin_inff();
+    const float hi = cc + 2 <= gdim - 2 ? 3.0f - f : __builtin_inff();
+    return fminf(lo, hi);
+  };
+  const float reach = g.h * fminf(axis(fx, cx, g.gx), fminf(axis(fy, cy, g.gy), axis(fz, cz, g.gz)));
+  out.aux = (all || out.best < reach * reach * kBoundSlack) ? 1.0f : 0.0f;
+  return out;
+}
+
+// (phase stamps of search_queries: off in a -DPP_PROBE_STAGE_A_ONLY probe build, which clocks the stage-A kernel alone)
+#if defined(PP_QUERY_PROBE) && !defined(PP_PROBE_STAGE_A_ONLY)
+#define PP_SPHASE(n) PP_QPHASE(n)
+#else
+#define PP_SPHASE(n)
+#endif
 template <bool LAB, int CAPW>
 __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                float* __restrict__ dist1, int* __restrict__ idx1,
@@ -1022,7 +1117,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
                                                const bool valid, const bool skip_a, lds_f4_wptr s_pts_w,
                                                lds_f_wptr s_lab_w) {
   PP_QPHASE_DECL;
-  PP_QPHASE(0);
+  PP_SPHASE(0);
   const int lane = threadIdx.x & 63;
   const int set = 2 * b + dir;
   const int nq = dir ? M : N, nr = dir ? N : M;
@@ -1130,7 +1225,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
   // Lanes whose block touches a crowded cell do not take part in the staged walk: their candidates are the
   // sub-cells near the query, found through the crowded cells' own grids further down.  (refined_set is
   // wave-uniform and false for every set of an evenly sampled surface: config 2 pays one scalar branch.)
-  PP_QPHASE(1);
+  PP_SPHASE(1);
   const float ninf = -__builtin_inff();
   auto lane63 = [](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); };
   int Lz, nz;
@@ -1198,7 +1293,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     }
     region(deferred, !__any(!deferred));
   }
-  PP_QPHASE(2);
+  PP_SPHASE(2);
   const lds_f4_ptr lpts = (lds_f4_ptr)s_pts_w;
   const lds_f_ptr llab = (lds_f_ptr)s_lab_w;
   if (staged) {
@@ -1243,7 +1338,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
-  PP_QPHASE(3);
+  PP_SPHASE(3);
 
   // ---- stage A: the four rows as ONE sequence of groups of four points -----------------------------------
   // A lane's rows hold t_r = ceil(len_r / 4) groups each; group k of the sequence belongs to the row r with
@@ -1344,7 +1439,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
       }
     }
   }
-  PP_QPHASE(4);
+  PP_SPHASE(4);
   float reach;
   int cx2, cy2, cz2, sx2, sy2, sz2;
   {
@@ -1372,7 +1467,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     }
   }
   }  // (!skip_a)
-  PP_QPHASE(5);
+  PP_SPHASE(5);
   const bool resolved = best < thr;
   if (resolved && valid) {
     od[j] = best;
@@ -1407,7 +1502,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
       pend = pend && !open_lane;
     }
   }
-  PP_QPHASE(6);
+  PP_SPHASE(6);
   // ---- few lanes: wide stages by the whole wave; then the whole cloud ---------------------------------------
   unsigned long long pending = __ballot(pend);
   unsigned long long open = __ballot(open_lane);  // lanes whose query the cube of radius 2 could not settle
@@ -1417,22 +1512,49 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     open |= pending;
     pending = 0ull;
   }
+  unsigned long long longscan = 0ull;
+  if (skip_a && pending) {
+    // (list kernel, few entries per wave) each of these queries is served by the whole wave, and what its search costs is
+    // its chain of dependent loads: the cube of radius 2 in ONE pass (all row bounds in one round trip, all candidates
+    // in the next) instead of radius 1, then 2, 64 candidates per dependent step
+    unsigned long long rest = 0ull;
+    for (unsigned long long todo = pending; todo;) {
+      const int l = (int)__builtin_ctzll(todo);
+      todo &= todo - 1;
+      const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
+      const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), l));
+      const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), l));
+      const int wj = __builtin_amdgcn_readlane(j, l);
+      Found f2;
+      f2.aux = 0.0f;
+      if (!LAB) f2 = wave_cube2_search(wx, wy, wz, reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted);
+      if (f2.aux == 1.0f) {
+        if (lane == 0) {
+          od[wj] = f2.best;
+          oi[wj] = f2.bidx;
+        }
+      } else {
+        rest |= 1ull << l;
+      }
+    }
+    pending = rest;
+  }
   if (pending) {  // wave-uniform
     const OpenMask om = serve_pending<LAB>(reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted, slab, od,
                                            oi, qx, qy, qz, ql, j, (unsigned)pending, (unsigned)(pending >> 32));
     open |= ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.hi) << 32) |
             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.lo);
-    const unsigned long long longscan = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.lhi) << 32) |
-                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.llo);
-    if (longscan) {  // wave-uniform: cubes through crowded cells (never on an evenly sampled surface)
-      const OpenMask ol = serve_long_scans<LAB>(reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted,
-                                                slab, od, oi, qx, qy, qz, ql, j, (unsigned)longscan,
-                                                (unsigned)(longscan >> 32));
-      open |= ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ol.hi) << 32) |
-              (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ol.lo);
-    }
+    longscan = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.lhi) << 32) |
+               (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.llo);
   }
-  PP_QPHASE(7);
+  if (longscan) {  // wave-uniform: cubes through crowded cells (never on an evenly sampled surface), or the list kernel's
+    const OpenMask ol = serve_long_scans<LAB>(reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted,
+                                              slab, od, oi, qx, qy, qz, ql, j, (unsigned)longscan,
+                                              (unsigned)(longscan >> 32));
+    open |= ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ol.hi) << 32) |
+            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ol.lo);
+  }
+  PP_SPHASE(7);
   if (open) {  // wave-uniform: far from everything the cubes hold -- group by group, the whole wave (see above)
     const bool finite = __builtin_isfinite(qx) && __builtin_isfinite(qy) && __builtin_isfinite(qz);
     const unsigned long long todo = open & __ballot(finite);
@@ -1448,7 +1570,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
       open &= ~todo;
     }
   }
-  PP_QPHASE(8);
+  PP_SPHASE(8);
   if (open) {  // non-finite queries: every pair, as the brute force orders them
     float sb;
     int si;
@@ -1459,7 +1581,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
       oi[j] = si;
     }
   }
-  PP_QPHASE(9);
+  PP_SPHASE(9);
 }
 
 // The whole search in one kernel (labeled searches; unlabeled ones when there is no stage-A kernel): 256-thread
@@ -1500,7 +1622,7 @@ __global__ __launch_bounds__(256, LAB ? (CAPW > 384 ? 3 : 4) : (CAPW > 384 ? 4 :
 // An entry carries bit 30 when stage A has been run for it (and failed): a wave of such entries skips stage A.
 constexpr int kPendTried = 1 << 30;
 template <int CAPW>
-__global__ __launch_bounds__(256, 6) void grid_query_list_kernel(const float* __restrict__ xyz1,
+__global__ __launch_bounds__(256, 5) void grid_query_list_kernel(const float* __restrict__ xyz1,
                                                                   const float* __restrict__ xyz2,
                                                                   float* __restrict__ dist1, int* __restrict__ idx1,
                                                                   float* __restrict__ dist2, int* __restrict__ idx2,
@@ -1677,7 +1799,7 @@ __device__ __forceinline__ void stage_a_issue(StageAFront<TQ>& f, int it, int pe
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(f.qq) : "v"((unsigned)f.jj << 4), "s"(qsorted) : "memory");
 }
 
-template <int TQ, int CAP, int WPE>
+template <int TQ, int CAP, int WPE, bool PERSIST>
 __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict__ dist1, int* __restrict__ idx1,
                                                               float* __restrict__ dist2, int* __restrict__ idx2,
                                                               unsigned char* __restrict__ ws, int B, int N, int M,
@@ -1690,15 +1812,32 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   const int t = threadIdx.x, lane = t & 63;
   const int wave = pp::wave_id_uniform();
   constexpr int kW = TQ / 64;
+  constexpr int kQueue = 64;  // leftovers of a tile served from the image (more than that stay for the list kernel)
   __shared__ pp::f4 s_img[(CAP + 63) / 64 * 64 + 4];  // (whole pieces of 64 points, then the padding)
+  __shared__ pp::f4 s_queue[kQueue];
+  __shared__ unsigned s_qres[kQueue];
+  __shared__ unsigned s_qn;
   PP_QPHASE_DECL;
   StageAFront<TQ> nx;
   stage_a_issue<TQ>(nx, (int)blockIdx.x, per_xcd, total, tiles1, tiles2, N, M, ws, L, t, lane);
-  for (int it = (int)blockIdx.x; it < nvt; it += (int)gridDim.x) {  // workgroup-uniform
+  // A tile's results are stored at the top of the NEXT iteration, behind that iteration's wait for its front: the
+  // wait below must be vmcnt(0) (the asm load), and scattered 4-byte stores issued just before it would make every
+  // tile wait for them to retire.
+  float sv_d = 0.0f;
+  int sv_i = 0, sv_off = 0, sv_dir = 0;
+  bool sv_ok = false;
+  // (!PERSIST: a workgroup per tile, the loop is one pass and the compiler knows it: no state lives across it)
+  for (int it = (int)blockIdx.x; it < (PERSIST ? nvt : (int)blockIdx.x + 1); it += (PERSIST ? (int)gridDim.x : 1)) {  // workgroup-uniform
   PP_APHASE(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's front has landed (the asm load of the query too)
+  if (sv_ok) {
+    (sv_dir ? dist2 : dist1)[sv_off] = sv_d;
+    (sv_dir ? idx2 : idx1)[sv_off] = sv_i;
+  }
+  sv_ok = false;
+  if (t == 0) s_qn = 0u;  // (the tile's queue of leftovers: filled after the barrier that follows the image's arrival)
   const StageAFront<TQ> f = nx;
-  if (it + (int)gridDim.x < nvt)  // the next tile's front goes out now and travels while this tile is walked
+  if (PERSIST && it + (int)gridDim.x < nvt)  // the next tile's front goes out now and travels while this tile is walked
     stage_a_issue<TQ>(nx, it + (int)gridDim.x, per_xcd, total, tiles1, tiles2, N, M, ws, L, t, lane);
   const int b = f.b, dir = f.dir, tile = f.tile, jj = f.jj;
   const bool valid = f.valid;
@@ -1879,11 +2018,97 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
       PP_APHASE(4);
       tried = kPendTried;
       if (valid && best < reach * reach * kBoundSlack) {  // settled (strict; a NaN bound settles nothing)
-        const int j = __float_as_int(qq.w);
-        (dir ? dist2 : dist1)[(size_t)b * nq + j] = best;
-        (dir ? idx2 : idx1)[(size_t)b * nq + j] = bidx;
+        sv_ok = true;  // (stored at the top of the next iteration, or after the loop)
+        sv_d = best;
+        sv_i = bidx;
+        sv_off = b * nq + __float_as_int(qq.w);  // (B * (N + M) < 2^31: grid_applicable)
         pend = false;
       }
+      sv_dir = dir;
+      // ---- what the block left (about one query in 150 on an evenly sampled surface): the cube of Chebyshev radius 1
+      // around the query's cell, FROM THE IMAGE (it holds the layers cz - 1 .. cz + 1 of every query of the tile), by
+      // a whole wave per query: the tile's leftovers are gathered in a queue in LDS, wave w takes entries w, w + kW,
+      // ...; lane r < 9 fetches the bounds of row r of the cube (the only trip to memory), the rows are laid end to
+      // end and every lane examines its share of the candidates in the exact (distance bits, index) order.  Settled
+      // if the best distance lies below what the cube guarantees.  Served here these queries cost a microsecond of
+      // the tile's time; left to the list kernel each costs that launch a chain of eight dependent round trips.
+      int qslot = -1;
+      if (pend) {
+        qslot = (int)atomicAdd(&s_qn, 1u);
+        if (qslot < kQueue) s_queue[qslot] = pp::f4{qx, qy, qz, qq.w};
+      }
+      __syncthreads();
+      const int nqueue = min((int)s_qn, kQueue);
+      for (int e = wave; e < nqueue; e += kW) {  // wave-uniform
+        const pp::f4 w = s_queue[e];
+        const int wcx = cell_coord(w.x, g.minx, g.invh, g.gx), wcy = cell_coord(w.y, g.miny, g.invh, g.gy),
+                  wcz = cell_coord(w.z, g.minz, g.invh, g.gz);
+        const int wx0 = max(wcx - 1, 0), wx1 = min(wcx + 1, gx1);
+        const int rz = wcz - 1 + lane / 3, ry = wcy - 1 + lane % 3;
+        const bool rok = lane < 9 && rz >= 0 && rz <= gz1 && ry >= 0 && ry <= gy1;
+        unsigned rs = 0, re = 0;
+        if (rok) {
+          const int c = pp::cell_linear(0, ry, rz, g.gx, g.gy);
+          rs = cell_start[c + wx0];
+          re = cell_start[c + wx1 + 1];
+        }
+        // (every row of the cube lies in the image by construction; a row that does not -- never, but the image's
+        //  extent is an estimate made from the chunk table -- leaves the query to the list kernel)
+        const bool inside = __all(!rok || (rs >= tb0 && re <= tb0 + ns));
+        const unsigned len = rok ? re - rs : 0u;
+        unsigned incl = len;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          const unsigned o = __shfl_up(incl, off);
+          if (lane >= off) incl += o;
+        }
+        const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 15);
+        const unsigned excl = incl - len, shift = (rs - tb0) - excl;  // candidate k of row r: image[k + shift_r]
+        unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, no index)
+        for (unsigned k0 = 0; k0 < tot; k0 += 64) {
+          const unsigned k = k0 + (unsigned)lane;
+          unsigned add = 0;
+#pragma unroll
+          for (int r = 0; r < 9; ++r) {  // the last row whose first candidate is <= k (empty rows are overridden)
+            const unsigned ex = (unsigned)__builtin_amdgcn_readlane((int)excl, r);
+            const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)shift, r);
+            add = k >= ex ? sh : add;
+          }
+          if (inside && k < tot) {
+            const pp::f4 p = s_img[k + add];
+            const float d = pp::chamfer_d3(p.x, p.y, p.z, w.x, w.y, w.z);
+            const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+            key = cand < key ? cand : key;  // (a NaN distance -- bits above +inf -- is never taken)
+          }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
+          const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+          key = o < key ? o : key;
+        }
+        const float kbest = __uint_as_float((unsigned)(key >> 32));
+        const int kidx = (int)(unsigned)key;
+        const float wfx = (w.x - g.minx) * g.invh - (float)wcx, wfy = (w.y - g.miny) * g.invh - (float)wcy,
+                    wfz = (w.z - g.minz) * g.invh - (float)wcz;
+        auto axis1 = [&](float ff, int cc, int g1) {  // distance (cells) to the nearer face of the cube with grid beyond it
+          const float lo = cc - 1 >= 1 ? 1.0f + ff : inf;
+          const float hi = cc + 1 < g1 ? 2.0f - ff : inf;
+          return fminf(lo, hi);
+        };
+        const float reach1 = g.h * fminf(axis1(wfx, wcx, gx1), fminf(axis1(wfy, wcy, gy1), axis1(wfz, wcz, gz1)));
+        const bool settled = inside && kidx != 0x7fffffff && kbest < reach1 * reach1 * kBoundSlack;
+        if (lane == 0) {
+          s_qres[e] = settled ? 1u : 0u;
+          if (settled) {
+            const int wj = __float_as_int(w.w);
+            (dir ? dist2 : dist1)[(size_t)b * nq + wj] = kbest;
+            (dir ? idx2 : idx1)[(size_t)b * nq + wj] = kidx;
+          }
+        }
+      }
+      __syncthreads();
+      if (pend && qslot < kQueue && s_qres[qslot] != 0u) pend = false;
     }
   }
   // what is left goes to the wave's slots of the pending list (in lane order: the order of the sorted cloud)
@@ -1896,6 +2121,10 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   PP_APHASE(5);
   __syncthreads();  // every wave has left the image: the next tile's may be written
   }  // (tiles)
+  if (sv_ok) {
+    (sv_dir ? dist2 : dist1)[sv_off] = sv_d;
+    (sv_dir ? idx2 : idx1)[sv_off] = sv_i;
+  }
 }
 
 }  // namespace
@@ -2013,7 +2242,13 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   const long long blocks = (long long)B * (tiles1 + tiles2);
   if (blocks > 0x7fffffffLL) return PP_EINVAL;
   const int per_xcd = (int)((blocks + 7) / 8);
-  const int tile = g_tile;
+  // (PP_NMDISTANCE_TILE: the debug knob's value from the environment, read once -- benchmarks of the forms in processes
+  //  that do not call the knob)
+  static const int tile_env = [] {
+    const char* e = getenv("PP_NMDISTANCE_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  const int tile = g_tile != 0 ? (int)g_tile : tile_env;
   const Layout lay = make_layout(B, N, M, LAB);
   const bool two_stage = !LAB && tile != -1 && lay.chunks > 0;
   if (two_stage) {  // stage A by tiles, then the whole-search kernel over what it left (LIST)
@@ -2038,14 +2273,17 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
     long long g_ = (long long)ncu * (PER_CU_);                                                                  \
     g_ = (g_ < (long long)aper * 8 ? g_ : (long long)aper * 8);                                                 \
     g_ = (g_ + 7) / 8 * 8;                                                                                      \
-    grid_stage_a_kernel<TQ_, CAP_, WPE_><<<dim3((unsigned)g_), dim3(TQ_), 0, s>>>(dist1, idx1, dist2, idx2, ws, B, N, M, ta1, \
+    grid_stage_a_kernel<TQ_, CAP_, WPE_, ((PER_CU_) < 1024)><<<dim3((unsigned)g_), dim3(TQ_), 0, s>>>(dist1, idx1, dist2, idx2, ws, B, N, M, ta1, \
                                                                          ta2, (int)ablocks, aper, lay);         \
   } while (0)
     switch (tq) {
-      case 256: PP_LAUNCH_A(256, 2044, 4, 4); break;
-      case 1024: PP_LAUNCH_A(1024, 4032, 2, 8); break;
-      case 513: PP_LAUNCH_A(512, 3068, 2, 5); break;   // (512 at 96 registers: two workgroups per CU)
-      default: PP_LAUNCH_A(512, 3068, 3, 6); break;
+      // (workgroups per CU: 1 << 20 = a workgroup per tile, not persistent -- measured as fast at config 2 (the front of
+      //  a tile is hidden by the other workgroups of the CU either way) and free of the loop's register pressure;
+      //  513: the persistent form, two workgroups per CU at 96 registers, kept for comparison)
+      case 256: PP_LAUNCH_A(256, 2044, 1 << 20, 4); break;
+      case 1024: PP_LAUNCH_A(1024, 4032, 1 << 20, 8); break;
+      case 513: PP_LAUNCH_A(512, 3068, 2, 5); break;
+      default: PP_LAUNCH_A(512, 3260, 1 << 20, 6); break;
     }
 #undef PP_LAUNCH_A
     PP_RETURN_IF_LAUNCH_FAILED();

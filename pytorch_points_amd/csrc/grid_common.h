@@ -439,13 +439,17 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
         }
       }
     } else {
+      // (32-bit byte offsets from the wave-uniform base: one address register per point instead of two per load --
+      //  with 48 64-bit addresses this form of the kernel spilled, 216 bytes of scratch per lane)
+      const char* __restrict__ rb = reinterpret_cast<const char*>(ref);
 #pragma unroll
       for (int i = 0; i < KP; ++i) {
         int k = base + t + kBuildThreads * i;
         k = k < nr ? k : nr - 1;
-        px[i] = ref[3 * (size_t)k];
-        py[i] = ref[3 * (size_t)k + 1];
-        pz[i] = ref[3 * (size_t)k + 2];
+        const unsigned off = (unsigned)k * 12u;  // (nr < 2^31 / 12 points per cloud: the searches' own limit is lower)
+        px[i] = *reinterpret_cast<const float*>(rb + off);
+        py[i] = *reinterpret_cast<const float*>(rb + off + 4);
+        pz[i] = *reinterpret_cast<const float*>(rb + off + 8);
       }
     }
   };

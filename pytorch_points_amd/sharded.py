@@ -202,6 +202,7 @@ class PackedShardGather:
         d1, d2, i1, i2 = self.out[slot]
         # (set_stream twice instead of the `with torch.cuda.stream(...)` context manager, and the side stream's raw
         #  handle straight to the C ABI: the exchange costs the issuing thread ~60 us per step, every piece counts)
+        prev_dev = torch.cuda.current_device()   # (set_stream also switches the current device to the stream's)
         prev = torch.cuda.current_stream(dev)
         torch.cuda.set_stream(self.side)
         try:
@@ -213,6 +214,8 @@ class PackedShardGather:
             self.done[slot].record(self.side)
         finally:
             torch.cuda.set_stream(prev)
+            if prev_dev != torch.cuda.current_device():
+                torch.cuda.set_device(prev_dev)   # the caller's device, not the exchange's
 
     def wait(self, slot):
         """Blocks the current stream (not the host, on RCCL) until the gather of ``slot`` is done and unpacked,

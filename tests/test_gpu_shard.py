@@ -77,15 +77,19 @@ print("exchange ok")
 """
 
 
-def test_packed_exchange_on_one_rank_rccl_group(cuda, tmp_path):
+@pytest.mark.parametrize("path", ["native", "python"])
+def test_packed_exchange_on_one_rank_rccl_group(cuda, tmp_path, path):
     """PackedShardGather on the GPU path proper: RCCL all-gather (a one-rank group: this box has one GPU),
-    unpack on the side stream into the slot's buffers, slot reuse, 16- and 32-bit indices.  In a subprocess:
-    the process group must not leak into the other tests."""
+    unpack on the side stream into the slot's buffers, slot reuse, 16- and 32-bit indices.  native: the whole exchange
+    as one C++ call (csrc/torch_bridge.cpp: PackedExchange over c10d, round 3); python: the same steps issued from
+    Python (PP_SHARD_EXCHANGE=python).  In a subprocess: the process group must not leak into the other tests."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "one_rank_exchange.py"
     script.write_text(_ONE_RANK_EXCHANGE)
-    out = subprocess.run([sys.executable, str(script), root, "29541"], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, PP_SHARD_EXCHANGE=path)
+    out = subprocess.run([sys.executable, str(script), root, "29541" if path == "native" else "29543"], capture_output=True,
+                         text=True, timeout=600, env=env)
     assert out.returncode == 0 and "exchange ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

@@ -6,7 +6,7 @@ import ctypes, os, subprocess, sys, numpy as np, torch
 sys.path.insert(0, ".")
 from pytorch_points_amd import _build
 # built in the container with tools/build_probe_lib.sh (hipcc takes minutes for the whole library: not on the GPU box)
-lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpp_hip_probe.so")
+lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("PP_PROBE_LIB", "libpp_hip_probe.so"))
 if not os.path.exists(lib):
     subprocess.run(["bash", os.path.join(os.path.dirname(os.path.abspath(__file__)), "build_probe_lib.sh")], check=True)
 _build.LIB = lib

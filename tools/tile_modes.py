@@ -23,6 +23,7 @@ def run(fn, n=20):
     return a.elapsed_time(b) / n
 def clouds(kind, seed):
     if kind == "sphere": return S.unit_sphere(seed, B, N)
+    if kind == "same": return S.unit_sphere(0, B, N)   # both clouds identical: stage A settles every query
     if kind == "cube": return rng.random((B, N, 3), dtype=np.float32)
     if kind == "gaussian": return rng.standard_normal((B, N, 3)).astype(np.float32)
     if kind == "blobs8":
