@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz fp32 lane-ops/s (same table)
+FWD_TRAFFIC_C2 = None          # bytes per forward at config 2, all launches (profiles/r3/pmc_summary.txt); set below
 
 
 def parse():
@@ -206,6 +207,11 @@ def _distribution(kind, seed, B, N):
     if kind == "two_scales":
         x = rng.random((B, N, 3), dtype=np.float32)
         x[:, : N // 2] *= 1e-2
+        return x
+    if kind == "disjoint":        # two uniformly filled cubes five units apart: every query far from every reference
+        x = rng.random((B, N, 3), dtype=np.float32)
+        if seed:
+            x += np.float32(5.0)
         return x
     if kind == "shapenet_like":   # thin surfaces: two planes and a cylinder in a box
         x = rng.random((B, N, 3), dtype=np.float32) - 0.5
@@ -480,19 +486,26 @@ def bench_chamfer(args, dist, world, rank, device):
                                 "unpack of one step's outputs with nothing beside it; ms_per_step has them overlapped "
                                 "(gather every %d step(s))" % gather_every)
     if grid:
-        dom_ms = search_ms if search_ms else fwd_ms
+        # the dominant kernel of the step: the stage-A kernel of the unlabeled search (round 3: the search is two launches,
+        # stage A by tiles + the kernel over what it leaves); the whole-search kernel where there is no stage-A kernel
+        two_stage = bool(stage_a_ms)
+        dom_ms = stage_a_ms if two_stage else (rest_ms if rest_ms else fwd_ms)
         gbs = alg_bytes_fwd / (dom_ms * 1e-3) / 1e9
         out["roofline"] = {
-            "bound": "hbm", "kernel": "grid_query_wave_kernel (the search; dominant kernel of the step)",
+            "bound": "hbm",
+            "kernel": ("grid_stage_a_kernel (stage A of the search by tiles; dominant kernel of the step)" if two_stage
+                       else "grid_query_wave_kernel (the search; dominant kernel of the step)"),
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            # rocprofv3 --pmc FETCH_SIZE (x2: 16-byte loads count half on gfx950) + WRITE_SIZE of this kernel
-            # per launch (profiles/r2/pmc_summary.txt)
-            "traffic": 33.2e6 if c2 else None,
-            "kernel_ms": search_ms, "build_kernel_ms": build_ms,
-            "note": "SURVEY.md §8(d): algorithmic forward bytes (%.0f) / the search kernel's average duration, HIP events "
-                    "on the launch stream around that kernel (pp_hip_debug.h), %d forwards after the timed region. The "
-                    "search is bound by VALU issue and LDS, not by HBM; 'bruteforce' carries the every-pair kernel with "
-                    "its VALU roofline" % (alg_bytes_fwd, 40)}
+            # FORWARD-level HBM-side traffic per step, all of the forward's launches (build + stage A + list kernel):
+            # rocprofv3 --pmc FETCH_SIZE (x2: 16-byte loads count half on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE
+            # per launch, profiles/r3/pmc_summary.txt
+            "traffic": FWD_TRAFFIC_C2 if (c2 and two_stage) else None,
+            "kernel_ms": dom_ms, "build_kernel_ms": build_ms, "stage_a_kernel_ms": stage_a_ms, "rest_kernel_ms": rest_ms,
+            "note": "SURVEY.md §8(d): algorithmic forward bytes (%.0f) / the dominant kernel's average duration, HIP events "
+                    "on the launch stream around each of the forward's launches (pp_hip_debug.h), %d forwards after the "
+                    "timed region; 'traffic' is for the whole forward (every launch), not the dominant kernel alone. The "
+                    "search is bound by VALU issue and LDS bandwidth, not by HBM; 'bruteforce' carries the every-pair kernel "
+                    "with its VALU roofline" % (alg_bytes_fwd, 40)}
         sgbs = alg_bytes_step / (ms * 1e-3) / 1e9
         out["roofline_step"] = {"bound": "hbm", "achieved": sgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": sgbs / HBM_PEAK_GBS,
@@ -519,7 +532,7 @@ def bench_chamfer(args, dist, world, rank, device):
     if rank == 0 and world == 1 and grid and args.launch == "all" and not args.no_extras:
         # other point distributions, forward only: same shapes, clouds that are not a sphere
         od = {}
-        for kind in ("gaussian", "blobs8", "two_scales", "shapenet_like"):
+        for kind in ("gaussian", "blobs8", "two_scales", "shapenet_like", "disjoint"):
             a = torch.from_numpy(_distribution(kind, 0, B, N)).to(device)
             b_ = torch.from_numpy(_distribution(kind, 1, B, N)).to(device)
             for _ in range(2):

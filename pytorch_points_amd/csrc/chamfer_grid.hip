@@ -29,7 +29,6 @@
 //         set whose grid is useless (non-finite coordinates).  Two launches per forward, no list.
 #include <cstdlib>
 #include <mutex>
-#include <vector>
 
 #include "grid_common.h"
 
@@ -1013,94 +1012,6 @@ __device__ __forceinline__ float min2(float a, float b) {
 // cloud has no grid), `valid` = the lane has a query; s_pts_w / s_lab_w = the wave's private slice of LDS (CAPW + 4
 // points / labels).  skip_a (wave-uniform): stage A has been run for every one of these queries already (the stage-A
 // kernel) and settled none of them -- go straight to the stages after it.
-// One query by the whole wave: the cube of Chebyshev radius 2 around its cell in ONE pass -- lane r < 25 fetches the
-// bounds of row r (one round trip), the rows are laid end to end, and every lane loads its share of the candidates with
-// all its loads in flight together (the next round trip); the smallest (distance bits, index) key of the wave is the
-// nearest examined point.  Returns true when that settles the query: the best distance lies below what the cube
-// guarantees (every unexamined point is beyond one of its faces that has grid beyond it), or the cube covers the grid.
-// False (nothing written) when the cube holds more than kCube2Max candidates or does not settle the query: the
-// caller's other stages take over.  Unlabeled searches, finite or not (a non-finite query settles nothing).
-// (Out of line, results by value, the grid by pointer: see serve_pending.)
-constexpr unsigned kCube2Max = 384;
-__device__ __attribute__((noinline)) Found wave_cube2_search(float qx, float qy, float qz, const GridSet* __restrict__ gp,
-                                                             const unsigned* __restrict__ cell_start,
-                                                             const pp::f4* __restrict__ sorted) {
-  const GridSet g = *gp;
-  Found out;
-  out.best = __builtin_inff();
-  out.bidx = 0x7fffffff;
-  out.aux = 0.0f;  // 1: settled
-  const int lane = threadIdx.x & 63;
-  const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
-  const int cy = cell_coord(qy, g.miny, g.invh, g.gy);
-  const int cz = cell_coord(qz, g.minz, g.invh, g.gz);
-  const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.gx - 1);
-  const int z = cz - 2 + lane / 5, y = cy - 2 + lane % 5;
-  const bool ok = lane < 25 && z >= 0 && z < g.gz && y >= 0 && y < g.gy;
-  const int c = pp::cell_linear(0, min(max(y, 0), g.gy - 1), min(max(z, 0), g.gz - 1), g.gx, g.gy);
-  unsigned rs = 0, re = 0;
-  if (ok) {
-    rs = cell_start[c + x0];
-    re = cell_start[c + x1 + 1];
-  }
-  const unsigned len = re - rs;
-  unsigned incl = len;
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) {
-    const unsigned o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
-  }
-  const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
-  if (total == 0u || total > kCube2Max) return out;  // (wave-uniform)
-  const unsigned excl = incl - len;
-  const unsigned shift = rs - excl;  // candidate k of row r sits at sorted[k + shift_r]
-  unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, no index)
-  constexpr int kU = kCube2Max / 64;
-  unsigned at[kU];
-#pragma unroll
-  for (int u = 0; u < kU; ++u) {
-    const unsigned k = min((unsigned)(u * 64 + lane), total - 1);  // (the tail repeats the last candidate: harmless)
-    unsigned add = 0;
-    for (int r = 0; r < 25; ++r) {  // the last row whose first candidate is <= k (empty rows are overridden)
-      const unsigned ex = (unsigned)__builtin_amdgcn_readlane((int)excl, r);
-      const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)shift, r);
-      add = k >= ex ? sh : add;
-    }
-    at[u] = k + add;
-  }
-  pp::f4 p[kU];
-#pragma unroll
-  for (int u = 0; u < kU; ++u)
-    if ((unsigned)(u * 64) < total) p[u] = sorted[at[u]];  // (wave-uniform conditions: the loads stay in flight together)
-#pragma unroll
-  for (int u = 0; u < kU; ++u)
-    if ((unsigned)(u * 64) < total) {
-      const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, qx, qy, qz);
-      const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w);
-      key = cand < key ? cand : key;  // (a NaN distance -- bits above +inf -- is never taken)
-    }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    key = o < key ? o : key;
-  }
-  out.best = __uint_as_float((unsigned)(key >> 32));
-  out.bidx = (int)(unsigned)key;
-  if (out.bidx == 0x7fffffff) return out;
-  const bool all = cz - 2 <= 0 && cz + 2 >= g.gz - 1 && cy - 2 <= 0 && cy + 2 >= g.gy - 1 && cx - 2 <= 0 && cx + 2 >= g.gx - 1;
-  const float fx = (qx - g.minx) * g.invh - (float)cx, fy = (qy - g.miny) * g.invh - (float)cy,
-              fz = (qz - g.minz) * g.invh - (float)cz;
-  auto axis = [&](float f, int cc, int gdim) {  // distance (cells) to the nearer face of the cube with grid beyond it
-    const float lo = cc - 2 >= 1 ? 2.0f + f : __builtin_inff();
-    const float hi = cc + 2 <= gdim - 2 ? 3.0f - f : __builtin_inff();
-    return fminf(lo, hi);
-  };
-  const float reach = g.h * fminf(axis(fx, cx, g.gx), fminf(axis(fy, cy, g.gy), axis(fz, cz, g.gz)));
-  out.aux = (all || out.best < reach * reach * kBoundSlack) ? 1.0f : 0.0f;
-  return out;
-}
-
 // (phase stamps of search_queries: off in a -DPP_PROBE_STAGE_A_ONLY probe build, which clocks the stage-A kernel alone)
 #if defined(PP_QUERY_PROBE) && !defined(PP_PROBE_STAGE_A_ONLY)
 #define PP_SPHASE(n) PP_QPHASE(n)
@@ -1513,32 +1424,6 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     pending = 0ull;
   }
   unsigned long long longscan = 0ull;
-  if (skip_a && pending) {
-    // (list kernel, few entries per wave) each of these queries is served by the whole wave, and what its search costs is
-    // its chain of dependent loads: the cube of radius 2 in ONE pass (all row bounds in one round trip, all candidates
-    // in the next) instead of radius 1, then 2, 64 candidates per dependent step
-    unsigned long long rest = 0ull;
-    for (unsigned long long todo = pending; todo;) {
-      const int l = (int)__builtin_ctzll(todo);
-      todo &= todo - 1;
-      const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qx), l));
-      const float wy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qy), l));
-      const float wz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz), l));
-      const int wj = __builtin_amdgcn_readlane(j, l);
-      Found f2;
-      f2.aux = 0.0f;
-      if (!LAB) f2 = wave_cube2_search(wx, wy, wz, reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted);
-      if (f2.aux == 1.0f) {
-        if (lane == 0) {
-          od[wj] = f2.best;
-          oi[wj] = f2.bidx;
-        }
-      } else {
-        rest |= 1ull << l;
-      }
-    }
-    pending = rest;
-  }
   if (pending) {  // wave-uniform
     const OpenMask om = serve_pending<LAB>(reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted, slab, od,
                                            oi, qx, qy, qz, ql, j, (unsigned)pending, (unsigned)(pending >> 32));
@@ -1622,7 +1507,7 @@ __global__ __launch_bounds__(256, LAB ? (CAPW > 384 ? 3 : 4) : (CAPW > 384 ? 4 :
 // An entry carries bit 30 when stage A has been run for it (and failed): a wave of such entries skips stage A.
 constexpr int kPendTried = 1 << 30;
 template <int CAPW>
-__global__ __launch_bounds__(256, 5) void grid_query_list_kernel(const float* __restrict__ xyz1,
+__global__ __launch_bounds__(256, 6) void grid_query_list_kernel(const float* __restrict__ xyz1,
                                                                   const float* __restrict__ xyz2,
                                                                   float* __restrict__ dist1, int* __restrict__ idx1,
                                                                   float* __restrict__ dist2, int* __restrict__ idx2,
@@ -1683,39 +1568,38 @@ __global__ __launch_bounds__(256, 5) void grid_query_list_kernel(const float* __
     if (cpl == 8) return scan_n(std::integral_constant<int, 8>{});
     return scan_n(std::integral_constant<int, 16>{});
   };
-  const unsigned total = scan_counts();  // (on an evenly sampled surface ~1 % of the queries: most waves leave here or after one piece)
+  // the direction's total first (one scalar load; the stage-A kernel adds it up per tile): on an evenly sampled surface
+  // nothing, or next to nothing, is left and the wave leaves here
+  const unsigned total = (reinterpret_cast<const unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords)[pp::kLayerPending];
   if (total == 0u) return;
   const unsigned per_wave = min(64u, max(1u, (total + (unsigned)waves_per_set - 1) / (unsigned)waves_per_set));
-  // pieces of per_wave entries: the first waves_per_set are dealt out statically (wave wi takes piece wi: a short list
-  // costs no atomic), the rest from a counter, so that waves whose pieces are cheap take more of them
-  unsigned* __restrict__ cursor = reinterpret_cast<unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords + pp::kLayerCursor;
-  bool fresh = true;  // the slice holds the prefix sums
-  for (unsigned piece = (unsigned)wi; piece * per_wave < total;) {  // wave-uniform
-    const unsigned first = piece * per_wave;
-    if ((unsigned)waves_per_set * per_wave < total) {  // (uniform) a long list: fetch the next piece
-      unsigned nxt = 0;
-      if (lane == 0) nxt = atomicAdd(cursor, 1u);
-      piece = (unsigned)waves_per_set + (unsigned)__builtin_amdgcn_readfirstlane((int)nxt);
-    } else {
-      piece = 0xffffffffu / 64u;  // the static deal covers the list: this piece is the wave's only one
-    }
-    if (!fresh) scan_counts();
-    fresh = false;
+  // ONE piece of per_wave entries per wave (the launch has a wave for every 64 queries of a direction, so a list of
+  // every query still fits; no loop: state that lives across the search costs this kernel registers it does not have)
+  const bool everything = total == (unsigned)nq;  // the stage-A kernel served nothing of this direction (sets with
+                                                  // crowded cells, degenerate sets): entry e is query e, no table needed
+  {
+    const unsigned first = (unsigned)wi * per_wave;
+    if (first >= total) return;  // (wave-uniform)
     const unsigned e = first + (unsigned)lane;
     const bool valid = (unsigned)lane < per_wave && e < total;
-    const unsigned ec = valid ? e : min(first, total - 1);
-    int lo = 0, hi = nwq - 1;  // the last wave whose first entry is <= ec (waves without entries are passed over)
+    int entry = (int)(valid ? e : total - 1);  // (everything pending: entry e is query e)
+    bool skip_a = false;
+    if (!everything) {
+      scan_counts();
+      const unsigned ec = valid ? e : min(first, total - 1);
+      int lo = 0, hi = nwq - 1;  // the last wave whose first entry is <= ec (waves without entries are passed over)
 #pragma unroll
-    for (int it = 0; it < 10; ++it) {
-      const int mid = (lo + hi + 1) >> 1;
-      const bool ge = pref[mid] <= ec;
-      lo = ge ? mid : lo;
-      hi = ge ? hi : mid - 1;
+      for (int it = 0; it < 10; ++it) {
+        const int mid = (lo + hi + 1) >> 1;
+        const bool ge = pref[mid] <= ec;
+        lo = ge ? mid : lo;
+        hi = ge ? hi : mid - 1;
+      }
+      entry = plist[lo * 64 + (int)(ec - pref[lo])];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // (the slice is the search's from here on)
+      skip_a = __all(!valid || (entry & kPendTried) != 0);
     }
-    const int entry = plist[lo * 64 + (int)(ec - pref[lo])];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // (the slice is the search's from here on)
-    const bool skip_a = __all(!valid || (entry & kPendTried) != 0);
     search_queries<false, CAPW>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, nullptr, nullptr, L, b, dir,
                                 entry & ~kPendTried, valid, skip_a, (lds_f4_wptr)(&s_pts[wave][0]), (lds_f_wptr) nullptr);
   }
@@ -1817,6 +1701,7 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   __shared__ pp::f4 s_queue[kQueue];
   __shared__ unsigned s_qres[kQueue];
   __shared__ unsigned s_qn;
+  __shared__ unsigned s_tot;  // queries of the tile left pending
   PP_QPHASE_DECL;
   StageAFront<TQ> nx;
   stage_a_issue<TQ>(nx, (int)blockIdx.x, per_xcd, total, tiles1, tiles2, N, M, ws, L, t, lane);
@@ -1835,7 +1720,11 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
     (sv_dir ? idx2 : idx1)[sv_off] = sv_i;
   }
   sv_ok = false;
-  if (t == 0) s_qn = 0u;  // (the tile's queue of leftovers: filled after the barrier that follows the image's arrival)
+  if (t == 0) {  // the tile's queue of leftovers and its count of pending queries
+    s_qn = 0u;
+    s_tot = 0u;
+  }
+  __syncthreads();  // (a tile that cannot be served adds to the count without meeting another barrier first)
   const StageAFront<TQ> f = nx;
   if (PERSIST && it + (int)gridDim.x < nvt)  // the next tile's front goes out now and travels while this tile is walked
     stage_a_issue<TQ>(nx, it + (int)gridDim.x, per_xcd, total, tiles1, tiles2, N, M, ws, L, t, lane);
@@ -1869,8 +1758,34 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   g.gx = meta(5); g.gy = meta(6); g.gz = meta(7);
   // (uniform over the set) grids without crowded cells on both sides (crowd: 1 useless, 2 second-level grids), no
   // degenerate set, and the query cloud's chunk table exists; no short-circuits: nothing here is worth a branch
-  const bool lean_ok = (f.live != 0) & (meta(8) == 0) & ((meta(12) | meta(13) | meta(14) | meta(15)) == 0) & (meta(16 + 8) == 0) &
-                       ((meta(16 + 12) | meta(16 + 13) | meta(16 + 14) | meta(16 + 15)) == 0) & (meta(16 + 10) == 1);
+  const bool grids_ok = (meta(8) == 0) & ((meta(12) | meta(13) | meta(14) | meta(15)) == 0) & (meta(16 + 8) == 0) &
+                        ((meta(16 + 12) | meta(16 + 13) | meta(16 + 14) | meta(16 + 15)) == 0) & (meta(16 + 10) == 1);
+  // ... and the images of this direction's tiles are likely to fit: a tile of TQ queries spans about TQ gz / nq layers
+  // of the reference grid, its image those and three more (one straddled, one either side), each at most as full as
+  // the grid's fullest layer.  A volume-filling cloud (coarser grid, fuller layers), a plane (one layer) or a Gaussian
+  // (its core) fails this, and its tiles would find their images too large one by one.
+  // (the fullest layer counts, not the average: the core of a Gaussian, a face of a box)
+  unsigned lmax;
+  {
+    const unsigned nxt = (unsigned)__shfl_down((int)lay, 1);
+    const float sz = lane < g.gz ? (float)(nxt - lay) : 0.0f;  // (layer populations are < 2^24: exact)
+    lmax = (unsigned)pp::wave_reduce_dpp<false>(sz);
+  }
+  const bool fits = (long long)(3 + (TQ * g.gz + nq - 1) / nq) * (long long)lmax <= (long long)CAP;
+  if (f.live && !(grids_ok && fits)) {
+    // (uniform over the direction) nothing of this direction is served here: its total is set to "every query" by the
+    // first tile (no list is written: the list kernel then takes entry e to be query e) and the tile is done -- a
+    // cloud stage A cannot serve costs this launch little more than its dispatch
+    if (tile == 0 && t == 0)
+      (reinterpret_cast<unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords)[pp::kLayerPending] = (unsigned)nq;
+    if constexpr (PERSIST) {
+      __syncthreads();
+      continue;
+    } else {
+      return;
+    }
+  }
+  const bool lean_ok = f.live != 0;
   if (lean_ok) {
     const float qx = qq.x, qy = qq.y, qz = qq.z;
     const unsigned* __restrict__ cell_start =
@@ -2116,10 +2031,17 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   const int wq = tile * (TQ / 64) + wave;  // this wave among the waves of the direction
   if (f.live && wq * 64 < nq) {
     if (pend) plist[wq * 64 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(pm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)pm, 0u))] = jj | tried;
-    if (lane == 0) pcnt[wq] = (unsigned)__builtin_popcountll(pm);  // (no atomics: the list kernel adds the counts up)
+    if (lane == 0) {
+      pcnt[wq] = (unsigned)__builtin_popcountll(pm);
+      if (pm) atomicAdd(&s_tot, (unsigned)__builtin_popcountll(pm));
+    }
   }
   PP_APHASE(5);
   __syncthreads();  // every wave has left the image: the next tile's may be written
+  // the direction's total (zeroed by the build), ONE global atomic per tile that leaves anything (a wave-by-wave
+  // count -- 256 adds to one word per direction -- cost the kernel 5 us): lets the list kernel's waves leave at once
+  if (t == 0 && s_tot != 0u)
+    atomicAdd(reinterpret_cast<unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords + pp::kLayerPending, s_tot);
   }  // (tiles)
   if (sv_ok) {
     (sv_dir ? dist2 : dist1)[sv_off] = sv_d;
@@ -2189,16 +2111,9 @@ extern "C" int pp_debug_nmdistance_pending(const void* workspace, int B, int N, 
   const Layout L = make_layout(B, N, M, false);
   if (L.chunks == 0) return PP_EINVAL;
   hipError_t e = hipDeviceSynchronize();
-  std::vector<unsigned> cnt;
-  for (int s = 0; s < 2 * B && e == hipSuccess; ++s) {
-    const int b = s >> 1, dir = s & 1, nwq = ((dir ? M : N) + 63) / 64;
-    cnt.resize((size_t)nwq);
-    e = hipMemcpy(cnt.data(), (const unsigned char*)workspace + L.pend_cnt + 4 * pend_count_offset(b, dir, N, M), 4 * (size_t)nwq,
+  for (int s = 0; s < 2 * B && e == hipSuccess; ++s)  // the direction's total: added up per tile by the stage-A kernel
+    e = hipMemcpy(totals + s, (const unsigned char*)workspace + L.layers + 4 * ((size_t)s * pp::kLayerWords + pp::kLayerPending), 4,
                   hipMemcpyDeviceToHost);
-    unsigned t = 0;
-    for (unsigned c : cnt) t += c;
-    totals[s] = t;
-  }
   return (int)e;
 }
 
@@ -2293,10 +2208,10 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   grid_query_wave_kernel<LAB, CAP_><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(                       \
       xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2)
   if (two_stage) {
-    // what stage A left: waves_per_set waves per direction (about 8192 waves in all), every wave by itself
+    // what stage A left: a wave for every 64 queries of a direction (as many as the whole-search kernel has, for the
+    // clouds stage A cannot serve), every wave by itself
     const int sets = 2 * B;
-    int wps = 8192 / sets;
-    wps = wps < 4 ? 4 : (wps > 256 ? 256 : wps);
+    const int wps = ((N > M ? N : M) + 63) / 64;  // a wave for every 64 queries of a direction: as the whole-search kernel
     const long long lwaves = (long long)sets * wps;
     grid_query_list_kernel<384><<<dim3((unsigned)(((lwaves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2,
                                                                                       ws, B, N, M, wps, lay);

@@ -73,11 +73,12 @@ def test_default_line_is_the_autograd_operator_and_carries_configs_3_and_4(cuda)
     _check_common(d)
     assert d["config"]["launch"].startswith("torch.autograd.Function")
     assert {"eager", "ext"} <= set(d["launch_modes_ms_per_step"])
-    assert d["roofline"]["kernel"].startswith("grid_query_wave_kernel") and d["roofline"]["kernel_ms"] > 0
+    assert d["roofline"]["kernel"].startswith("grid_stage_a_kernel") and d["roofline"]["kernel_ms"] > 0
+    assert d["ms_per_step_events_median"] > 0
     assert d["roofline"]["kernel_ms"] < d["fwd_ms"] < d["ms_per_step"]
     for key, metric in (("fps", "fps_point_updates_per_s"), ("ball_group", "group_points_output_bytes_per_s")):
         sub = d[key]
         assert sub["metric"] == metric and sub["value"] > 0 and 0.0 < sub["roofline"]["frac"] < 1.0
         assert "workload" in sub["config"]
     od = d["other_distributions_fwd_ms"]
-    assert all(od[k] > 0 for k in ("gaussian", "blobs8", "two_scales", "shapenet_like"))
+    assert all(od[k] > 0 for k in ("gaussian", "blobs8", "two_scales", "shapenet_like", "disjoint"))
