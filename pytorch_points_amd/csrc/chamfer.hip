@@ -748,7 +748,17 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_lds64_kernel(
   PP_PHASE(3);
   __syncthreads();
   PP_PHASE(4);
-  for (int e = t; e < 3 * len; e += 1024) out[3 * (size_t)k0 + e] = (float)s_acc64[e];  // coalesced
+  // (coalesced; non-temporal: nobody on this chip reads the gradients soon, and 12 MB of lines left dirty in the L2s are
+  //  written back at the kernel's end, in front of the next launch -- PP_BWD_NT_STORES=0 at build time for comparison)
+#ifndef PP_BWD_NT_STORES
+#define PP_BWD_NT_STORES 1
+#endif
+  for (int e = t; e < 3 * len; e += 1024) {
+    if (PP_BWD_NT_STORES)
+      __builtin_nontemporal_store((float)s_acc64[e], &out[3 * (size_t)k0 + e]);
+    else
+      out[3 * (size_t)k0 + e] = (float)s_acc64[e];
+  }
   PP_PHASE(5);
 }
 

@@ -367,6 +367,13 @@ constexpr int kStageLayers = 8;
 constexpr int kLaneCubeMaxGroups = 48;  // groups of four points a lane walks per four rows of a cube before it gives up
 constexpr int kSubMaxRho = 2;  // widest cube of sub-cells a lane examines inside a crowded cell
 constexpr int kGroupBatch = 256;  // candidates per LDS batch of wave_group_search (<= the smallest per-wave slice)
+// a blind seed's group: the open queries within this fraction of its candidate's distance (round 3: 1/4 made groups as
+// long as a row of the query grid -- 64 consecutive sorted queries run along x -- and the bound of a group is its
+// farthest member's: disjoint clouds examined 6000 candidates per query)
+#ifndef PP_BLIND_GROUP
+#define PP_BLIND_GROUP 0.25f
+#endif
+constexpr float kBlindGroup = PP_BLIND_GROUP;
 constexpr int kSerialMax = 24;  // open lanes of a wave from which the whole-wave cubes are skipped for the group search
 constexpr int kLaneStageMin = 6;  // open lanes of a wave from which the cubes are searched a lane per query
 
@@ -697,12 +704,15 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     float us = rl(best, seed);
     // wave-uniform: the seed has seen no candidate yet, or only one picked up by accident far outside its cubes
     const bool blind = !(us < 16.0f * g.h * g.h);
+    bool have_smp = false;  // (blind seeds) the nearest of the sample points, a bound for every member
+    float spx = 0.0f, spy = 0.0f, spz = 0.0f;
     if (blind) {
       // one sample per non-empty cell row -- the first point at or after the seed's cell along x, else the row's last
       // point -- four chunks of rows in flight; the nearest sample bounds the seed's neighbour
       const int nall = g.gy * g.gz;
       const int cxs = cell_coord(sx, g.minx, g.invh, g.gx);
       float u1 = inf;
+      float smx = 0.0f, smy = 0.0f, smz = 0.0f;  // this lane's nearest sample
       for (int r0 = 0; r0 < nall; r0 += 256) {
         unsigned rs[4], rm[4], re[4];
 #pragma unroll
@@ -725,12 +735,27 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float d = pp::chamfer_d3(smp[u].x, smp[u].y, smp[u].z, sx, sy, sz);
-          u1 = (re[u] > rs[u] && (!LAB || sml[u] == sl) && d < u1) ? d : u1;
+          const bool tk = re[u] > rs[u] && (!LAB || sml[u] == sl) && d < u1;
+          u1 = tk ? d : u1;
+          smx = tk ? smp[u].x : smx;
+          smy = tk ? smp[u].y : smy;
+          smz = tk ? smp[u].z : smz;
         }
       }
+      const float mine = u1;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) u1 = fminf(u1, __shfl_xor(u1, off));
       us = fminf(us, u1 * 1.0001f);
+      // the nearest sample itself (a real point of the cloud, of the seed's label): every query that joins the group
+      // has a neighbour within ITS OWN distance to it -- a far tighter bound for the members than the triangle
+      // inequality through the seed (round 3: disjoint clouds examined ~2000 candidates per query with that one)
+      have_smp = u1 < inf;
+      if (have_smp) {
+        const int wl = (int)__builtin_ctzll(__ballot(mine == u1));
+        spx = rl(smx, wl);
+        spy = rl(smy, wl);
+        spz = rl(smz, wl);
+      }
     }
     // The seed takes along the open queries within r of it, r = a quarter of the distance of its candidate.  Where
     // the seed knew a candidate: at least two cells, and only queries whose own candidate is no more than twice as
@@ -741,7 +766,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     pp_nblind += blind ? 1 : 0;
 #endif
     const float ds = sqrtf(us);
-    const float r = blind ? 0.25f * ds : fmaxf(2.0f * g.h, 0.25f * ds);
+    const float r = blind ? kBlindGroup * ds : fmaxf(2.0f * g.h, 0.25f * ds);
     const float via = ds + 1.7321f * r;
     const bool member = (((open >> lane) & 1ull) != 0ull && (blind ? (!LAB || ql == sl) : best <= 4.0f * us) &&
                          !(fmaxf(fabsf(qx - sx), fmaxf(fabsf(qy - sy), fabsf(qz - sz))) > r)) ||
@@ -754,9 +779,46 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     const float bhx = rl(v[3], 63), bhy = rl(v[4], 63), bhz = rl(v[5], 63);
     // every member has a neighbour within its own best so far (the seed: within us)
     float ub = member ? (lane == seed ? us : (blind ? fminf(best, via * via) : best)) : 0.0f;
+    if (have_smp && member && lane != seed && (!LAB || ql == sl))
+      ub = fminf(ub, pp::chamfer_d3(spx, spy, spz, qx, qy, qz) * 1.0001f);
+    // The group along x in kSub pieces, each with its own extent and bound (round 3): 64 consecutive queries of the
+    // sorted cloud run along x, and a candidate must lie within SOME member's bound -- cutting a cell row by the whole
+    // box and the largest bound made far clouds examine the union of the box's ends' needs (6000 candidates per query
+    // between disjoint clouds).  A row's cut along x is the hull of the pieces' cuts.
+    constexpr int kSub = 4;
+    float sbl[kSub], sbh[kSub], su[kSub];
+    const float wx = bhx - blx;
+    if (!(wx > 8.0f * g.h)) {  // (wave-uniform) a short group: one piece (the reductions below cost a small group more
+                               // than the cut saves: the tail of a Gaussian makes 80000 groups of a few queries)
+      sbl[0] = blx;
+      sbh[0] = bhx;
+      su[0] = pp::wave_reduce_dpp<false>(ub) * 1.0001f;
+#pragma unroll
+      for (int k = 1; k < kSub; ++k) {
+        sbl[k] = blx;
+        sbh[k] = bhx;
+        su[k] = -1.0f;
+      }
+    } else {
+      const int mypiece = min(kSub - 1, (int)((qx - blx) / wx * (float)kSub));
+#pragma unroll
+      for (int k = 0; k < kSub; ++k) {
+        const bool in = member && mypiece == k;
+        float a = in ? -qx : -inf, b2 = in ? qx : -inf, c = in ? ub : -1.0f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          a = fmaxf(a, __shfl_xor(a, off));
+          b2 = fmaxf(b2, __shfl_xor(b2, off));
+          c = fmaxf(c, __shfl_xor(c, off));
+        }
+        sbl[k] = -a;
+        sbh[k] = b2;
+        su[k] = c >= 0.0f ? c * 1.0001f : -1.0f;  // (a piece without members cuts nothing)
+      }
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) ub = fmaxf(ub, __shfl_xor(ub, off));
-    const float U = ub * 1.0001f;
+    float U = ub * 1.0001f;
     // the rows within sqrt(U) of the box (cell coordinates are monotonic in the coordinate: exact)
     const bool bounded = U < inf;
     const float R = bounded ? sqrtf(U) * 1.0001f + slack : 0.0f;
@@ -769,7 +831,16 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
 #ifdef PP_QUERY_PROBE
     pp_nrows += (unsigned long long)nrows;
 #endif
+    bool dirty = false;
     for (int r0 = 0; r0 < nrows; r0 += 64) {  // wave-uniform
+      if (dirty) {  // (wave-uniform) candidates have been examined since the bound was last taken
+        // the bound follows what the members have found in the rows examined so far: the rows still to come are cut
+        // by the candidates already seen (a member's own best is always a valid bound for it)
+        dirty = false;
+        U = fminf(U, pp::wave_reduce_dpp<false>(member ? best : 0.0f) * 1.0001f);
+#pragma unroll
+        for (int k = 0; k < kSub; ++k) su[k] = fminf(su[k], U);
+      }
       const int rr = r0 + lane;
       // (rr < 2^11, ny < 2^6: the rounded product is the exact quotient)
       const int dz = (int)(((float)rr + 0.5f) * inv_ny);
@@ -777,17 +848,31 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
       unsigned cs = 0u, len = 0u;
       if (rr < nrows) {
         const float gy_ = axis_gap(bly, bhy, g.miny, cy, g.gy), gz_ = axis_gap(blz, bhz, g.minz, cz, g.gz);
-        const float rem = U - __builtin_fmaf(gz_, gz_, gy_ * gy_) * 0.9999f;  // budget left along x (+inf if unbounded)
+        const float gyz = __builtin_fmaf(gz_, gz_, gy_ * gy_) * 0.9999f;
+        const float rem = U - gyz;  // budget left along x (+inf if unbounded)
         if (rem >= 0.0f) {
-          const float rx = bounded ? sqrtf(rem) * 1.0001f + slack : 0.0f;
-          const int x0 = bounded ? cell_coord(blx - rx, g.minx, g.invh, g.gx) : 0;
-          const int x1 = bounded ? cell_coord(bhx + rx, g.minx, g.invh, g.gx) : g.gx - 1;
+          float xlo = inf, xhi = -inf;  // hull of the pieces' cuts
+#pragma unroll
+          for (int k = 0; k < kSub; ++k) {
+            const float remk = su[k] - gyz;
+            if (remk >= 0.0f) {
+              const float rxk = sqrtf(remk) * 1.0001f + slack;
+              xlo = fminf(xlo, sbl[k] - rxk);
+              xhi = fmaxf(xhi, sbh[k] + rxk);
+            }
+          }
+          const bool any = xlo <= xhi;
+          const int x0 = bounded ? cell_coord(xlo, g.minx, g.invh, g.gx) : 0;
+          const int x1 = bounded ? cell_coord(xhi, g.minx, g.invh, g.gx) : g.gx - 1;
           const int base = pp::cell_linear(0, cy, cz, g.gx, g.gy);
+          if (any || !bounded) {
           cs = cell_start[base + x0];
           len = cell_start[base + x1 + 1] - cs;
+          }
         }
       }
       if (__ballot(len != 0u) == 0ull) continue;  // wave-uniform: nothing in these rows
+      dirty = true;
       unsigned incl = len;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -1720,11 +1805,10 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
     (sv_dir ? idx2 : idx1)[sv_off] = sv_i;
   }
   sv_ok = false;
-  if (t == 0) {  // the tile's queue of leftovers and its count of pending queries
-    s_qn = 0u;
+  if (t == 0) {  // the tile's queue of leftovers and its count of pending queries: ordered before their first use by the
+    s_qn = 0u;   // barrier behind the image's arrival -- or by the one a tile whose image does not fit meets instead
     s_tot = 0u;
   }
-  __syncthreads();  // (a tile that cannot be served adds to the count without meeting another barrier first)
   const StageAFront<TQ> f = nx;
   if (PERSIST && it + (int)gridDim.x < nvt)  // the next tile's front goes out now and travels while this tile is walked
     stage_a_issue<TQ>(nx, it + (int)gridDim.x, per_xcd, total, tiles1, tiles2, N, M, ws, L, t, lane);
@@ -1800,6 +1884,7 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
     const int Hz = min(__builtin_amdgcn_readfirstlane(cell_coord(pp::zkey_inv(kmax), g.minz, g.invh, g.gz)) + 1, gz1);
     const unsigned tb0 = (unsigned)__builtin_amdgcn_readlane((int)lay, Lz);
     const unsigned ns = (unsigned)__builtin_amdgcn_readlane((int)lay, Hz + 1) - tb0;
+    if (!(ns > 0u && ns <= (unsigned)CAP)) __syncthreads();  // (the counters above are zero before anyone adds to them)
     if (ns > 0u && ns <= (unsigned)CAP) {  // workgroup-uniform
       // the image: [tb0, tb0 + ns) of the sorted cloud, by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write),
       // in pieces of 64 points, wave w the pieces w, w + kW, ...; ordered here, before anything waits.  A piece's lanes
