@@ -44,7 +44,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz fp32 lane-ops/s (same table)
-FWD_TRAFFIC_C2 = None          # bytes per forward at config 2, all launches (profiles/r3/pmc_summary.txt); set below
+FWD_TRAFFIC_C2 = 71565312      # bytes per forward at config 2, all three launches: 2 x FETCH_SIZE (11949 + 6383 + 22 KB)
+                               # + WRITE_SIZE (8257 + 24923 + 0 KB), profiles/r3/pmc_summary.txt = 3.4x the algorithmic bytes
 
 
 def parse():
