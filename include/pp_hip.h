@@ -79,6 +79,17 @@ int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2, const float
                                float* gradxyz1, float* gradxyz2, int B, int N, int M, int C,
                                void* stream);
 
+/* The same two operators for double clouds: the reference dispatches its kernels over the floating types
+ * (AT_DISPATCH_FLOATING_TYPES_AND_HALF, _ext/nmdistance_cuda.cu:125,210), scalar_t = double for coordinates,
+ * distances and gradients, int indices.  Every-pair scan (no workspace form); same tie rule and rounding order
+ * as the reference's kernel instantiated for double.  half is not provided (the Python layer raises TypeError). */
+int pp_nmdistance_forward_f64(const double* xyz1, const double* xyz2, double* dist1, int* idx1,
+                              double* dist2, int* idx2, int B, int N, int M, int C, void* stream);
+int pp_nmdistance_backward_f64(const double* xyz1, const double* xyz2, const double* graddist1,
+                               const double* graddist2, const int* idx1, const int* idx2,
+                               double* gradxyz1, double* gradxyz2, int B, int N, int M, int C,
+                               void* stream);
+
 /* ---- _ext.sampling ----------------------------------------------------------------------- */
 
 /* Replaces sampling.furthest_sampling(m, seedIdx, input, temp, idx)

@@ -38,7 +38,6 @@ int pp_debug_nmdistance_kernel_ms3(float* build_ms, float* stage_a_ms, float* re
 int pp_debug_nmdistance_pending(const void* workspace, int B, int N, int M, unsigned* totals);
 
 void pp_debug_set_fps_v1(int on); /* 1 = one workgroup per batch element instead of the CU cluster */
-void pp_debug_set_fps_variant(int v); /* cluster kernel: bit 0 pipelined polling, bit 1 every wave polls (no second hand-off); -1 = default (3) */
 void pp_debug_set_gather_variant(int variant);
 void pp_debug_set_ball_query_variant(int variant); /* scan kernels: 1 = one wave per 64 centres */
 void pp_debug_set_ball_query_search(int mode);     /* 0 automatic, 1 scan, 2 grid wherever possible */

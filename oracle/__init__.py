@@ -92,6 +92,37 @@ def chamfer_forward(xyz1, xyz2, structural=False):
     return d1, i1, d2, i2
 
 
+def chamfer_forward_f64(xyz1, xyz2):
+    """the reference's kernel instantiated for double (nmdistance_cuda.cu:125): -> dist1 f64, idx1 i32, dist2, idx2"""
+    xyz1 = np.ascontiguousarray(xyz1, dtype=np.float64)
+    xyz2 = np.ascontiguousarray(xyz2, dtype=np.float64)
+    b, n, c = xyz1.shape
+    _, m, c2 = xyz2.shape
+    assert c == c2 and xyz2.shape[0] == b
+    d1 = np.zeros((b, n), np.float64)
+    d2 = np.zeros((b, m), np.float64)
+    i1 = np.zeros((b, n), np.int32)
+    i2 = np.zeros((b, m), np.int32)
+    lib().oracle_chamfer_forward_f64(_p(xyz1), _p(xyz2), _p(d1), _p(i1), _p(d2), _p(i2), b, n, m, c)
+    return d1, i1, d2, i2
+
+
+def chamfer_backward_f64(xyz1, xyz2, graddist1, graddist2, idx1, idx2):
+    """-> gradxyz1 (B,N,C), gradxyz2 (B,M,C), double (nmdistance_cuda.cu:210)"""
+    xyz1 = np.ascontiguousarray(xyz1, dtype=np.float64)
+    xyz2 = np.ascontiguousarray(xyz2, dtype=np.float64)
+    graddist1 = np.ascontiguousarray(graddist1, dtype=np.float64)
+    graddist2 = np.ascontiguousarray(graddist2, dtype=np.float64)
+    idx1, q1 = _i(idx1)
+    idx2, q2 = _i(idx2)
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    gx1 = np.zeros_like(xyz1)
+    gx2 = np.zeros_like(xyz2)
+    lib().oracle_chamfer_backward_f64(_p(xyz1), _p(xyz2), _p(graddist1), _p(graddist2), q1, q2, _p(gx1), _p(gx2), b, n, m, c)
+    return gx1, gx2
+
+
 def labeled_chamfer_forward(xyz1, xyz2, label1, label2):
     xyz1, p1 = _f(xyz1)
     xyz2, p2 = _f(xyz2)

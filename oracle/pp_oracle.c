@@ -269,6 +269,75 @@ void oracle_chamfer_backward(const float* xyz1, const float* xyz2, const float* 
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * K1 / K3 instantiated for double (AT_DISPATCH_FLOATING_TYPES_AND_HALF, nmdistance_cuda.cu:125,210:
+ * scalar_t = double for coordinates, distances and gradients; indices stay int).  Literal, as the
+ * structural fp32 form above: 512-chunks, `k==0 || d<best` (:36), `k2==0 || result>best` (:41);
+ * d += tmp*tmp contracted to fma by nvcc (:34).  OpenMP over queries only (no data shared).
+ * ------------------------------------------------------------------------------------------- */
+static void nmdistance_f64_1dir(int b, int n, int c, const double* xyz, int m, const double* xyz2,
+                                double* result, int* result_i) {
+  for (int i = 0; i < b; ++i) {
+    for (int k2 = 0; k2 < m; k2 += PP_CHUNK) {
+      const int end_k = (m < k2 + PP_CHUNK ? m : k2 + PP_CHUNK) - k2;
+      const double* buf = xyz2 + ((size_t)i * m + k2) * c;
+#pragma omp parallel for schedule(static)
+      for (int j = 0; j < n; ++j) {
+        const double* q = xyz + ((size_t)i * n + j) * c;
+        int best_i = 0;
+        double best = 0;
+        for (int k = 0; k < end_k; ++k) {
+          double d = 0;
+          for (int e = 0; e < c; ++e) {
+            const double t = buf[(size_t)k * c + e] - q[e]; /* :33 */
+            d = fma(t, t, d);                               /* :34 */
+          }
+          if (k == 0 || d < best) {
+            best = d;
+            best_i = k + k2;
+          }
+        }
+        if (k2 == 0 || result[(size_t)i * n + j] > best) {
+          result[(size_t)i * n + j] = best;
+          result_i[(size_t)i * n + j] = best_i;
+        }
+      }
+    }
+  }
+}
+
+void oracle_chamfer_forward_f64(const double* xyz1, const double* xyz2, double* dist1, int* idx1,
+                                double* dist2, int* idx2, int b, int n, int m, int c) {
+  nmdistance_f64_1dir(b, n, c, xyz1, m, xyz2, dist1, idx1);
+  nmdistance_f64_1dir(b, m, c, xyz2, n, xyz1, dist2, idx2);
+}
+
+static void nmdistance_grad_f64_1dir(int b, int n, int c, const double* xyz1, int m, const double* xyz2,
+                                     const double* grad_dist1, const int* idx1, double* grad_xyz1,
+                                     double* grad_xyz2) {
+  for (int i = 0; i < b; ++i)
+    for (int j = 0; j < n; ++j) {
+      const int j2 = idx1[(size_t)i * n + j];
+      if (j2 < 0) continue;
+      const double g = grad_dist1[(size_t)i * n + j] * 2;
+      for (int k = 0; k < c; ++k) {
+        const double xyz_g =
+            g * (xyz1[((size_t)i * n + j) * c + k] - xyz2[((size_t)i * m + j2) * c + k]);
+        grad_xyz1[((size_t)i * n + j) * c + k] += xyz_g;
+        grad_xyz2[((size_t)i * m + j2) * c + k] += -xyz_g;
+      }
+    }
+}
+
+void oracle_chamfer_backward_f64(const double* xyz1, const double* xyz2, const double* graddist1,
+                                 const double* graddist2, const int* idx1, const int* idx2,
+                                 double* gradxyz1, double* gradxyz2, int b, int n, int m, int c) {
+  memset(gradxyz1, 0, sizeof(double) * (size_t)b * n * c);
+  memset(gradxyz2, 0, sizeof(double) * (size_t)b * m * c);
+  nmdistance_grad_f64_1dir(b, n, c, xyz1, m, xyz2, graddist1, idx1, gradxyz1, gradxyz2);
+  nmdistance_grad_f64_1dir(b, m, c, xyz2, n, xyz1, graddist2, idx2, gradxyz2, gradxyz1);
+}
+
+/* ---------------------------------------------------------------------------------------------
  * K6  furthest_point_sampling_forward_kernel, sampling_cuda.cu:162-233, launched with
  * T = opt_n_threads(n) threads and one block per batch element (:239-243).
  * Literal restatement of the thread decomposition, because it fixes the tie-break:

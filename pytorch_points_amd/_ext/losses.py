@@ -41,12 +41,26 @@ def nmdistance_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
     ints = (("idx1", idx1), ("idx2", idx2))
     dev = _lib.require_cuda(*floats, *ints)
     _lib.require_contiguous(*floats, *ints)
-    _lib.require_float(*floats)
+    dt = _lib.require_float_or_double(*floats)
     _lib.require_int(*ints)
     if dist1.numel() != b * n or idx1.numel() != b * n or dist2.numel() != b * m or idx2.numel() != b * m:
         raise RuntimeError("output tensors must be (B, N) and (B, M)")
-    _launch_forward(xyz1, xyz2, dist1, dist2, idx1, idx2, b, n, m, c, dev)
+    if dt is torch.float64:
+        _launch_f64("pp_nmdistance_forward_f64", "nmdistance_forward", dev,
+                    xyz1, xyz2, dist1, idx1, dist2, idx2, b, n, m, c)
+    else:
+        _launch_forward(xyz1, xyz2, dist1, dist2, idx1, idx2, b, n, m, c, dev)
     return 1
+
+
+def _launch_f64(symbol, what, dev, *args):
+    """double clouds (the reference's scalar_t = double instantiation, _ext/nmdistance_cuda.cu:125,210): tensors
+    first (passed by address), then the four sizes; arguments already validated"""
+    fn = getattr(_lib.lib(), symbol)
+    with _lib.on_device(dev) as stream:
+        code = fn(*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args], stream)
+    if code:
+        _lib.check(code, what)
 
 
 def _launch_forward(xyz1, xyz2, dist1, dist2, idx1, idx2, b, n, m, c, dev):
@@ -103,11 +117,15 @@ def nmdistance_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, id
     ints = (("idx1", idx1), ("idx2", idx2))
     dev = _lib.require_cuda(*floats, *ints)
     _lib.require_contiguous(*floats, *ints)
-    _lib.require_float(*floats)
+    dt = _lib.require_float_or_double(*floats)
     _lib.require_int(*ints)
     if gradxyz1.shape != xyz1.shape or gradxyz2.shape != xyz2.shape:
         raise RuntimeError("gradxyz tensors must have the shapes of xyz1 / xyz2")
-    _launch_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2, b, n, m, c, dev)
+    if dt is torch.float64:
+        _launch_f64("pp_nmdistance_backward_f64", "nmdistance_backward", dev,
+                    xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, b, n, m, c)
+    else:
+        _launch_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2, b, n, m, c, dev)
     return 1
 
 

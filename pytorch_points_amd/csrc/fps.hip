@@ -220,107 +220,11 @@ struct ClusterGeom {
   int per_xcd8;  // cl * ceil(B / 8): blocks that share blockIdx % 8
 };
 
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-// One poll of the cluster's granules of a step.  Every lane loads (lanes that are not pollers re-read the
-// workgroup's own granule and ignore it).
-// PIPE: three loads in flight, issued a third of an L2 round trip apart and re-issued as they return: a granule
-// that lands just after a load has passed is seen a third of a round trip later instead of a whole one.  Written
-// in assembly because the waits must be `vmcnt(2)` (the compiler's register rotation turns them into vmcnt(0)).
-// On success two loads are still in flight: their destination registers are handed back in `fl` and must be kept
-// alive until poll_drain() (placed where the wait is free), so that nothing else is allocated to them meanwhile.
-struct PollFlight {
-  u64 a, b, c;
-};
-__device__ __forceinline__ void poll_drain(PollFlight& fl) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(fl.a), "+v"(fl.b), "+v"(fl.c));
-}
-template <bool PIPE>
-__device__ __forceinline__ u64 poll_cluster(gu64* slot, int mine, int lane, bool poller, unsigned tag, u64 own,
-                                            bool& dead, PollFlight& fl) {
-  gu64* src = slot + (poller ? lane : mine);
-  const u64 t0 = __builtin_amdgcn_s_memrealtime();
-  u64 v;
-  if constexpr (PIPE) {
-    const u64 np = __ballot(!poller);            // lanes whose granule does not count
-    const u64 tag56 = (u64)tag << 56;            // the tag byte, shifted to the top like the granule below
-    const u64 deadline = t0 + kSpinLimitTicks;
-    u64 tmp, now;
-    unsigned timed_out;
-    asm volatile(
-        "global_load_dwordx2 %[a], %[src], off sc1\n\t"
-        "s_sleep 3\n\t"
-        "global_load_dwordx2 %[b], %[src], off sc1\n\t"
-        "s_sleep 3\n\t"
-        "global_load_dwordx2 %[c], %[src], off sc1\n\t"
-        "s_mov_b32 %[to], 0\n"
-        "1:\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
-        "v_lshlrev_b64 %[tmp], 56, %[a]\n\t"
-        "v_cmp_eq_u64_e32 vcc, %[tag56], %[tmp]\n\t"
-        "s_or_b64 vcc, vcc, %[np]\n\t"
-        "s_cmp_eq_u64 vcc, exec\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "global_load_dwordx2 %[a], %[src], off sc1\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
-        "v_lshlrev_b64 %[tmp], 56, %[b]\n\t"
-        "v_cmp_eq_u64_e32 vcc, %[tag56], %[tmp]\n\t"
-        "s_or_b64 vcc, vcc, %[np]\n\t"
-        "s_cmp_eq_u64 vcc, exec\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        "global_load_dwordx2 %[b], %[src], off sc1\n\t"
-        "s_waitcnt vmcnt(2)\n\t"
-        "v_lshlrev_b64 %[tmp], 56, %[c]\n\t"
-        "v_cmp_eq_u64_e32 vcc, %[tag56], %[tmp]\n\t"
-        "s_or_b64 vcc, vcc, %[np]\n\t"
-        "s_cmp_eq_u64 vcc, exec\n\t"
-        "s_cbranch_scc1 4f\n\t"
-        "global_load_dwordx2 %[c], %[src], off sc1\n\t"
-        "s_memrealtime %[now]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_lt_u64_e32 vcc, %[now], %[deadline]\n\t"
-        "s_cbranch_vccnz 1b\n\t"
-        "s_mov_b32 %[to], 1\n\t"
-        "s_waitcnt vmcnt(0)\n"
-        "2:\n\t"
-        "v_mov_b64 %[v], %[a]\n\t"
-        "s_branch 5f\n"
-        "3:\n\t"
-        "v_mov_b64 %[v], %[b]\n\t"
-        "s_branch 5f\n"
-        "4:\n\t"
-        "v_mov_b64 %[v], %[c]\n"
-        "5:"
-        : [a] "=&v"(fl.a), [b] "=&v"(fl.b), [c] "=&v"(fl.c), [tmp] "=&v"(tmp), [v] "=&v"(v), [now] "=&s"(now),
-          [to] "=&s"(timed_out)
-        : [src] "v"(src), [tag56] "s"(tag56), [np] "s"(np), [deadline] "v"(deadline)
-        : "vcc", "scc", "memory");
-    if (timed_out) dead = true;
-  } else {
-    auto ld = [&]() { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    for (;;) {
-      v = ld();
-      if (__all(!poller || (unsigned)(v & 0xFFu) == tag)) break;
-      if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
-        dead = true;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-  return (poller && !dead) ? v : own;
-}
-
-// VAR bit 0: pipelined polling; bit 1: every wave polls and reduces for itself (no second LDS hand-off, one
-// barrier per step).  The distance update runs on packed fp32 pairs (v_pk_add/mul/fma_f32: same IEEE
-// operations, two points per instruction).
-template <int R, int VAR>
+template <int R>
 __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
     const float* __restrict__ xyz, float* __restrict__ temp, int* __restrict__ idx, int B, int N,
     int npoint, int seed, TieOrder order, ClusterGeom geo, u64* __restrict__ ring,
     unsigned* __restrict__ err) {
-  constexpr bool PIPE = (VAR & 1) != 0, POLLALL = (VAR & 2) != 0;
-  constexpr int RP = (R + 1) / 2;  // slot pairs of a thread (R = 1: the second slot of the pair is padding)
   __shared__ u64 s_key[2][kClWaves];
   __shared__ int s_old[2];
   // members of one batch element share blockIdx % 8 (one XCD under round-robin dispatch): speed only
@@ -337,23 +241,21 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
   const int wave = pp::wave_id_uniform();
   const int k0 = c * geo.slice;
 
-  v2f px[RP], py[RP], pz[RP];
-  float td[2 * RP];
+  float px[R], py[R], pz[R], td[R];
 #pragma unroll
-  for (int i = 0; i < 2 * RP; ++i) {
+  for (int i = 0; i < R; ++i) {
     const int k = k0 + t + kClThreads * i;
-    const bool ok = i < R && k < N && t + kClThreads * i < geo.slice;
+    const bool ok = k < N && t + kClThreads * i < geo.slice;
     const int kc = ok ? k : 0;
-    px[i >> 1][i & 1] = p[3 * (size_t)kc + 0];
-    py[i >> 1][i & 1] = p[3 * (size_t)kc + 1];
-    pz[i >> 1][i & 1] = p[3 * (size_t)kc + 2];
+    px[i] = p[3 * (size_t)kc + 0];
+    py[i] = p[3 * (size_t)kc + 1];
+    pz[i] = p[3 * (size_t)kc + 2];
     // points outside the slice never win: -1 < every real d2 (>= 0); min(d, -1) stays -1
     td[i] = ok ? tmp[kc] : -1.0f;
   }
   int old = seed;
   if (c == 0 && t == 0) out[0] = old;
   bool dead = false;
-  PollFlight fl = {0ull, 0ull, 0ull};
   for (int j = 1; j < npoint; ++j) {
     PP_FPS_MARK(0);
     const float ox = p[3 * (size_t)old + 0], oy = p[3 * (size_t)old + 1], oz = p[3 * (size_t)old + 2];
@@ -364,58 +266,55 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
     // Padding slots carry -1 (min(d, -1) = -1): they beat the initial -2 but produce the losing key below.
     float bd = -2.0f;
     int bi = 0;
-    const v2f o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
 #pragma unroll
-    for (int i = 0; i < RP; ++i) {
-      // pp::dist3 on two points: fma(dz, dz, fma(dx, dx, dy * dy))
-      const v2f dx = px[i] - o2x, dy = py[i] - o2y, dz = pz[i] - o2z;
-      v2f d = dy * dy;
-      d = __builtin_elementwise_fma(dx, dx, d);
-      d = __builtin_elementwise_fma(dz, dz, d);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const float d2 = __builtin_fminf(d[h], td[2 * i + h]);
-        td[2 * i + h] = d2;
-        const bool take = d2 > bd;
-        bd = take ? d2 : bd;
-        bi = take ? 2 * i + h : bi;
-      }
+    for (int i = 0; i < R; ++i) {
+      const float d = dist3(px[i], py[i], pz[i], ox, oy, oz);
+      const float d2 = __builtin_fminf(d, td[i]);
+      td[i] = d2;
+      const bool take = d2 > bd;
+      bd = take ? d2 : bd;
+      bi = take ? i : bi;
     }
     // a workgroup whose slice is empty still publishes a tagged (losing) granule
     u64 best = bd < 0.0f ? (u64)tag
                          : (((u64)__float_as_uint(bd) << 32) |
                             ((u64)(0xFFFFFFu - order.rank(k0 + t + kClThreads * bi)) << 8) | tag);
     PP_FPS_MARK(1);
-    if (PIPE) poll_drain(fl);  // the last step's two trailing loads have long landed: free here
     best = wave_max_key<6>(best);
     if (lane == 0) s_key[j & 1][wave] = best;
     __syncthreads();
     PP_FPS_MARK(2);
-    if (POLLALL || wave == 0) {
+    if (wave == 0) {
       u64 m = s_key[j & 1][lane & (kClWaves - 1)];
       m = wave_max_key<3>(m);  // the eight wave results sit in lanes 0..7: three row steps
       gu64* slot = bring + (size_t)(j & 1) * geo.cl;
-      if (wave == 0 && lane == 0) __hip_atomic_store(slot + c, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(slot + c, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       PP_FPS_MARK(3);
       // poll the cluster's granules of this step
-      u64 v = poll_cluster<PIPE>(slot, c, lane, lane < geo.cl && lane != c, tag, m, dead, fl);
+      u64 v = m;
+      const bool poller = lane < geo.cl && lane != c;
+      const u64 t0 = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        if (poller) v = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = !poller || (unsigned)(v & 0xFFu) == tag;
+        if (__all(ready)) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks) {
+          dead = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
       PP_FPS_MARK(4);
       if (lane >= geo.cl) v = 0ull;
-      v = geo.cl <= 16 ? wave_max_key<4>(v) : wave_max_key<6>(v);
+      v = wave_max_key<6>(v);
       const unsigned r = 0xFFFFFFu - (unsigned)((v >> 8) & 0xFFFFFFull);
-      if (POLLALL)
-        old = __builtin_amdgcn_readfirstlane(dead ? -1 : order.unrank(r));
-      else if (lane == 0)
-        s_old[j & 1] = dead ? -1 : order.unrank(r);
+      if (lane == 0) s_old[j & 1] = dead ? -1 : order.unrank(r);
     }
-    if (!POLLALL) {
-      __syncthreads();
-      PP_FPS_MARK(5);
-      old = __builtin_amdgcn_readfirstlane(s_old[j & 1]);
-    }
-    if (old < 0) {  // timed out: flag, leave defined (zero) indices behind and go (uniform across the wave)
-      if (PIPE) poll_drain(fl);
-      if (lane == 0) atomicOr(err, 1u);
+    __syncthreads();
+    PP_FPS_MARK(5);
+    old = __builtin_amdgcn_readfirstlane(s_old[j & 1]);
+    if (old < 0) {  // timed out: flag, leave defined (zero) indices behind and go (uniform across the workgroup)
+      if (t == 0) atomicOr(err, 1u);
       if (c == 0)
         for (int jj = j + t; jj < npoint; jj += kClThreads) out[jj] = 0;
       return;
@@ -423,7 +322,6 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
     if (c == 0 && t == 0) out[j] = old;
   }
   PP_FPS_MARK_END();
-  if (PIPE) poll_drain(fl);
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int k = k0 + t + kClThreads * i;
@@ -431,21 +329,12 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
   }
 }
 
-// poll form of the cluster kernel (pp_debug_set_fps_variant: -1 = default)
-constexpr int kFpsDefaultVariant = 3;
-int fps_variant();
-
 template <int R>
 void launch_fps_cluster(const float* xyz, float* temp, int* idx, int B, int N, int npoint, int seed,
                         TieOrder order, ClusterGeom geo, u64* ring, unsigned* err, hipStream_t s) {
   const int groups8 = (B + 7) / 8;
-  const dim3 grid(8 * groups8 * geo.cl), block(kClThreads);
-  switch (fps_variant()) {
-    case 0: fps_cluster_kernel<R, 0><<<grid, block, 0, s>>>(xyz, temp, idx, B, N, npoint, seed, order, geo, ring, err); break;
-    case 1: fps_cluster_kernel<R, 1><<<grid, block, 0, s>>>(xyz, temp, idx, B, N, npoint, seed, order, geo, ring, err); break;
-    case 2: fps_cluster_kernel<R, 2><<<grid, block, 0, s>>>(xyz, temp, idx, B, N, npoint, seed, order, geo, ring, err); break;
-    default: fps_cluster_kernel<R, 3><<<grid, block, 0, s>>>(xyz, temp, idx, B, N, npoint, seed, order, geo, ring, err); break;
-  }
+  fps_cluster_kernel<R><<<dim3(8 * groups8 * geo.cl), dim3(kClThreads), 0, s>>>(
+      xyz, temp, idx, B, N, npoint, seed, order, geo, ring, err);
 }
 
 // Workgroups the cluster kernel may count on being resident together: one 512-thread workgroup per CU of the
@@ -459,7 +348,7 @@ int resident_cluster_blocks() {
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_cluster_kernel<R, kFpsDefaultVariant>, kClThreads, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_cluster_kernel<R>, kClThreads, 0) != hipSuccess) return 0;
   if (per_cu < 1) return 0;
   return cus < kMaxClusterBlocks ? cus : kMaxClusterBlocks;  // one per CU, whatever the query allows beyond that
 }
@@ -488,12 +377,7 @@ void launch_fps(const float* xyz, float* temp, int* idx, int B, int N, int npoin
 }  // namespace
 
 static pp::Knob g_fps_force_v1;
-static pp::Knob g_fps_variant;  // 0 = default; v + 1 otherwise
 extern "C" void pp_debug_set_fps_v1(int on) { g_fps_force_v1.set(on); }
-extern "C" void pp_debug_set_fps_variant(int v) { g_fps_variant.set(v < 0 ? 0 : (v & 3) + 1); }
-namespace {
-int fps_variant() { return g_fps_variant ? (int)g_fps_variant - 1 : kFpsDefaultVariant; }
-}  // namespace
 
 extern "C" size_t pp_furthest_sampling_workspace_bytes(int B, int N, int npoint) {
   (void)npoint;

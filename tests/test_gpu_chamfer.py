@@ -215,7 +215,9 @@ def test_rejects_bad_inputs(cuda):
     with pytest.raises(RuntimeError):
         losses.nmdistance_forward(x.cpu(), x, d, d, i, i)
     with pytest.raises(RuntimeError):
-        losses.nmdistance_forward(x.double(), x.double(), d, d, i, i)
+        losses.nmdistance_forward(x.double(), x.double(), d, d, i, i)       # mixed double / float arguments
+    with pytest.raises(TypeError, match="half"):
+        losses.nmdistance_forward(x.half(), x.half(), d.half(), d.half(), i, i)
     with pytest.raises(RuntimeError):
         losses.nmdistance_forward(x, x, d, d, i.long(), i)
     with pytest.raises(RuntimeError):
@@ -312,8 +314,10 @@ def test_native_autograd_nodes_equal_the_python_functions(cuda):
     x1.grad = x2.grad = None
     ml.NmDistanceFunction.apply(x1, x2)[0].sum().backward()
     assert torch.allclose(ga, x1.grad, rtol=1e-5, atol=1e-9) and torch.allclose(gb, x2.grad, rtol=1e-5, atol=1e-9)
-    with pytest.raises(RuntimeError, match="float tensor"):
-        ml.nndistance(x1.double(), x2.double())
+    with pytest.raises(TypeError, match="half"):
+        ml.nndistance(x1.half(), x2.half())
+    with pytest.raises(TypeError, match="half"):
+        ml.nndistance(x1.bfloat16(), x2.bfloat16())
     with pytest.raises(RuntimeError, match="disagree"):
         ml.nndistance(x1, torch.zeros(2, 4, 3, device=cuda))
 
@@ -340,3 +344,70 @@ def test_forward_other_point_dimensions_tiled_and_plain(cuda, shape, variant):
         setter(0)
     for g, e in zip(got, exp):
         assert np.array_equal(g, e)
+
+
+# ------------------------------------------------------------------ double clouds (reference: scalar_t = double)
+@pytest.mark.parametrize("b,n,m,c", [(2, 700, 900, 3), (1, 1, 5, 3), (3, 257, 256, 2), (1, 513, 1030, 5), (2, 64, 64, 1),
+                                     (1, 300, 200, 8), (1, 100, 90, 11)])
+def test_double_forward_equals_oracle(cuda, b, n, m, c):
+    """nndistance on double clouds: the reference dispatches its kernel over the floating types
+    (_ext/nmdistance_cuda.cu:125); bit-exact distances and indices against the fp64 restatement."""
+    from pytorch_points_amd._ext import losses
+    x1 = S.normal(800 + n, (b, n, c)).astype(np.float64) + S.normal(801 + n, (b, n, c)).astype(np.float64) * 1e-9
+    x2 = S.normal(802 + m, (b, m, c)).astype(np.float64) + S.normal(803 + m, (b, m, c)).astype(np.float64) * 1e-9
+    t1, t2 = torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda)
+    d1 = torch.empty(b, n, dtype=torch.float64, device=cuda)
+    d2 = torch.empty(b, m, dtype=torch.float64, device=cuda)
+    i1 = torch.empty(b, n, dtype=torch.int32, device=cuda)
+    i2 = torch.empty(b, m, dtype=torch.int32, device=cuda)
+    assert losses.nmdistance_forward(t1, t2, d1, d2, i1, i2) == 1
+    e = oracle.chamfer_forward_f64(x1, x2)
+    for g, x in zip([d1, i1, d2, i2], e):
+        assert np.array_equal(g.cpu().numpy(), x)
+
+
+def test_double_ties_take_the_lowest_index(cuda):
+    from pytorch_points_amd.network.model_loss import nndistance
+    x2 = np.zeros((1, 1200, 3), np.float64)
+    x2[0, :, 0] = np.arange(1200) % 7          # many exact duplicates, also across the reference's 512-chunks
+    x1 = np.zeros((1, 9, 3), np.float64)
+    x1[0, :, 0] = np.arange(9) - 1.0
+    d1, d2, i1, i2 = nndistance(torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda))
+    e = oracle.chamfer_forward_f64(x1, x2)
+    assert d1.dtype is torch.float64 and i1.dtype is torch.int32
+    for g, x in zip([d1, i1, d2, i2], e):
+        assert np.array_equal(g.cpu().numpy(), x)
+    assert i1[0, 1].item() == 0 and i1[0, 2].item() == 1      # first of the equal candidates
+
+
+def test_double_backward_and_autograd(cuda):
+    """gradients in double: C ABI against the oracle (sums of at most a few terms: 1e-12), and the autograd node
+    against torch's own double arithmetic"""
+    from pytorch_points_amd._ext import losses
+    from pytorch_points_amd.network import model_loss as ml
+    b, n, m, c = 2, 600, 450, 3
+    x1 = S.normal(810, (b, n, c)).astype(np.float64)
+    x2 = S.normal(811, (b, m, c)).astype(np.float64)
+    g1 = S.normal(812, (b, n)).astype(np.float64)
+    g2 = S.normal(813, (b, m)).astype(np.float64)
+    _, i1, _, i2 = oracle.chamfer_forward_f64(x1, x2)
+    e1, e2 = oracle.chamfer_backward_f64(x1, x2, g1, g2, i1, i2)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    o1 = torch.full((b, n, c), 7.0, dtype=torch.float64, device=cuda)     # overwritten, not accumulated into
+    o2 = torch.full((b, m, c), 7.0, dtype=torch.float64, device=cuda)
+    assert losses.nmdistance_backward(T(x1), T(x2), o1, o2, T(g1), T(g2), T(i1), T(i2)) == 1
+    assert np.allclose(o1.cpu().numpy(), e1, rtol=1e-12, atol=1e-13)
+    assert np.allclose(o2.cpu().numpy(), e2, rtol=1e-12, atol=1e-13)
+    t1, t2 = T(x1).requires_grad_(True), T(x2).requires_grad_(True)
+    d1, d2, j1, j2 = ml.nndistance(t1, t2)
+    (d1.sum() + 2 * d2.sum()).backward()
+    a1, a2 = T(x1).requires_grad_(True), T(x2).requires_grad_(True)
+    r1 = ((a1 - torch.gather(a2, 1, j1.long()[..., None].expand(-1, -1, c))) ** 2).sum(-1)
+    r2 = ((a2 - torch.gather(a1, 1, j2.long()[..., None].expand(-1, -1, c))) ** 2).sum(-1)
+    (r1.sum() + 2 * r2.sum()).backward()
+    assert torch.allclose(d1, r1.detach(), rtol=1e-12, atol=1e-14)
+    assert torch.allclose(t1.grad, a1.grad, rtol=1e-11, atol=1e-12) and torch.allclose(t2.grad, a2.grad, rtol=1e-11, atol=1e-12)
+    # empty clouds
+    z = torch.zeros(1, 0, 3, dtype=torch.float64, device=cuda)
+    d1, d2, j1, j2 = ml.nndistance(z, T(x2[:1]))
+    assert d1.shape == (1, 0) and (d2 == 0).all() and (j2 == 0).all()

@@ -16,25 +16,19 @@ def _t(a, cuda):
 
 
 # ---------------------------------------------------------------- furthest point sampling + gather
-@pytest.fixture(params=["cluster", "cluster_v0", "cluster_v1", "cluster_v2", "single_block"])
+@pytest.fixture(params=["cluster", "single_block"])
 def fps_path(request, cuda):
-    """Run every FPS test on both decompositions: the CU-cluster kernel (default where it applies; its
-    poll forms v0..v2 beside the default, pp_debug_set_fps_variant) and the one-workgroup-per-batch
-    kernel; afterwards no inter-workgroup wait may have timed out."""
+    """Run every FPS test on both decompositions: the CU-cluster kernel (default where it applies)
+    and the one-workgroup-per-batch kernel; afterwards no inter-workgroup wait may have timed out."""
     import ctypes
     from pytorch_points_amd import _lib
     from pytorch_points_amd._ext import sampling
     setter = _lib.lib().pp_debug_set_fps_v1
     setter.argtypes = [ctypes.c_int]
     setter.restype = None
-    variant = _lib.lib().pp_debug_set_fps_variant
-    variant.argtypes = [ctypes.c_int]
-    variant.restype = None
     setter(1 if request.param == "single_block" else 0)
-    variant(int(request.param[-1]) if request.param.startswith("cluster_v") else -1)
     yield request.param
     setter(0)
-    variant(-1)
     assert sampling.furthest_sampling_status(cuda) == 0
 
 

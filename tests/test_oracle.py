@@ -348,3 +348,25 @@ def test_oracle_matches_real_reference():
         g = np.load(path)
         _, ti = oracle.three_nn(g["unknown"], g["known"])
         assert np.array_equal(ti, ref["cuda/%s/idx" % name]), name
+
+
+def test_double_restatement_matches_bruteforce():
+    """the reference's Chamfer kernels instantiated for double (nmdistance_cuda.cu:125,210) against numpy: lowest
+    index among exact ties, also across the 512-chunks; gradients are the analytic ones"""
+    rng = np.random.default_rng(5)
+    x1 = rng.standard_normal((2, 300, 3))
+    x2 = rng.standard_normal((2, 1100, 3))
+    x2[:, 600:700] = x2[:, 100:200]                      # exact duplicates in another chunk: the earlier one wins
+    d1, i1, d2, i2 = oracle.chamfer_forward_f64(x1, x2)
+    D = ((x1[:, :, None] - x2[:, None]) ** 2).sum(-1)
+    assert np.array_equal(i1, D.argmin(2)) and np.array_equal(i2, D.argmin(1))
+    assert np.allclose(d1, D.min(2), rtol=1e-14, atol=0) and np.allclose(d2, D.min(1), rtol=1e-14, atol=0)
+    assert not np.isin(i1, np.arange(600, 700)).any()
+    g1, g2 = rng.standard_normal((2, 300)), rng.standard_normal((2, 1100))
+    gx1, gx2 = oracle.chamfer_backward_f64(x1, x2, g1, g2, i1, i2)
+    e1 = 2 * g1[..., None] * (x1 - np.take_along_axis(x2, i1[..., None].astype(np.int64), 1))
+    e2 = 2 * g2[..., None] * (x2 - np.take_along_axis(x1, i2[..., None].astype(np.int64), 1))
+    for b in range(2):
+        np.add.at(e2[b], i1[b], -2 * g1[b][:, None] * (x1[b] - x2[b][i1[b]]))
+        np.add.at(e1[b], i2[b], -2 * g2[b][:, None] * (x2[b] - x1[b][i2[b]]))
+    assert np.allclose(gx1, e1, rtol=1e-12, atol=1e-13) and np.allclose(gx2, e2, rtol=1e-12, atol=1e-13)

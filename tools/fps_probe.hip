@@ -24,10 +24,8 @@ __device__ unsigned long long g_probe_ts[64 * 8];
 #include <stdlib.h>
 #include <vector>
 
-int main(int argc, char** argv) {
+int main() {
   const int B = 16, N = 65536, npoint = 4096;
-  if (argc > 1) pp_debug_set_fps_variant(atoi(argv[1]));
-  printf("variant %s\n", argc > 1 ? argv[1] : "default");
   std::vector<float> h((size_t)B * N * 3);
   srand(1);
   for (size_t i = 0; i < (size_t)B * N; ++i) {
