@@ -38,7 +38,8 @@
 constexpr int kQWaves = 1 << 17;
 __device__ unsigned long long g_qphase[8][16];
 __device__ unsigned g_qwave[kQWaves][10];
-__device__ unsigned long long g_qgroup[8];  // group search: calls, groups, blind groups, candidates staged, max candidates of one call, rows visited
+__device__ unsigned long long g_qgroup[8];  // group search: calls, groups, blind groups, candidates of the row cuts, max of them in one call, rows of the
+                                             // boxes, rows listed by pass 1, candidates the whole wave walked
 extern "C" int pp_debug_read_query_phases(void* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qphase), sizeof(g_qphase));
 }
@@ -687,15 +688,22 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
   auto rl = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
   // (a point may sit in the neighbouring cell by the rounding of its cell coordinate, and the faces themselves
   //  are rounded: every gap is shortened by this much)
-  const float slack = 1.0e-4f * g.h;
+  // ... or by a few ulps of the coordinates themselves where the cloud sits far from the origin against its extent
+  const float slack = fmaxf(1.0e-4f * g.h, 5.0e-7f * (fabsf(g.minx) + fabsf(g.miny) + fabsf(g.minz) +
+                                                        (float)(g.gx + g.gy + g.gz) * g.h));
   // distance from the interval [blo, bhi] to the slab of cell c along one axis (rim cells hold the outliers: they
   // extend to infinity)
+  // (round 3) ... where the box was trimmed to the bulk of the cloud.  An untrimmed box is the bounding box of all
+  // points: its rim cells end where it ends -- between far clouds every nearest face is a rim cell, and open rims
+  // made every row of them a candidate (2500 candidates per group between disjoint clouds)
+  const bool rim_open = g.pad[2] != 0;
   auto axis_gap = [&](float blo, float bhi, float mn, int c, int gdim) {
-    const float lo = c == 0 ? -inf : mn + (float)c * g.h, hi = c == gdim - 1 ? inf : mn + (float)(c + 1) * g.h;
+    const float lo = (c == 0 && rim_open) ? -inf : mn + (float)c * g.h,
+                hi = (c == gdim - 1 && rim_open) ? inf : mn + (float)(c + 1) * g.h;
     return fmaxf(fmaxf(lo - bhi, blo - hi) - slack, 0.0f);
   };
 #ifdef PP_QUERY_PROBE
-  unsigned long long pp_ngroups = 0, pp_nblind = 0, pp_ncand = 0, pp_nrows = 0;
+  unsigned long long pp_ngroups = 0, pp_nblind = 0, pp_ncand = 0, pp_nrows = 0, pp_nwalk = 0, pp_nlist = 0;
 #endif
   while (open) {
     const int seed = (int)__builtin_ctzll(open);
@@ -781,6 +789,8 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     float ub = member ? (lane == seed ? us : (blind ? fminf(best, via * via) : best)) : 0.0f;
     if (have_smp && member && lane != seed && (!LAB || ql == sl))
       ub = fminf(ub, pp::chamfer_d3(spx, spy, spz, qx, qy, qz) * 1.0001f);
+    float ubm = ub * 1.0001f;  // the member's own bound (kept per lane: the rows are cut member by member below)
+    const unsigned long long members = __ballot(member);
     // The group along x in kSub pieces, each with its own extent and bound (round 3): 64 consecutive queries of the
     // sorted cloud run along x, and a candidate must lie within SOME member's bound -- cutting a cell row by the whole
     // box and the largest bound made far clouds examine the union of the box's ends' needs (6000 candidates per query
@@ -831,8 +841,61 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
 #ifdef PP_QUERY_PROBE
     pp_nrows += (unsigned long long)nrows;
 #endif
+    // The rows' cut along x by the pieces (the hull of the pieces' cuts; a piece whose cut ends before an untrimmed
+    // box begins, or begins behind its end, has nothing in this row -- cell_coord would clamp it into the rim cell)
+    const float box_x0 = g.minx - slack, box_x1 = g.minx + (float)g.gx * g.h + slack;
+    auto piece_cut = [&](int rr, int cy, int cz, float& xlo, float& xhi) {
+      xlo = inf;
+      xhi = -inf;
+      if (rr >= nrows) return;
+      const float gy_ = axis_gap(bly, bhy, g.miny, cy, g.gy), gz_ = axis_gap(blz, bhz, g.minz, cz, g.gz);
+      const float gyz = __builtin_fmaf(gz_, gz_, gy_ * gy_) * 0.9999f;
+      if (!bounded) {
+        xlo = -inf;
+        xhi = inf;
+        return;
+      }
+#pragma unroll
+      for (int k = 0; k < kSub; ++k) {
+        const float remk = su[k] - gyz;
+        const float rxk = sqrtf(fmaxf(remk, 0.0f)) * 1.0001f + slack;
+        const float lo = sbl[k] - rxk, hi = sbh[k] + rxk;
+        const bool ok = remk >= 0.0f && (rim_open || (hi >= box_x0 && lo <= box_x1));
+        xlo = ok ? fminf(xlo, lo) : xlo;
+        xhi = ok ? fmaxf(xhi, hi) : xhi;
+      }
+    };
+    // Pass 1 (round 3): the rows the pieces' cuts leave, packed into a list in the wave's slice behind the candidate
+    // batch (<= 1024 rows, two bytes each).  Between far clouds that is a tenth of the rows of the box around the
+    // group; the member-by-member cut below is then paid for full blocks of rows that have a chance.
+    typedef unsigned short __attribute__((address_space(3))) * lds_u16_ptr;
+    const lds_u16_ptr rowq = (lds_u16_ptr)(lw + kGroupBatch);
+    int nq = 0;
+#ifdef PP_NO_ROWLIST
+    const bool listed = false;
+#else
+    const bool listed = nrows > 64;  // (a box of at most 64 rows is one block anyway: no list)
+#endif
+    if (!listed) nq = nrows;  // PP_NO_ROWLIST: every block of rows
+    for (int r0 = 0; listed && r0 < nrows; r0 += 64) {  // wave-uniform
+      const int rr = r0 + lane;
+      // (rr < 2^11, ny < 2^6: the rounded product is the exact quotient)
+      const int dz = (int)(((float)rr + 0.5f) * inv_ny);
+      float xlo, xhi;
+      piece_cut(rr, y0 + (rr - dz * ny), z0 + dz, xlo, xhi);
+      const bool pass = xlo <= xhi;
+      const unsigned long long bal = __ballot(pass);
+      if (pass) rowq[nq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] =
+          (unsigned short)rr;
+      nq += (int)__builtin_popcountll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#ifdef PP_QUERY_PROBE
+    pp_nlist += (unsigned long long)nq;
+#endif
     bool dirty = false;
-    for (int r0 = 0; r0 < nrows; r0 += 64) {  // wave-uniform
+    for (int r0 = 0; r0 < nq; r0 += 64) {  // wave-uniform
       if (dirty) {  // (wave-uniform) candidates have been examined since the bound was last taken
         // the bound follows what the members have found in the rows examined so far: the rows still to come are cut
         // by the candidates already seen (a member's own best is always a valid bound for it)
@@ -840,36 +903,55 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         U = fminf(U, pp::wave_reduce_dpp<false>(member ? best : 0.0f) * 1.0001f);
 #pragma unroll
         for (int k = 0; k < kSub; ++k) su[k] = fminf(su[k], U);
+        ubm = fminf(ubm, best * 1.0001f);
       }
-      const int rr = r0 + lane;
-      // (rr < 2^11, ny < 2^6: the rounded product is the exact quotient)
+      const int rr = r0 + lane < nq ? (listed ? (int)rowq[r0 + lane] : r0 + lane) : nrows;
       const int dz = (int)(((float)rr + 0.5f) * inv_ny);
       const int cz = z0 + dz, cy = y0 + (rr - dz * ny);
       unsigned cs = 0u, len = 0u;
-      if (rr < nrows) {
-        const float gy_ = axis_gap(bly, bhy, g.miny, cy, g.gy), gz_ = axis_gap(blz, bhz, g.minz, cz, g.gz);
-        const float gyz = __builtin_fmaf(gz_, gz_, gy_ * gy_) * 0.9999f;
-        const float rem = U - gyz;  // budget left along x (+inf if unbounded)
-        if (rem >= 0.0f) {
-          float xlo = inf, xhi = -inf;  // hull of the pieces' cuts
-#pragma unroll
-          for (int k = 0; k < kSub; ++k) {
-            const float remk = su[k] - gyz;
-            if (remk >= 0.0f) {
-              const float rxk = sqrtf(remk) * 1.0001f + slack;
-              xlo = fminf(xlo, sbl[k] - rxk);
-              xhi = fmaxf(xhi, sbh[k] + rxk);
-            }
-          }
-          const bool any = xlo <= xhi;
-          const int x0 = bounded ? cell_coord(xlo, g.minx, g.invh, g.gx) : 0;
-          const int x1 = bounded ? cell_coord(xhi, g.minx, g.invh, g.gx) : g.gx - 1;
+      float xlo, xhi;  // the row's cut along x
+      piece_cut(rr, cy, cz, xlo, xhi);
+      if (__ballot(xlo <= xhi) == 0ull) continue;  // wave-uniform: no row of these within the group's bound
+      auto load_span = [&]() {
+        cs = 0u;
+        len = 0u;
+        if (rr < nrows && xlo <= xhi) {
+          const int x0 = cell_coord(xlo, g.minx, g.invh, g.gx);
+          const int x1 = cell_coord(xhi, g.minx, g.invh, g.gx);
           const int base = pp::cell_linear(0, cy, cz, g.gx, g.gy);
-          if (any || !bounded) {
           cs = cell_start[base + x0];
           len = cell_start[base + x1 + 1] - cs;
-          }
         }
+      };
+      load_span();
+      unsigned box_total = len;  // candidates of the pieces' cuts in these rows
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) box_total += (unsigned)__shfl_xor((int)box_total, off);
+      // (the member-by-member cut costs the wave ~30 instructions per member: it pays when the cut above left more
+      //  candidates than that buys examined by every lane)
+      if (bounded && box_total > 8u * (unsigned)__builtin_popcountll(members) && members != (1ull << seed)) {  // (wave-uniform)
+        // Member by member (round 3): the cut above measures from the BOX (its nearest face) with the LARGEST bound of
+        // a piece -- between far clouds that is the box's diagonal too generous, thousands of candidates where every
+        // member's own ball holds a handful.  A candidate of this row matters only if it lies within SOME member's own
+        // bound: the hull of the members' own cuts, intersected with the cut above.
+        const float ylo = (cy == 0 && rim_open) ? -inf : g.miny + (float)cy * g.h,
+                    yhi = (cy == g.gy - 1 && rim_open) ? inf : g.miny + (float)(cy + 1) * g.h;
+        const float zlo = (cz == 0 && rim_open) ? -inf : g.minz + (float)cz * g.h,
+                    zhi = (cz == g.gz - 1 && rim_open) ? inf : g.minz + (float)(cz + 1) * g.h;
+        float mlo = inf, mhi = -inf;
+        for (unsigned long long mm = members; mm; mm &= mm - 1ull) {
+          const int m = (int)__builtin_ctzll(mm);
+          const float mx = rl(qx, m), my = rl(qy, m), mz = rl(qz, m), mu = rl(ubm, m);
+          const float gy_ = fmaxf(fmaxf(ylo - my, my - yhi) - slack, 0.0f), gz_ = fmaxf(fmaxf(zlo - mz, mz - zhi) - slack, 0.0f);
+          const float remm = mu - __builtin_fmaf(gz_, gz_, gy_ * gy_) * 0.9999f;
+          const float rxm = sqrtf(fmaxf(remm, 0.0f)) * 1.0001f + slack;
+          const bool ok = remm >= 0.0f && (rim_open || (mx + rxm >= box_x0 && mx - rxm <= box_x1));
+          mlo = ok ? fminf(mlo, mx - rxm) : mlo;
+          mhi = ok ? fmaxf(mhi, mx + rxm) : mhi;
+        }
+        xlo = fmaxf(xlo, mlo);
+        xhi = fminf(xhi, mhi);
+        load_span();
       }
       if (__ballot(len != 0u) == 0ull) continue;  // wave-uniform: nothing in these rows
       dirty = true;
@@ -886,6 +968,14 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
       pp_ncand += total;
 #endif
       for (unsigned t0 = 0; t0 < total; t0 += kGroupBatch) {  // wave-uniform
+        if (t0 != 0u) {
+          // the bound follows the batches too (round 3): a crowded cell is a thousand candidates, and after the first
+          // few hundred of them the members know their neighbour to within a little -- the test below then drops most
+          // of the rest before the whole wave looks at them
+          U = fminf(U, pp::wave_reduce_dpp<false>(member ? best : 0.0f) * 1.0001f);
+#pragma unroll
+          for (int k = 0; k < kSub; ++k) su[k] = fminf(su[k], U);
+        }
         // kGroupBatch candidates into the wave's slice of LDS: a lane per candidate, its row found by bisection over
         // the lanes' offsets (the last lane whose first candidate is <= c; empty rows are passed over because the
         // row after them starts at the same offset)
@@ -906,14 +996,51 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
           pt[u] = sorted[at];
           ptl[u] = LAB ? slab[at] : 0.0f;
         }
+        // One lane, one candidate: is it within the bound of the piece of the group it is nearest to?  (The row cuts
+        // keep whole cells; a candidate outside every piece's bound is farther from every member than what that member
+        // already has -- strictly, with room for the rounding of this test -- and is dropped here, for one lane's ~30
+        // operations instead of eight by each of the 64.)  The survivors are packed; the tail up to a multiple of four
+        // is filled with points at infinity.
+        unsigned cnt = 0u;
+#ifdef PP_NO_SIFT
+        const bool sift = false;
+#else
+        const bool sift = bounded && total - t0 > 64u;  // (wave-uniform; a few candidates are cheaper examined than sifted)
+#endif
 #pragma unroll
         for (int u = 0; u < kGroupBatch / 64; ++u) {
-          lw[u * 64 + lane] = pt[u];
-          if (LAB) lwl[u * 64 + lane] = ptl[u];
+          const pp::f4 c4 = pt[u];
+          const float ey = fmaxf(fmaxf(bly - c4.y, c4.y - bhy), 0.0f), ez = fmaxf(fmaxf(blz - c4.z, c4.z - bhz), 0.0f);
+          const float eyz = __builtin_fmaf(ez, ez, ey * ey);
+          bool keep = !sift;
+#pragma unroll
+          for (int k = 0; k < kSub; ++k) {
+            const float ex = fmaxf(fmaxf(sbl[k] - c4.x, c4.x - sbh[k]), 0.0f);
+            keep = keep || (__builtin_fmaf(ex, ex, eyz) * 0.9999f <= su[k]);  // (su < 0: a piece without members)
+          }
+          keep = keep && t0 + (unsigned)(u * 64 + lane) < total;
+          const unsigned long long bal = __ballot(keep);
+          const unsigned at = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          if (keep) {
+            lw[at] = c4;
+            if (LAB) lwl[at] = ptl[u];
+          }
+          cnt += (unsigned)__builtin_popcountll(bal);
+        }
+        const unsigned n = (cnt + 3u) & ~3u;
+        if (lane < (int)(n - cnt)) {
+          pp::f4 far4;
+          far4.x = far4.y = far4.z = inf;
+          far4.w = __int_as_float(0x7fffffff);
+          lw[cnt + lane] = far4;
+          if (LAB) lwl[cnt + lane] = ql;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const unsigned n = min((unsigned)kGroupBatch, (total - t0 + 3u) & ~3u);
+#ifdef PP_QUERY_PROBE
+        pp_nwalk += n;
+#endif
+        if (n == 0u) continue;  // (wave-uniform)
         // Every lane, every candidate (uniform address: LDS broadcast), trimmed for VALU issue like the staged walk of
         // stage A: per group of four only the running minimum (v_min3 + v_min) and the group that last lowered it;
         // the winner's index is recovered from that group afterwards (it is still in the slice).  A distance EQUAL to
@@ -974,7 +1101,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
       }
     }
   }
-#ifdef PP_QUERY_PROBE
+#if defined(PP_QUERY_PROBE) && !defined(PP_QUERY_PROBE_NO_GROUP_STATS)  // (same-address atomics: they distort p7)
   if (lane == 0) {
     atomicAdd(&g_qgroup[0], 1ull);
     atomicAdd(&g_qgroup[1], pp_ngroups);
@@ -982,7 +1109,8 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     atomicAdd(&g_qgroup[3], pp_ncand);
     atomicMax(&g_qgroup[4], pp_ncand);
     atomicAdd(&g_qgroup[5], pp_nrows);
-    atomicMax(&g_qgroup[6], pp_ngroups);
+    atomicAdd(&g_qgroup[6], pp_nlist);
+    atomicAdd(&g_qgroup[7], pp_nwalk);
   }
 #endif
   Found o;
@@ -1474,6 +1602,16 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
   // a cube around them holds thousands of points.)
   bool pend = !resolved && valid;
   bool open_lane = false;
+  // A query more than three cells outside the grid's box has nothing to find in the cubes around the rim cell it is
+  // clamped to (whatever they hold is too far to settle it): straight to the group search (round 3: between disjoint
+  // clouds the cubes were 47 us of a wave's life).  A choice of route only: the group search is complete.
+  const float out_x = fmaxf(g.minx - qx, qx - (g.minx + (float)g.gx * g.h)), out_y = fmaxf(g.miny - qy, qy - (g.miny + (float)g.gy * g.h)),
+              out_z = fmaxf(g.minz - qz, qz - (g.minz + (float)g.gz * g.h));
+  const bool far_out = fmaxf(out_x, fmaxf(out_y, out_z)) > 3.0f * g.h;
+  if (pend && far_out && !deferred) {
+    open_lane = true;
+    pend = false;
+  }
   if (__builtin_popcountll(__ballot(pend && !deferred)) >= kLaneStageMin) {
     const bool mine = pend && !deferred;
     Found f = lane_cube_search<LAB>(g, cell_start, sorted, slab, qx, qy, qz, ql, 1, mine, best, bidx);
@@ -1494,7 +1632,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
         oi[j] = bidx;
         pend = false;
       }
-      open_lane = pend && mine2 && f.aux == 0.0f;  // radius 2 examined in full and not enough
+      open_lane = open_lane || (pend && mine2 && f.aux == 0.0f);  // radius 2 examined in full and not enough
       pend = pend && !open_lane;
     }
   }
@@ -1591,8 +1729,12 @@ __global__ __launch_bounds__(256, LAB ? (CAPW > 384 ? 3 : 4) : (CAPW > 384 ? 4 :
 // waves, 64 entries each, in the order of the sorted query cloud (neighbours stay together), piece after piece.
 // An entry carries bit 30 when stage A has been run for it (and failed): a wave of such entries skips stage A.
 constexpr int kPendTried = 1 << 30;
+#ifndef PP_LIST_WAVES
+#define PP_LIST_WAVES 6  // waves per SIMD the kernel is compiled for (80 registers; 4 changes nothing: the scratch it
+                         // reports is the call frames of the rare stages, not spills)
+#endif
 template <int CAPW>
-__global__ __launch_bounds__(256, 6) void grid_query_list_kernel(const float* __restrict__ xyz1,
+__global__ __launch_bounds__(256, PP_LIST_WAVES) void grid_query_list_kernel(const float* __restrict__ xyz1,
                                                                   const float* __restrict__ xyz2,
                                                                   float* __restrict__ dist1, int* __restrict__ idx1,
                                                                   float* __restrict__ dist2, int* __restrict__ idx2,
@@ -1608,6 +1750,10 @@ __global__ __launch_bounds__(256, 6) void grid_query_list_kernel(const float* __
   // Speed only: whatever the placement, the results are the same.
   const int gw = pp::xcd_virtual_block((int)blockIdx.x, (int)(gridDim.x >> 3)) * 4 + wave;  // (the grid is a multiple of 8)
   const int set = gw / waves_per_set, wi = gw - set * waves_per_set;
+  // (round 3, tried: a set's waves from its two ends inwards -- the rim waves are the expensive ones -- changed nothing;
+  //  the XCD's sets interleaved as well spread the expensive waves over the launch -- gaussian 0.265 -> 0.243 ms, blobs8
+  //  0.83 -> 0.78 -- but cost the clouds whose neighbouring waves share cells their cache hits: two_scales 0.316 -> 0.335,
+  //  shapenet_like 0.21 -> 0.23.  Plain order.)
   if (set >= 2 * B) return;
   const int b = set >> 1, dir = set & 1;
   const int nq = dir ? M : N;

@@ -47,6 +47,7 @@ struct GridSet {  // one per (batch, direction); written by the build kernel
   int useless;             // 1: degenerate data (non-finite / zero extent): no grid at all
   int pad[3];              // pad[0]: free for the caller (ball_query / three_nn: "the grid path serves this set");
                            // pad[1]: 1 = the set's chunk table (tile_z) has been written
+                           // pad[2]: 1 = the box was trimmed (outliers): points lie outside it, in the rim cells
   int crowd[kBuildSlabs];  // crowd[s] = 1: slab s found a cell too crowded to be of use; 2: it refined its crowded
                            // cells into sub-grids (REFINE builds: see SubGrid)
 };
@@ -519,6 +520,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   // and every bound is stated in terms of the (monotone) cell coordinate -- so when the box reaches
   // beyond 6 sigma of the mean on some side, it is replaced by the box of the points within 4 sigma on
   // every axis.  Uniform over the workgroup; clouds without outliers skip the second pass.
+  bool trimmed = false;  // the box does not hold every point (the outliers sit in the rim cells)
   if (!any_bad) {
     const float inv_n = 1.0f / (float)nr;
     const float mean[3] = {sm[0] * inv_n, sm[1] * inv_n, sm[2] * inv_n};
@@ -555,6 +557,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       for (int e = 0; e < 6; ++e) w[e] = wave_reduce_dpp<false>(s_box[(t & 15) * 16 + e]);
       if (w[3] > -w[0] || w[4] > -w[1] || w[5] > -w[2]) {  // the trimmed set has an extent: use its box
         mnx = -w[0]; mny = -w[1]; mnz = -w[2]; mxx = w[3]; mxy = w[4]; mxz = w[5];
+        trimmed = true;
       }
       if (nchunks > 1) load_chunk(0);  // (the passes below reload their chunks themselves)
     }
@@ -825,7 +828,8 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       gs->minx = mnx; gs->miny = mny; gs->minz = mnz; gs->h = h; gs->invh = invh;
       gs->gx = gx; gs->gy = gy; gs->gz = gz;
       gs->useless = degenerate ? 1 : 0;
-      for (int i = 0; i < 3; ++i) gs->pad[i] = 0;
+      for (int i = 0; i < 2; ++i) gs->pad[i] = 0;
+      gs->pad[2] = trimmed ? 1 : 0;
       if (REFINE && track_z && place) gs->pad[1] = 1;
       for (int i = nslab; i < kBuildSlabs; ++i) gs->crowd[i] = 0;
     }

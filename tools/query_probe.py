@@ -47,7 +47,7 @@ for mode in [int(a) for a in sys.argv[1:]] or [0]:
     gs = np.zeros(8, np.uint64)
     rdg = L.pp_debug_read_query_group_stats; rdg.argtypes = [ctypes.c_void_p, ctypes.c_int]; rdg.restype = ctypes.c_int
     assert rdg(gs.ctypes.data, 1) == 0
-    print("   group search (all launches so far): calls %d groups %d blind %d candidates %d (max per call %d) rows %d, most groups in a call %d" % tuple(int(x) for x in gs[:7]))
+    print("   group search (all launches so far): calls %d groups %d blind %d candidates %d (max per call %d) rows %d, rows listed %d, candidates walked %d" % tuple(int(x) for x in gs[:8]))
     tot = wv.sum(1)
     print("   wave total: mean %.1f  p99 %.1f  max %.1f us; waves over 4x the mean: %d" % (tot.mean(), np.percentile(tot, 99), tot.max(), int((tot > 4 * tot.mean()).sum())))
     print("mode %d: fwd %.1f us" % (mode, a.elapsed_time(b) / 20 * 1e3))

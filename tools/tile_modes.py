@@ -3,6 +3,11 @@
 compared bit for bit with the every-pair kernel.  python tools/tile_modes.py [kinds...]"""
 import ctypes, sys, numpy as np, torch
 sys.path.insert(0, ".")
+import os
+if os.environ.get("PP_LIB"):   # a variant of the library (tools/build_variant_lib.sh)
+    from pytorch_points_amd import _build
+    _build.LIB = os.path.abspath(os.environ["PP_LIB"])
+    _build.is_stale = lambda: False
 from pytorch_points_amd import _lib, synthetic as S
 from pytorch_points_amd._ext import losses
 dev = torch.device("cuda:0")
