@@ -544,15 +544,14 @@ __global__ __launch_bounds__(1024) void nmdist_bwd_csr_kernel(
     }
     const unsigned e0 = s_start[kk], e1 = s_start[kk + 1];
     if (ORDERED) {  // ascending source index (the cursors filled the list in arrival order)
-      for (unsigned i = e0 + 1; i < e1; ++i) {
-        const unsigned v = s_list[i];
-        unsigned j = i;
-        while (j > e0 && s_list[j - 1] > v) {
-          s_list[j] = s_list[j - 1];
-          --j;
-        }
-        s_list[j] = v;
-      }
+      unsigned* lst = s_list + e0;
+      pp::lane_sort(
+          e1 - e0, [&](unsigned i) { return lst[i]; },
+          [&](unsigned i, unsigned j) {
+            const unsigned v = lst[i];
+            lst[i] = lst[j];
+            lst[j] = v;
+          });
     }
     // cloud 1's rows receive their own term first (first launch), cloud 2's last (second launch); a row
     // without an own term (labeled Chamfer, idx < 0) receives none at all, as in the reference (:175)

@@ -75,6 +75,36 @@ __device__ __forceinline__ float dist3(float ax, float ay, float az, float bx, f
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
 }
 
+// In-place ascending sort of a[0..n) by key(a[i]) by ONE lane: insertion sort for the short lists the callers
+// normally see (a handful of entries: its cost is the number of inversions), heapsort beyond -- O(n log n) whatever
+// the arrival order, so that a degenerate input (thousands of sources sharing one destination) costs milliseconds,
+// not the 10^8 steps of an insertion sort.  swap(i, j) exchanges entries i and j (and whatever travels
+// with them); keys are distinct in both callers (source positions), so the order is total.
+template <typename KEY, typename SWAP>
+__device__ __forceinline__ void lane_sort(unsigned n, KEY key, SWAP swap) {
+  if (n < 2) return;
+  if (n <= 24) {
+    for (unsigned i = 1; i < n; ++i)
+      for (unsigned j = i; j > 0 && key(j - 1) > key(j); --j) swap(j - 1, j);
+    return;
+  }
+  auto sift = [&](unsigned root, unsigned end) {  // max-heap on [0, end)
+    for (;;) {
+      unsigned child = 2 * root + 1;
+      if (child >= end) return;
+      if (child + 1 < end && key(child + 1) > key(child)) ++child;
+      if (!(key(child) > key(root))) return;
+      swap(root, child);
+      root = child;
+    }
+  };
+  for (unsigned i = n / 2; i-- > 0;) sift(i, n);
+  for (unsigned end = n - 1; end > 0; --end) {
+    swap(0, end);
+    sift(0, end);
+  }
+}
+
 // v_min3_f32: one VALU op for two candidates.  Operands are results of fma/mul chains (never
 // signalling NaNs), so no canonicalisation is needed; spelled in asm so that the compiler cannot
 // split it back into two v_min_f32 or insert v_max canonicalisations.

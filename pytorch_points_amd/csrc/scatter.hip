@@ -100,24 +100,27 @@ __global__ __launch_bounds__(kSsaThreads) void ssa_build_kernel(const int* __res
   }
   if (!ordered) return;
   // ORDERED: the cursors handed the positions inside a (chunk, destination) group out in arrival order;
-  // the owner of the destination sorts the group by source position (insertion sort: the groups are short)
+  // the owner of the destination sorts the group by source position (pp::lane_sort: insertion sort for the usual
+  // short groups, heapsort for long ones)
   __threadfence_block();
   __syncthreads();
   unsigned g0 = first;
   for (int c = c0; c < c1; ++c) {
     const unsigned g1 = s_cnt[sk(c)];  // the cursor now stands at the group's end
-    for (unsigned i = g0 + 1; i < g1; ++i) {
-      const unsigned e = entries[i];
-      const float w = wout ? wout[i] : 0.0f;
-      unsigned j = i;
-      while (j > g0 && (entries[j - 1] & 0xffffu) > (e & 0xffffu)) {
-        entries[j] = entries[j - 1];
-        if (wout) wout[j] = wout[j - 1];
-        --j;
-      }
-      entries[j] = e;
-      if (wout) wout[j] = w;
-    }
+    unsigned* grp = entries + g0;
+    float* gw = wout ? wout + g0 : nullptr;
+    pp::lane_sort(
+        g1 - g0, [&](unsigned i) { return grp[i] & 0xffffu; },
+        [&](unsigned i, unsigned j) {
+          const unsigned e = grp[i];
+          grp[i] = grp[j];
+          grp[j] = e;
+          if (gw) {
+            const float w = gw[i];
+            gw[i] = gw[j];
+            gw[j] = w;
+          }
+        });
     g0 = g1;
   }
 }

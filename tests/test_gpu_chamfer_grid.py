@@ -110,7 +110,7 @@ def test_grid_search_full_size_c2(cuda):
         assert np.array_equal(u[:2], v)
 
 
-@pytest.mark.parametrize("kind", ["gaussian", "blobs8", "two_scales", "shapenet_like"])
+@pytest.mark.parametrize("kind", ["gaussian", "blobs8", "two_scales", "shapenet_like", "disjoint"])
 def test_grid_search_full_size_other_distributions(cuda, kind):
     """The distributions of bench.py's other_distributions_fwd_ms at config-2 cloud size: grid == brute force,
     and two runs of the grid path agree (no order dependence in the in-kernel fallbacks)."""
@@ -133,6 +133,9 @@ def test_grid_search_large_clustered_clouds(cuda, kind, n, m):
     b = _run(cuda, x1, x2, 1)
     for u, v in zip(a, b):
         assert np.array_equal(u, v)
+    e = oracle.chamfer_forward(x1, x2)          # (the oracle, not only the every-pair kernel)
+    for u, v, what in zip(a, e, ["dist1", "idx1", "dist2", "idx2"]):
+        assert np.array_equal(u, v), "%s: %s differs at %d places" % (kind, what, int((u != v).sum()))
 
 
 def test_grid_workspace_reused_across_shapes(cuda):
@@ -334,3 +337,41 @@ def test_stage_a_serves_an_evenly_sampled_surface(cuda):
     assert fn(ws.data_ptr(), b, n, n, tot) == 0
     left = sum(tot) / (2.0 * b * n)
     assert left < 0.02, left
+
+
+def _far_cases():
+    """clouds far from each other (round 3: the group search cuts rows by the untrimmed box's own faces, member by
+    member, and sifts candidates): boxes that end exactly at their extreme points, trimmed boxes whose outliers sit
+    next to the far queries, clouds far from the origin against their extent, flat and degenerate extents"""
+    n = 6000
+    u = lambda seed, shape: _u(seed, shape)
+    c = {}
+    for k, off in enumerate([(5, 0, 0), (0, -7, 0), (3, 3, 3), (-2, 4, -9), (0.5, 0, 0), (1.02, 0, 0)]):
+        c["offset_%s" % "_".join(str(v) for v in off)] = (u(500 + k, (2, n, 3)), u(520 + k, (2, n, 3)) + np.array(off, np.float32))
+    # a trimmed box: 12 outliers of the reference cloud sit right beside the far query cloud
+    ref = S.normal(540, (1, n, 3)).astype(np.float32) * np.float32(0.05)
+    ref[0, :12] = u(541, (12, 3)) * np.float32(0.1) + np.float32(9.0)
+    c["outliers_next_to_the_queries"] = (u(542, (1, n, 3)) * np.float32(0.2) + np.float32(9.0), ref)
+    c["outliers_on_the_far_side"] = (u(543, (1, n, 3)) * np.float32(0.2) - np.float32(9.0), ref)
+    # far from the origin against the extent (cell faces are rounded at the coordinates' magnitude)
+    c["both_far_from_origin"] = (u(544, (1, n, 3)) + np.float32(2000.0), u(545, (1, n, 3)) + np.float32(2003.0))
+    flat = u(546, (1, n, 3)).copy()
+    flat[..., 2] = 0.25
+    c["plane_vs_far_plane"] = (flat, flat[:, ::-1].copy() + np.array([0, 0, 4], np.float32))
+    line = np.zeros((1, n, 3), np.float32)
+    line[..., 0] = u(547, (1, n))
+    c["line_vs_far_cloud"] = (line, u(548, (1, n, 3)) + np.array([2, 2, 2], np.float32))
+    c["small_far_big"] = (u(549, (1, 700, 3)) * np.float32(0.01), u(550, (1, n, 3)) * np.float32(30.0) + np.float32(40.0))
+    return c
+
+
+FAR = _far_cases()
+
+
+@pytest.mark.parametrize("name", sorted(FAR))
+def test_far_clouds_equal_oracle(cuda, name):
+    x1, x2 = [np.ascontiguousarray(a) for a in FAR[name]]
+    exp = oracle.chamfer_forward(x1, x2)
+    got = _run(cuda, x1, x2, 2)
+    for g, e, what in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
+        assert np.array_equal(g, e), "%s: %s differs at %d places" % (name, what, int((g != e).sum()))

@@ -198,3 +198,46 @@ def test_autograd_wrappers_route_to_the_ordered_forms(cuda):
             loss.backward()
             outs.append(f.grad)
     assert torch.equal(outs[0], outs[1])
+
+
+def test_ordered_backwards_with_one_destination_for_everything(cuda):
+    """every point of a cloud shares ONE nearest neighbour (a list of ~16000 entries), and a gather whose
+    indices are all equal: the ordered forms sort such lists in O(n log n) (heapsort beyond 24 entries) -- bit-exact
+    against the oracle, and within a runtime bound an insertion sort (10^8 single-lane steps) would miss"""
+    import time
+    from pytorch_points_amd.network import model_loss as ml
+    from pytorch_points_amd._ext import sampling
+    n, m = 16000, 4096
+    x1 = (S.unit_sphere(90, 1, n) * np.float32(1e-3) + np.float32(5.0)).astype(np.float32)   # a tiny far cluster
+    x2 = S.unit_sphere(91, 1, m)
+    x2[0, 77] = np.float32(4.9)                     # ... whose every point is nearest to reference 77
+    g1, g2 = S.normal(92, (1, n)), S.normal(93, (1, m))
+    fwd = oracle.chamfer_forward(x1, x2)
+    assert (fwd[1] == 77).all()
+    e1, e2 = oracle.chamfer_backward(x1, x2, g1, g2, fwd[1], fwd[3])
+    with deterministic():
+        _chamfer_grads(cuda, x1, x2, g1, g2, ml.nndistance)                  # (warm-up: workspaces, first launch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        a1, a2 = _chamfer_grads(cuda, x1, x2, g1, g2, ml.nndistance)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert np.array_equal(a1.cpu().numpy(), e1) and np.array_equal(a2.cpu().numpy(), e2)
+    assert dt < 0.25, "ordered Chamfer backward with one 16000-entry list took %.3f s" % dt
+    # gather backward: 60000 sources, one destination
+    b, c, nn, mm = 1, 3, 5000, 60000
+    gi = np.full((b, mm), 1234, np.int32)
+    go = S.normal(94, (b, c, mm))
+    gp = torch.zeros(b, c, nn, device=cuda)
+    with deterministic():
+        sampling.gather_backward(b, c, nn, mm, torch.from_numpy(go).to(cuda), torch.from_numpy(gi).to(cuda), gp)
+        torch.cuda.synchronize()
+        gp = torch.zeros(b, c, nn, device=cuda)          # (the operator accumulates into its output, as the reference's)
+        tgo, tgi = torch.from_numpy(go).to(cuda), torch.from_numpy(gi).to(cuda)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sampling.gather_backward(b, c, nn, mm, tgo, tgi, gp)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert np.array_equal(gp.cpu().numpy(), oracle.gather_backward(go, gi, nn))
+    assert dt < 0.25, "ordered gather backward with one 60000-entry group took %.3f s" % dt
