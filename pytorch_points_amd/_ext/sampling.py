@@ -10,8 +10,40 @@ import torch
 
 from .. import _lib
 
-# device index -> pinned int32[1]: host mirror of the FPS workspace's sticky status word (see furthest_sampling)
+# (device index, raw stream) -> [pinned int32[1], event]: host mirror of the sticky status word of THAT stream's FPS
+# workspace (one workspace per device and stream: _lib.workspace), and an event recorded behind the copy into it
 _fps_status_mirror = {}
+_FPS_TIMEOUT = ("pytorch_points_amd: an earlier furthest_sampling call on %s timed out waiting for its workgroups to be "
+                "co-resident (another stream kept the GPU busy); its indices are zeros from the failing step on.  "
+                "Re-run it, or serialise it with the other stream.")
+
+
+def _fps_clear(dev, key, entry):
+    """forget a reported timeout: the mirror, and the status word of the workspace it mirrors (on that workspace's
+    own stream: the current one -- the key is (device, current stream))"""
+    entry[0].zero_()
+    ws = _lib._WS.get((dev.index, key[1], "fps"))   # (keyed as _lib.workspace keys it)
+    if ws is not None:
+        ws[:4].zero_()
+
+
+def furthest_sampling_check(device=None):
+    """Explicit check for callers that want to know at the end of a step: waits for the last
+    furthest_sampling call issued on the CURRENT stream of ``device`` (an event behind its status copy -- not a
+    device synchronisation) and raises RuntimeError if one of that stream's calls timed out since the last report.
+    Without it a timeout is reported by the next furthest_sampling call on the same device and stream; a call that
+    was captured into a graph (torch.cuda.graph) never reports one: there is no host code in a replay."""
+    dev = torch.device("cuda", _lib.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else _lib.current_device()
+    key = (idx, _lib.raw_stream(dev))
+    entry = _fps_status_mirror.get(key)
+    if entry is None:
+        return
+    entry[1].synchronize()
+    if int(entry[0][0]) != 0:
+        with torch.cuda.device(idx):
+            _fps_clear(dev, key, entry)
+        raise RuntimeError(_FPS_TIMEOUT % dev)
 
 
 def _workspace(device, nbytes):
@@ -54,18 +86,17 @@ def furthest_sampling(m, seedIdx, input, temp, idx):
     nbytes = int(L.pp_furthest_sampling_workspace_bytes(b, n, int(m)))
     ws = _workspace(dev, nbytes)
     capturing = _lib.is_capturing()
-    key = dev.index if dev.index is not None else _lib.current_device()
-    mirror = _fps_status_mirror.get(key)
-    if mirror is not None and not capturing and int(mirror[0]) != 0:
-        # The status word of an EARLIER call, copied to pinned host memory behind that call (no synchronisation
-        # here): a bounded wait between the workgroups of the cluster kernel timed out, e.g. because a kernel of
-        # another stream held the CUs its members were waiting for.  That call left zeros in its indices.
-        mirror.zero_()
-        for w in _lib.cached_workspaces("fps", dev):
-            w[:4].zero_()
-        raise RuntimeError("pytorch_points_amd: an earlier furthest_sampling call on %s timed out waiting for "
-                           "its workgroups to be co-resident (another stream kept the GPU busy); its indices "
-                           "are zeros from the failing step on.  Re-run it, or serialise it with the other stream." % dev)
+    didx = dev.index if dev.index is not None else _lib.current_device()
+    key = (didx, _lib.raw_stream(dev))
+    entry = _fps_status_mirror.get(key)
+    if entry is not None and not capturing and int(entry[0][0]) != 0:
+        # The status word of an EARLIER call on this device and stream, copied to pinned host memory behind that call
+        # (no synchronisation here): a bounded wait between the workgroups of the cluster kernel timed out, e.g.
+        # because a kernel of another stream held the CUs its members were waiting for.  That call left zeros in its
+        # indices.  (furthest_sampling_check() reports it without waiting for the next call.)
+        with torch.cuda.device(didx):
+            _fps_clear(dev, key, entry)
+        raise RuntimeError(_FPS_TIMEOUT % dev)
     if ws is not None and not getattr(ws, "_pp_status_zeroed", False):
         ws[:256].zero_()             # the sticky status word in front of the scratch (include/pp_hip.h)
         ws._pp_status_zeroed = True
@@ -73,10 +104,17 @@ def furthest_sampling(m, seedIdx, input, temp, idx):
         _lib.check(L.pp_furthest_sampling_f32(
             _lib.ptr(input), _lib.ptr(temp), _lib.ptr(idx), b, n, int(m), int(seedIdx),
             _lib.ptr(ws) if ws is not None else None, nbytes, stream), "furthest_sampling")
-    if ws is not None and not capturing:
-        if mirror is None:
-            mirror = _fps_status_mirror[key] = torch.zeros(1, dtype=torch.int32).pin_memory()
-        mirror.copy_(ws[:4].view(torch.int32), non_blocking=True)   # looked at by the NEXT call, never waited for
+        if ws is not None and not capturing:
+            if entry is None:
+                entry = _fps_status_mirror[key] = [torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event()]
+                while len(_fps_status_mirror) > 64:      # (streams come and go: oldest first)
+                    _fps_status_mirror.pop(next(iter(_fps_status_mirror)))
+            # the word is sticky on the device (set by a timed-out wait, cleared only by _fps_clear), so the copy of a
+            # later clean call on the same workspace still carries an unreported 1; other streams have other
+            # workspaces and other mirrors.  Looked at by the NEXT call or by furthest_sampling_check, never waited
+            # for here.
+            entry[0].copy_(ws[:4].view(torch.int32), non_blocking=True)
+            entry[1].record()
     return idx
 
 

@@ -131,6 +131,41 @@ def test_fps_cluster_beside_other_work(cuda):
     assert np.array_equal(ref[:1].cpu().numpy(), e_idx)
 
 
+def test_fps_timeout_is_reported_per_stream(cuda):
+    """a timed-out cluster wait sets the sticky status word of THAT stream's workspace; it is reported by
+    furthest_sampling_check() or by the next call on the same device and stream -- not by, nor wiped out by, a clean
+    call on another stream.  (The timeout itself is faked by setting the word the kernel would set.)"""
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd._ext import sampling
+    from pytorch_points_amd.network.geo_operations import furthest_point_sample
+    x = _t(S.unit_sphere(15, 16, 8192), cuda)                  # a shape served by the cluster kernel (has a workspace)
+    ref, _ = furthest_point_sample(x, 64, NCHW=False)
+    sampling.furthest_sampling_check(cuda)                     # clean so far
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        other, _ = furthest_point_sample(x, 64, NCHW=False)    # the side stream's own workspace and mirror
+        side.synchronize()
+        sampling.furthest_sampling_check(cuda)
+    ws = _lib._WS[(cuda.index, _lib.raw_stream(cuda), "fps")]
+    ws[:4].view(torch.int32).fill_(1)                          # "a wait of the last call on the main stream timed out"
+    again, _ = furthest_point_sample(x, 64, NCHW=False)        # copies the word behind itself
+    with torch.cuda.stream(side):
+        furthest_point_sample(x, 64, NCHW=False)               # a clean call elsewhere neither reports nor clears it
+        sampling.furthest_sampling_check(cuda)
+    with pytest.raises(RuntimeError, match="timed out"):
+        sampling.furthest_sampling_check(cuda)
+    sampling.furthest_sampling_check(cuda)                     # reported once, then cleared (mirror and device word)
+    assert sampling.furthest_sampling_status(cuda) == 0
+    ws[:4].view(torch.int32).fill_(1)
+    furthest_point_sample(x, 64, NCHW=False)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="timed out"):       # ... or by the next call on the same stream
+        furthest_point_sample(x, 64, NCHW=False)
+    idx, _ = furthest_point_sample(x, 64, NCHW=False)
+    assert torch.equal(idx, ref) and torch.equal(other, ref) and torch.equal(again, ref)
+    assert sampling.furthest_sampling_status(cuda) == 0
+
+
 def test_gather_matches_torch_and_backward(cuda):
     from pytorch_points_amd.network.operations import gather_points
     b, c, n, m = 3, 37, 500, 123
