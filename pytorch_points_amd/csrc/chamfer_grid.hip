@@ -32,6 +32,11 @@
 
 #include "grid_common.h"
 
+// waves per SIMD the unlabeled search kernels are compiled for (tools/build_variant_lib.sh -DPP_WAVE_WAVES=4 ...)
+#ifndef PP_WAVE_WAVES
+#define PP_WAVE_WAVES 6
+#endif
+
 #ifdef PP_QUERY_PROBE
 // diagnostic build only (tools/query_probe.py): 100 MHz clock at the phase boundaries of a few workgroups, and
 // what every wave spent in each phase (10 ns units; the first kQWaves waves of the launch)
@@ -545,7 +550,7 @@ struct OpenMask {
   unsigned lo, hi;      // queries the cube of radius 2 left open
   unsigned llo, lhi;    // serve_pending: queries whose scans are long (for serve_long_scans)
 };
-template <bool LAB>
+template <bool LAB, int W>
 __device__ __attribute__((noinline)) OpenMask serve_long_scans(const GridSet* __restrict__ gp,
                                                                const unsigned* __restrict__ cell_start,
                                                                const pp::f4* __restrict__ sorted,
@@ -588,7 +593,7 @@ __device__ __attribute__((noinline)) OpenMask serve_long_scans(const GridSet* __
 // any -- one in five at config 2 -- so the cubes' code and registers are not the search kernel's).  Short scans are
 // done here; a query whose cubes run through crowded cells is reported back for serve_long_scans.  Writes the results
 // of the queries it settles; returns the masks of those the cube of radius 2 left open and of the long scans.
-template <bool LAB>
+template <bool LAB, int W>
 __device__ __attribute__((noinline)) OpenMask serve_pending(const GridSet* __restrict__ gp,
                                                             const unsigned* __restrict__ cell_start,
                                                             const pp::f4* __restrict__ sorted,
@@ -633,7 +638,7 @@ __device__ __attribute__((noinline)) OpenMask serve_pending(const GridSet* __res
   return o;
 }
 
-template <bool LAB>
+template <bool LAB, int W>
 __device__ __attribute__((noinline)) Found refined_block_search(
     const GridSet g, const unsigned* __restrict__ cell_start, const pp::f4* __restrict__ sorted,
     const float* __restrict__ slab, const unsigned* __restrict__ sub_start, const pp::SubGrid* __restrict__ sub_desc,
@@ -673,7 +678,7 @@ __device__ __attribute__((noinline)) Found refined_block_search(
 // harmless, so no lane is masked.  Finite queries only.  Labeled searches: a candidate counts for a query of the
 // same label only, so a seed without a candidate samples points of its own label and takes along queries of its
 // label only (a label nobody carries ends in one scan of the whole cloud, which settles every open query).
-template <bool LAB>
+template <bool LAB, int W>
 __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, const unsigned* __restrict__ cell_start,
                                                              const pp::f4* __restrict__ sorted,
                                                              const float* __restrict__ slab, float qx, float qy,
@@ -1138,7 +1143,7 @@ __device__ __forceinline__ RowSpan cube_row(int r, int nrows, int side, int rho,
   return o;
 }
 
-template <bool LAB>
+template <bool LAB, int W>
 __device__ __attribute__((noinline)) Found lane_cube_search(const GridSet g, const unsigned* __restrict__ cell_start,
                                                             const pp::f4* __restrict__ sorted,
                                                             const float* __restrict__ slab, float qx, float qy, float qz,
@@ -1231,7 +1236,10 @@ __device__ __forceinline__ float min2(float a, float b) {
 #else
 #define PP_SPHASE(n)
 #endif
-template <bool LAB, int CAPW>
+// W: the waves per SIMD the calling kernel is compiled for -- it only makes the out-of-line stages below separate
+// functions per kernel, each compiled for its caller's register budget (the list kernel runs at 5: 96 registers, no
+// spills in the group search; gaussian -8 %, blobs8 -6 %, disjoint -6 % against 6 waves and 80 registers)
+template <bool LAB, int CAPW, int W>
 __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                float* __restrict__ dist1, int* __restrict__ idx1,
                                                float* __restrict__ dist2, int* __restrict__ idx2,
@@ -1583,7 +1591,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
   if (refined_set && __any(deferred)) {  // wave-uniform
     // ---- second level: the block's cells one by one; a crowded cell through its own grid ---------------------
     if (deferred) {
-      const Found f = refined_block_search<LAB>(g, cell_start, sorted, slab, sub_start, sub_desc, qx, qy, qz, ql, cx2, cy2,
+      const Found f = refined_block_search<LAB, W>(g, cell_start, sorted, slab, sub_start, sub_desc, qx, qy, qz, ql, cx2, cy2,
                                                 cz2, sx2, sy2, sz2, reach);
       best = f.best;
       bidx = f.bidx;
@@ -1614,7 +1622,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
   }
   if (__builtin_popcountll(__ballot(pend && !deferred)) >= kLaneStageMin) {
     const bool mine = pend && !deferred;
-    Found f = lane_cube_search<LAB>(g, cell_start, sorted, slab, qx, qy, qz, ql, 1, mine, best, bidx);
+    Found f = lane_cube_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, 1, mine, best, bidx);
     best = f.best;
     bidx = f.bidx;
     if (f.aux == 1.0f) {
@@ -1624,7 +1632,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     }
     const bool mine2 = pend && !deferred && f.aux != 2.0f;
     if (__builtin_popcountll(__ballot(mine2)) >= kLaneStageMin) {
-      f = lane_cube_search<LAB>(g, cell_start, sorted, slab, qx, qy, qz, ql, 2, mine2, best, bidx);
+      f = lane_cube_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, 2, mine2, best, bidx);
       best = f.best;
       bidx = f.bidx;
       if (f.aux == 1.0f) {
@@ -1648,7 +1656,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
   }
   unsigned long long longscan = 0ull;
   if (pending) {  // wave-uniform
-    const OpenMask om = serve_pending<LAB>(reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted, slab, od,
+    const OpenMask om = serve_pending<LAB, W>(reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted, slab, od,
                                            oi, qx, qy, qz, ql, j, (unsigned)pending, (unsigned)(pending >> 32));
     open |= ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.hi) << 32) |
             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.lo);
@@ -1656,7 +1664,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)om.llo);
   }
   if (longscan) {  // wave-uniform: cubes through crowded cells (never on an evenly sampled surface), or the list kernel's
-    const OpenMask ol = serve_long_scans<LAB>(reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted,
+    const OpenMask ol = serve_long_scans<LAB, W>(reinterpret_cast<const GridSet*>(ws + L.sets) + set, cell_start, sorted,
                                               slab, od, oi, qx, qy, qz, ql, j, (unsigned)longscan,
                                               (unsigned)(longscan >> 32));
     open |= ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ol.hi) << 32) |
@@ -1667,7 +1675,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     const bool finite = __builtin_isfinite(qx) && __builtin_isfinite(qy) && __builtin_isfinite(qz);
     const unsigned long long todo = open & __ballot(finite);
     if (todo) {
-      const Found f = wave_group_search<LAB>(g, cell_start, sorted, slab, qx, qy, qz, ql, best, bidx, (unsigned)todo,
+      const Found f = wave_group_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, best, bidx, (unsigned)todo,
                                              (unsigned)(todo >> 32), s_pts_w,
                                              s_lab_w);
       if ((todo >> lane) & 1ull) {
@@ -1695,7 +1703,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
 // The whole search in one kernel (labeled searches; unlabeled ones when there is no stage-A kernel): 256-thread
 // workgroups of four independent waves, workgroup `tile` of (b, dir) takes queries [256 tile, 256 tile + 256).
 template <bool LAB, int CAPW>
-__global__ __launch_bounds__(256, LAB ? (CAPW > 384 ? 3 : 4) : (CAPW > 384 ? 4 : 6)) void grid_query_wave_kernel(
+__global__ __launch_bounds__(256, LAB ? (CAPW > 384 ? 3 : 4) : (CAPW > 384 ? 4 : PP_WAVE_WAVES)) void grid_query_wave_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1, int* __restrict__ idx1,
     float* __restrict__ dist2, int* __restrict__ idx2, unsigned char* __restrict__ ws, int B, int N, int M, int tiles1,
     int tiles2, int total, int per_xcd, const float* __restrict__ label1, const float* __restrict__ label2) {
@@ -1715,7 +1723,7 @@ __global__ __launch_bounds__(256, LAB ? (CAPW > 384 ? 3 : 4) : (CAPW > 384 ? 4 :
   __shared__ pp::f4 s_pts[4][CAPW + 4];
   __shared__ float s_lab[4][LAB ? CAPW + 4 : 1];
   const int wave = pp::wave_id_uniform();
-  search_queries<LAB, CAPW>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, label1, label2, L, b, dir, jj, valid, false,
+  search_queries<LAB, CAPW, (LAB ? (CAPW > 384 ? 3 : 4) : (CAPW > 384 ? 4 : PP_WAVE_WAVES))>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, label1, label2, L, b, dir, jj, valid, false,
                             (lds_f4_wptr)(&s_pts[wave][0]), (lds_f_wptr)(&s_lab[wave][0]));
 }
 
@@ -1730,8 +1738,7 @@ __global__ __launch_bounds__(256, LAB ? (CAPW > 384 ? 3 : 4) : (CAPW > 384 ? 4 :
 // An entry carries bit 30 when stage A has been run for it (and failed): a wave of such entries skips stage A.
 constexpr int kPendTried = 1 << 30;
 #ifndef PP_LIST_WAVES
-#define PP_LIST_WAVES 6  // waves per SIMD the kernel is compiled for (80 registers; 4 changes nothing: the scratch it
-                         // reports is the call frames of the rare stages, not spills)
+#define PP_LIST_WAVES 5  // waves per SIMD the kernel and its out-of-line stages are compiled for (96 registers)
 #endif
 template <int CAPW>
 __global__ __launch_bounds__(256, PP_LIST_WAVES) void grid_query_list_kernel(const float* __restrict__ xyz1,
@@ -1831,7 +1838,7 @@ __global__ __launch_bounds__(256, PP_LIST_WAVES) void grid_query_list_kernel(con
       __builtin_amdgcn_wave_barrier();  // (the slice is the search's from here on)
       skip_a = __all(!valid || (entry & kPendTried) != 0);
     }
-    search_queries<false, CAPW>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, nullptr, nullptr, L, b, dir,
+    search_queries<false, CAPW, PP_LIST_WAVES>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, nullptr, nullptr, L, b, dir,
                                 entry & ~kPendTried, valid, skip_a, (lds_f4_wptr)(&s_pts[wave][0]), (lds_f_wptr) nullptr);
   }
 }
