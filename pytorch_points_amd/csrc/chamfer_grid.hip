@@ -721,15 +721,16 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     float spx = 0.0f, spy = 0.0f, spz = 0.0f;
     if (blind) {
       // one sample per non-empty cell row -- the first point at or after the seed's cell along x, else the row's last
-      // point -- four chunks of rows in flight; the nearest sample bounds the seed's neighbour
+      // point -- kSmp chunks of rows in flight; the nearest sample bounds the seed's neighbour
       const int nall = g.gy * g.gz;
       const int cxs = cell_coord(sx, g.minx, g.invh, g.gx);
       float u1 = inf;
       float smx = 0.0f, smy = 0.0f, smz = 0.0f;  // this lane's nearest sample
-      for (int r0 = 0; r0 < nall; r0 += 256) {
-        unsigned rs[4], rm[4], re[4];
+      constexpr int kSmp = 6;  // chunks of 64 rows in flight (676 rows of a 26^3 grid: two rounds of two dependent loads)
+      for (int r0 = 0; r0 < nall; r0 += 64 * kSmp) {
+        unsigned rs[kSmp], rm[kSmp], re[kSmp];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kSmp; ++u) {
           const int r = r0 + u * 64 + lane;
           const bool ok = r < nall;
           const int base = (ok ? r : 0) * g.gx;
@@ -737,16 +738,16 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
           rm[u] = cell_start[base + cxs];
           re[u] = ok ? cell_start[base + g.gx] : rs[u];
         }
-        pp::f4 smp[4];
-        float sml[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        pp::f4 smp[kSmp];
+        float sml[kSmp] = {};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kSmp; ++u) {
           const unsigned at = re[u] > rs[u] ? min(rm[u], re[u] - 1) : 0u;
           smp[u] = sorted[at];
           if (LAB) sml[u] = slab[at];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kSmp; ++u) {
           const float d = pp::chamfer_d3(smp[u].x, smp[u].y, smp[u].z, sx, sy, sz);
           const bool tk = re[u] > rs[u] && (!LAB || sml[u] == sl) && d < u1;
           u1 = tk ? d : u1;
@@ -1995,8 +1996,8 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   g.gx = meta(5); g.gy = meta(6); g.gz = meta(7);
   // (uniform over the set) grids without crowded cells on both sides (crowd: 1 useless, 2 second-level grids), no
   // degenerate set, and the query cloud's chunk table exists; no short-circuits: nothing here is worth a branch
-  const bool grids_ok = (meta(8) == 0) & ((meta(12) | meta(13) | meta(14) | meta(15)) == 0) & (meta(16 + 8) == 0) &
-                        ((meta(16 + 12) | meta(16 + 13) | meta(16 + 14) | meta(16 + 15)) == 0) & (meta(16 + 10) == 1);
+  const bool grids_ok = ((meta(8) | meta(12) | meta(13) | meta(14) | meta(15) | meta(16 + 8) | meta(16 + 12) | meta(16 + 13) |
+                          meta(16 + 14) | meta(16 + 15) | (meta(16 + 10) ^ 1)) == 0);
   // ... and the images of this direction's tiles are likely to fit: a tile of TQ queries spans about TQ gz / nq layers
   // of the reference grid, its image those and three more (one straddled, one either side), each at most as full as
   // the grid's fullest layer.  A volume-filling cloud (coarser grid, fuller layers), a plane (one layer) or a Gaussian

@@ -414,9 +414,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   // requests than three 4-byte loads at a 12-byte lane stride; the mapping only has to be the same
   // in every pass.
   constexpr bool vec = VEC;  // the cloud is 16-byte aligned
-  auto kidx = [&](int base, int i) {
-    return vec ? base + (i >> 2) * (4 * kBuildThreads) + 4 * t + (i & 3) : base + t + kBuildThreads * i;
-  };
+  auto kidx = [&](int base, int i) { return base + (i >> 2) * (4 * kBuildThreads) + 4 * t + (i & 3); };
   auto load_chunk = [&](int base) {
     if (vec) {
 #pragma unroll
@@ -440,17 +438,43 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
         }
       }
     } else {
-      // (32-bit byte offsets from the wave-uniform base: one address register per point instead of two per load --
-      //  with 48 64-bit addresses this form of the kernel spilled, 216 bytes of scratch per lane)
-      const char* __restrict__ rb = reinterpret_cast<const char*>(ref);
+      // A cloud that starts at any 4-byte boundary (odd point counts in a batch, views): the same four consecutive
+      // points per thread, read as ALIGNED 16-byte vectors -- the 48 bytes begin `sh` dwords into the first of four
+      // (three when sh == 0) -- and shifted into place; `sh` is uniform over the workgroup (12 t dwords per thread
+      // keep the phase).  No 12-byte loads at a 12-byte lane stride (which the compiler made dwordx3 tuples of and
+      // spilled: 168-216 bytes of scratch per lane), the same cache-line traffic as the aligned form.
+      // The vectors stay inside the 16-byte granules that hold the cloud's first and last bytes: no page is touched
+      // that the cloud does not touch.
+      const uintptr_t a0 = reinterpret_cast<uintptr_t>(ref);
 #pragma unroll
-      for (int i = 0; i < KP; ++i) {
-        int k = base + t + kBuildThreads * i;
-        k = k < nr ? k : nr - 1;
-        const unsigned off = (unsigned)k * 12u;  // (nr < 2^31 / 12 points per cloud: the searches' own limit is lower)
-        px[i] = *reinterpret_cast<const float*>(rb + off);
-        py[i] = *reinterpret_cast<const float*>(rb + off + 4);
-        pz[i] = *reinterpret_cast<const float*>(rb + off + 8);
+      for (int gq = 0; gq < KP / 4; ++gq) {
+        const int p0 = base + gq * (4 * kBuildThreads) + 4 * t;
+        if (p0 + 3 < nr) {
+          const uintptr_t a = a0 + (uintptr_t)12 * (uintptr_t)p0;
+          const int sh = (int)((a0 + (uintptr_t)12 * (uintptr_t)(base + gq * (4 * kBuildThreads))) >> 2) & 3;  // uniform
+          const f4* __restrict__ src = reinterpret_cast<const f4*>(a & ~(uintptr_t)15);
+          const f4 v0 = src[0], v1 = src[1], v2 = src[2];
+          f4 v3 = v2;
+          if (sh != 0) v3 = src[3];  // (uniform)
+          const float w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+          float o[12];
+#pragma unroll
+          for (int e = 0; e < 12; ++e) o[e] = sh == 0 ? w[e] : (sh == 1 ? w[e + 1] : (sh == 2 ? w[e + 2] : w[e + 3]));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            px[4 * gq + j] = o[3 * j];
+            py[4 * gq + j] = o[3 * j + 1];
+            pz[4 * gq + j] = o[3 * j + 2];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = min(p0 + j, nr - 1);
+            px[4 * gq + j] = ref[3 * (size_t)k];
+            py[4 * gq + j] = ref[3 * (size_t)k + 1];
+            pz[4 * gq + j] = ref[3 * (size_t)k + 2];
+          }
+        }
       }
     }
   };
