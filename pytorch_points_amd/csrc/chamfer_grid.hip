@@ -30,6 +30,19 @@
 #include <cstdlib>
 #include <mutex>
 
+#ifdef PP_BUILD_PROBE
+// diagnostic build only (tools/build_phases.py): the 100 MHz clock at the phase boundaries of the build, thread 0 of
+// every workgroup of the build launch (256 at config 2)
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_bphase[512][16];
+#define PP_PHASE(n)                                                                                        \
+  do {                                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < 512) g_bphase[blockIdx.x][n] = __builtin_amdgcn_s_memrealtime();   \
+  } while (0)
+extern "C" int pp_debug_read_build_phases(void* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bphase), sizeof(g_bphase));
+}
+#endif
 #include "grid_common.h"
 
 // waves per SIMD the unlabeled search kernels are compiled for (tools/build_variant_lib.sh -DPP_WAVE_WAVES=4 ...)

@@ -291,13 +291,27 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
       for (unsigned ci = 0; ci < ncrowd; ++ci) {
         const unsigned start = s_clist[ci][0], n = s_clist[ci][1];
         if (n <= kWaveMaxPoints) continue;
+        // every pass over the cell's points: eight loads of a thread in flight, then the work (a plain loop waits for
+        // each load where it is used: eight round trips per pass, five passes -- 40 us of the 65 a cell of 8192 points
+        // cost the two-scale cloud's build)
+        auto for_points = [&](const f4* __restrict__ src, auto&& fn) {
+          for (unsigned k0 = 0; k0 < n; k0 += 8u * kBuildThreads) {
+            f4 q8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q8[u] = src[start + min(k0 + (unsigned)u * kBuildThreads + (unsigned)t, n - 1u)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const unsigned k = k0 + (unsigned)u * kBuildThreads + (unsigned)t;
+              if (k < n) fn(q8[u], k);
+            }
+          }
+        };
         float bmn[6] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(),
                         -__builtin_inff()};
-        for (unsigned k = t; k < n; k += kBuildThreads) {
-          const f4 q = sorted[start + k];
+        for_points(sorted, [&](const f4& q, unsigned) {
           bmn[0] = fmaxf(bmn[0], -q.x); bmn[1] = fmaxf(bmn[1], -q.y); bmn[2] = fmaxf(bmn[2], -q.z);
           bmn[3] = fmaxf(bmn[3], q.x); bmn[4] = fmaxf(bmn[4], q.y); bmn[5] = fmaxf(bmn[5], q.z);
-        }
+        });
         wave_reduce6_dpp<false, 6>(bmn);
         __syncthreads();  // s_box / s_sub of the previous cell are no longer read
         if ((t & 63) == 63)
@@ -312,12 +326,11 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
         {
           const float c0 = 0.5f * (bmn[3] - bmn[0]), c1 = 0.5f * (bmn[4] - bmn[1]), c2 = 0.5f * (bmn[5] - bmn[2]);
           float sm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-          for (unsigned k = t; k < n; k += kBuildThreads) {
-            const f4 q = sorted[start + k];
+          for_points(sorted, [&](const f4& q, unsigned) {
             const float dx = q.x - c0, dy = q.y - c1, dz = q.z - c2;
             sm[0] += dx; sm[1] += dy; sm[2] += dz;
             sm[3] = __builtin_fmaf(dx, dx, sm[3]); sm[4] = __builtin_fmaf(dy, dy, sm[4]); sm[5] = __builtin_fmaf(dz, dz, sm[5]);
-          }
+          });
           wave_reduce6_dpp<true, 6>(sm);
           __syncthreads();  // s_box: the bounding-box partials have been read
           if ((t & 63) == 63)
@@ -335,7 +348,7 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
         const int total2 = sg.gx * sg.gy * sg.gz;
         for (int c = t; c < total2; c += kBuildThreads) s_sub[c] = 0u;
         __syncthreads();
-        for (unsigned k = t; k < n; k += kBuildThreads) atomicAdd(&s_sub[cell2(sg, sorted[start + k])], 1u);
+        for_points(sorted, [&](const f4& q, unsigned) { atomicAdd(&s_sub[cell2(sg, q)], 1u); });
         __syncthreads();
         {  // exclusive scan of the total2 counters (contiguous runs per thread, as above)
           const int per2 = (total2 + kBuildThreads - 1) / kBuildThreads;
@@ -362,18 +375,17 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
           if (t == 0) tbl[total2] = start + n;
         }
         __syncthreads();
-        for (unsigned k = t; k < n; k += kBuildThreads) {
-          const f4 q = sorted[start + k];
+        for_points(sorted, [&](const f4& q, unsigned k) {
           const unsigned pos = atomicAdd(&s_sub[cell2(sg, q)], 1u);
           sorted2[pos] = q;
           if (sorted_payload) payload2[pos] = sorted_payload[start + k];
-        }
+        });
         __threadfence_block();
         __syncthreads();
-        for (unsigned k = t; k < n; k += kBuildThreads) {  // back into place (coalesced)
-          sorted[start + k] = sorted2[start + k];
+        for_points(sorted2, [&](const f4& q, unsigned k) {  // back into place (coalesced)
+          sorted[start + k] = q;
           if (sorted_payload) sorted_payload[start + k] = payload2[start + k];
-        }
+        });
         if (t == 0) sub_desc[(start + kCrowd - 1) / kCrowd] = sg;
       }
     }
@@ -651,8 +663,40 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
           if (mine) atomicAdd(&s_cnt[slot], 1u);
         };
         if ((ch + 1) * kBuildThreads * KP <= nr) {  // uniform: a full chunk needs no per-point bounds test
+          // A thread's four consecutive points at a time.  Where every lane of the wave finds its four in ONE cell
+          // (a dense part of the cloud that is also contiguous in memory: the dense scale of a two-scale cloud put
+          // 8192 points into one counter, 8192 same-address LDS atomics in this pass and again in the scatter: 27 us
+          // each) the counter is bumped once per thread, or once per wave if all its lanes agree.
 #pragma unroll
-          for (int i = 0; i < KP; ++i) mark(i);
+          for (int g4 = 0; g4 < KP / 4; ++g4) {
+            int c4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int i = 4 * g4 + u;
+              c4[u] = cell_linear(cell_coord(px[i], mnx, invh, gx), cell_coord(py[i], mny, invh, gy),
+                                  cell_coord(pz[i], mnz, invh, gz), gx, gy);
+            }
+            const bool same4 = (c4[0] == c4[1]) & (c4[1] == c4[2]) & (c4[2] == c4[3]);
+            if (__all(same4)) {  // (wave-uniform, rare)
+              const int c = c4[0];
+              atomicOr(&s_occ[c >> 5], 1u << (c & 31));
+              const int cl = c - lo;
+              below += cl < 0 ? 4u : 0u;
+              const bool mine = (unsigned)cl < (unsigned)nl;
+              const int slot = sk(cl);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) s_cid[(4 * g4 + u) * kBuildThreads + t] = mine ? slot : -1;
+              const int lead = __builtin_amdgcn_readfirstlane(c);
+              if (__all(c == lead)) {
+                if ((t & 63) == 0 && mine) atomicAdd(&s_cnt[slot], 256u);
+              } else if (mine) {
+                atomicAdd(&s_cnt[slot], 4u);
+              }
+            } else {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) mark(4 * g4 + u);
+            }
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < KP; ++i)
@@ -783,8 +827,25 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
             c[i] = (kidx(ch * kBuildThreads * KP, i0 + i) < nr && cc >= 0 && cc < nloc) ? sk(cc) : -1;
           }
         }
+        // (the same shortcut as in the count: one cursor bump per thread, or per wave, where four consecutive points
+        //  share a cell in every lane)
+        const bool same4s = (c[0] >= 0) & (c[0] == c[1]) & (c[1] == c[2]) & (c[2] == c[3]);
+        if (__all(same4s)) {  // (wave-uniform, rare)
+          const int lead = __builtin_amdgcn_readfirstlane(c[0]);
+          unsigned base;
+          if (__all(c[0] == lead)) {
+            base = 0u;
+            if ((t & 63) == 0) base = atomicAdd(&s_cnt[lead], 256u);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + 4u * (unsigned)(t & 63);
+          } else {
+            base = atomicAdd(&s_cnt[c[0]], 4u);
+          }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pos[i] = c[i] >= 0 ? atomicAdd(&s_cnt[c[i]], 1u) : 0u;
+          for (int i = 0; i < 4; ++i) pos[i] = base + (unsigned)i;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pos[i] = c[i] >= 0 ? atomicAdd(&s_cnt[c[i]], 1u) : 0u;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (c[i] >= 0) {
