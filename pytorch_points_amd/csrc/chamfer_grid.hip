@@ -953,23 +953,25 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         // a piece -- between far clouds that is the box's diagonal too generous, thousands of candidates where every
         // member's own ball holds a handful.  A candidate of this row matters only if it lies within SOME member's own
         // bound: the hull of the members' own cuts, intersected with the cut above.
-        const float ylo = (cy == 0 && rim_open) ? -inf : g.miny + (float)cy * g.h,
-                    yhi = (cy == g.gy - 1 && rim_open) ? inf : g.miny + (float)(cy + 1) * g.h;
-        const float zlo = (cz == 0 && rim_open) ? -inf : g.minz + (float)cz * g.h,
-                    zhi = (cz == g.gz - 1 && rim_open) ? inf : g.minz + (float)(cz + 1) * g.h;
+        // (the slack folded into the row's faces: gap = max3(lo' - q, q - hi', 0))
+        const float ylo = ((cy == 0 && rim_open) ? -inf : g.miny + (float)cy * g.h) - slack,
+                    yhi = ((cy == g.gy - 1 && rim_open) ? inf : g.miny + (float)(cy + 1) * g.h) + slack;
+        const float zlo = ((cz == 0 && rim_open) ? -inf : g.minz + (float)cz * g.h) - slack,
+                    zhi = ((cz == g.gz - 1 && rim_open) ? inf : g.minz + (float)(cz + 1) * g.h) + slack;
         float mlo = inf, mhi = -inf;
         for (unsigned long long mm = members; mm; mm &= mm - 1ull) {
           const int m = (int)__builtin_ctzll(mm);
           const float mx = rl(qx, m), my = rl(qy, m), mz = rl(qz, m), mu = rl(ubm, m);
-          const float gy_ = fmaxf(fmaxf(ylo - my, my - yhi) - slack, 0.0f), gz_ = fmaxf(fmaxf(zlo - mz, mz - zhi) - slack, 0.0f);
+          const float gy_ = fmaxf(fmaxf(ylo - my, my - yhi), 0.0f), gz_ = fmaxf(fmaxf(zlo - mz, mz - zhi), 0.0f);
           const float remm = mu - __builtin_fmaf(gz_, gz_, gy_ * gy_) * 0.9999f;
-          const float rxm = sqrtf(fmaxf(remm, 0.0f)) * 1.0001f + slack;
-          const bool ok = remm >= 0.0f && (rim_open || (mx + rxm >= box_x0 && mx - rxm <= box_x1));
-          mlo = ok ? fminf(mlo, mx - rxm) : mlo;
-          mhi = ok ? fmaxf(mhi, mx + rxm) : mhi;
+          // (a member out of reach of the row: a cut of -inf width leaves the hull alone)
+          const float rxm = remm >= 0.0f ? sqrtf(remm) * 1.0001f + slack : -inf;
+          mlo = fminf(mlo, mx - rxm);
+          mhi = fmaxf(mhi, mx + rxm);
         }
         xlo = fmaxf(xlo, mlo);
         xhi = fminf(xhi, mhi);
+        if (!rim_open && (xhi < box_x0 || xlo > box_x1)) xhi = -inf;  // (no member reaches the box in this row)
         load_span();
       }
       if (__ballot(len != 0u) == 0ull) continue;  // wave-uniform: nothing in these rows

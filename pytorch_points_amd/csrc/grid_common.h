@@ -218,25 +218,37 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
         for (unsigned ci = wave; ci < ncrowd; ci += kBuildThreads / 64) {  // wave-uniform
           const unsigned start = s_clist[ci][0], n = s_clist[ci][1];
           if (n > kWaveMaxPoints) continue;
+          // (every pass: eight loads of a lane in flight, then the work -- a plain loop waits for each load where it is
+          //  used, 4 to 32 round trips per pass: 49 of the 70 us of a clustered cloud's build)
+          auto for_points = [&](const f4* __restrict__ src, auto&& fn) {
+            for (unsigned k0 = 0; k0 < n; k0 += 512u) {
+              f4 q8[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) q8[u] = src[start + min(k0 + 64u * (unsigned)u + (unsigned)lane, n - 1u)];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const unsigned k = k0 + 64u * (unsigned)u + (unsigned)lane;
+                if (k < n) fn(q8[u], k);
+              }
+            }
+          };
           float bmn[6] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(),
                           -__builtin_inff()};  // max of (-x, -y, -z, x, y, z)
-          for (unsigned k = lane; k < n; k += 64) {
-            const f4 q = sorted[start + k];
+          for_points(sorted, [&](const f4& q, unsigned) {
             bmn[0] = fmaxf(bmn[0], -q.x); bmn[1] = fmaxf(bmn[1], -q.y); bmn[2] = fmaxf(bmn[2], -q.z);
             bmn[3] = fmaxf(bmn[3], q.x); bmn[4] = fmaxf(bmn[4], q.y); bmn[5] = fmaxf(bmn[5], q.z);
-          }
+          });
           wave_reduce6_dpp<false, 6>(bmn);
 #pragma unroll
           for (int e = 0; e < 6; ++e) bmn[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bmn[e]), 63));
           {
             const float c0 = 0.5f * (bmn[3] - bmn[0]), c1 = 0.5f * (bmn[4] - bmn[1]), c2 = 0.5f * (bmn[5] - bmn[2]);
             float sm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-            for (unsigned k = lane; k < n; k += 64) {
-              const f4 q = sorted[start + k];
+            for_points(sorted, [&](const f4& q, unsigned) {
               const float dx = q.x - c0, dy = q.y - c1, dz = q.z - c2;
               sm[0] += dx; sm[1] += dy; sm[2] += dz;
               sm[3] = __builtin_fmaf(dx, dx, sm[3]); sm[4] = __builtin_fmaf(dy, dy, sm[4]); sm[5] = __builtin_fmaf(dz, dz, sm[5]);
-            }
+            });
             wave_reduce6_dpp<true, 6>(sm);
 #pragma unroll
             for (int e = 0; e < 6; ++e) sm[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm[e]), 63));
@@ -246,7 +258,7 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
           const int total2 = sg.gx * sg.gy * sg.gz;
           for (int c = lane; c < total2; c += 64) s_sub[c] = 0u;
           wave_sync();
-          for (unsigned k = lane; k < n; k += 64) atomicAdd(&s_sub[cell2(sg, sorted[start + k])], 1u);
+          for_points(sorted, [&](const f4& q, unsigned) { atomicAdd(&s_sub[cell2(sg, q)], 1u); });
           wave_sync();
           {  // exclusive scan: lane l owns a contiguous run of counters
             const int per2 = (total2 + 63) / 64;
@@ -270,18 +282,17 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
             if (lane == 0) tbl[total2] = start + n;
           }
           wave_sync();
-          for (unsigned k = lane; k < n; k += 64) {
-            const f4 q = sorted[start + k];
+          for_points(sorted, [&](const f4& q, unsigned k) {
             const unsigned pos = atomicAdd(&s_sub[cell2(sg, q)], 1u);
             sorted2[pos] = q;
             if (sorted_payload) payload2[pos] = sorted_payload[start + k];
-          }
+          });
           wave_sync();
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          for (unsigned k = lane; k < n; k += 64) {  // back into place (coalesced)
-            sorted[start + k] = sorted2[start + k];
+          for_points(sorted2, [&](const f4& q, unsigned k) {  // back into place (coalesced)
+            sorted[start + k] = q;
             if (sorted_payload) sorted_payload[start + k] = payload2[start + k];
-          }
+          });
           if (lane == 0) sub_desc[(start + kCrowd - 1) / kCrowd] = sg;
         }
       }
