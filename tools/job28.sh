@@ -1,3 +1,3 @@
 #!/bin/bash
-python tools/build_phases.py sphere two_scales blobs8 gaussian > gpurun_out/build_phases.log 2>&1
-cat gpurun_out/build_phases.log
+python tools/build_phases.py sphere sphere > gpurun_out/build_phases3.log 2>&1
+cat gpurun_out/build_phases3.log
