@@ -109,6 +109,12 @@ size_t pp_furthest_sampling_workspace_bytes(int B, int N, int npoint);
 int pp_furthest_sampling_status(const void* workspace, void* stream);
 int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx, int B, int N, int npoint,
                              int seed_idx, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the picked points' coordinates written as well: the caller one level up,
+ * network/geo_operations.py:59-63 (furthest_point_sample = the sampling + gather_points of the coordinates; SURVEY.md
+ * §8f N3), in ONE launch.  sampled (B,npoint,3), or (B,3,npoint) with channels_first != 0; NULL = idx only. */
+int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, int* idx, float* sampled, int channels_first,
+                                    int B, int N, int npoint, int seed_idx, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /* Replaces sampling.gather_forward(b,c,n,npoints,points,idx,out)
  *   (_ext/sampling.cpp:19-28 -> _ext/sampling_cuda.cu:9-45).  points (B,C,N), idx (B,M) -> out (B,C,M) */

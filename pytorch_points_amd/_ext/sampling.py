@@ -70,9 +70,11 @@ def furthest_sampling_status(device):
     return status
 
 
-def furthest_sampling(m, seedIdx, input, temp, idx):
+def furthest_sampling(m, seedIdx, input, temp, idx, sampled=None, channels_first=False):
     """furthest_sampling_forward (sampling.cpp:68-82): input (B,N,3), temp (B,N) in/out, idx (B,m)
-    out; returns idx."""
+    out; returns idx.  Beyond the reference's signature: ``sampled`` (B,m,3) -- or (B,3,m) with
+    ``channels_first`` -- receives the picked points' coordinates in the same launch (what
+    network/geo_operations.py:59-63 does with a gather_points call afterwards)."""
     dev = _lib.require_cuda(("input", input), ("temp", temp), ("idx", idx))
     _lib.require_contiguous(("input", input), ("temp", temp), ("idx", idx))  # CHECK_INPUT :76-77
     _lib.require_float(("input", input), ("temp", temp))
@@ -82,6 +84,12 @@ def furthest_sampling(m, seedIdx, input, temp, idx):
     b, n, _ = input.shape
     if temp.numel() != b * n or idx.numel() != b * int(m):
         raise RuntimeError("temp must be (B, N) and idx (B, m)")
+    if sampled is not None:
+        _lib.require_cuda(("input", input), ("sampled", sampled))
+        _lib.require_contiguous(("sampled", sampled))
+        _lib.require_float(("sampled", sampled))
+        if tuple(sampled.shape) != ((b, 3, int(m)) if channels_first else (b, int(m), 3)):
+            raise RuntimeError("sampled must be (B, m, 3), or (B, 3, m) with channels_first")
     L = _lib.lib()
     nbytes = int(L.pp_furthest_sampling_workspace_bytes(b, n, int(m)))
     ws = _workspace(dev, nbytes)
@@ -101,8 +109,9 @@ def furthest_sampling(m, seedIdx, input, temp, idx):
         ws[:256].zero_()             # the sticky status word in front of the scratch (include/pp_hip.h)
         ws._pp_status_zeroed = True
     with _lib.on_device(dev) as stream:
-        _lib.check(L.pp_furthest_sampling_f32(
-            _lib.ptr(input), _lib.ptr(temp), _lib.ptr(idx), b, n, int(m), int(seedIdx),
+        _lib.check(L.pp_furthest_sampling_gather_f32(
+            _lib.ptr(input), _lib.ptr(temp), _lib.ptr(idx), _lib.ptr(sampled) if sampled is not None else None,
+            1 if channels_first else 0, b, n, int(m), int(seedIdx),
             _lib.ptr(ws) if ws is not None else None, nbytes, stream), "furthest_sampling")
         if ws is not None and not capturing:
             if entry is None:

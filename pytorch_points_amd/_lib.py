@@ -31,6 +31,7 @@ SIGNATURES = {
     "pp_nmdistance_backward_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_furthest_sampling_workspace_bytes": [_I, _I, _I],
     "pp_furthest_sampling_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
+    "pp_furthest_sampling_gather_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_furthest_sampling_status": [_P, _P],
     "pp_gather_forward_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
     "pp_gather_backward_f32": [_P, _P, _P, _I, _I, _I, _I, _P],

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kFpsThreads) void fps_block_kernel(const float* __r
                                                                 float* __restrict__ temp,
                                                                 int* __restrict__ idx, int N,
                                                                 int npoint, int seed,
-                                                                TieOrder order) {
+                                                                TieOrder order, float* __restrict__ sampled, int cf) {
   __shared__ unsigned long long s_key[2][kFpsWaves];
   const int b = blockIdx.x;
   const float* __restrict__ p = xyz + (size_t)b * N * 3;
@@ -139,8 +139,19 @@ __global__ __launch_bounds__(kFpsThreads) void fps_block_kernel(const float* __r
   }
   int old = seed;
   if (t == 0) out[0] = old;
+  // (sampled != nullptr: the coordinates of the picks as well -- furthest_point_sample's gather_points, fused: the
+  //  coordinates of pick j - 1 are in registers at the top of step j)
+  float* __restrict__ smp = sampled ? sampled + (size_t)blockIdx.x * npoint * 3 : nullptr;
+  auto put = [&](int j, float x, float y, float z) {
+    if (cf) {
+      smp[j] = x; smp[(size_t)npoint + j] = y; smp[2 * (size_t)npoint + j] = z;
+    } else {
+      smp[3 * (size_t)j] = x; smp[3 * (size_t)j + 1] = y; smp[3 * (size_t)j + 2] = z;
+    }
+  };
   for (int j = 1; j < npoint; ++j) {
     const float ox = p[3 * (size_t)old + 0], oy = p[3 * (size_t)old + 1], oz = p[3 * (size_t)old + 2];
+    if (smp && t == 0) put(j - 1, ox, oy, oz);
     unsigned long long best = 0ull;
     if (R > 0) {
 #pragma unroll
@@ -178,6 +189,7 @@ __global__ __launch_bounds__(kFpsThreads) void fps_block_kernel(const float* __r
     old = __builtin_amdgcn_readfirstlane(order.unrank(0xFFFFFFFFu - (unsigned)(m & 0xFFFFFFFFull)));
     if (t == 0) out[j] = old;
   }
+  if (smp && t == 0) put(npoint - 1, p[3 * (size_t)old + 0], p[3 * (size_t)old + 1], p[3 * (size_t)old + 2]);
   if (R > 0) {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
@@ -224,7 +236,7 @@ template <int R>
 __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
     const float* __restrict__ xyz, float* __restrict__ temp, int* __restrict__ idx, int B, int N,
     int npoint, int seed, TieOrder order, ClusterGeom geo, u64* __restrict__ ring,
-    unsigned* __restrict__ err) {
+    unsigned* __restrict__ err, float* __restrict__ sampled, int cf) {
   __shared__ u64 s_key[2][kClWaves];
   __shared__ int s_old[2];
   // members of one batch element share blockIdx % 8 (one XCD under round-robin dispatch): speed only
@@ -254,11 +266,25 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
     td[i] = ok ? tmp[kc] : -1.0f;
   }
   int old = seed;
-  if (c == 0 && t == 0) out[0] = old;
+  // The results -- the pick, and its coordinates if asked for -- are stored by lane 0 of WAVE 1 of member 0: wave 0
+  // polls the cluster's granules with vector loads, and its wait for a poll (vmcnt counts in order) would wait for the
+  // stores of the step before as well; wave 1 issues no vector load inside the loop.
+  const bool writer = c == 0 && t == 64;
+  if (writer) out[0] = old;
   bool dead = false;
+  // (sampled != nullptr: the picks' coordinates as well -- see fps_block_kernel)
+  float* __restrict__ smp = (sampled && writer) ? sampled + (size_t)b * npoint * 3 : nullptr;
+  auto put = [&](int j, float x, float y, float z) {
+    if (cf) {
+      smp[j] = x; smp[(size_t)npoint + j] = y; smp[2 * (size_t)npoint + j] = z;
+    } else {
+      smp[3 * (size_t)j] = x; smp[3 * (size_t)j + 1] = y; smp[3 * (size_t)j + 2] = z;
+    }
+  };
   for (int j = 1; j < npoint; ++j) {
     PP_FPS_MARK(0);
     const float ox = p[3 * (size_t)old + 0], oy = p[3 * (size_t)old + 1], oz = p[3 * (size_t)old + 2];
+    if (smp) put(j - 1, ox, oy, oz);
     const unsigned tag = (((unsigned)j & 63u) << 1) | 1u;  // odd, 7 bits: never 0, never 0xFF
     // A thread's points k0 + t + 512 i have tie ranks that grow with i (T = 512 = the stride: the launcher
     // checks it), so "strictly greater, first wins" over i keeps exactly the point the packed key would:
@@ -316,12 +342,17 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
     if (old < 0) {  // timed out: flag, leave defined (zero) indices behind and go (uniform across the workgroup)
       if (t == 0) atomicOr(err, 1u);
       if (c == 0)
-        for (int jj = j + t; jj < npoint; jj += kClThreads) out[jj] = 0;
+        for (int jj = j + t; jj < npoint; jj += kClThreads) {
+          out[jj] = 0;
+          if (sampled)  // (defined values behind a reported failure: point 0's coordinates, as the indices say)
+            for (int a = 0; a < 3; ++a) sampled[(size_t)b * npoint * 3 + (cf ? (size_t)a * npoint + jj : 3 * (size_t)jj + a)] = p[a];
+        }
       return;
     }
-    if (c == 0 && t == 0) out[j] = old;
+    if (writer) out[j] = old;
   }
   PP_FPS_MARK_END();
+  if (smp) put(npoint - 1, p[3 * (size_t)old + 0], p[3 * (size_t)old + 1], p[3 * (size_t)old + 2]);
 #pragma unroll
   for (int i = 0; i < R; ++i) {
     const int k = k0 + t + kClThreads * i;
@@ -331,10 +362,10 @@ __global__ __launch_bounds__(kClThreads) void fps_cluster_kernel(
 
 template <int R>
 void launch_fps_cluster(const float* xyz, float* temp, int* idx, int B, int N, int npoint, int seed,
-                        TieOrder order, ClusterGeom geo, u64* ring, unsigned* err, hipStream_t s) {
+                        TieOrder order, ClusterGeom geo, u64* ring, unsigned* err, float* sampled, int cf, hipStream_t s) {
   const int groups8 = (B + 7) / 8;
   fps_cluster_kernel<R><<<dim3(8 * groups8 * geo.cl), dim3(kClThreads), 0, s>>>(
-      xyz, temp, idx, B, N, npoint, seed, order, geo, ring, err);
+      xyz, temp, idx, B, N, npoint, seed, order, geo, ring, err, sampled, cf);
 }
 
 // Workgroups the cluster kernel may count on being resident together: one 512-thread workgroup per CU of the
@@ -370,8 +401,8 @@ constexpr size_t kFpsErrBytes = 256;  // error word + padding in front of the ri
 
 template <int R>
 void launch_fps(const float* xyz, float* temp, int* idx, int B, int N, int npoint, int seed,
-                TieOrder order, hipStream_t s) {
-  fps_block_kernel<R><<<dim3(B), dim3(kFpsThreads), 0, s>>>(xyz, temp, idx, N, npoint, seed, order);
+                TieOrder order, float* sampled, int cf, hipStream_t s) {
+  fps_block_kernel<R><<<dim3(B), dim3(kFpsThreads), 0, s>>>(xyz, temp, idx, N, npoint, seed, order, sampled, cf);
 }
 
 }  // namespace
@@ -398,9 +429,21 @@ extern "C" int pp_furthest_sampling_status(const void* workspace, void* stream) 
   return (int)v;
 }
 
+extern "C" int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, int* idx, float* sampled,
+                                               int channels_first, int B, int N, int npoint, int seed_idx,
+                                               void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx, int B, int N,
                                         int npoint, int seed_idx, void* workspace,
                                         size_t workspace_bytes, void* stream) {
+  return pp_furthest_sampling_gather_f32(xyz, temp, idx, nullptr, 0, B, N, npoint, seed_idx, workspace, workspace_bytes,
+                                         stream);
+}
+
+extern "C" int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, int* idx, float* sampled,
+                                               int channels_first, int B, int N, int npoint, int seed_idx,
+                                               void* workspace, size_t workspace_bytes, void* stream) {
+  const int cf = channels_first ? 1 : 0;
   if (B < 0 || N < 0 || npoint < 0) return PP_EINVAL;
   if (B == 0 || npoint <= 0) return PP_OK;  // ref: `if (m <= 0) return;` (sampling_cuda.cu:166)
   if (N == 0 || !xyz || !temp || !idx) return PP_EINVAL;
@@ -443,24 +486,24 @@ extern "C" int pp_furthest_sampling_f32(const float* xyz, float* temp, int* idx,
     u64* ring = (u64*)((char*)workspace + kFpsErrBytes);
     unsigned* err = (unsigned*)workspace;
     const int r = geo.slice / kClThreads;
-    if (r <= 1) launch_fps_cluster<1>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
-    else if (r <= 2) launch_fps_cluster<2>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
-    else if (r <= 4) launch_fps_cluster<4>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
-    else if (r <= 8) launch_fps_cluster<8>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
-    else if (r <= 16) launch_fps_cluster<16>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
-    else launch_fps_cluster<32>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, s);
+    if (r <= 1) launch_fps_cluster<1>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, sampled, cf, s);
+    else if (r <= 2) launch_fps_cluster<2>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, sampled, cf, s);
+    else if (r <= 4) launch_fps_cluster<4>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, sampled, cf, s);
+    else if (r <= 8) launch_fps_cluster<8>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, sampled, cf, s);
+    else if (r <= 16) launch_fps_cluster<16>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, sampled, cf, s);
+    else launch_fps_cluster<32>(xyz, temp, idx, B, N, npoint, seed_idx, order, geo, ring, err, sampled, cf, s);
     PP_RETURN_IF_LAUNCH_FAILED();
     return PP_OK;
   }
   const int per_thread = (N + kFpsThreads - 1) / kFpsThreads;
-  if (per_thread <= 1) launch_fps<1>(xyz, temp, idx, B, N, npoint, seed_idx, order, s);
-  else if (per_thread <= 2) launch_fps<2>(xyz, temp, idx, B, N, npoint, seed_idx, order, s);
-  else if (per_thread <= 4) launch_fps<4>(xyz, temp, idx, B, N, npoint, seed_idx, order, s);
-  else if (per_thread <= 8) launch_fps<8>(xyz, temp, idx, B, N, npoint, seed_idx, order, s);
-  else if (per_thread <= 16) launch_fps<16>(xyz, temp, idx, B, N, npoint, seed_idx, order, s);
-  else if (per_thread <= 32) launch_fps<32>(xyz, temp, idx, B, N, npoint, seed_idx, order, s);
-  else if (per_thread <= 64) launch_fps<64>(xyz, temp, idx, B, N, npoint, seed_idx, order, s);
-  else launch_fps<0>(xyz, temp, idx, B, N, npoint, seed_idx, order, s);
+  if (per_thread <= 1) launch_fps<1>(xyz, temp, idx, B, N, npoint, seed_idx, order, sampled, cf, s);
+  else if (per_thread <= 2) launch_fps<2>(xyz, temp, idx, B, N, npoint, seed_idx, order, sampled, cf, s);
+  else if (per_thread <= 4) launch_fps<4>(xyz, temp, idx, B, N, npoint, seed_idx, order, sampled, cf, s);
+  else if (per_thread <= 8) launch_fps<8>(xyz, temp, idx, B, N, npoint, seed_idx, order, sampled, cf, s);
+  else if (per_thread <= 16) launch_fps<16>(xyz, temp, idx, B, N, npoint, seed_idx, order, sampled, cf, s);
+  else if (per_thread <= 32) launch_fps<32>(xyz, temp, idx, B, N, npoint, seed_idx, order, sampled, cf, s);
+  else if (per_thread <= 64) launch_fps<64>(xyz, temp, idx, B, N, npoint, seed_idx, order, sampled, cf, s);
+  else launch_fps<0>(xyz, temp, idx, B, N, npoint, seed_idx, order, sampled, cf, s);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
 }

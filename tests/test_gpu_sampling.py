@@ -131,6 +131,40 @@ def test_fps_cluster_beside_other_work(cuda):
     assert np.array_equal(ref[:1].cpu().numpy(), e_idx)
 
 
+@pytest.mark.parametrize("b,n,m,seed", [(2, 2048, 256, 0), (1, 300, 64, 7), (16, 8192, 200, 5), (3, 1024, 1, 9), (1, 70000, 24, 0)])
+def test_fps_writes_the_picked_points_in_the_same_launch(cuda, fps_path, b, n, m, seed):
+    """furthest_point_sample = sampling + gather_points of the coordinates (reference geo_operations.py:59-63), here one
+    launch: both layouts equal the composition, through both kernels, gradients included"""
+    from pytorch_points_amd._ext import sampling
+    from pytorch_points_amd.network.geo_operations import furthest_point_sample, FurthestPointSampling
+    from pytorch_points_amd.network.operations import gather_points
+    x = S.unit_sphere(40 + n, b, n)
+    e_idx, _ = oracle.furthest_sampling(x, m, seed)
+    xt = _t(x, cuda).requires_grad_(True)
+    idx, chosen = furthest_point_sample(xt, m, NCHW=False, seedIdx=seed)               # (B, m, 3)
+    assert np.array_equal(idx.cpu().numpy(), e_idx)
+    ref = np.take_along_axis(x, e_idx[..., None].astype(np.int64), 1)
+    assert np.array_equal(chosen.detach().cpu().numpy(), ref)
+    w = _t(S.normal(41, (b, m, 3)), cuda)
+    (chosen * w).sum().backward()
+    x2 = _t(x, cuda).requires_grad_(True)                                              # the composition
+    i2 = FurthestPointSampling.apply(x2, m, seed)
+    c2 = gather_points(x2.transpose(2, 1).contiguous(), i2).transpose(2, 1)
+    (c2 * w).sum().backward()
+    assert torch.equal(i2, idx) and torch.equal(c2.detach(), chosen.detach())
+    assert torch.allclose(xt.grad, x2.grad, rtol=1e-6, atol=1e-7)
+    idx_c, chosen_c = furthest_point_sample(_t(np.ascontiguousarray(x.transpose(0, 2, 1)), cuda), m, NCHW=True, seedIdx=seed)
+    assert torch.equal(idx_c, idx) and np.array_equal(chosen_c.cpu().numpy(), ref.transpose(0, 2, 1))
+    # the C ABI's points-last layout, and temp as an in/out argument as in the reference's call
+    temp = torch.full((b, n), 1e10, device=cuda)
+    out_i = torch.empty(b, m, dtype=torch.int32, device=cuda)
+    out_p = torch.empty(b, m, 3, device=cuda)
+    sampling.furthest_sampling(m, seed, _t(x, cuda), temp, out_i, out_p, False)
+    assert np.array_equal(out_i.cpu().numpy(), e_idx) and np.array_equal(out_p.cpu().numpy(), ref)
+    with pytest.raises(RuntimeError, match="sampled"):
+        sampling.furthest_sampling(m, seed, _t(x, cuda), temp, out_i, torch.empty(b, m + 1, 3, device=cuda), False)
+
+
 def test_fps_timeout_is_reported_per_stream(cuda):
     """a timed-out cluster wait sets the sticky status word of THAT stream's workspace; it is reported by
     furthest_sampling_check() or by the next call on the same device and stream -- not by, nor wiped out by, a clean
