@@ -696,7 +696,8 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
                                                              const pp::f4* __restrict__ sorted,
                                                              const float* __restrict__ slab, float qx, float qy,
                                                              float qz, float ql, float best, int bidx, unsigned open_lo,
-                                                             unsigned open_hi, lds_f4_wptr lw, lds_f_wptr lwl) {
+                                                             unsigned open_hi, lds_f4_wptr lw, lds_f_wptr lwl,
+                                                             int row_room) {
   const lds_f4_ptr lr = (lds_f4_ptr)lw;
   const lds_f_ptr lrl = (lds_f_ptr)lwl;
   const int lane = threadIdx.x & 63;
@@ -893,7 +894,9 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
 #ifdef PP_NO_ROWLIST
     const bool listed = false;
 #else
-    const bool listed = nrows > 64;  // (a box of at most 64 rows is one block anyway: no list)
+    // (a box of at most 64 rows is one block anyway: no list; row_room: the two-byte entries the wave's slice holds
+    //  behind the candidate batch -- 1056 for slices of 384 points, the default; a smaller slice lists smaller boxes only)
+    const bool listed = nrows > 64 && nrows <= row_room;
 #endif
     if (!listed) nq = nrows;  // PP_NO_ROWLIST: every block of rows
     for (int r0 = 0; listed && r0 < nrows; r0 += 64) {  // wave-uniform
@@ -1699,8 +1702,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     const unsigned long long todo = open & __ballot(finite);
     if (todo) {
       const Found f = wave_group_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, best, bidx, (unsigned)todo,
-                                             (unsigned)(todo >> 32), s_pts_w,
-                                             s_lab_w);
+                                             (unsigned)(todo >> 32), s_pts_w, s_lab_w, (CAPW + 4 - kGroupBatch) * 8);
       if ((todo >> lane) & 1ull) {
         const bool none = f.bidx == 0x7fffffff;  // (labeled: nobody carries this label -- ref nmdistance_cuda.cu:110-113)
         od[j] = (LAB && none) ? 0.0f : f.best;
