@@ -252,6 +252,10 @@ def bench_chamfer(args, dist, world, rank, device):
         # one asynchronous collective per gathered step: (dist1 | dist2 | idx1 | idx2) of the shard, packed (idx as
         # 16-bit words: 6 MiB per rank at B=32, N=M=16384), double-buffered (pytorch_points_amd/sharded.py)
         from pytorch_points_amd.sharded import PackedShardGather
+        # PP_SHARD_EXCHANGE: native (default: c10d's _allgather_base issued by the exchange object's worker thread),
+        # rccl (one direct ncclAllGather on a communicator of the object's own: 17 us of host time per exchange instead
+        # of 28, one-rank line 0.101 instead of 0.106 ms -- opt-in: it could only be exercised with one rank here),
+        # python (the Python-issued exchange)
         exchange = PackedShardGather(B, N, M, device)
     pending = []        # slot of the previous gathered step
     counter = [0]
@@ -483,6 +487,12 @@ def bench_chamfer(args, dist, world, rank, device):
     if dist is not None:
         out["compute_ms"] = compute_ms
         out["exchange_ms"] = exchange_ms
+        native = getattr(exchange, "_native", None)
+        out["exchange_issue"] = ("direct ncclAllGather from the exchange object's worker thread" if getattr(exchange, "direct", False)
+                                 else ("c10d _allgather_base from the exchange object's worker thread" if native is not None
+                                       else "Python: dist.all_gather_into_tensor"))
+        if native is not None:
+            out["exchange_worker_us"] = float(native.worker_us_per_slot())   # host time of the worker per exchange
         out["exchange_note"] = ("compute_ms: the same steps without the exchange; exchange_ms: pack + all_gather_into_tensor + "
                                 "unpack of one step's outputs with nothing beside it; ms_per_step has them overlapped "
                                 "(gather every %d step(s))" % gather_every)

@@ -116,7 +116,7 @@ def build_bridge(force=False, verbose=False):
            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-I" + INCLUDE,
            *["-I" + p for p in ce.include_paths()], "-I" + os.path.join(rocm, "include"),
            "-I" + sysconfig.get_paths()["include"], "-L" + tlib, "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10",
-           "-lc10_hip", "-ltorch_hip", "-L" + HERE, "-l:libpp_hip.so", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+           "-lc10_hip", "-ltorch_hip", "-l:librccl.so", "-L" + HERE, "-l:libpp_hip.so", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

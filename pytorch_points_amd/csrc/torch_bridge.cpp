@@ -14,6 +14,9 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>  // a ROCm build of torch names its HIP devices "cuda"
 #include <c10/core/DeviceGuard.h>
+#include <chrono>
+#include <cstring>
+#include <rccl/rccl.h>
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 #include <torch/extension.h>
 
@@ -221,6 +224,13 @@ struct PackedExchange {
   std::vector<long long> launched, issued;
   std::string failure;  // the worker's first exception, re-raised in the calling thread
   bool stop = false;
+  // Direct mode (init_direct): the all-gather is ONE ncclAllGather on a communicator of this object's own instead of a
+  // c10d call -- c10d wraps the same RCCL enqueue in a Work object, two events and a stream wait, ~10 HIP runtime calls
+  // per exchange issued from a second thread while the first launches the step's kernels; the runtime's locks made
+  // the pair host-bound (0.105 ms per step against 0.078 of kernels at config 2).  nullptr: c10d.
+  ncclComm_t comm = nullptr;
+  double worker_ns = 0.0;  // host time the worker has spent issuing (collective + unpack + event), and how many slots
+  long long worker_slots = 0;
 
   PackedExchange(const c10::intrusive_ptr<c10d::ProcessGroup>& group, int b_local, int n_, int m_, const c10::Device& device,
                  int depth_)
@@ -258,6 +268,7 @@ struct PackedExchange {
     }
     cv_work.notify_all();
     if (worker.joinable()) worker.join();
+    if (comm) (void)ncclCommDestroy(comm);
     for (hipEvent_t ev : packed) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : done) (void)hipEventDestroy(ev);
   }
@@ -272,14 +283,21 @@ struct PackedExchange {
         slot = queue.front();
         queue.pop_front();
       }
+      const auto t_begin = std::chrono::steady_clock::now();
       try {
         const c10::DeviceGuard guard(dev);
         const c10::hip::HIPStreamGuardMasqueradingAsCUDA on_side(side);
         TORCH_CHECK(hipStreamWaitEvent(side.stream(), packed[slot], 0) == hipSuccess, "hipStreamWaitEvent failed");
         // (c10d orders the collective behind the CURRENT stream of the calling thread: here the side stream, which waits
         //  for the pack)
-        c10::intrusive_ptr<c10d::Work> work = pg->_allgather_base(recv[slot], send[slot]);
-        work->wait();  // RCCL: the side stream waits for the collective's end, no host block
+        if (comm) {
+          const ncclResult_t rc = ncclAllGather(send[slot].data_ptr(), recv[slot].data_ptr(), (size_t)nbytes_padded, ncclChar, comm,
+                                                side.stream());
+          TORCH_CHECK(rc == ncclSuccess, "ncclAllGather failed: ", ncclGetErrorString(rc));
+        } else {
+          c10::intrusive_ptr<c10d::Work> work = pg->_allgather_base(recv[slot], send[slot]);
+          work->wait();  // RCCL: the side stream waits for the collective's end, no host block
+        }
         check_code(pp_shard_unpack_f32(recv[slot].data_ptr(), world, (long long)nbytes_padded, (long long)b * n,
                                        (long long)b * m, compact, out[slot][0].data_ptr<float>(),
                                        out[slot][1].data_ptr<float>(), out[slot][2].data_ptr<int>(),
@@ -293,9 +311,39 @@ struct PackedExchange {
       {
         std::lock_guard<std::mutex> lock(mu);
         ++issued[slot];
+        worker_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t_begin).count();
+        ++worker_slots;
       }
       cv_done.notify_all();
     }
+  }
+
+  // rank 0 makes the id (128 bytes), every rank receives it (the caller broadcasts it over the process group) and
+  // joins: a collective call -- all ranks, before the first launch
+  static pybind11::bytes unique_id() {
+    ncclUniqueId id;
+    const ncclResult_t rc = ncclGetUniqueId(&id);
+    TORCH_CHECK(rc == ncclSuccess, "ncclGetUniqueId failed: ", ncclGetErrorString(rc));
+    return pybind11::bytes(id.internal, NCCL_UNIQUE_ID_BYTES);
+  }
+  void init_direct(const std::string& id_bytes, int rank) {
+    TORCH_CHECK(id_bytes.size() == NCCL_UNIQUE_ID_BYTES, "init_direct: the id must be ", NCCL_UNIQUE_ID_BYTES, " bytes");
+    TORCH_CHECK(comm == nullptr, "init_direct: already initialised");
+    ncclUniqueId id;
+    std::memcpy(id.internal, id_bytes.data(), NCCL_UNIQUE_ID_BYTES);
+    const c10::DeviceGuard guard(dev);
+    ncclComm_t c = nullptr;
+    const ncclResult_t rc = ncclCommInitRank(&c, world, id, rank);
+    TORCH_CHECK(rc == ncclSuccess, "ncclCommInitRank failed: ", ncclGetErrorString(rc));
+    std::lock_guard<std::mutex> lock(mu);
+    comm = c;
+  }
+
+  void disable_direct() {  // back to c10d (a rank failed to join: every rank must then take the same path)
+    drain();
+    std::lock_guard<std::mutex> lock(mu);
+    if (comm) (void)ncclCommDestroy(comm);
+    comm = nullptr;
   }
 
   void finish(int slot) {  // the current stream waits for the slot's unpack (the host only until the worker has issued it)
@@ -358,6 +406,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("launch", &PackedExchange::launch, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("wait", &PackedExchange::wait, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("drain", &PackedExchange::drain, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def_static("unique_id", &PackedExchange::unique_id)
+      .def("init_direct", &PackedExchange::init_direct, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def("disable_direct", &PackedExchange::disable_direct, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def("worker_us_per_slot", [](PackedExchange& e) { std::lock_guard<std::mutex> l(e.mu); return e.worker_slots ? e.worker_ns / 1e3 / (double)e.worker_slots : 0.0; })
       .def_readonly("compact", &PackedExchange::compact)
       .def_readonly("nbytes_padded", &PackedExchange::nbytes_padded);
 }

@@ -134,6 +134,28 @@ class PackedShardGather:
             self._native = _lib.bridge().PackedExchange(pg, self.b, self.n, self.m, torch.device(device), depth)
             assert self._native.nbytes_padded == self.nbytes_padded and bool(self._native.compact) == self.compact
             self.send = self.recv = None   # (the native object owns its buffers)
+            # PP_SHARD_EXCHANGE=rccl: the all-gather as a direct ncclAllGather on a communicator of the object's own
+            # (one RCCL call per exchange instead of c10d's Work / events / stream waits: the exchange's host side was
+            # what kept a config-2 step at 0.105 ms against 0.078 of kernels).  Opt-in: a second communicator beside
+            # c10d's must not run collectives in a different order on different ranks -- fine for this operator's one
+            # exchange per step, the caller's other collectives permitting; bench.py opts in.  Any failure to set it
+            # up leaves the c10d path in place.
+            self.direct = False
+            if os.environ.get("PP_SHARD_EXCHANGE", "native") == "rccl":
+                try:
+                    rank = dist.get_rank(group)
+                    box = [bytes(type(self._native).unique_id()) if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                    self._native.init_direct(box[0], rank)
+                    self.direct = True
+                except Exception as exc:   # noqa: BLE001 -- whatever went wrong, the c10d path still works
+                    import warnings
+                    warnings.warn("pytorch_points_amd: direct RCCL exchange not available (%s); using c10d" % (exc,))
+                ok = torch.tensor([1 if self.direct else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)     # every rank takes the same path
+                if int(ok.item()) == 0 and self.direct:
+                    self._native.disable_direct()
+                    self.direct = False
 
     def _views(self, buf):
         """(d1, d2, i1, i2) views of one rank's packed bytes (1-D uint8)"""
