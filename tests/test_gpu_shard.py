@@ -58,6 +58,7 @@ dev = torch.device("cuda:0")
 B, N, M = 3, 5000, 70000                                  # M > 65536: 32-bit indices; then a 16-bit case
 for (n, m) in ((N, M), (4096, 2048)):
     ex = PackedShardGather(B, n, m, dev)
+    assert bool(getattr(ex, 'direct', False)) == (os.environ.get('PP_SHARD_EXCHANGE') == 'rccl'), 'exchange path'
     gen = torch.Generator(device="cpu").manual_seed(n)
     steps = []
     for s in range(5):                                     # more launches than slots: the slots are reused
@@ -77,12 +78,13 @@ print("exchange ok")
 """
 
 
-@pytest.mark.parametrize("path", ["native", "python"])
+@pytest.mark.parametrize("path", ["native", "python", "rccl"])
 def test_packed_exchange_on_one_rank_rccl_group(cuda, tmp_path, path):
     """PackedShardGather on the GPU path proper: RCCL all-gather (a one-rank group: this box has one GPU),
     unpack on the side stream into the slot's buffers, slot reuse, 16- and 32-bit indices.  native: the whole exchange
     as one C++ call (csrc/torch_bridge.cpp: PackedExchange over c10d, round 3); python: the same steps issued from
-    Python (PP_SHARD_EXCHANGE=python).  In a subprocess: the process group must not leak into the other tests."""
+    Python (PP_SHARD_EXCHANGE=python); rccl: the native call with the all-gather as a direct ncclAllGather on the
+    exchange object's own communicator.  In a subprocess: the process group must not leak into the other tests."""
     import os
     import subprocess
     import sys
@@ -90,6 +92,6 @@ def test_packed_exchange_on_one_rank_rccl_group(cuda, tmp_path, path):
     script = tmp_path / "one_rank_exchange.py"
     script.write_text(_ONE_RANK_EXCHANGE)
     env = dict(os.environ, PP_SHARD_EXCHANGE=path)
-    out = subprocess.run([sys.executable, str(script), root, "29541" if path == "native" else "29543"], capture_output=True,
+    out = subprocess.run([sys.executable, str(script), root, {"native": "29541", "python": "29543", "rccl": "29545"}[path]], capture_output=True,
                          text=True, timeout=600, env=env)
     assert out.returncode == 0 and "exchange ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
