@@ -121,3 +121,42 @@ def test_fuzz_three_nn_and_knn(cuda, seed):
     e_d, e_i = oracle.knn(u, k, K)
     assert np.array_equal(out.idx.cpu().numpy(), e_i) and np.array_equal(out.dists.cpu().numpy(), e_d), \
         "knn seed %d b=%d n=%d m=%d K=%d" % (seed, b, n, m, K)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PP_FUZZ_SEEDS", "100")) // 2))
+def test_fuzz_far_and_offset_clouds(cuda, seed):
+    """round 3: clouds at random offsets and scales from each other (far-field group search: finite rim cells of an
+    untrimmed box, member-by-member row cuts, sifted candidates), with and without a few outliers (trimmed boxes),
+    far from the origin or not -- grid search forced, against the oracle"""
+    import ctypes
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd.network.model_loss import nndistance
+    rng = np.random.default_rng(7000 + seed)
+    b = int(rng.integers(1, 3))
+    n = int(rng.choice([2048, 3000, 4096, 6001, 8192]))
+    m = int(rng.choice([2048, 2500, 4096, 7000, 8192]))
+    x1 = _cloud(rng, b, n, int(rng.integers(0, 8)))
+    x2 = _cloud(rng, b, m, int(rng.integers(0, 8)))
+    x2 = x2 * np.float32(rng.choice([0.01, 0.3, 1.0, 5.0]))
+    direction = rng.standard_normal(3).astype(np.float32)
+    direction /= np.linalg.norm(direction)
+    x2 = x2 + direction * np.float32(rng.choice([0.0, 0.7, 3.0, 40.0]))
+    if seed % 3 == 0:      # a few outliers of one cloud inside / beside the other (a trimmed box with a populated rim)
+        k = int(rng.integers(1, 6))
+        x2[:, :k] = x1[:, :k] + np.float32(1e-3)
+    if seed % 5 == 0:      # both far from the origin
+        shift = np.float32(rng.choice([100.0, 3000.0]))
+        x1, x2 = x1 + shift, x2 + shift
+    x1, x2 = np.ascontiguousarray(x1, np.float32), np.ascontiguousarray(x2, np.float32)
+    knob = _lib.lib().pp_debug_set_nmdistance_search
+    knob.argtypes = [ctypes.c_int]
+    knob.restype = None
+    knob(2)
+    try:
+        got = nndistance(torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda))
+    finally:
+        knob(0)
+    exp = oracle.chamfer_forward(x1, x2)
+    for g, e, what in zip((got[0], got[2], got[1], got[3]), exp, ("dist1", "idx1", "dist2", "idx2")):
+        assert np.array_equal(g.cpu().numpy(), e), "seed %d (b=%d n=%d m=%d): %s differs at %d places" % (
+            seed, b, n, m, what, int((g.cpu().numpy() != e).sum()))
