@@ -15,7 +15,7 @@
 // v1 decomposition: one 1024-thread workgroup per batch element, thread t owns k = t + 1024*i;
 // the running minima (temp) live in registers for the whole call (read once, written once), the
 // coordinates are re-read from L2 every step, one barrier per step (double-buffered LDS slots).
-#include "pp_common.h"
+#include "fps_common.h"
 
 // per-step phase marks of the cluster kernel (tools/fps_probe.hip accumulates clocks; nothing otherwise)
 #ifndef PP_FPS_MARK
@@ -26,92 +26,10 @@
 namespace {
 
 using pp::dist3;
+using namespace ppfps;
 
 constexpr int kFpsThreads = 1024;
 constexpr int kFpsWaves = kFpsThreads / 64;
-
-// Wave-wide unsigned 64-bit max, result in every lane.  DPP row shifts / row broadcasts (VALU
-// speed, no LDS crossbar): six steps leave the maximum in lane 63, one v_readlane pair broadcasts
-// it.  max is idempotent, so full row/bank masks are fine (an element may be folded in twice).
-// (2.10 -> 1.78 us per pick at config 3 against the __shfl_xor butterfly.)
-template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
-  const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
-  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
-  const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
-  return o > v ? o : v;
-}
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-  v = dpp_max_step<0x111>(v);  // row_shr:1
-  v = dpp_max_step<0x112>(v);  // row_shr:2
-  v = dpp_max_step<0x114>(v);  // row_shr:4
-  v = dpp_max_step<0x118>(v);  // row_shr:8   -> lane 15 of each row holds the row maximum
-  v = dpp_max_step<0x142>(v);  // row_bcast:15
-  v = dpp_max_step<0x143>(v);  // row_bcast:31 -> lane 63 holds the wave maximum
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-// The same maximum as two 32-bit passes -- the high words, then the low words of the lanes that hold the
-// maximal high word -- each a chain of six in-place `v_max_u32_dpp` (lanes without a source keep their
-// value; a nop between dependent DPP operations, which need two wait states after the VALU write): 12
-// VALU instructions instead of the 30 of the 64-bit compare-and-select steps above.  Every lane active.
-template <int STEPS>
-__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
-  static_assert(STEPS == 3 || STEPS == 4 || STEPS == 6, "");
-  if constexpr (STEPS == 3) {  // values in lanes 0..7 -> lane 7
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-        : "+v"(x));
-    return (unsigned)__builtin_amdgcn_readlane((int)x, 7);
-  } else if constexpr (STEPS == 4) {  // values in lanes 0..15 -> lane 15
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
-        : "+v"(x));
-    return (unsigned)__builtin_amdgcn_readlane((int)x, 15);
-  } else {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
-        "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
-        : "+v"(x));
-    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
-  }
-}
-// STEPS = 6: all 64 lanes; 4: the values sit in lanes 0..15; 3: in lanes 0..7 (what the other lanes hold is
-// ignored: row shifts only move values towards higher lanes)
-template <int STEPS>
-__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v) {
-  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
-  const unsigned mh = wave_max_u32<STEPS>(hi);
-  const unsigned ml = wave_max_u32<STEPS>(hi == mh ? lo : 0u);
-  return ((unsigned long long)mh << 32) | ml;
-}
-
-struct TieOrder {
-  int t_mask;   // T - 1
-  int t_shift;  // log2(T)
-  int rows;     // ceil(N / T)
-  __device__ __forceinline__ unsigned rank(int k) const {
-    return (unsigned)((k & t_mask) * rows + (k >> t_shift));
-  }
-  __device__ __forceinline__ int unrank(unsigned r) const {
-    return (int)((r % (unsigned)rows) << t_shift) + (int)(r / (unsigned)rows);
-  }
-};
 
 // R > 0: temp of this thread's R points in registers.  R == 0: temp stays in global memory
 // (any N); slower, only used when N > 1024 * 64.
@@ -223,7 +141,6 @@ constexpr int kClThreads = 512;
 constexpr int kClWaves = kClThreads / 64;
 constexpr unsigned long long kSpinLimitTicks = 200000000ull;  // 2 s at 100 MHz
 
-typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 
 struct ClusterGeom {
@@ -410,12 +327,20 @@ void launch_fps(const float* xyz, float* temp, int* idx, int B, int N, int npoin
 static pp::Knob g_fps_force_v1;
 extern "C" void pp_debug_set_fps_v1(int on) { g_fps_force_v1.set(on); }
 
-extern "C" size_t pp_furthest_sampling_workspace_bytes(int B, int N, int npoint) {
-  (void)npoint;
-  if (B <= 0 || N <= 0) return 0;
+// bytes of the cluster kernel's ring (0 = that kernel does not serve these sizes), 256-byte granules
+static size_t ring_bytes(int B, int N) {
   const int cl = pick_cluster(B, N);
   if (cl == 0) return 0;
-  return kFpsErrBytes + (size_t)8 * ((B + 7) / 8) * 2 * cl * sizeof(u64);
+  return ((size_t)8 * ((B + 7) / 8) * 2 * cl * sizeof(u64) + 255) / 256 * 256;
+}
+
+// layout: status word (256 B) | ring of the cluster kernel | scratch of the bucketed kernel
+extern "C" size_t pp_furthest_sampling_workspace_bytes(int B, int N, int npoint) {
+  if (B <= 0 || N <= 0) return 0;
+  const size_t ring = ring_bytes(B, N);
+  const size_t bucket = ppfps::bucket_applies(B, N, npoint) ? ppfps::bucket_workspace_bytes(B, N) : 0;
+  if (ring == 0 && bucket == 0) return 0;
+  return kFpsErrBytes + ring + bucket;
 }
 
 // 0 = ok; 1 = a cluster wait timed out in some earlier call that used this workspace (that call's
@@ -455,8 +380,19 @@ extern "C" int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, in
   order.t_shift = __builtin_ctz((unsigned)T);
   order.rows = (N + T - 1) / T;
   if ((long long)T * order.rows > 0xFFFFFFFELL) return PP_EINVAL;
+  // The bucketed kernel (fps_bucket.hip) wherever it applies: a step visits the buckets the pick can change instead
+  // of every point, and no workgroup waits for another.  Knob: 0 = this choice, 1 = one workgroup per batch element
+  // over all points, 2 = the CU cluster over all points, 3 = bucketed.
+  const int form = g_fps_force_v1;
+  if ((form == 0 || form == 3) && ppfps::bucket_applies(B, N, npoint)) {
+    const size_t need = pp_furthest_sampling_workspace_bytes(B, N, npoint);
+    if (workspace && workspace_bytes >= need)
+      return ppfps::bucket_launch(xyz, temp, idx, B, N, npoint, seed_idx, order,
+                                  (char*)workspace + kFpsErrBytes + ring_bytes(B, N), sampled, cf, s);
+    if (form == 3) return PP_EINVAL;
+  }
   // (the cluster kernel's per-thread tie rule assumes the reference's thread count equals its point stride)
-  int cl = (g_fps_force_v1 || T != kClThreads) ? 0 : pick_cluster(B, N);
+  int cl = (form == 1 || T != kClThreads) ? 0 : pick_cluster(B, N);
   if (cl >= 2 && npoint > 1) {
     // the members of a cluster spin on each other: never launch more workgroups than this device keeps
     // resident at once (a partitioned device, a CU mask).  Fewer CUs -> a smaller cluster or the
@@ -472,7 +408,7 @@ extern "C" int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, in
     if (cl >= 2 && (long long)8 * ((B + 7) / 8) * cl > blocks_for(r_of(cl))) cl = 0;
   }
   if (cl >= 2 && npoint > 1) {
-    const size_t need = pp_furthest_sampling_workspace_bytes(B, N, npoint);
+    const size_t need = kFpsErrBytes + ring_bytes(B, N);
     if (!workspace || workspace_bytes < need) return PP_EINVAL;
     ClusterGeom geo;
     geo.cl = cl;
@@ -481,7 +417,7 @@ extern "C" int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, in
     // reset the ring (tag 0xFF never matches a step tag).  The status word in front of it is STICKY: the
     // caller zeroes it once after allocating the workspace, a timed-out wait sets it, and it stays set until
     // the caller clears it -- so a failure cannot be wiped out by the next call before anybody has looked.
-    hipError_t e = hipMemsetAsync((char*)workspace + kFpsErrBytes, 0xFF, need - kFpsErrBytes, s);
+    hipError_t e = hipMemsetAsync((char*)workspace + kFpsErrBytes, 0xFF, ring_bytes(B, N), s);
     if (e != hipSuccess) return (int)e;
     u64* ring = (u64*)((char*)workspace + kFpsErrBytes);
     unsigned* err = (unsigned*)workspace;

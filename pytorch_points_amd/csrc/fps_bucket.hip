@@ -1,0 +1,543 @@
+// fps_bucket.hip -- exact furthest point sampling over a spatially bucketed cloud (gfx950).
+// Third decomposition of the reference's furthest_point_sampling_forward_kernel
+// (_ext/sampling_cuda.cu:162-233); same picks, same temp, bit for bit (semantics: fps.hip's header,
+// SURVEY.md Appendix A.3).
+//
+// The reference's step visits every point: d2 = min(dist3(x_k, x_old), temp[k]).  A point's temp only
+// changes if the new pick is closer than every earlier one, i.e. for the points of the pick's own
+// neighbourhood -- N / j of them on average at step j.  So the cloud is sorted ONCE into buckets of 64
+// (64 m) points that are neighbours in space, and a step only visits the buckets it can change:
+//
+//   * per bucket, in the registers of ONE thread of the workgroup: its bounding box, the 64-bit key
+//     {float_bits(max temp) : 32 | ~tie_rank : 32} of its best point, and that point's coordinates;
+//   * a pick p SKIPS a bucket when box_d2(p) >= max temp, where box_d2 is dist3's own instruction
+//     sequence applied to the per-axis gaps max(lo - p, p - hi, 0).  Every fp32 operation of that
+//     sequence is monotone, so box_d2 <= dist3(x_k, p) for every point of the box EXACTLY (no slack):
+//     then min(d, temp[k]) = temp[k] for all of them -- the step would not have changed a bit there;
+//   * a touched bucket is re-evaluated by one wave (a lane per point: the reference's arithmetic,
+//     temp written back only where it changed, as the reference does) and its key refreshed;
+//   * the next pick is the maximum of the bucket keys: one DPP reduction per wave, one barrier, one
+//     16-value reduction.  The winner's coordinates travel with its key through LDS, so the chain of a
+//     step holds no dependent global load except the touched buckets' points (L2 hits).
+//
+// One 1024-thread workgroup per batch element does all of it -- sort, bucket summaries, the serial
+// chain -- so nothing waits for another workgroup: no cluster, no polling, no co-residency condition,
+// no timeout.  Late steps touch 4-10 buckets (a few hundred points instead of N).
+//
+// The sort is a counting sort by a 15-bit cell key (LDS histogram, 32768 bins).  The 15 bits are dealt
+// to the axes greedily (always halve the axis whose cells are longest, at most 8 bits per axis), and
+// interleaved in that order, so surfaces, slabs and volumes all get roughly cubic cells in a
+// Z-order-like sequence.  Any order is CORRECT (the boxes are computed from the points); a good one
+// is fast.
+#include "fps_common.h"
+
+// phase clocks and touched-bucket counts of the chain (tools/fps_bucket_probe.hip defines these; nothing otherwise)
+#ifndef PP_FPSB_DOUBLE
+#define PP_FPSB_DOUBLE 0  // probe builds: bit k set = one link of the chain is executed twice (same results)
+#endif
+#ifndef PP_FPSB_PROBE_DECL
+#define PP_FPSB_PROBE_DECL
+#define PP_FPSB_MARK(n)
+#define PP_FPSB_TOUCHED(mask)
+#define PP_FPSB_END()
+#endif
+
+namespace {
+
+using pp::dist3;
+using pp::f4;
+using namespace ppfps;
+
+constexpr int kBkThreads = 1024;
+constexpr int kBkWaves = kBkThreads / 64;
+constexpr int kBkBits = 15;
+constexpr int kBkBins = 1 << kBkBits;
+constexpr int kBkAxisBits = 8;  // at most this many key bits per axis (LUT of 256 entries per axis)
+constexpr int kBkLdsBytes = kBkBins * 4;
+
+struct BucketGeom {
+  int m;     // a bucket = 64 m consecutive points of the sorted order
+  int nb;    // buckets per batch element (<= 1024)
+  int npad;  // nb * 64 * m
+  int naux;  // entries of `aux` per batch element: npad, or 65536 when m == 1 (a register per bucket and lane)
+};
+
+__device__ __forceinline__ int wave_scan_incl(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+__device__ __forceinline__ float rl(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Wave-wide maximum of 64-bit keys {hi, lo} and the lane that holds it.  One chain of six `v_max_u32_dpp` over the
+// high words; the low words only matter when several lanes hold the maximal high word (exactly equal distances:
+// duplicates, lattices) -- then, and only then, a second chain over those lanes' low words.  Keys are distinct
+// (the tie ranks are), except all-zero keys of padding lanes, which never win against a real point.
+__device__ __forceinline__ u64 wave_argmax_key(unsigned hi, unsigned lo, int& src) {
+  const unsigned mh = wave_max_u32<6>(hi);
+  u64 tied = __ballot(hi == mh);
+  unsigned ml;
+  if (__builtin_popcountll(tied) > 1) {
+    ml = wave_max_u32<6>(hi == mh ? lo : 0u);
+    tied = __ballot(hi == mh && lo == ml);
+    src = __builtin_ctzll(tied);
+  } else {
+    src = __builtin_ctzll(tied);
+    ml = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+  }
+  return ((u64)mh << 32) | ml;
+}
+
+constexpr unsigned kRcMax = 0x0FFFFFFFu;  // ~tie rank in 28 bits (rank < N + 512 <= 2^22 + 2^9); four bits below it
+                                          // carry the wave number in the workgroup-wide maximum
+
+// REG (buckets of exactly 64 points, N <= 65536): the running minima live in REGISTERS -- lane i of wave w keeps
+// temp of point i of each of the wave's 64 buckets (td[l], indexed by the wave-uniform bucket number) -- so a visit is
+// one 16-byte load per lane (x, y, z, ~tie rank) and no store at all: nothing in the chain waits for a write to be
+// acknowledged.  Otherwise (larger clouds) temp travels in the record's fourth word and ~tie rank in an array of its
+// own (`aux`); with REG `aux` holds the incoming temp in sorted order, read once.
+template <bool REG>
+__global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
+    const float* __restrict__ xyz, float* __restrict__ temp, int* __restrict__ idx, int N, int npoint,
+    int seed, TieOrder order, BucketGeom geo, f4* __restrict__ sorted_all, unsigned* __restrict__ aux_all,
+    float* __restrict__ sampled, int cf) {
+  extern __shared__ unsigned s_hist[];  // kBkBins counters, then cursors (the sort only)
+  __shared__ float s_box[kBkWaves][6];
+  __shared__ int s_wsum[kBkWaves];
+  __shared__ unsigned s_lut[3][1 << kBkAxisBits];
+  __shared__ u64 s_g[3];
+  __shared__ float s_c[3][kBkWaves][4];
+
+  const int b = blockIdx.x;
+  const float* __restrict__ p = xyz + (size_t)b * N * 3;
+  float* __restrict__ tmp = temp + (size_t)b * N;
+  int* __restrict__ out = idx + (size_t)b * npoint;
+  f4* __restrict__ sorted = sorted_all + (size_t)b * geo.npad;
+  unsigned* __restrict__ rc = aux_all + (size_t)b * geo.naux;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = pp::wave_id_uniform();
+
+  // ---------------------------------------------------------------- A. bounding box of the cloud
+  {
+    float v[6] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};  // -lo, hi
+    for (int k = t; k < N; k += kBkThreads) {
+      const float x = p[3 * (size_t)k], y = p[3 * (size_t)k + 1], z = p[3 * (size_t)k + 2];
+      v[0] = fmaxf(v[0], -x); v[1] = fmaxf(v[1], -y); v[2] = fmaxf(v[2], -z);
+      v[3] = fmaxf(v[3], x);  v[4] = fmaxf(v[4], y);  v[5] = fmaxf(v[5], z);
+    }
+    pp::wave_reduce6_dpp<false, 6>(v);
+    if (lane == 63)
+      for (int a = 0; a < 6; ++a) s_box[wave][a] = v[a];
+  }
+  __syncthreads();
+  float blo[3], bsc[3];
+  int qmax[3];
+  {
+    float bv[6];
+    for (int a = 0; a < 6; ++a) {
+      float m = s_box[0][a];
+      for (int w = 1; w < kBkWaves; ++w) m = fmaxf(m, s_box[w][a]);
+      bv[a] = m;
+    }
+    // ---------------------------------------------------------------- B. key plan: 15 bits dealt to the axes
+    float e0 = bv[3] + bv[0], e1 = bv[4] + bv[1], e2 = bv[5] + bv[2];  // extents (hi - lo)
+    const float ext0 = e0, ext1 = e1, ext2 = e2;
+    int n0 = 0, n1 = 0, n2 = 0;
+    unsigned plan = 0;  // two bits per step, first step in the low bits
+    for (int s = 0; s < kBkBits; ++s) {
+      const float c0 = n0 < kBkAxisBits ? e0 : -INFINITY, c1 = n1 < kBkAxisBits ? e1 : -INFINITY,
+                  c2 = n2 < kBkAxisBits ? e2 : -INFINITY;
+      int a = 0;
+      float best = c0;
+      if (c1 > best) { a = 1; best = c1; }
+      if (c2 > best) { a = 2; best = c2; }
+      // (nothing compares greater when no axis has a finite extent: take the first axis with room)
+      if (a == 0 && n0 >= kBkAxisBits) a = n1 < kBkAxisBits ? 1 : 2;
+      plan |= (unsigned)a << (2 * s);
+      if (a == 0) { ++n0; e0 *= 0.5f; } else if (a == 1) { ++n1; e1 *= 0.5f; } else { ++n2; e2 *= 0.5f; }
+    }
+    blo[0] = -bv[0]; blo[1] = -bv[1]; blo[2] = -bv[2];
+    qmax[0] = (1 << n0) - 1; qmax[1] = (1 << n1) - 1; qmax[2] = (1 << n2) - 1;
+    // cells per unit length; an empty or unbounded extent puts everything into cell 0 of that axis
+    bsc[0] = (ext0 > 0.0f && ext0 < INFINITY) ? (float)(1 << n0) / ext0 : 0.0f;
+    bsc[1] = (ext1 > 0.0f && ext1 < INFINITY) ? (float)(1 << n1) / ext1 : 0.0f;
+    bsc[2] = (ext2 > 0.0f && ext2 < INFINITY) ? (float)(1 << n2) / ext2 : 0.0f;
+    // per-axis table: cell coordinate -> its bits at their places in the key
+    if (t < 3 * (1 << kBkAxisBits)) {
+      const int a = t >> kBkAxisBits, q = t & ((1 << kBkAxisBits) - 1);
+      int left = a == 0 ? n0 : a == 1 ? n1 : n2;
+      unsigned val = 0;
+      for (int s = 0; s < kBkBits; ++s)
+        if ((int)((plan >> (2 * s)) & 3u) == a) {
+          --left;
+          val |= (unsigned)((q >> left) & 1) << (kBkBits - 1 - s);
+        }
+      s_lut[a][q] = val;
+    }
+  }
+  for (int i = t; i < kBkBins; i += kBkThreads) s_hist[i] = 0u;
+  if (t < 3) s_g[t] = 0ull;
+  __syncthreads();
+  auto key_of = [&](float x, float y, float z) -> unsigned {
+    const int qx = min(max((int)((x - blo[0]) * bsc[0]), 0), qmax[0]);
+    const int qy = min(max((int)((y - blo[1]) * bsc[1]), 0), qmax[1]);
+    const int qz = min(max((int)((z - blo[2]) * bsc[2]), 0), qmax[2]);
+    return s_lut[0][qx] | s_lut[1][qy] | s_lut[2][qz];
+  };
+  // ---------------------------------------------------------------- C. count
+  for (int k = t; k < N; k += kBkThreads)
+    atomicAdd(&s_hist[key_of(p[3 * (size_t)k], p[3 * (size_t)k + 1], p[3 * (size_t)k + 2])], 1u);
+  __syncthreads();
+  // ---------------------------------------------------------------- D. exclusive scan (a wave per 2048 bins)
+  {
+    constexpr int kRows = kBkBins / kBkWaves / 64;
+    int carry = 0;
+    for (int r = 0; r < kRows; ++r) {
+      const int i = wave * (kBkBins / kBkWaves) + 64 * r + lane;
+      const int c = (int)s_hist[i];
+      const int inc = wave_scan_incl(c);
+      s_hist[i] = (unsigned)(carry + inc - c);
+      carry += __builtin_amdgcn_readlane(inc, 63);
+    }
+    if (lane == 0) s_wsum[wave] = carry;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+    for (int r = 0; r < kRows; ++r) s_hist[wave * (kBkBins / kBkWaves) + 64 * r + lane] += (unsigned)base;
+  }
+  __syncthreads();
+  // ---------------------------------------------------------------- E. scatter: (x, y, z, temp) and ~tie rank
+  for (int k = t; k < N; k += kBkThreads) {
+    const float x = p[3 * (size_t)k], y = p[3 * (size_t)k + 1], z = p[3 * (size_t)k + 2];
+    const unsigned pos = atomicAdd(&s_hist[key_of(x, y, z)], 1u);
+    f4 rec;
+    rec.x = x; rec.y = y; rec.z = z;
+    if (REG) {
+      rec.w = __uint_as_float(kRcMax - order.rank(k));
+      rc[pos] = __float_as_uint(tmp[k]);
+    } else {
+      rec.w = tmp[k];
+      rc[pos] = kRcMax - order.rank(k);
+    }
+    sorted[pos] = rec;
+  }
+  // padding behind the last point: temp 0 and the lowest key -- never picked, never rewritten
+  for (int pos = N + t; pos < geo.npad; pos += kBkThreads) {
+    f4 rec;
+    rec.x = 0.0f; rec.y = 0.0f; rec.z = 0.0f; rec.w = 0.0f;
+    sorted[pos] = rec;
+  }
+  for (int pos = N + t; pos < geo.naux; pos += kBkThreads) rc[pos] = 0u;
+  __syncthreads();  // (the stores are drained before the barrier; one CU, one L1: visible to every wave)
+
+  // ---------------------------------------------------------------- F. bucket summaries + the seed's step
+  // thread (wave w, lane l) owns bucket l * 16 + w: neighbouring buckets live in different waves, so the
+  // handful of buckets a pick touches are re-evaluated side by side.
+  const int m = geo.m;
+  const int bsize = 64 * m;
+  float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
+  u64 bkey = 0ull;
+  float ax = 0.0f, ay = 0.0f, az = 0.0f;
+  float ox = p[3 * (size_t)seed], oy = p[3 * (size_t)seed + 1], oz = p[3 * (size_t)seed + 2];
+  ox = rl(ox, 0); oy = rl(oy, 0); oz = rl(oz, 0);
+  float* __restrict__ smp = sampled ? sampled + (size_t)b * npoint * 3 : nullptr;
+  auto put = [&](int j, float x, float y, float z) {
+    if (cf) {
+      smp[j] = x; smp[(size_t)npoint + j] = y; smp[2 * (size_t)npoint + j] = z;
+    } else {
+      smp[3 * (size_t)j] = x; smp[3 * (size_t)j + 1] = y; smp[3 * (size_t)j + 2] = z;
+    }
+  };
+  if (t == 0) {
+    out[0] = seed;
+    if (smp) put(0, ox, oy, oz);
+  }
+  // evaluate one bucket against the pick (ox, oy, oz): the reference's step for its 64 m points; a lane's best
+  // point as (distance bits, ~tie rank) and its coordinates
+  // td: lane i's running minimum for point i of each of the wave's 64 buckets.  Buckets 0..31 of the wave: one
+  // 32-element register vector, read and written with a WAVE-UNIFORM index (the compiler indexes the register file
+  // for that: s_set_gpr_idx_on / v_mov_b32).  Buckets 32..63: the 128 KB of LDS the sort's histogram occupied
+  // (a word per lane: conflict-free).  (A 64-entry array indexed by a variable went to scratch memory; a 64-way
+  // switch over constant indices cost a thousand cycles a visit in register shuffling; two register vectors met in
+  // 32-register copies or one of them in scratch.)
+  typedef float f32x32 __attribute__((ext_vector_type(32)));
+  f32x32 td_lo;
+  float* const s_td = (float*)s_hist + (wave * 32 * 64 + lane);
+  auto td_get = [&](int l) -> float { return l < 32 ? td_lo[l] : s_td[(l - 32) * 64]; };
+  auto td_set = [&](int l, float v) {
+    if (l < 32) td_lo[l] = v; else s_td[(l - 32) * 64] = v;
+  };
+  auto td_min = [&](int l, float d) -> float {
+    float d2 = 0.0f;
+    if (REG) {
+      d2 = __builtin_fminf(d, td_get(l));
+      td_set(l, d2);
+    }
+    return d2;
+  };
+  auto visit = [&](int l, int bk, unsigned& whi, unsigned& wlo, float& wx, float& wy, float& wz) {
+    f4* __restrict__ sp = sorted + (unsigned)(bk * bsize + lane);
+    if (REG) {
+      const f4 q = sp[0];
+      const float d = dist3(q.x, q.y, q.z, ox, oy, oz);
+      const float d2 = td_min(l, d);
+      whi = __float_as_uint(d2);
+      wlo = __float_as_uint(q.w);
+      wx = q.x; wy = q.y; wz = q.z;
+      return;
+    }
+    const unsigned* __restrict__ rp = rc + (unsigned)(bk * bsize + lane);
+    if (m == 1) {
+      const f4 q = sp[0];
+      wlo = rp[0];
+      const float d = dist3(q.x, q.y, q.z, ox, oy, oz);
+      const float d2 = __builtin_fminf(d, q.w);
+      if (d2 != q.w) ((float*)sp)[3] = d2;  // (ref: written only when changed, :203-205)
+      whi = __float_as_uint(d2);
+      wx = q.x; wy = q.y; wz = q.z;
+      return;
+    }
+    u64 wk = 0ull;
+    wx = wy = wz = 0.0f;
+    for (int r = 0; r < m; ++r) {
+      const f4 q = sp[64 * r];
+      const unsigned c = rp[64 * r];
+      const float d = dist3(q.x, q.y, q.z, ox, oy, oz);
+      const float d2 = __builtin_fminf(d, q.w);
+      if (d2 != q.w) ((float*)(sp + 64 * r))[3] = d2;
+      const u64 k = ((u64)__float_as_uint(d2) << 32) | c;
+      if (k > wk) { wk = k; wx = q.x; wy = q.y; wz = q.z; }
+    }
+    whi = (unsigned)(wk >> 32);
+    wlo = (unsigned)wk;
+  };
+  if (REG) {  // (`aux` has 65536 entries per batch element in this form; behind the last point: zeros)
+    unsigned first = (unsigned)(wave * 64 + lane);
+#pragma unroll
+    for (int l = 0; l < 64; ++l) td_set(l, __uint_as_float(rc[first + (unsigned)(l * kBkWaves * 64)]));
+  }
+  if (npoint > 1) {
+    for (int l = 0; l < 64; ++l) {
+      const int bk = l * kBkWaves + wave;
+      if (bk >= geo.nb) break;  // (uniform)
+      // box of the bucket's real points
+      float v[6] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      for (int r = 0; r < m; ++r) {
+        const int pos = bk * bsize + 64 * r + lane;
+        if (pos < N) {
+          const f4 q = sorted[pos];
+          v[0] = fmaxf(v[0], -q.x); v[1] = fmaxf(v[1], -q.y); v[2] = fmaxf(v[2], -q.z);
+          v[3] = fmaxf(v[3], q.x);  v[4] = fmaxf(v[4], q.y);  v[5] = fmaxf(v[5], q.z);
+        }
+      }
+      pp::wave_reduce6_dpp<false, 6>(v);
+      const float b0 = rl(v[0], 63), b1 = rl(v[1], 63), b2 = rl(v[2], 63), b3 = rl(v[3], 63), b4 = rl(v[4], 63),
+                  b5 = rl(v[5], 63);
+      unsigned whi, wlo;
+      float wx, wy, wz;
+      visit(l, bk, whi, wlo, wx, wy, wz);
+      int src;
+      const u64 M = wave_argmax_key(whi, wlo, src);
+      const float cx = rl(wx, src), cy = rl(wy, src), cz = rl(wz, src);
+      if (lane == l) {
+        lox = -b0; loy = -b1; loz = -b2; hix = b3; hiy = b4; hiz = b5;
+        bkey = M; ax = cx; ay = cy; az = cz;
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- G. the chain
+  // Keys only ever fall (temp = min(...)), so a wave's best bucket stays its best until that very bucket is
+  // re-evaluated: only then is the wave's maximum taken again.  The workgroup's maximum is ONE LDS atomic per wave
+  // (ds_max_u64 on a word of a three-deep ring, the wave's number in the key's low bits), one barrier, one read.
+  u64 wkey = 0ull;
+  int wl = 0;  // the lane whose bucket holds wkey
+  float wcx = 0.0f, wcy = 0.0f, wcz = 0.0f;
+  bool redo = true;
+  int buf = 1;  // j % 3
+  PP_FPSB_PROBE_DECL
+  for (int j = 1; j < npoint; ++j) {
+    PP_FPSB_MARK(0);
+    if (redo) {  // this wave's best bucket
+      wkey = wave_argmax_key((unsigned)(bkey >> 32), (unsigned)bkey, wl);
+      wcx = rl(ax, wl); wcy = rl(ay, wl); wcz = rl(az, wl);
+    }
+    if (lane == 0) {
+      s_c[buf][wave][0] = wcx; s_c[buf][wave][1] = wcy; s_c[buf][wave][2] = wcz;
+      __hip_atomic_fetch_max(&s_g[buf], (wkey & 0xFFFFFFFF00000000ull) | ((wkey & (u64)kRcMax) << 4) | (u64)wave,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    PP_FPSB_MARK(1);
+    // LDS only: what the loop writes to global memory (temp, the picks) is read back by the SAME wave (a bucket is
+    // always visited by its owner's wave) or after the loop's closing __syncthreads -- no store's acknowledgement is
+    // waited for here
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (PP_FPSB_DOUBLE & 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    PP_FPSB_MARK(2);
+    const u64 G = s_g[buf];
+    const int wv = (int)(G & 15ull);
+    ox = s_c[buf][wv][0]; oy = s_c[buf][wv][1]; oz = s_c[buf][wv][2];
+    // the pick, as its ~tie rank (turned into the index after the loop: a division, off the chain); one wave per
+    // step stores, in turn; and the ring word of the step after the next is cleared (nobody reads it any more)
+    const int nbuf = buf == 2 ? 0 : buf + 1;
+    if (t == ((j & (kBkWaves - 1)) << 6)) {
+      out[j] = (int)((unsigned)(G >> 4) & kRcMax);
+      if (smp) put(j, ox, oy, oz);
+      s_g[nbuf == 2 ? 0 : nbuf + 1] = 0ull;
+    }
+    buf = nbuf;
+    if (j == npoint - 1) break;  // (ref: temp ends as the minimum over every pick but the last)
+    PP_FPSB_MARK(3);
+    // which of my buckets can this pick change?
+    const float gx = fmaxf(fmaxf(lox - ox, ox - hix), 0.0f);
+    const float gy = fmaxf(fmaxf(loy - oy, oy - hiy), 0.0f);
+    const float gz = fmaxf(fmaxf(loz - oz, oz - hiz), 0.0f);
+    const float bd = __builtin_fmaf(gz, gz, __builtin_fmaf(gx, gx, gy * gy));
+    const float bmax = __uint_as_float((unsigned)(bkey >> 32));
+    u64 mask = __ballot(!(bd >= bmax));
+    if (PP_FPSB_DOUBLE & 16) {  // the box test and its ballot once more, dependent on the first
+      float gx2 = fmaxf(fmaxf(lox - ox, ox - hix), __uint_as_float((unsigned)mask & 0u));
+      asm volatile("" : "+v"(gx2));
+      const float bd2 = __builtin_fmaf(gz, gz, __builtin_fmaf(gx2, gx2, gy * gy));
+      mask = __ballot(!(bd2 >= bmax));
+    }
+    if (PP_FPSB_DOUBLE & 32) mask = 0;  // no visits at all (WRONG picks: the cost of a step without its visits)
+    redo = (mask >> wl) & 1ull;
+    PP_FPSB_TOUCHED(mask);
+    PP_FPSB_MARK(4);
+    if (REG) {
+      // A step lasts as long as its busiest wave (one step in nine has a wave with two or more buckets to visit):
+      // the next bucket's record is loaded before this one is evaluated, so every visit after the first costs its
+      // arithmetic only.
+      const unsigned at = (unsigned)(wave * 64 + lane);
+      int l = 0;
+      f4 q;
+      float told = 0.0f;
+      if (mask) {
+        l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        q = sorted[at + (unsigned)l * (kBkWaves * 64)];
+        told = td_get(l);
+      } else {
+        l = -1;
+      }
+      while (l >= 0) {
+        int ln = -1;
+        f4 qn = q;
+        float tn = 0.0f;
+        if (mask) {
+          ln = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          qn = sorted[at + (unsigned)ln * (kBkWaves * 64)];
+          tn = td_get(ln);
+        }
+        if (PP_FPSB_DOUBLE & 1) {  // a second, dependent load of the same record
+          const unsigned zero = __float_as_uint(q.x) & 0u;
+          asm volatile("" ::: "memory");
+          q = sorted[at + (unsigned)l * (kBkWaves * 64) + zero];
+        }
+        if (PP_FPSB_DOUBLE & 2) td_set(l, __builtin_fminf(INFINITY, td_get(l)));
+        const float d2 = __builtin_fminf(dist3(q.x, q.y, q.z, ox, oy, oz), told);
+        td_set(l, d2);
+        const unsigned whi = __float_as_uint(d2);
+        int src;
+        if (PP_FPSB_DOUBLE & 4) {
+          u64 M0 = wave_argmax_key(whi, __float_as_uint(q.w), src);
+          asm volatile("" : "+s"(src), "+s"(M0));
+        }
+        const u64 M = wave_argmax_key(whi, __float_as_uint(q.w), src);
+        const float cx = rl(q.x, src), cy = rl(q.y, src), cz = rl(q.z, src);
+        if (lane == l) { bkey = M; ax = cx; ay = cy; az = cz; }
+        l = ln;
+        q = qn;
+        told = tn;
+      }
+    } else {
+      while (mask) {
+        const int l = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        unsigned whi, wlo;
+        float wx, wy, wz;
+        visit(l, l * kBkWaves + wave, whi, wlo, wx, wy, wz);
+        int src;
+        const u64 M = wave_argmax_key(whi, wlo, src);
+        const float cx = rl(wx, src), cy = rl(wy, src), cz = rl(wz, src);
+        if (lane == l) { bkey = M; ax = cx; ay = cy; az = cz; }
+      }
+    }
+    PP_FPSB_MARK(5);
+  }
+  PP_FPSB_END();
+  __syncthreads();
+  // ---------------------------------------------------------------- H. picks as indices; temp back in place
+  for (int j = 1 + t; j < npoint; j += kBkThreads) out[j] = order.unrank(kRcMax - (unsigned)out[j]);
+  if (REG) {
+    unsigned first = (unsigned)(wave * 64 + lane);
+    asm volatile("" : "+v"(first));  // (computed afresh: sixty-four addresses kept alive across the chain spilled)
+#pragma unroll
+    for (int l = 0; l < 64; ++l) {
+      const unsigned pos = first + (unsigned)(l * kBkWaves * 64);
+      if (pos < (unsigned)N) tmp[order.unrank(kRcMax - __float_as_uint(sorted[pos].w))] = td_get(l);
+    }
+  } else {
+    for (int pos = t; pos < N; pos += kBkThreads) tmp[order.unrank(kRcMax - rc[pos])] = sorted[pos].w;
+  }
+}
+
+pp::DeviceFlags g_bucket_lds[2];
+
+}  // namespace
+
+namespace ppfps {
+
+// buckets of 64 m points, at most 1024 of them (one per thread)
+static BucketGeom bucket_geom(int N) {
+  BucketGeom g;
+  g.m = (N + 65535) / 65536;
+  if (g.m < 1) g.m = 1;
+  g.nb = (N + 64 * g.m - 1) / (64 * g.m);
+  g.npad = g.nb * 64 * g.m;
+  g.naux = g.m == 1 ? 65536 : g.npad;
+  return g;
+}
+
+bool bucket_applies(int B, int N, int npoint) {
+  (void)B;
+  // the sort pays for itself after a few dozen steps; tie ranks and positions are 32-bit
+  return N >= 2048 && N <= (1 << 22) && npoint >= 32;
+}
+
+size_t bucket_workspace_bytes(int B, int N) {
+  const BucketGeom g = bucket_geom(N);
+  return (size_t)B * ((size_t)g.npad * sizeof(f4) + (size_t)g.naux * sizeof(unsigned));
+}
+
+int bucket_launch(const float* xyz, float* temp, int* idx, int B, int N, int npoint, int seed, TieOrder order,
+                  void* ws, float* sampled, int cf, hipStream_t s) {
+  const BucketGeom g = bucket_geom(N);
+  f4* sorted = (f4*)ws;
+  unsigned* aux = (unsigned*)((char*)ws + (size_t)B * g.npad * sizeof(f4));
+  if (g.m == 1) {
+    hipError_t e = pp::allow_big_lds(fps_bucket_kernel<true>, kBkLdsBytes, g_bucket_lds[0]);
+    if (e != hipSuccess) return (int)e;
+    fps_bucket_kernel<true><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed, order, g,
+                                                                          sorted, aux, sampled, cf);
+  } else {
+    hipError_t e = pp::allow_big_lds(fps_bucket_kernel<false>, kBkLdsBytes, g_bucket_lds[1]);
+    if (e != hipSuccess) return (int)e;
+    fps_bucket_kernel<false><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed, order, g,
+                                                                           sorted, aux, sampled, cf);
+  }
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+
+}  // namespace ppfps

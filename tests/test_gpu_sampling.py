@@ -16,19 +16,27 @@ def _t(a, cuda):
 
 
 # ---------------------------------------------------------------- furthest point sampling + gather
-@pytest.fixture(params=["cluster", "single_block"])
-def fps_path(request, cuda):
-    """Run every FPS test on both decompositions: the CU-cluster kernel (default where it applies)
-    and the one-workgroup-per-batch kernel; afterwards no inter-workgroup wait may have timed out."""
+_FPS_FORMS = {"default": 0, "single_block": 1, "cluster": 2, "bucket": 3}
+
+
+def _fps_form(name):
     import ctypes
     from pytorch_points_amd import _lib
-    from pytorch_points_amd._ext import sampling
     setter = _lib.lib().pp_debug_set_fps_v1
     setter.argtypes = [ctypes.c_int]
     setter.restype = None
-    setter(1 if request.param == "single_block" else 0)
+    setter(_FPS_FORMS[name])
+
+
+@pytest.fixture(params=["default", "cluster", "single_block"])
+def fps_path(request, cuda):
+    """Run every FPS test on the three decompositions: the operator's own choice (the bucketed kernel where it
+    applies: N >= 2048 and 32 or more picks), the CU-cluster kernel and the one-workgroup-per-batch kernel over all
+    points; afterwards no inter-workgroup wait may have timed out."""
+    from pytorch_points_amd._ext import sampling
+    _fps_form(request.param)
     yield request.param
-    setter(0)
+    _fps_form("default")
     assert sampling.furthest_sampling_status(cuda) == 0
 
 
@@ -66,6 +74,94 @@ def test_fps_ties_and_degenerate(cuda, fps_path):
     assert (e_idx[1, 1:] == 0).all()
 
 
+def _fps_clouds(n):
+    """clouds the bucketed kernel's pruning is weakest or its sort most lopsided on"""
+    rng = np.random.default_rng(77)
+    out = {}
+    out["sphere"] = S.unit_sphere(20, 1, n)[0]
+    g = S.normal(21, (n, 3))
+    out["gaussian"] = g
+    c = rng.normal(size=(8, 3)).astype(np.float32) * 3
+    out["blobs"] = (c[rng.integers(0, 8, n)] + 0.01 * S.normal(22, (n, 3))).astype(np.float32)
+    two = S.unit_sphere(23, 1, n)[0].copy()
+    two[: n // 2] = two[: n // 2] * 0.01 + 0.3            # half the points in 1e-6 of the volume
+    out["two_scales"] = two
+    pl = S.normal(24, (n, 3)); pl[:, 2] = 0.25
+    out["plane"] = pl
+    ln = np.zeros((n, 3), np.float32); ln[:, 0] = S.normal(25, (n,)); ln[:, 1] = 2 * ln[:, 0]
+    out["line"] = ln
+    lat = np.stack(np.meshgrid(*[np.arange(16, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    out["lattice"] = np.ascontiguousarray(lat[rng.integers(0, len(lat), n)])       # exact ties everywhere, duplicates
+    out["identical"] = np.full((n, 3), 0.5, np.float32)
+    far = S.unit_sphere(26, 1, n)[0] + np.float32(1000.0)
+    out["offset_1000"] = far.astype(np.float32)
+    outl = S.unit_sphere(27, 1, n)[0].copy(); outl[::997] *= 500.0
+    out["outliers"] = outl
+    return out
+
+
+@pytest.mark.parametrize("n,m,seed", [(2048, 64, 0), (5000, 300, 7), (4099, 4099, 4098), (16384, 700, 3)])
+def test_fps_bucketed_kernel_on_hard_clouds(cuda, n, m, seed):
+    """The bucketed kernel (every step only visits the buckets the pick can change) against the oracle: picks AND
+    temp, on clouds with exact ties, duplicates, degenerate extents, clusters and outliers."""
+    from pytorch_points_amd._ext import sampling
+    clouds = _fps_clouds(n)
+    names = sorted(clouds)
+    x = np.stack([clouds[k] for k in names]).astype(np.float32)
+    e_idx, e_temp = oracle.furthest_sampling(x, m, seed)
+    _fps_form("bucket")
+    try:
+        idx = torch.empty(len(names), m, dtype=torch.int32, device=cuda)
+        temp = torch.full((len(names), n), 1e10, dtype=torch.float32, device=cuda)
+        pts = torch.empty(len(names), m, 3, device=cuda)
+        sampling.furthest_sampling(m, seed, _t(x, cuda), temp, idx, pts, False)
+    finally:
+        _fps_form("default")
+    got = idx.cpu().numpy()
+    for i, k in enumerate(names):
+        assert np.array_equal(got[i], e_idx[i]), (k, int(np.argmax(got[i] != e_idx[i])))
+        assert np.array_equal(temp[i].cpu().numpy(), e_temp[i]), k
+    assert np.array_equal(pts.cpu().numpy(), np.take_along_axis(x, e_idx[..., None].astype(np.int64), 1))
+
+
+def test_fps_bucketed_kernel_honours_the_incoming_temp(cuda):
+    """temp is an in/out argument (ref sampling_cuda.cu:190,204-205): whatever the caller passes bounds every
+    point's distance from the start -- also for the bucket maxima the pruning relies on"""
+    from pytorch_points_amd._ext import sampling
+    b, n, m = 3, 6000, 200
+    x = S.unit_sphere(30, b, n)
+    t0 = (np.abs(S.normal(31, (b, n))) * 0.05).astype(np.float32)
+    t0[1] = 1e10
+    t0[2, ::3] = 0.0
+    e_idx, e_temp = oracle.furthest_sampling(x, m, 11, temp=t0)
+    _fps_form("bucket")
+    try:
+        idx = torch.empty(b, m, dtype=torch.int32, device=cuda)
+        temp = _t(t0, cuda)
+        sampling.furthest_sampling(m, 11, _t(x, cuda), temp, idx)
+    finally:
+        _fps_form("default")
+    assert np.array_equal(idx.cpu().numpy(), e_idx)
+    assert np.array_equal(temp.cpu().numpy(), e_temp)
+
+
+def test_fps_bucketed_kernel_beyond_65536_points(cuda):
+    """N > 65536: buckets of 128 or more points (at most 1024 buckets, one per thread)"""
+    from pytorch_points_amd._ext import sampling
+    for n, m in [(70000, 40), (200001, 33)]:
+        x = S.unit_sphere(32, 1, n)
+        e_idx, e_temp = oracle.furthest_sampling(x, m, 5)
+        _fps_form("bucket")
+        try:
+            idx = torch.empty(1, m, dtype=torch.int32, device=cuda)
+            temp = torch.full((1, n), 1e10, dtype=torch.float32, device=cuda)
+            sampling.furthest_sampling(m, 5, _t(x, cuda), temp, idx)
+        finally:
+            _fps_form("default")
+        assert np.array_equal(idx.cpu().numpy(), e_idx)
+        assert np.array_equal(temp.cpu().numpy(), e_temp)
+
+
 def test_fps_large_n_paths(cuda, fps_path):
     """N > 1024 (several points per thread) and N > 65536 (temp kept in global memory)."""
     from pytorch_points_amd.network.geo_operations import furthest_point_sample
@@ -77,8 +173,9 @@ def test_fps_large_n_paths(cuda, fps_path):
 
 
 def test_fps_config3_full_size(cuda):
-    """BASELINE config 3 (B=16, N=65536 -> 4096): cluster kernel == single-block kernel on every
-    batch element, == oracle on one; repeated calls reuse the workspace ring safely."""
+    """BASELINE config 3 (B=16, N=65536 -> 4096): the operator's choice (the bucketed kernel) == the cluster kernel on
+    every batch element, == the single-block kernel on three, == oracle on one; repeated calls reuse the workspace
+    safely."""
     import ctypes
     from pytorch_points_amd import _lib
     from pytorch_points_amd._ext import sampling
@@ -89,15 +186,15 @@ def test_fps_config3_full_size(cuda):
     runs = [furthest_point_sample(xt, m, NCHW=False)[0] for _ in range(3)]
     assert sampling.furthest_sampling_status(cuda) == 0
     assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
-    setter = _lib.lib().pp_debug_set_fps_v1
-    setter.argtypes = [ctypes.c_int]
-    setter.restype = None
-    setter(1)
+    _fps_form("single_block")
     try:
         v1, _ = furthest_point_sample(xt[:3].contiguous(), m, NCHW=False)
+        _fps_form("cluster")
+        v2, _ = furthest_point_sample(xt, m, NCHW=False)
     finally:
-        setter(0)
-    assert torch.equal(runs[0][:3], v1)
+        _fps_form("default")
+    assert torch.equal(runs[0][:3], v1) and torch.equal(runs[0], v2)
+    assert sampling.furthest_sampling_status(cuda) == 0
     e_idx, _ = oracle.furthest_sampling(x[:1], m, 0)
     assert np.array_equal(runs[0][:1].cpu().numpy(), e_idx)
     for b in range(B):
@@ -112,6 +209,7 @@ def test_fps_cluster_beside_other_work(cuda):
     B, N, m = 8, 32768, 512
     x = S.unit_sphere(14, B, N)
     xt = _t(x, cuda)
+    _fps_form("cluster")
     ref, _ = furthest_point_sample(xt, m, NCHW=False)
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
@@ -124,9 +222,11 @@ def test_fps_cluster_beside_other_work(cuda):
         idx, _ = furthest_point_sample(xt, m, NCHW=False)
         outs.append(idx)
     torch.cuda.synchronize()
+    _fps_form("default")
     assert sampling.furthest_sampling_status(cuda) == 0
     for idx in outs:
         assert torch.equal(idx, ref)
+    assert torch.equal(furthest_point_sample(xt, m, NCHW=False)[0], ref)      # the bucketed kernel
     e_idx, _ = oracle.furthest_sampling(x[:1], m, 0)
     assert np.array_equal(ref[:1].cpu().numpy(), e_idx)
 
