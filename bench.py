@@ -594,16 +594,52 @@ def bench_fps(args, dist, world, rank, device):
     updates = float(B) * (npoint - 1) * N * world
     alg_bytes = 12.0 * B * N + 4.0 * B * npoint
     gbs = alg_bytes / (ms * 1e-3) / 1e9
+    # the same call on clouds where the bucketed kernel prunes least ("report that time too") and
+    # through the kernel it replaced (the CU cluster over all points), same box, same run
+    other = {}
+    if rank == 0:
+        import ctypes
+        from pytorch_points_amd import _lib
+        setter = _lib.lib().pp_debug_set_fps_v1
+        setter.argtypes = [ctypes.c_int]
+        setter.restype = None
+
+        def ms_of(xt, reps=3):
+            furthest_point_sample(xt, npoint, NCHW=False, seedIdx=0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                furthest_point_sample(xt, npoint, NCHW=False, seedIdx=0)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        rng = np.random.default_rng(5)
+        centres = rng.normal(size=(B, 8, 3)).astype(np.float32) * 3
+        sel = rng.integers(0, 8, (B, N))
+        clouds = {
+            "gaussian": S.normal(1, (B, N, 3)),
+            "cube": S.uniform01(2, (B, N, 3)).reshape(B, N, 3).astype(np.float32),
+            "blobs8": (np.take_along_axis(centres, sel[..., None].repeat(3, -1), 1)
+                       + 0.02 * S.normal(3, (B, N, 3))).astype(np.float32),
+        }
+        for name, c in clouds.items():
+            other[name] = round(ms_of(torch.from_numpy(np.ascontiguousarray(c)).to(device)), 4)
+        setter(2)
+        try:
+            other["sphere_cluster_kernel"] = round(ms_of(x), 4)
+        finally:
+            setter(0)
     return {"metric": "fps_point_updates_per_s", "value": updates / (dt / args.steps), "unit": "updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "furthest_point_sample + gather_points B=%d N=%d npoint=%d" % (B, N, npoint),
                        "parallelism": "replicas x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "fps_cluster_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "fps_bucket_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                          "note": "serial chain of npoint-1 dependent steps: latency-bound, not HBM-bound"},
-            "us_per_pick": ms * 1e3 / (npoint - 1)}
+            "us_per_pick": ms * 1e3 / (npoint - 1),
+            "other_clouds_ms": other}
 
 
 # ------------------------------------------------------------- ball_query + group_points (config 4)

@@ -384,7 +384,10 @@ extern "C" int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, in
   // of every point, and no workgroup waits for another.  Knob: 0 = this choice, 1 = one workgroup per batch element
   // over all points, 2 = the CU cluster over all points, 3 = bucketed.
   const int form = g_fps_force_v1;
-  if ((form == 0 || form == 3) && ppfps::bucket_applies(B, N, npoint)) {
+  // (beyond 65536 points the minima no longer fit the registers and LDS of one CU: there the CU cluster, where the
+  //  batch leaves room for one, is the faster of the two -- B=4, N=262144: 11.3 against 13.7 ms)
+  const bool cluster_first = form == 0 && N > 65536 && T == kClThreads && pick_cluster(B, N) >= 2;
+  if ((form == 0 || form == 3) && !cluster_first && ppfps::bucket_applies(B, N, npoint)) {
     const size_t need = pp_furthest_sampling_workspace_bytes(B, N, npoint);
     if (workspace && workspace_bytes >= need)
       return ppfps::bucket_launch(xyz, temp, idx, B, N, npoint, seed_idx, order,

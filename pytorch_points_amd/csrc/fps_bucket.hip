@@ -35,6 +35,9 @@
 #ifndef PP_FPSB_DOUBLE
 #define PP_FPSB_DOUBLE 0  // probe builds: bit k set = one link of the chain is executed twice (same results)
 #endif
+#ifndef PP_FPSB_STOP
+#define PP_FPSB_STOP 99  // probe builds: leave after phase n of the set-up (what each phase costs)
+#endif
 #ifndef PP_FPSB_PROBE_DECL
 #define PP_FPSB_PROBE_DECL
 #define PP_FPSB_MARK(n)
@@ -52,7 +55,8 @@ constexpr int kBkThreads = 1024;
 constexpr int kBkWaves = kBkThreads / 64;
 constexpr int kBkBits = 15;
 constexpr int kBkBins = 1 << kBkBits;
-constexpr int kBkAxisBits = 8;  // at most this many key bits per axis (LUT of 256 entries per axis)
+constexpr int kBkAxisBits = 10;  // at most this many key bits per axis
+constexpr int kBkFine = 1024;    // fine bins per axis: the per-axis histograms the cell boundaries are taken from
 constexpr int kBkLdsBytes = kBkBins * 4;
 
 struct BucketGeom {
@@ -71,6 +75,10 @@ __device__ __forceinline__ int wave_scan_incl(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
   return v;
 }
+
+struct __attribute__((packed, aligned(4))) P3 {
+  float x, y, z;
+};
 
 __device__ __forceinline__ float rl(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   extern __shared__ unsigned s_hist[];  // kBkBins counters, then cursors (the sort only)
   __shared__ float s_box[kBkWaves][6];
   __shared__ int s_wsum[kBkWaves];
-  __shared__ unsigned s_lut[3][1 << kBkAxisBits];
+  __shared__ unsigned s_lut[3][kBkFine];
   __shared__ u64 s_g[3];
   __shared__ float s_c[3][kBkWaves][4];
 
@@ -165,37 +173,66 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       if (a == 0) { ++n0; e0 *= 0.5f; } else if (a == 1) { ++n1; e1 *= 0.5f; } else { ++n2; e2 *= 0.5f; }
     }
     blo[0] = -bv[0]; blo[1] = -bv[1]; blo[2] = -bv[2];
-    qmax[0] = (1 << n0) - 1; qmax[1] = (1 << n1) - 1; qmax[2] = (1 << n2) - 1;
-    // cells per unit length; an empty or unbounded extent puts everything into cell 0 of that axis
-    bsc[0] = (ext0 > 0.0f && ext0 < INFINITY) ? (float)(1 << n0) / ext0 : 0.0f;
-    bsc[1] = (ext1 > 0.0f && ext1 < INFINITY) ? (float)(1 << n1) / ext1 : 0.0f;
-    bsc[2] = (ext2 > 0.0f && ext2 < INFINITY) ? (float)(1 << n2) / ext2 : 0.0f;
-    // per-axis table: cell coordinate -> its bits at their places in the key
-    if (t < 3 * (1 << kBkAxisBits)) {
-      const int a = t >> kBkAxisBits, q = t & ((1 << kBkAxisBits) - 1);
-      int left = a == 0 ? n0 : a == 1 ? n1 : n2;
-      unsigned val = 0;
-      for (int s = 0; s < kBkBits; ++s)
-        if ((int)((plan >> (2 * s)) & 3u) == a) {
-          --left;
-          val |= (unsigned)((q >> left) & 1) << (kBkBits - 1 - s);
-        }
-      s_lut[a][q] = val;
+    qmax[0] = n0; qmax[1] = n1; qmax[2] = n2;  // (bits per axis)
+    // fine bins per unit length; an empty or unbounded extent puts everything into bin 0 of that axis
+    bsc[0] = (ext0 > 0.0f && ext0 < INFINITY) ? (float)kBkFine / ext0 : 0.0f;
+    bsc[1] = (ext1 > 0.0f && ext1 < INFINITY) ? (float)kBkFine / ext1 : 0.0f;
+    bsc[2] = (ext2 > 0.0f && ext2 < INFINITY) ? (float)kBkFine / ext2 : 0.0f;
+    for (int i = t; i < 3 * kBkFine; i += kBkThreads) (&s_lut[0][0])[i] = 0u;
+    for (int i = t; i < kBkBins; i += kBkThreads) s_hist[i] = 0u;
+    if (t < 3) s_g[t] = 0ull;
+    __syncthreads();
+    if (PP_FPSB_STOP <= 1) return;
+    // ---------------------------------------------------------------- B2. cells of equal COUNT along every axis
+    // A uniform grid gives a cluster a handful of cells, and its buckets -- random subsets of it -- boxes as large
+    // as the cluster: every pick there visits all of them.  So the 2^n cells of an axis are cut where its points
+    // are: a 1024-bin histogram per axis, its running sum, cell = floor(2^n * (points below the bin's middle) / N).
+    // A separable approximation of a k-d split, built in one extra pass; an evenly sampled cloud gets the uniform
+    // grid back.
+    auto bin_of = [&](float v, int a) -> int { return min(max((int)((v - blo[a]) * bsc[a]), 0), kBkFine - 1); };
+    for (int k = t; k < N; k += kBkThreads) {
+      atomicAdd(&s_lut[0][bin_of(p[3 * (size_t)k], 0)], 1u);
+      atomicAdd(&s_lut[1][bin_of(p[3 * (size_t)k + 1], 1)], 1u);
+      atomicAdd(&s_lut[2][bin_of(p[3 * (size_t)k + 2], 2)], 1u);
+    }
+    __syncthreads();
+    if (wave < 3) {
+      const int a = wave;
+      const int nbits = qmax[a];
+      int carry = 0;
+      for (int r = 0; r < kBkFine / 64; ++r) {
+        const int i = 64 * r + lane;
+        const int c = (int)s_lut[a][i];
+        const int inc = wave_scan_incl(c);
+        const unsigned below = (unsigned)(carry + inc - c) + (unsigned)c / 2u;
+        carry += __builtin_amdgcn_readlane(inc, 63);
+        unsigned q = (unsigned)(((u64)below << nbits) / (u64)(N > 0 ? N : 1));
+        q = min(q, (1u << nbits) - 1u);
+        // the cell coordinate's bits at their places in the key
+        int left = nbits;
+        unsigned val = 0;
+        for (int st = 0; st < kBkBits; ++st)
+          if ((int)((plan >> (2 * st)) & 3u) == a) {
+            --left;
+            val |= ((q >> left) & 1u) << (kBkBits - 1 - st);
+          }
+        s_lut[a][i] = val;
+      }
     }
   }
-  for (int i = t; i < kBkBins; i += kBkThreads) s_hist[i] = 0u;
-  if (t < 3) s_g[t] = 0ull;
   __syncthreads();
   auto key_of = [&](float x, float y, float z) -> unsigned {
-    const int qx = min(max((int)((x - blo[0]) * bsc[0]), 0), qmax[0]);
-    const int qy = min(max((int)((y - blo[1]) * bsc[1]), 0), qmax[1]);
-    const int qz = min(max((int)((z - blo[2]) * bsc[2]), 0), qmax[2]);
+    const int qx = min(max((int)((x - blo[0]) * bsc[0]), 0), kBkFine - 1);
+    const int qy = min(max((int)((y - blo[1]) * bsc[1]), 0), kBkFine - 1);
+    const int qz = min(max((int)((z - blo[2]) * bsc[2]), 0), kBkFine - 1);
     return s_lut[0][qx] | s_lut[1][qy] | s_lut[2][qz];
   };
+  if (PP_FPSB_STOP <= 2) return;
   // ---------------------------------------------------------------- C. count
   for (int k = t; k < N; k += kBkThreads)
     atomicAdd(&s_hist[key_of(p[3 * (size_t)k], p[3 * (size_t)k + 1], p[3 * (size_t)k + 2])], 1u);
   __syncthreads();
+  if (PP_FPSB_STOP <= 3) return;
   // ---------------------------------------------------------------- D. exclusive scan (a wave per 2048 bins)
   {
     constexpr int kRows = kBkBins / kBkWaves / 64;
@@ -214,12 +251,21 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     for (int r = 0; r < kRows; ++r) s_hist[wave * (kBkBins / kBkWaves) + 64 * r + lane] += (unsigned)base;
   }
   __syncthreads();
-  // ---------------------------------------------------------------- E. scatter: (x, y, z, temp) and ~tie rank
+  if (PP_FPSB_STOP <= 4) return;
+  // ---------------------------------------------------------------- E. scatter, as a permutation + a gather
+  // (Scattering the 16-byte records themselves -- every lane of a store in a line of its own -- took 183 us of a
+  //  470 us set-up; 4-byte scattered stores of the source index, then coalesced record stores, takes a third.)
   for (int k = t; k < N; k += kBkThreads) {
-    const float x = p[3 * (size_t)k], y = p[3 * (size_t)k + 1], z = p[3 * (size_t)k + 2];
-    const unsigned pos = atomicAdd(&s_hist[key_of(x, y, z)], 1u);
+    const unsigned pos = atomicAdd(&s_hist[key_of(p[3 * (size_t)k], p[3 * (size_t)k + 1], p[3 * (size_t)k + 2])], 1u);
+    rc[pos] = (unsigned)k;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int pos = t; pos < N; pos += kBkThreads) {
+    const int k = (int)rc[pos];
+    const P3 v = *(const P3*)(p + 3 * (size_t)k);  // (one 12-byte load: a gathered access costs per instruction)
     f4 rec;
-    rec.x = x; rec.y = y; rec.z = z;
+    rec.x = v.x; rec.y = v.y; rec.z = v.z;
     if (REG) {
       rec.w = __uint_as_float(kRcMax - order.rank(k));
       rc[pos] = __float_as_uint(tmp[k]);
@@ -238,6 +284,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   for (int pos = N + t; pos < geo.naux; pos += kBkThreads) rc[pos] = 0u;
   __syncthreads();  // (the stores are drained before the barrier; one CU, one L1: visible to every wave)
 
+  if (PP_FPSB_STOP <= 5) return;
   // ---------------------------------------------------------------- F. bucket summaries + the seed's step
   // thread (wave w, lane l) owns bucket l * 16 + w: neighbouring buckets live in different waves, so the
   // handful of buckets a pick touches are re-evaluated side by side.
@@ -354,6 +401,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     }
   }
 
+  if (PP_FPSB_STOP <= 6) return;
   // ---------------------------------------------------------------- G. the chain
   // Keys only ever fall (temp = min(...)), so a wave's best bucket stays its best until that very bucket is
   // re-evaluated: only then is the wave's maximum taken again.  The workgroup's maximum is ONE LDS atomic per wave
