@@ -51,7 +51,7 @@ def clouds(kind, seed):
         if seed: x += 5.0
         return x
 kinds = sys.argv[1:] or ["sphere", "cube", "gaussian", "blobs8", "two_scales", "plane", "line", "shapenet_like", "disjoint"]
-modes = (-1, 512, 513, 1024)
+modes = tuple(int(v) for v in os.environ.get("PP_TILE_MODES", "-1,512,513,1024").split(","))
 for kind in kinds:
     x1 = torch.from_numpy(np.ascontiguousarray(clouds(kind, 0))).to(dev); x2 = torch.from_numpy(np.ascontiguousarray(clouds(kind, 1))).to(dev)
     def outs():
