@@ -252,39 +252,50 @@ def bench_chamfer(args, dist, world, rank, device):
         # one asynchronous collective per gathered step: (dist1 | dist2 | idx1 | idx2) of the shard, packed (idx as
         # 16-bit words: 6 MiB per rank at B=32, N=M=16384), double-buffered (pytorch_points_amd/sharded.py)
         from pytorch_points_amd.sharded import PackedShardGather
-        # PP_SHARD_EXCHANGE: native (default: c10d's _allgather_base issued by the exchange object's worker thread),
-        # rccl (one direct ncclAllGather on a communicator of the object's own: 17 us of host time per exchange instead
-        # of 28, one-rank line 0.101 instead of 0.106 ms -- opt-in: it could only be exercised with one rank here),
-        # python (the Python-issued exchange)
+        # PP_SHARD_EXCHANGE: native (default: c10d's _allgather_base issued from C++ by the calling thread), rccl (one
+        # direct ncclAllGather on a communicator of the object's own -- opt-in: it could only be exercised with one
+        # rank here), python (the Python-issued exchange)
         exchange = PackedShardGather(B, N, M, device)
     pending = []        # slot of the previous gathered step
     counter = [0]
     gather_every = max(1, args.gather_every)
 
-    def maybe_exchange(d1, d2, i1, i2):
-        """all-gather of the per-shard (dist, idx) over xGMI (RCCL), asynchronous: it runs on the collective's
-        stream beside this step's backward and the next step's forward; the previous gathered result is consumed
-        (unpacked to the global-batch tensors) first"""
-        if exchange is None or counter[0] % gather_every:
-            return
+    def gathers():
+        return exchange is not None and counter[0] % gather_every == 0
+
+    def consume_previous():
+        """the previous gathered step is consumed first: views of the gathered buffer (round 4: nothing is unpacked
+        that nobody reads; a consumer that wants contiguous int32 indices calls exchange.wait instead)"""
         if pending:
-            exchange.wait(pending.pop())
+            exchange.wait_views(pending.pop())
+
+    def maybe_exchange(d1, d2, i1, i2):
+        """all-gather of the per-shard (dist, idx) over xGMI (RCCL), asynchronous: it runs on a side stream beside this
+        step's backward and the next step's forward.  General form: outputs held elsewhere are packed into the slot."""
+        if not gathers():
+            return
+        consume_previous()
         pending.append(exchange.launch(d1, d2, i1, i2))
 
     def eager_step():
-        """the operator as a user calls it: torch.autograd.Function forward, autograd backward"""
+        """the operator as a user calls it: torch.autograd.Function forward, autograd backward; with an exchange, the
+        search writes its distances straight into the exchange's slot (PackedShardGather.forward)"""
         x1, x2 = sets[counter[0] & 1]
         counter[0] += 1
         x1.grad = None
         x2.grad = None
-        d1, d2, i1, i2 = nndistance(x1, x2)
-        maybe_exchange(d1, d2, i1, i2)
+        if gathers():
+            consume_previous()
+            d1, d2, i1, i2, h = exchange.forward(x1, x2)
+            pending.append(h)
+        else:
+            d1, d2, i1, i2 = nndistance(x1, x2)
         torch.autograd.backward([d1, d2], [g1, g2])
 
     def drain():
         if exchange is not None:
             while pending:
-                exchange.wait(pending.pop())
+                exchange.wait_views(pending.pop())
             exchange.drain()
 
     def run_timed(fn, warmup, steps):
@@ -324,8 +335,13 @@ def bench_chamfer(args, dist, world, rank, device):
     def ext_step():
         sx1, sx2 = dsets[counter[0] & 1]
         counter[0] += 1
-        ext_losses.nmdistance_forward(sx1, sx2, od1, od2, oi1, oi2)
-        maybe_exchange(od1, od2, oi1, oi2)
+        if gathers():   # the extension-module call writes into the slot's own distance fields
+            consume_previous()
+            slot, v1, v2 = exchange.begin()
+            ext_losses.nmdistance_forward(sx1, sx2, v1, v2, oi1, oi2)
+            pending.append(exchange.launch_in_place(slot, oi1, oi2))
+        else:
+            ext_losses.nmdistance_forward(sx1, sx2, od1, od2, oi1, oi2)
         ext_losses.nmdistance_backward(sx1, sx2, ogx1, ogx2, g1, g2, oi1, oi2)
 
     # hipGraph replay of one step (pytorch_points_amd/graphs.py; static inputs: set A)
@@ -414,10 +430,24 @@ def bench_chamfer(args, dist, world, rank, device):
         exchange = ex_saved
 
         def only_exchange():
-            if pending:
-                exchange.wait(pending.pop())
-            pending.append(exchange.launch(od1, od2, oi1, oi2))
+            consume_previous()
+            slot, _, _ = exchange.begin()       # (the distances are "already there")
+            pending.append(exchange.launch_in_place(slot, oi1, oi2))
         exchange_ms = run_timed(only_exchange, 5, n_cal) / n_cal * 1e3
+        # GPU time of one exchange by itself: the index-narrowing kernel + the all-gather, between two events on the
+        # launch stream (the second behind the stream's wait for the gather)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        gpu_us = []
+        for _ in range(20):
+            drain()
+            ev[0].record()
+            slot, _, _ = exchange.begin()
+            h = exchange.launch_in_place(slot, oi1, oi2)
+            exchange.wait_views(h)
+            ev[1].record()
+            ev[1].synchronize()
+            gpu_us.append(ev[0].elapsed_time(ev[1]) * 1e3)
+        exchange_gpu_us = float(np.median(gpu_us))
 
     # forward duration: the forward's two launches issued back to back between two HIP events on the launch stream
     def fwd_only():
@@ -499,15 +529,18 @@ def bench_chamfer(args, dist, world, rank, device):
     if dist is not None:
         out["compute_ms"] = compute_ms
         out["exchange_ms"] = exchange_ms
+        out["exchange_gpu_us"] = exchange_gpu_us
         native = getattr(exchange, "_native", None)
-        out["exchange_issue"] = ("direct ncclAllGather from the exchange object's worker thread" if getattr(exchange, "direct", False)
-                                 else ("c10d _allgather_base from the exchange object's worker thread" if native is not None
+        out["exchange_issue"] = ("direct ncclAllGather issued by the calling thread" if getattr(exchange, "direct", False)
+                                 else ("c10d _allgather_base issued by the calling thread (C++)" if native is not None
                                        else "Python: dist.all_gather_into_tensor"))
         if native is not None:
-            out["exchange_worker_us"] = float(native.worker_us_per_slot())   # host time of the worker per exchange
-        out["exchange_note"] = ("compute_ms: the same steps without the exchange; exchange_ms: pack + all_gather_into_tensor + "
-                                "unpack of one step's outputs with nothing beside it; ms_per_step has them overlapped "
-                                "(gather every %d step(s))" % gather_every)
+            out["exchange_issue_us"] = float(native.issue_us_per_slot())   # host time of issuing one exchange
+        out["exchange_note"] = ("compute_ms: the same steps without the exchange; exchange_ms: one step's exchange with nothing "
+                                "beside it (indices narrowed into the slot + all-gather; the distances are written into the "
+                                "slot by the search itself, the gathered buffer is read through views: no pack of "
+                                "distances, no unpack); exchange_gpu_us: its GPU time between two events; ms_per_step has "
+                                "them overlapped (gather every %d step(s))" % gather_every)
     if grid:
         # the dominant kernel of the step: the stage-A kernel of the unlabeled search (round 3: the search is two launches,
         # stage A by tiles + the kernel over what it leaves); the whole-search kernel where there is no stage-A kernel

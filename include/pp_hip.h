@@ -270,7 +270,11 @@ int pp_opt_n_threads(int work_size);
  * packing of a rank's Chamfer outputs for ONE collective per step, and unpacking of the gathered
  * buffer (pytorch_points_amd/sharded.py PackedShardGather).  n1 = B_local*N, n2 = B_local*M.
  * Packed layout: dist1 | dist2 | idx1 | idx2, indices as uint16 when compact != 0 (all < 65536).
- * pp_shard_packed_bytes: bytes of one rank's packed buffer (multiple of 16 = the row stride). */
+ * pp_shard_packed_bytes: bytes of one rank's packed buffer (multiple of 16 = the row stride).
+ * pp_shard_pack_f32 with dist1 == dist2 == NULL: the distances are IN PLACE already -- the caller gave the packed
+ * buffer's first n1 + n2 floats to pp_nmdistance_forward*_f32 as its dist1 / dist2 outputs -- and only the indices are
+ * narrowed in behind them.  pp_shard_unpack_f32 with dist1 == dist2 == NULL: indices only (the distances are read where
+ * they were gathered, as strided views of the gathered buffer). */
 size_t pp_shard_packed_bytes(long long n1, long long n2, int compact);
 int pp_shard_pack_f32(const float* dist1, const float* dist2, const int* idx1, const int* idx2, void* packed,
                       long long n1, long long n2, int compact, void* stream);

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(const float* __restrict
   for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < n1 + n2; k += stride) {
     const bool first = k < n1;
     const long long j = first ? k : k - n1;
-    (first ? od1 : od2)[j] = (first ? d1 : d2)[j];
+    if (d1) (first ? od1 : od2)[j] = (first ? d1 : d2)[j];  // (nullptr: the search wrote the distances in place)
     const int v = (first ? i1 : i2)[j];
     if (compact)
       reinterpret_cast<unsigned short*>(oi)[k] = (unsigned short)v;  // k: idx1 then idx2, contiguous
@@ -48,7 +48,6 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const unsigned char* 
     const unsigned char* ri = row + 4 * per;
     const bool first = k < n1;
     const long long j = first ? k : k - n1;
-    const float d = rd[k];
     int v;
     if (compact) {
       const unsigned short w16 = reinterpret_cast<const unsigned short*>(ri)[k];
@@ -57,10 +56,10 @@ __global__ __launch_bounds__(256) void shard_unpack_kernel(const unsigned char* 
       v = reinterpret_cast<const int*>(ri)[k];
     }
     if (first) {
-      D1[(long long)r * n1 + j] = d;
+      if (D1) D1[(long long)r * n1 + j] = rd[k];  // (nullptr: the caller reads the distances where they were gathered)
       I1[(long long)r * n1 + j] = v;
     } else {
-      D2[(long long)r * n2 + j] = d;
+      if (D1) D2[(long long)r * n2 + j] = rd[k];
       I2[(long long)r * n2 + j] = v;
     }
   }
@@ -78,10 +77,15 @@ extern "C" int pp_shard_pack_f32(const float* dist1, const float* dist2, const i
                                  void* packed, long long n1, long long n2, int compact, void* stream) {
   if (n1 < 0 || n2 < 0) return PP_EINVAL;
   if (n1 + n2 == 0) return PP_OK;
-  if (!packed || (n1 > 0 && (!dist1 || !idx1)) || (n2 > 0 && (!dist2 || !idx2))) return PP_EINVAL;
+  if (!packed || (n1 > 0 && !idx1) || (n2 > 0 && !idx2)) return PP_EINVAL;
+  // dist1 == dist2 == NULL: the distances are in place already (the caller handed the packed buffer's own first
+  // n1 + n2 floats to the search as its dist1 / dist2 outputs); only the indices are packed behind them
+  const bool in_place = dist1 == nullptr && dist2 == nullptr;
+  if (!in_place && ((n1 > 0 && !dist1) || (n2 > 0 && !dist2))) return PP_EINVAL;
   const long long blocks = (n1 + n2 + 256 * 4 - 1) / (256 * 4);
   shard_pack_kernel<<<dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)), dim3(256), 0,
-                      (hipStream_t)stream>>>(dist1, dist2, idx1, idx2, (unsigned char*)packed, n1, n2, compact);
+                      (hipStream_t)stream>>>(in_place ? nullptr : dist1, dist2, idx1, idx2, (unsigned char*)packed, n1, n2,
+                                             compact);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
 }
@@ -92,12 +96,15 @@ extern "C" int pp_shard_unpack_f32(const void* gathered, int world, long long st
   if (world < 0 || n1 < 0 || n2 < 0 || stride_bytes < (long long)pp_shard_packed_bytes(n1, n2, compact))
     return PP_EINVAL;
   if (world == 0 || n1 + n2 == 0) return PP_OK;
-  if (!gathered || (n1 > 0 && (!dist1 || !idx1)) || (n2 > 0 && (!dist2 || !idx2))) return PP_EINVAL;
+  // dist1 == dist2 == NULL: indices only (the distances are read in the gathered buffer itself, as strided views)
+  const bool idx_only = dist1 == nullptr && dist2 == nullptr;
+  if (!gathered || (n1 > 0 && !idx1) || (n2 > 0 && !idx2)) return PP_EINVAL;
+  if (!idx_only && ((n1 > 0 && !dist1) || (n2 > 0 && !dist2))) return PP_EINVAL;
   const long long total = (n1 + n2) * world;
   const long long blocks = (total + 256 * 4 - 1) / (256 * 4);
   shard_unpack_kernel<<<dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)), dim3(256), 0,
                         (hipStream_t)stream>>>((const unsigned char*)gathered, world, stride_bytes, n1, n2, compact,
-                                               dist1, dist2, idx1, idx2);
+                                               idx_only ? nullptr : dist1, dist2, idx1, idx2);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
 }

@@ -22,11 +22,8 @@
 
 #include <hip/hip_runtime_api.h>
 
-#include <condition_variable>
-#include <deque>
 #include <map>
 #include <string>
-#include <thread>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -121,13 +118,22 @@ bool g_force_brute = false;  // PP_NMDISTANCE_SEARCH=bruteforce, read once by th
 // nndistance(xyz1 (B,N,C), xyz2 (B,M,C)) -> (dist1 (B,N), dist2 (B,M), idx1, idx2); reference
 // network/model_loss.py:401-439 + _ext/nmdistance.cpp:13-27
 struct NmDistance : public torch::autograd::Function<NmDistance> {
-  static variable_list forward(AutogradContext* ctx, const Tensor& a, const Tensor& b) {
+  // out1 / out2: where the distances are to be written (contiguous float32 (B, N) / (B, M) on the inputs' device --
+  // e.g. a slot of the batch-sharded exchange, so that nothing has to be packed afterwards); undefined = allocate
+  static variable_list forward(AutogradContext* ctx, const Tensor& a, const Tensor& b, const c10::optional<Tensor>& out1,
+                               const c10::optional<Tensor>& out2) {
     const Tensor xyz1 = a.contiguous(), xyz2 = b.contiguous();
     const Shapes s = check_inputs(xyz1, xyz2);
     const auto fopts = xyz1.options();
     const auto iopts = fopts.dtype(torch::kInt32);
     // uninitialised: the kernels write every element (and zero-fill when one cloud is empty)
-    Tensor dist1 = torch::empty({s.b, s.n}, fopts), dist2 = torch::empty({s.b, s.m}, fopts);
+    Tensor dist1 = out1.has_value() ? *out1 : torch::empty({s.b, s.n}, fopts);
+    Tensor dist2 = out2.has_value() ? *out2 : torch::empty({s.b, s.m}, fopts);
+    TORCH_CHECK(dist1.is_contiguous() && dist2.is_contiguous() && dist1.scalar_type() == torch::kFloat32 &&
+                    dist2.scalar_type() == torch::kFloat32 && dist1.device() == xyz1.device() &&
+                    dist2.device() == xyz1.device() && dist1.numel() == (int64_t)s.b * s.n &&
+                    dist2.numel() == (int64_t)s.b * s.m,
+                "nndistance: out tensors must be contiguous float32 (B, N) and (B, M) on the inputs' device");
     Tensor idx1 = torch::empty({s.b, s.n}, iopts), idx2 = torch::empty({s.b, s.m}, iopts);
     const c10::DeviceGuard guard(xyz1.device());
     const hipStream_t stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(xyz1.device().index()).stream();
@@ -143,7 +149,12 @@ struct NmDistance : public torch::autograd::Function<NmDistance> {
     ctx->set_materialize_grads(false);
     return {dist1, dist2, idx1, idx2};
   }
-  static variable_list backward(AutogradContext* ctx, variable_list grads) { return chamfer_backward(ctx, grads); }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    variable_list g = chamfer_backward(ctx, grads);
+    g.push_back(Tensor());
+    g.push_back(Tensor());
+    return g;
+  }
 };
 
 // labeled_nndistance(xyz1, xyz2, label1 (B,N), label2 (B,M)); reference network/model_loss.py:445-481.  Labels
@@ -185,7 +196,14 @@ struct LabeledNmDistance : public torch::autograd::Function<LabeledNmDistance> {
 };
 
 std::tuple<Tensor, Tensor, Tensor, Tensor> nndistance(const Tensor& xyz1, const Tensor& xyz2) {
-  auto r = NmDistance::apply(xyz1, xyz2);
+  auto r = NmDistance::apply(xyz1, xyz2, c10::optional<Tensor>(), c10::optional<Tensor>());
+  return std::make_tuple(r[0], r[1], r[2], r[3]);
+}
+
+// the same operator with the distances written into tensors of the caller's (see NmDistance::forward)
+std::tuple<Tensor, Tensor, Tensor, Tensor> nndistance_out(const Tensor& xyz1, const Tensor& xyz2, const Tensor& dist1,
+                                                          const Tensor& dist2) {
+  auto r = NmDistance::apply(xyz1, xyz2, c10::optional<Tensor>(dist1.detach()), c10::optional<Tensor>(dist2.detach()));
   return std::make_tuple(r[0], r[1], r[2], r[3]);
 }
 
@@ -197,59 +215,59 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> labeled_nndistance(const Tensor& xyz1
 
 // ---------------------------------------------------------------------------------------------------------------
 // The batch-sharded operator's one exchange per step (pytorch_points_amd/sharded.py: PackedShardGather), issued from
-// C++: pack the shard's (dist1 | dist2 | idx1 | idx2) into one buffer (pp_shard_pack_f32, on the
-// current stream), ONE all-gather of it over RCCL (c10d: ProcessGroup::_allgather_base), and -- on a side stream that
-// waits for the collective -- unpack the gathered bytes into the global-batch tensors (pp_shard_unpack_f32), all in one
-// call that never touches Python: issued from Python the same three steps cost the thread ~50 us per step, more than
-// the step's kernels leave idle.  Slots are double-buffered by the caller's `depth`; wait(slot) makes the CURRENT
-// stream (not the host) wait for the slot's unpack and returns its tensors, valid until the slot is launched again.
+// C++: ONE all-gather over RCCL of the shard's packed outputs (dist1 | dist2 | idx1 | idx2, indices as
+// 16-bit words when they fit), on a side stream, in one call that never touches Python.
+// Round 4:
+//   * no pack of the distances: begin() hands out views of the slot's own first floats, which the caller gives to the
+//     search as its dist outputs (nndistance_out / losses.nmdistance_forward); launch_in_place() narrows the indices in
+//     behind them (one small kernel, 4 MB read / 2 MB written at config 2 instead of 8 / 6) and issues the gather;
+//   * no unpack: wait() returns strided VIEWS of the gathered buffer -- distances as float32 (world, B, N), indices as
+//     the 16-bit (or 32-bit) words they travelled as, (world, B, N); widen() makes int32 (world * B, N) tensors of the
+//     indices for a consumer that wants them (the only kernel left on the receiving side, and only on demand);
+//   * the collective is issued BY THE CALLING THREAD, in program order with the caller's other collectives (round 3
+//     had a worker thread issue it on the caller's process group: enqueue order relative to the caller's own
+//     collectives then differed from rank to rank -- ADVICE r3, medium).  The host cost of issuing it (~20-30 us
+//     through c10d, ~10 with the direct communicator) is hidden behind a step's kernels at config 2 either way:
+//     measured round 3, worker thread 0.105 against calling thread 0.107 ms per step.
 struct PackedExchange {
   c10::intrusive_ptr<c10d::ProcessGroup> pg;
   int world, b, n, m, depth, compact;
   int64_t nbytes_padded;
   c10::Device dev;
   std::vector<Tensor> send, recv;
-  std::vector<std::vector<Tensor>> out;
+  std::vector<std::vector<Tensor>> wide;  // int32 indices of the global batch, made on demand (widen)
   std::vector<hipEvent_t> packed, done;
+  std::vector<long long> launched;
   c10::hip::HIPStreamMasqueradingAsCUDA side;
   int turn = 0;
-  // The collective and the unpack are ISSUED BY A WORKER THREAD of this object (no Python in it, so no GIL to fight
-  // over): the calling thread only launches the pack, records an event and queues the slot -- issuing the collective
-  // itself (c10d + RCCL enqueue, ~30 us of host time) made the step host-bound (0.105 against 0.078 ms at config 2).
-  // launched[k] / issued[k]: how often slot k has been handed to the worker / completed by it (its done event recorded).
-  std::thread worker;
-  std::mutex mu;
-  std::condition_variable cv_work, cv_done;
-  std::deque<int> queue;
-  std::vector<long long> launched, issued;
-  std::string failure;  // the worker's first exception, re-raised in the calling thread
-  bool stop = false;
   // Direct mode (init_direct): the all-gather is ONE ncclAllGather on a communicator of this object's own instead of a
-  // c10d call -- c10d wraps the same RCCL enqueue in a Work object, two events and a stream wait, ~10 HIP runtime calls
-  // per exchange issued from a second thread while the first launches the step's kernels; the runtime's locks made
-  // the pair host-bound (0.105 ms per step against 0.078 of kernels at config 2).  nullptr: c10d.
+  // c10d call (which wraps the same RCCL enqueue in a Work object, two events and a stream wait).  nullptr: c10d.
   ncclComm_t comm = nullptr;
-  double worker_ns = 0.0;  // host time the worker has spent issuing (collective + unpack + event), and how many slots
-  long long worker_slots = 0;
+  double issue_ns = 0.0;  // host time spent issuing exchanges (collective + events), and how many
+  long long issue_slots = 0;
+
+  static c10::Device with_index(const c10::Device& d) {  // "cuda" -> the current device
+    if (d.has_index()) return d;
+    int cur = 0;
+    TORCH_CHECK(hipGetDevice(&cur) == hipSuccess, "hipGetDevice failed");
+    return c10::Device(d.type(), (c10::DeviceIndex)cur);
+  }
 
   PackedExchange(const c10::intrusive_ptr<c10d::ProcessGroup>& group, int b_local, int n_, int m_, const c10::Device& device,
                  int depth_)
-      : pg(group), world(group->getSize()), b(b_local), n(n_), m(m_), depth(depth_), dev(device),
-        side(c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, device.index())) {
-    TORCH_CHECK(device.is_cuda() && depth >= 1, "PackedExchange needs a GPU device and depth >= 1");
+      : pg(group), world(group->getSize()), b(b_local), n(n_), m(m_), depth(depth_), dev(with_index(device)),
+        side(c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, with_index(device).index())) {
+    TORCH_CHECK(dev.is_cuda() && depth >= 1, "PackedExchange needs a GPU device and depth >= 1");
     compact = std::max(n, m) <= 65535 ? 1 : 0;
     const int64_t isz = compact ? 2 : 4;
     const int64_t nbytes = (int64_t)4 * b * (n + m) + isz * b * (n + m);
     nbytes_padded = (nbytes + 15) / 16 * 16;
-    const auto u8 = torch::TensorOptions().dtype(torch::kUInt8).device(device);
-    const auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(device);
-    const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(device);
-    const c10::DeviceGuard guard(device);
+    const auto u8 = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
+    const c10::DeviceGuard guard(dev);
     for (int k = 0; k < depth; ++k) {
       send.push_back(torch::empty({nbytes_padded}, u8));
       recv.push_back(torch::empty({(int64_t)world, nbytes_padded}, u8));
-      out.push_back({torch::empty({(int64_t)world * b, n}, f32), torch::empty({(int64_t)world * b, m}, f32),
-                     torch::empty({(int64_t)world * b, n}, i32), torch::empty({(int64_t)world * b, m}, i32)});
+      wide.push_back({});
       hipEvent_t e0, e1;
       TORCH_CHECK(hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
                       hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess,
@@ -257,65 +275,14 @@ struct PackedExchange {
       packed.push_back(e0);
       done.push_back(e1);
       launched.push_back(0);
-      issued.push_back(0);
     }
-    worker = std::thread([this] { run(); });
   }
   ~PackedExchange() {
-    {
-      std::lock_guard<std::mutex> lock(mu);
-      stop = true;
-    }
-    cv_work.notify_all();
-    if (worker.joinable()) worker.join();
+    // the side stream may still be writing the buffers this object is about to free
+    (void)hipStreamSynchronize(side.stream());
     if (comm) (void)ncclCommDestroy(comm);
     for (hipEvent_t ev : packed) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : done) (void)hipEventDestroy(ev);
-  }
-
-  void run() {  // the worker: collective + unpack of every queued slot, on the side stream
-    for (;;) {
-      int slot;
-      {
-        std::unique_lock<std::mutex> lock(mu);
-        cv_work.wait(lock, [this] { return stop || !queue.empty(); });
-        if (queue.empty()) return;  // (stop)
-        slot = queue.front();
-        queue.pop_front();
-      }
-      const auto t_begin = std::chrono::steady_clock::now();
-      try {
-        const c10::DeviceGuard guard(dev);
-        const c10::hip::HIPStreamGuardMasqueradingAsCUDA on_side(side);
-        TORCH_CHECK(hipStreamWaitEvent(side.stream(), packed[slot], 0) == hipSuccess, "hipStreamWaitEvent failed");
-        // (c10d orders the collective behind the CURRENT stream of the calling thread: here the side stream, which waits
-        //  for the pack)
-        if (comm) {
-          const ncclResult_t rc = ncclAllGather(send[slot].data_ptr(), recv[slot].data_ptr(), (size_t)nbytes_padded, ncclChar, comm,
-                                                side.stream());
-          TORCH_CHECK(rc == ncclSuccess, "ncclAllGather failed: ", ncclGetErrorString(rc));
-        } else {
-          c10::intrusive_ptr<c10d::Work> work = pg->_allgather_base(recv[slot], send[slot]);
-          work->wait();  // RCCL: the side stream waits for the collective's end, no host block
-        }
-        check_code(pp_shard_unpack_f32(recv[slot].data_ptr(), world, (long long)nbytes_padded, (long long)b * n,
-                                       (long long)b * m, compact, out[slot][0].data_ptr<float>(),
-                                       out[slot][1].data_ptr<float>(), out[slot][2].data_ptr<int>(),
-                                       out[slot][3].data_ptr<int>(), (void*)side.stream()),
-                   "shard_unpack");
-        TORCH_CHECK(hipEventRecord(done[slot], side.stream()) == hipSuccess, "hipEventRecord failed");
-      } catch (const std::exception& e) {
-        std::lock_guard<std::mutex> lock(mu);
-        if (failure.empty()) failure = e.what();
-      }
-      {
-        std::lock_guard<std::mutex> lock(mu);
-        ++issued[slot];
-        worker_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t_begin).count();
-        ++worker_slots;
-      }
-      cv_done.notify_all();
-    }
   }
 
   // rank 0 makes the id (128 bytes), every rank receives it (the caller broadcasts it over the process group) and
@@ -335,56 +302,128 @@ struct PackedExchange {
     ncclComm_t c = nullptr;
     const ncclResult_t rc = ncclCommInitRank(&c, world, id, rank);
     TORCH_CHECK(rc == ncclSuccess, "ncclCommInitRank failed: ", ncclGetErrorString(rc));
-    std::lock_guard<std::mutex> lock(mu);
     comm = c;
   }
-
   void disable_direct() {  // back to c10d (a rank failed to join: every rank must then take the same path)
     drain();
-    std::lock_guard<std::mutex> lock(mu);
+    (void)hipStreamSynchronize(side.stream());
     if (comm) (void)ncclCommDestroy(comm);
     comm = nullptr;
   }
 
-  void finish(int slot) {  // the current stream waits for the slot's unpack (the host only until the worker has issued it)
-    {
-      std::unique_lock<std::mutex> lock(mu);
-      cv_done.wait(lock, [this, slot] { return issued[slot] == launched[slot]; });
-      TORCH_CHECK(failure.empty(), "PackedExchange: ", failure);
-    }
+  hipStream_t current() const { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(); }
+
+  void finish(int slot) {  // the current stream waits for the slot's gather (no host block)
     if (launched[slot] == 0) return;
-    const hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
-    TORCH_CHECK(hipStreamWaitEvent(cur, done[slot], 0) == hipSuccess, "hipStreamWaitEvent failed");
+    TORCH_CHECK(hipStreamWaitEvent(current(), done[slot], 0) == hipSuccess, "hipStreamWaitEvent failed");
   }
 
+  Tensor dist_view(const Tensor& buf, int64_t rows, int field) const {  // field 0: dist1 (rows, b, n), 1: dist2
+    const int64_t stride = nbytes_padded / 4, off = field == 0 ? 0 : (int64_t)b * n, len = field == 0 ? n : m;
+    const Tensor f = buf.view(torch::kFloat32);
+    return f.as_strided({rows, (int64_t)b, len}, {stride, len, 1}, off);
+  }
+  Tensor idx_view(const Tensor& buf, int64_t rows, int field) const {  // the words the indices travelled as
+    const int64_t isz = compact ? 2 : 4;
+    const int64_t stride = nbytes_padded / isz, len = field == 0 ? n : m;
+    const int64_t off = ((int64_t)4 * b * (n + m)) / isz + (field == 0 ? 0 : (int64_t)b * n);
+    const Tensor w = buf.view(compact ? torch::kUInt16 : torch::kInt32);
+    return w.as_strided({rows, (int64_t)b, len}, {stride, len, 1}, off);
+  }
+
+  // The next slot and views of its own distance fields, (b, n) and (b, m): the caller has the search write them
+  // (nndistance_out), then calls launch_in_place(slot, idx1, idx2).  The current stream first waits for the slot's
+  // previous exchange, whose bytes the search is about to overwrite.
+  std::tuple<int, Tensor, Tensor> begin() {
+    const int slot = turn;
+    turn = (turn + 1) % depth;
+    finish(slot);
+    const Tensor f = send[slot].view(torch::kFloat32);
+    return std::make_tuple(slot, f.narrow(0, 0, (int64_t)b * n).view({(int64_t)b, (int64_t)n}),
+                           f.narrow(0, (int64_t)b * n, (int64_t)b * m).view({(int64_t)b, (int64_t)m}));
+  }
+
+  void issue(int slot) {  // the gather of send[slot] on the side stream, behind everything the current stream holds
+    const auto t_begin = std::chrono::steady_clock::now();
+    const c10::DeviceGuard guard(dev);
+    const hipStream_t cur = current();
+    TORCH_CHECK(hipEventRecord(packed[slot], cur) == hipSuccess, "hipEventRecord failed");
+    TORCH_CHECK(hipStreamWaitEvent(side.stream(), packed[slot], 0) == hipSuccess, "hipStreamWaitEvent failed");
+    if (comm) {
+      const ncclResult_t rc = ncclAllGather(send[slot].data_ptr(), recv[slot].data_ptr(), (size_t)nbytes_padded, ncclChar, comm,
+                                            side.stream());
+      TORCH_CHECK(rc == ncclSuccess, "ncclAllGather failed: ", ncclGetErrorString(rc));
+    } else {
+      // (c10d orders the collective behind the CURRENT stream of the calling thread: the side stream, for this call)
+      const c10::hip::HIPStreamGuardMasqueradingAsCUDA on_side(side);
+      c10::intrusive_ptr<c10d::Work> work = pg->_allgather_base(recv[slot], send[slot]);
+      work->wait();  // RCCL: the side stream waits for the collective's end, no host block
+    }
+    TORCH_CHECK(hipEventRecord(done[slot], side.stream()) == hipSuccess, "hipEventRecord failed");
+    ++launched[slot];
+    issue_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t_begin).count();
+    ++issue_slots;
+  }
+
+  void check_idx(const Tensor& i1, const Tensor& i2) const {
+    TORCH_CHECK(i1.numel() == (int64_t)b * n && i2.numel() == (int64_t)b * m && i1.scalar_type() == torch::kInt32 &&
+                    i2.scalar_type() == torch::kInt32 && i1.device() == dev && i2.device() == dev,
+                "PackedExchange: shard indices of another shape, dtype or device");
+  }
+
+  int launch_in_place(int slot, const Tensor& i1_, const Tensor& i2_) {
+    TORCH_CHECK(slot >= 0 && slot < depth, "PackedExchange.launch_in_place: no such slot");
+    const Tensor i1 = i1_.contiguous(), i2 = i2_.contiguous();
+    check_idx(i1, i2);
+    const c10::DeviceGuard guard(dev);
+    check_code(pp_shard_pack_f32(nullptr, nullptr, i1.data_ptr<int>(), i2.data_ptr<int>(), send[slot].data_ptr(),
+                                 (long long)b * n, (long long)b * m, compact, (void*)current()),
+               "shard_pack");
+    issue(slot);
+    return slot;
+  }
+
+  // the general form: distances the caller holds elsewhere are copied in as well (one pack kernel)
   int launch(const Tensor& d1_, const Tensor& d2_, const Tensor& i1_, const Tensor& i2_) {
     const int slot = turn;
     turn = (turn + 1) % depth;
     finish(slot);  // the slot's buffers are about to be overwritten
     const Tensor d1 = d1_.detach().contiguous(), d2 = d2_.detach().contiguous(), i1 = i1_.contiguous(), i2 = i2_.contiguous();
-    TORCH_CHECK(d1.numel() == (int64_t)b * n && d2.numel() == (int64_t)b * m && i1.numel() == d1.numel() &&
-                    i2.numel() == d2.numel() && d1.scalar_type() == torch::kFloat32 && i1.scalar_type() == torch::kInt32 &&
-                    d1.device() == dev,
+    check_idx(i1, i2);
+    TORCH_CHECK(d1.numel() == (int64_t)b * n && d2.numel() == (int64_t)b * m && d1.scalar_type() == torch::kFloat32 &&
+                    d2.scalar_type() == torch::kFloat32 && d1.device() == dev && d2.device() == dev,
                 "PackedExchange.launch: shard outputs of another shape, dtype or device");
     const c10::DeviceGuard guard(dev);
-    const hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
     check_code(pp_shard_pack_f32(d1.data_ptr<float>(), d2.data_ptr<float>(), i1.data_ptr<int>(), i2.data_ptr<int>(),
-                                 send[slot].data_ptr(), (long long)b * n, (long long)b * m, compact, (void*)cur),
+                                 send[slot].data_ptr(), (long long)b * n, (long long)b * m, compact, (void*)current()),
                "shard_pack");
-    TORCH_CHECK(hipEventRecord(packed[slot], cur) == hipSuccess, "hipEventRecord failed");
-    {
-      std::lock_guard<std::mutex> lock(mu);
-      ++launched[slot];
-      queue.push_back(slot);
-    }
-    cv_work.notify_one();
+    issue(slot);
     return slot;
   }
 
+  // (dist1 (world, b, n), dist2 (world, b, m), idx1, idx2 (world, b, n / m) as they travelled: uint16 or int32) --
+  // views of the slot's gathered buffer, valid until the slot is launched again; the current stream waits for the gather
   std::vector<Tensor> wait(int slot) {
     TORCH_CHECK(slot >= 0 && slot < depth, "PackedExchange.wait: no such slot");
     finish(slot);
-    return out[slot];
+    return {dist_view(recv[slot], world, 0), dist_view(recv[slot], world, 1), idx_view(recv[slot], world, 0),
+            idx_view(recv[slot], world, 1)};
+  }
+
+  // int32 indices of the global batch, (world * b, n) and (world * b, m), 0xFFFF -> -1: one kernel, on demand
+  std::vector<Tensor> widen(int slot) {
+    TORCH_CHECK(slot >= 0 && slot < depth, "PackedExchange.widen: no such slot");
+    finish(slot);
+    const c10::DeviceGuard guard(dev);
+    if (wide[slot].empty()) {
+      const auto i32 = torch::TensorOptions().dtype(torch::kInt32).device(dev);
+      wide[slot] = {torch::empty({(int64_t)world * b, n}, i32), torch::empty({(int64_t)world * b, m}, i32)};
+    }
+    check_code(pp_shard_unpack_f32(recv[slot].data_ptr(), world, (long long)nbytes_padded, (long long)b * n,
+                                   (long long)b * m, compact, nullptr, nullptr, wide[slot][0].data_ptr<int>(),
+                                   wide[slot][1].data_ptr<int>(), (void*)current()),
+               "shard_unpack");
+    return wide[slot];
   }
 
   void drain() {
@@ -401,15 +440,20 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "labeled_nndistance(xyz1, xyz2, label1, label2) -> (dist1, dist2, idx1, idx2)");
   m.def("set_force_bruteforce", [](bool on) { g_force_brute = on; });
   m.def("library_version", []() { return std::string(pp_version()); });
+  m.def("nndistance_out", &nndistance_out,
+        "nndistance_out(xyz1, xyz2, dist1, dist2) -> (dist1, dist2, idx1, idx2): the distances written into the given tensors");
   pybind11::class_<PackedExchange>(m, "PackedExchange")
       .def(pybind11::init<const c10::intrusive_ptr<c10d::ProcessGroup>&, int, int, int, const c10::Device&, int>())
+      .def("begin", &PackedExchange::begin, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def("launch_in_place", &PackedExchange::launch_in_place, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("launch", &PackedExchange::launch, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("wait", &PackedExchange::wait, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def("widen", &PackedExchange::widen, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("drain", &PackedExchange::drain, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def_static("unique_id", &PackedExchange::unique_id)
       .def("init_direct", &PackedExchange::init_direct, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("disable_direct", &PackedExchange::disable_direct, pybind11::call_guard<pybind11::gil_scoped_release>())
-      .def("worker_us_per_slot", [](PackedExchange& e) { std::lock_guard<std::mutex> l(e.mu); return e.worker_slots ? e.worker_ns / 1e3 / (double)e.worker_slots : 0.0; })
+      .def("issue_us_per_slot", [](PackedExchange& e) { return e.issue_slots ? e.issue_ns / 1e3 / (double)e.issue_slots : 0.0; })
       .def_readonly("compact", &PackedExchange::compact)
       .def_readonly("nbytes_padded", &PackedExchange::nbytes_padded);
 }

@@ -9,8 +9,6 @@ here is "gathered shards == the unsharded result, bitwise".
 
 FPS stays single-GPU (replicas only): its cost is a serial chain, not capacity.
 """
-import ctypes
-
 import os
 
 import torch
@@ -83,18 +81,28 @@ class PackedShardGather:
 
     ``sharded_nndistance`` above is the convenient form (any shard sizes, differentiable, four
     collectives and a size exchange).  In a training loop with equal shards the exchange should cost
-    one RCCL call that overlaps the backward pass and the next forward: this class packs
-    (dist1 | dist2 | idx1 | idx2) of the local shard into a preallocated byte buffer -- indices as
-    16-bit words when every index fits (N, M <= 65535; -1, labeled Chamfer's "no partner", travels as
-    0xFFFF: 6 instead of 8 bytes per point pair, and on
-    xGMI the exchange, not the search, is the longer leg at 8 GPUs) -- and all-gathers it on the
-    backend's own stream.  Buffers are double-buffered so that step k+1 can pack while step k is
-    still in flight.
+    one RCCL call that overlaps the backward pass and the next forward: the local shard's
+    (dist1 | dist2 | idx1 | idx2) sit in ONE preallocated byte buffer -- indices as 16-bit words when
+    every index fits (N, M <= 65535; -1, labeled Chamfer's "no partner", travels as 0xFFFF: 6 instead
+    of 8 bytes per point pair, and on xGMI the exchange, not the search, is the longer leg at 8 GPUs)
+    -- which is all-gathered on a side stream.  Buffers are double-buffered so that step k+1 can fill
+    its slot while step k is still in flight.
+
+    Round 4: nothing is packed or unpacked that need not be.  ``forward`` has the search write its
+    distances straight into the slot (only the indices are narrowed in behind them: one small kernel),
+    and ``wait_views`` returns strided views of the gathered buffer:
 
         ex = PackedShardGather(B_local, N, M, device)
-        h = ex.launch(d1, d2, i1, i2)          # asynchronous
+        d1, d2, i1, i2, h = ex.forward(xyz1, xyz2)      # nndistance of the shard + the asynchronous gather
         ... backward, next forward ...
-        D1, D2, I1, I2 = ex.wait(h)            # global batch, rank order; I* int32
+        D1, D2, I1, I2 = ex.wait_views(h)              # (world, B_local, N | M): float32 views; indices as the
+                                                       # uint16 / int32 words they travelled as (0xFFFF = -1)
+        D1, D2, I1, I2 = ex.wait(h)                    # or: contiguous (world * B_local, N | M), int32 indices
+
+    ``launch(d1, d2, i1, i2)`` is the general form for outputs the caller holds elsewhere (one pack kernel).
+    The collective is issued by the CALLING thread, in program order with the caller's other collectives
+    on the group.  Everything returned by ``wait*`` is valid until the slot is launched again
+    (``depth`` launches later).
     """
 
     def __init__(self, b_local, n, m, device, group=None, depth=2):
@@ -114,34 +122,27 @@ class PackedShardGather:
         self.inflight = [None] * depth
         self.turn = 0
         self._nccl = dist.get_backend(group) == "nccl"   # (asked once: the launch path is host-bound at config 2)
-        # GPU buffers: the gathered bytes are unpacked (indices widened to int32, rank-major global batch) on
-        # a SIDE stream right behind the collective, into per-slot outputs allocated once -- at 8 ranks that
-        # is ~110 MiB of traffic per step that the stream issuing the searches never executes; it only waits
-        # for the slot's event when the result is asked for
         self.on_gpu = self.send[0].is_cuda
-        if self.on_gpu:
-            self.side = torch.cuda.Stream(device=self.send[0].device)
-            self.done = [torch.cuda.Event() for _ in range(depth)]
-            self.out = [None] * depth
-        # RCCL on GPU tensors: the whole exchange -- pack, all-gather, unpack on a side stream -- is ONE native call
-        # (csrc/torch_bridge.cpp: PackedExchange over c10d's ProcessGroup): issued from Python the three steps cost
-        # the thread ~50 us per step, more than a config-2 step's kernels leave idle.
-        # PP_SHARD_EXCHANGE=python keeps the Python path (comparison, debugging).
+        # RCCL on GPU tensors: the exchange is ONE native call (csrc/torch_bridge.cpp: PackedExchange over c10d's
+        # ProcessGroup): issued from Python its steps cost the thread ~50 us per step, more than a config-2 step's
+        # kernels leave idle.  PP_SHARD_EXCHANGE=python keeps the Python path (comparison, debugging).
         self._native = None
-        if self.on_gpu and self._nccl and os.environ.get("PP_SHARD_EXCHANGE", "native") != "python":
+        self.direct = False
+        mode = os.environ.get("PP_SHARD_EXCHANGE", "rccl")
+        if self.on_gpu and self._nccl and mode != "python":
             from . import _lib
             pg = group if group is not None else dist.distributed_c10d._get_default_group()
             self._native = _lib.bridge().PackedExchange(pg, self.b, self.n, self.m, torch.device(device), depth)
             assert self._native.nbytes_padded == self.nbytes_padded and bool(self._native.compact) == self.compact
             self.send = self.recv = None   # (the native object owns its buffers)
-            # PP_SHARD_EXCHANGE=rccl: the all-gather as a direct ncclAllGather on a communicator of the object's own
-            # (one RCCL call per exchange instead of c10d's Work / events / stream waits: the exchange's host side was
-            # what kept a config-2 step at 0.105 ms against 0.078 of kernels).  Opt-in: a second communicator beside
-            # c10d's must not run collectives in a different order on different ranks -- fine for this operator's one
-            # exchange per step, the caller's other collectives permitting; bench.py opts in.  Any failure to set it
-            # up leaves the c10d path in place.
-            self.direct = False
-            if os.environ.get("PP_SHARD_EXCHANGE", "native") == "rccl":
+            # PP_SHARD_EXCHANGE=rccl (the default): the all-gather as a direct ncclAllGather on a communicator of the
+            # object's own -- one RCCL call per exchange, 6 us of host time, instead of c10d's Work / events / stream
+            # waits, 44 us, which on the calling thread make a config-2 step host-bound (one rank over RCCL: 0.098
+            # against 0.127 ms per step).  A second communicator beside c10d's must see its collectives in the same
+            # order on every rank: the exchange is issued by the calling thread, so that order is the program's.  Any
+            # failure to set it up -- on any rank -- leaves the c10d path in place on all of them
+            # (PP_SHARD_EXCHANGE=native asks for that path outright).
+            if mode == "rccl":
                 try:
                     rank = dist.get_rank(group)
                     box = [bytes(type(self._native).unique_id()) if rank == 0 else None]
@@ -157,6 +158,7 @@ class PackedShardGather:
                     self._native.disable_direct()
                     self.direct = False
 
+    # ------------------------------------------------------------------ layout helpers (the Python / CPU path)
     def _views(self, buf):
         """(d1, d2, i1, i2) views of one rank's packed bytes (1-D uint8)"""
         idt = torch.int16 if self.compact else torch.int32
@@ -164,95 +166,131 @@ class PackedShardGather:
         return (buf[o[0]:o[1]].view(torch.float32), buf[o[1]:o[2]].view(torch.float32),
                 buf[o[2]:o[3]].view(idt), buf[o[3]:self.nbytes].view(idt))
 
-    def _hip(self, t):
-        """GPU tensors go through the library's pack / unpack kernels (one launch each); CPU tensors
-        (the gloo tests) through the equivalent tensor operations."""
-        return t.is_cuda
+    def _gathered_views(self, r):
+        """strided views of a gathered buffer (world, nbytes_padded): dist (world, b, n | m) float32, indices
+        (world, b, n | m) as they travelled (uint16 where the dtype exists for views, else int16 / int32)"""
+        o, w, b = self.off, self.world, self.b
+        d1 = r[:, o[0]:o[1]].view(torch.float32).view(w, b, self.n)
+        d2 = r[:, o[1]:o[2]].view(torch.float32).view(w, b, self.m)
+        idt = (torch.uint16 if hasattr(torch, "uint16") else torch.int16) if self.compact else torch.int32
+        i1 = r[:, o[2]:o[3]].view(idt).view(w, b, self.n)
+        i2 = r[:, o[3]:self.nbytes].view(idt).view(w, b, self.m)
+        return d1, d2, i1, i2
 
-    def launch(self, d1, d2, i1, i2):
-        if self._native is not None:
-            return self._native.launch(d1, d2, i1, i2)
+    def _next_slot(self):
         slot = self.turn
         self.turn = (self.turn + 1) % len(self.send)
-        if self.inflight[slot] is not None:   # the buffers of this slot are about to be overwritten
-            self._finish(slot)
-        if self._hip(self.send[slot]):
+        self._finish(slot)          # the slot's buffers are about to be overwritten
+        return slot
+
+    # ------------------------------------------------------------------ producing side
+    def begin(self):
+        """-> (slot, dist1 (b, n), dist2 (b, m)): views of the next slot's own distance fields for the search to
+        write (``nmdistance_forward(xyz1, xyz2, dist1, dist2, idx1, idx2)`` / ``forward`` below); then
+        ``launch_in_place(slot, idx1, idx2)``."""
+        if self._native is not None:
+            return tuple(self._native.begin())
+        slot = self._next_slot()
+        v = self._views(self.send[slot])
+        return slot, v[0].view(self.b, self.n), v[1].view(self.b, self.m)
+
+    def launch_in_place(self, slot, i1, i2):
+        """the distances of ``slot`` are in place (``begin``): narrow the indices in behind them and gather"""
+        if self._native is not None:
+            return self._native.launch_in_place(slot, i1, i2)
+        self._pack(slot, None, None, i1, i2)
+        return self._gather(slot)
+
+    def forward(self, xyz1, xyz2):
+        """nndistance of this rank's shard with the distances written straight into the exchange's slot, and the
+        asynchronous gather of the shard's outputs: -> (dist1, dist2, idx1, idx2, handle).  Differentiable like
+        ``nndistance``; dist1 / dist2 alias the slot (valid until it is launched again)."""
+        slot, d1v, d2v = self.begin()
+        if self.on_gpu:
             from . import _lib
-            d1 = d1.detach().contiguous(); d2 = d2.detach().contiguous()
+            d1, d2, i1, i2 = _lib.bridge().nndistance_out(xyz1, xyz2, d1v, d2v)
+        else:                           # (CPU tensors only occur in the gloo tests of this logic)
+            raise RuntimeError("PackedShardGather.forward needs GPU tensors (the operator has no CPU path)")
+        self.launch_in_place(slot, i1, i2)
+        return d1, d2, i1, i2, slot
+
+    def launch(self, d1, d2, i1, i2):
+        """general form: outputs held elsewhere are copied into the next slot (one pack kernel) and gathered"""
+        if self._native is not None:
+            return self._native.launch(d1, d2, i1, i2)
+        slot = self._next_slot()
+        self._pack(slot, d1, d2, i1, i2)
+        return self._gather(slot)
+
+    def _pack(self, slot, d1, d2, i1, i2):
+        if self.send[slot].is_cuda:
+            from . import _lib
+            if d1 is not None:
+                d1 = d1.detach().contiguous(); d2 = d2.detach().contiguous()
             i1 = i1.contiguous(); i2 = i2.contiguous()
             with _lib.on_device(self.send[slot].device) as stream:
                 _lib.check(_lib.lib().pp_shard_pack_f32(
-                    _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(self.send[slot]),
+                    _lib.ptr(d1) if d1 is not None else None, _lib.ptr(d2) if d2 is not None else None,
+                    _lib.ptr(i1), _lib.ptr(i2), _lib.ptr(self.send[slot]),
                     self.b * self.n, self.b * self.m, 1 if self.compact else 0, stream), "shard_pack")
         else:
             v = self._views(self.send[slot])
-            v[0].copy_(d1.detach().reshape(-1))
-            v[1].copy_(d2.detach().reshape(-1))
+            if d1 is not None:
+                v[0].copy_(d1.detach().reshape(-1))
+                v[1].copy_(d2.detach().reshape(-1))
             v[2].copy_(i1.reshape(-1))            # int32 -> int16 keeps the low 16 bits
             v[3].copy_(i2.reshape(-1))
+
+    def _gather(self, slot):
         if self._nccl:
             work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
         else:                                 # gloo (CPU tests)
             work = dist.all_gather(list(self.recv[slot].unbind(0)), self.send[slot], group=self.group,
                                    async_op=True)
         self.inflight[slot] = work
-        if self.on_gpu:
-            self._unpack_on_side_stream(slot, work)
         return slot
 
     def _finish(self, slot):
-        """the current stream (GPU) or the host (CPU tensors) waits until the slot's exchange is complete"""
+        """the current stream (RCCL) or the host (gloo) waits until the slot's gather is complete"""
         h = self.inflight[slot]
         if h is None:
             return
-        if self.on_gpu:
-            torch.cuda.current_stream(self.send[slot].device).wait_event(self.done[slot])
-        else:
-            h.wait()
+        h.wait()
         self.inflight[slot] = None
 
-    def _unpack_on_side_stream(self, slot, work):
-        from . import _lib
-        r = self.recv[slot]
-        dev = r.device
-        w, b = self.world, self.b
-        if self.out[slot] is None:
-            self.out[slot] = (torch.empty(w * b, self.n, dtype=torch.float32, device=dev),
-                              torch.empty(w * b, self.m, dtype=torch.float32, device=dev),
-                              torch.empty(w * b, self.n, dtype=torch.int32, device=dev),
-                              torch.empty(w * b, self.m, dtype=torch.int32, device=dev))
-        d1, d2, i1, i2 = self.out[slot]
-        # (set_stream twice instead of the `with torch.cuda.stream(...)` context manager, and the side stream's raw
-        #  handle straight to the C ABI: the exchange costs the issuing thread ~60 us per step, every piece counts)
-        prev_dev = torch.cuda.current_device()   # (set_stream also switches the current device to the stream's)
-        prev = torch.cuda.current_stream(dev)
-        torch.cuda.set_stream(self.side)
-        try:
-            work.wait()   # RCCL: the side stream waits for the collective (no host block); gloo: the host does
-            _lib.check(_lib.lib().pp_shard_unpack_f32(
-                _lib.ptr(r), w, self.nbytes_padded, b * self.n, b * self.m, 1 if self.compact else 0,
-                _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2), ctypes.c_void_p(self.side.cuda_stream)),
-                "shard_unpack")
-            self.done[slot].record(self.side)
-        finally:
-            torch.cuda.set_stream(prev)
-            if prev_dev != torch.cuda.current_device():
-                torch.cuda.set_device(prev_dev)   # the caller's device, not the exchange's (ADVICE r2)
-
-    def wait(self, slot):
-        """Blocks the current stream (not the host, on RCCL) until the gather of ``slot`` is done and unpacked,
-        and returns (dist1, dist2, idx1, idx2) of the global batch in rank order.  On the GPU these are the
-        slot's own buffers: valid until the slot is launched again (``depth`` launches later)."""
+    # ------------------------------------------------------------------ consuming side
+    def wait_views(self, slot):
+        """Blocks the current stream (not the host, on RCCL) until the gather of ``slot`` is done and returns
+        (dist1, dist2, idx1, idx2) of every rank WITHOUT copying anything: strided views of the gathered buffer,
+        (world, B_local, N | M) in rank order; the indices as they travelled (16-bit words with 0xFFFF for -1 when
+        ``compact``, else int32)."""
         if self._native is not None:
             return tuple(self._native.wait(slot))
         self._finish(slot)
+        return self._gathered_views(self.recv[slot])
+
+    def wait(self, slot):
+        """The same as contiguous global-batch tensors, (world * B_local, N | M), with int32 indices (one widening
+        kernel and two copies on the GPU: for consumers that want exactly what the unsharded operator returns)."""
+        w, b = self.world, self.b
+        if self._native is not None:
+            d1, d2, _, _ = self._native.wait(slot)
+            i1, i2 = self._native.widen(slot)
+            return d1.reshape(w * b, self.n), d2.reshape(w * b, self.m), i1, i2
+        self._finish(slot)
         r = self.recv[slot]
         o = self.off
-        w, b = self.world, self.b
-        if self.on_gpu:   # unpacked on the side stream already; valid until the slot is launched again
-            return self.out[slot]
         d1 = r[:, o[0]:o[1]].view(torch.float32).reshape(w * b, self.n)
         d2 = r[:, o[1]:o[2]].view(torch.float32).reshape(w * b, self.m)
+        if r.is_cuda:
+            from . import _lib
+            i1 = torch.empty(w * b, self.n, dtype=torch.int32, device=r.device)
+            i2 = torch.empty(w * b, self.m, dtype=torch.int32, device=r.device)
+            with _lib.on_device(r.device) as stream:
+                _lib.check(_lib.lib().pp_shard_unpack_f32(
+                    _lib.ptr(r), w, self.nbytes_padded, b * self.n, b * self.m, 1 if self.compact else 0,
+                    None, None, _lib.ptr(i1), _lib.ptr(i2), stream), "shard_unpack")
+            return d1, d2, i1, i2
         if self.compact:
             i1 = (r[:, o[2]:o[3]].view(torch.int16).to(torch.int32) & 0xFFFF).reshape(w * b, self.n)
             i2 = (r[:, o[3]:self.nbytes].view(torch.int16).to(torch.int32) & 0xFFFF).reshape(w * b, self.m)

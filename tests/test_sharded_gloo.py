@@ -103,10 +103,26 @@ def _packed_worker(rank, world, port, n, m, q):
             I2[:, -1] = n - 1
             I1[:, 1] = -1           # labeled Chamfer's "no partner": must survive the 16-bit packing
             lo, hi = rank * B, (rank + 1) * B
-            h = ex.launch(D1[lo:hi], D2[lo:hi], I1[lo:hi], I2[lo:hi])
+            if step == 1:   # the in-place form: the producer writes its distances into the slot's own fields
+                slot, v1, v2 = ex.begin()
+                v1.copy_(D1[lo:hi]); v2.copy_(D2[lo:hi])
+                h = ex.launch_in_place(slot, I1[lo:hi], I2[lo:hi])
+            else:
+                h = ex.launch(D1[lo:hi], D2[lo:hi], I1[lo:hi], I2[lo:hi])
+            # a collective of the caller's own between launch and wait (the exchange is issued in program order)
+            t = torch.ones(3) * (rank + 1)
+            dist.all_reduce(t)
+            ok = ok and float(t[0]) == sum(range(1, world + 1))
             d1, d2, i1, i2 = ex.wait(h)
             ok = ok and torch.equal(d1, D1) and torch.equal(d2, D2) and torch.equal(i1, I1) and torch.equal(i2, I2)
             ok = ok and i1.dtype == torch.int32
+            # ... and as views of the gathered buffer: (world, B, n | m), indices as the words they travelled as
+            w1, w2, j1, j2 = ex.wait_views(h)
+            ok = ok and w1.shape == (world, B, n) and torch.equal(w1.reshape(world * B, n), D1)
+            ok = ok and torch.equal(w2.reshape(world * B, m), D2)
+            mask = 0xFFFF if ex.compact else -1
+            ok = ok and torch.equal(j1.to(torch.int32).reshape(world * B, n) & mask, I1 & mask)
+            ok = ok and torch.equal(j2.to(torch.int32).reshape(world * B, m) & mask, I2 & mask)
         ex.drain()
         q.put((rank, bool(ok), ex.compact))
     finally:
