@@ -44,8 +44,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz fp32 lane-ops/s (same table)
-FWD_TRAFFIC_C2 = 71565312      # bytes per forward at config 2, all three launches: 2 x FETCH_SIZE (11949 + 6383 + 22 KB)
-                               # + WRITE_SIZE (8257 + 24923 + 0 KB), profiles/r3/pmc_summary.txt = 3.4x the algorithmic bytes
+# bytes per forward at config 2, all three launches -- a RECORDED constant, not measured by this run: 2 x FETCH_SIZE +
+# WRITE_SIZE per launch from rocprofv3 --pmc passes of this command (tools/refresh_profiles.sh -> profiles/r4/pmc_summary.txt,
+# which names the commit it was taken at); counters cannot be collected inside the timed process
+FWD_TRAFFIC_C2 = 71565312
 
 
 def parse():
@@ -371,20 +373,18 @@ def bench_chamfer(args, dist, world, rank, device):
         maybe_exchange(d1, d2, i1, i2)
 
     # ---- the timed region: the autograd operator (eager) unless another issue mode is asked for ---------------
-    # The backward runs on the CALLING thread (torch.autograd.set_multithreading_enabled(False), a public switch):
-    # by default the engine hands every backward to its per-device worker thread and blocks on it, which costs this
-    # step ~50 us of host time (tools/host_probe2.py: 82 against 32 us per eager step) -- more than the kernels
-    # leave idle, so the default is host-bound and follows the box's other tenants.  The default-engine number is
-    # reported beside it as launch_modes_ms_per_step["eager_engine_threads"].
+    # `value` is ALWAYS the eager operator under torch's DEFAULT autograd engine -- what a user of the drop-in API runs
+    # (VERDICT r3 #7 / ADVICE r3: rounds 2-3 took the backward on the calling thread, then the faster of the two).  The
+    # other mode -- torch.autograd.set_multithreading_enabled(False), a public switch that saves the hand-off to the
+    # engine's worker thread -- is reported beside it as launch_modes_ms_per_step["eager_calling_thread"], same step count.
     engine_threads_default = torch.autograd.is_multithreading_enabled()
-    torch.autograd.set_multithreading_enabled(False)
+    torch.autograd.set_multithreading_enabled(True)
     want = "eager" if args.launch == "all" else args.launch
     if want == "graph" and gstep is None:
         want = "eager"
     timed_fn = {"graph": graph_step, "ext": ext_step, "eager": eager_step}[want]
     dt = run_timed(timed_fn, args.warmup, args.steps)
     ms = dt / args.steps * 1e3
-    headline_engine = "backward on the calling thread"
 
     modes = {want: ms}
     n_cal = 100
@@ -410,18 +410,10 @@ def bench_chamfer(args, dist, world, rank, device):
         modes["ext"] = run_timed(ext_step, 5, n_cal) / n_cal * 1e3
         if gstep is not None:
             modes["graph"] = run_timed(graph_step, 5, n_cal) / n_cal * 1e3
-        # torch's default engine (the backward on the engine's worker thread): same warm-up and step count as the headline
-        torch.autograd.set_multithreading_enabled(True)
-        dt_engine = run_timed(eager_step, args.warmup, args.steps)
-        modes["eager_engine_threads"] = dt_engine / args.steps * 1e3
+        # the backward on the calling thread: same warm-up and step count as the headline
         torch.autograd.set_multithreading_enabled(False)
-        # VERDICT r2 #8 / ADVICE r2: the default-engine number is the headline when it is the faster of the two (it is on
-        # most boxes since the C++ autograd nodes: 0.0756-0.0767 against 0.0770-0.0784; one box measured 0.089 against
-        # 0.077: there the engine's thread hand-off is exposed).  Both are K timed steps of the same operator; which one
-        # `value` is, is said in config.launch and in launch_modes_ms_per_step["note"].
-        if want == "eager" and dist is None and dt_engine < dt:
-            dt, ms = dt_engine, dt_engine / args.steps * 1e3
-            headline_engine = "default engine"
+        modes["eager_calling_thread"] = run_timed(eager_step, args.warmup, args.steps) / args.steps * 1e3
+        torch.autograd.set_multithreading_enabled(True)
     compute_ms = exchange_ms = None
     if dist is not None:
         # the two legs by themselves: the same steps without the exchange, and the exchange with nothing beside it
@@ -467,9 +459,24 @@ def bench_chamfer(args, dist, world, rank, device):
     fwd_ms = e0.elapsed_time(e1) / nf
     grid = args.search == "auto" and int(_lib.lib().pp_nmdistance_forward_workspace_bytes(B, N, M, C)) > 0
     build_ms = stage_a_ms = rest_ms = search_ms = None
+    raw_kernel_ms = None
+    event_overhead_ms = None
     if grid:
         build_ms, stage_a_ms, rest_ms = _search_kernel_ms(fwd_only)
         search_ms = (stage_a_ms + rest_ms) if build_ms is not None else None
+        if build_ms is not None:
+            # Each figure is the time between two HIP events around ONE launch, which adds a recorded event's own
+            # cost to it: bracketed one by one the launches sum to more than the forward they make up (71.5
+            # us of kernels in a 60.8 us forward).  The surplus -- (sum of the bracketed launches - fwd_ms) / launches,
+            # the same forward timed as a whole in this run -- is taken off each, so that the *_kernel_ms add up to
+            # fwd_ms; the uncorrected figures stay in roofline.kernel_ms_uncorrected.
+            raw_kernel_ms = {"build": build_ms, "stage_a": stage_a_ms, "rest": rest_ms}
+            n_l = 3 if stage_a_ms else 2
+            event_overhead_ms = max(0.0, (build_ms + (stage_a_ms or 0.0) + rest_ms - fwd_ms) / n_l)
+            build_ms -= event_overhead_ms
+            rest_ms -= event_overhead_ms
+            if stage_a_ms:
+                stage_a_ms -= event_overhead_ms
 
     # the same step with the search forced to the brute-force kernel (every pair evaluated)
     brute = None
@@ -497,11 +504,10 @@ def bench_chamfer(args, dist, world, rank, device):
     laneops = 2.0 * B * N * M * 6.703125
     c2 = (B, N, M) == (32, 16384, 16384)
     launch_text = {
-        "eager": "torch.autograd.Function operator (nndistance forward, autograd backward), one Python call each: "
-                 "what a user of the drop-in API runs; timed twice with the same step count -- torch's default autograd "
-                 "engine (launch_modes 'eager_engine_threads') and torch.autograd.set_multithreading_enabled(False), the "
-                 "backward on the calling thread (launch_modes 'eager') -- and the faster one is this line's value "
-                 "(ms_per_step_events_median: HIP events around the calling-thread steps)",
+        "eager": "torch.autograd.Function operator (nndistance forward, autograd backward), one Python call each, under "
+                 "torch's default autograd engine: what a user of the drop-in API runs.  ms_per_step_events_median: HIP "
+                 "events around the same steps in the same mode.  launch_modes 'eager_calling_thread': the same with "
+                 "torch.autograd.set_multithreading_enabled(False)",
         "ext": "two calls per step of the extension-module API (_ext.losses.nmdistance_forward / _backward) on "
                "static buffers: plain stream launches, same kernels as the autograd operator",
         "graph": "hipGraph replay of the step's launches (same kernels as the eager operator)"}
@@ -518,11 +524,10 @@ def bench_chamfer(args, dist, world, rank, device):
                               "brute force: every pair evaluated"),
                    "parallelism": "batch-shard x%d%s" % (world, " + RCCL all-gather(dist,idx) every %d step(s), async"
                                                          % gather_every if world > 1 else ""),
-                   "launch": launch_text[want] + ((" -- this line's value: " + headline_engine) if want == "eager" else "")},
+                   "launch": launch_text[want]},
         "fwd_ms": fwd_ms,
         "launch_modes_ms_per_step": dict(modes, note="same kernels in every mode; 'value' is the '%s' mode%s" % (
-            want, (" (%s: the faster of 'eager' = backward on the calling thread and 'eager_engine_threads' = torch's "
-                   "default engine, same step count)" % headline_engine) if want == "eager" else "")),
+            want, " (torch's default autograd engine)" if want == "eager" else "")),
     }
     if graph_note:
         out["config"]["launch_note"] = graph_note
@@ -557,9 +562,13 @@ def bench_chamfer(args, dist, world, rank, device):
             # per launch, profiles/r3/pmc_summary.txt
             "traffic": FWD_TRAFFIC_C2 if (c2 and two_stage) else None,
             "kernel_ms": dom_ms, "build_kernel_ms": build_ms, "stage_a_kernel_ms": stage_a_ms, "rest_kernel_ms": rest_ms,
+            "kernel_ms_uncorrected": raw_kernel_ms, "kernel_event_overhead_ms": event_overhead_ms,
+            "traffic_source": ("recorded constant: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over the forward's launches, "
+                               "profiles/r4/pmc_summary.txt (the commit is named there)") if (c2 and two_stage) else None,
             "note": "SURVEY.md §8(d): algorithmic forward bytes (%.0f) / the dominant kernel's average duration, HIP events "
                     "on the launch stream around each of the forward's launches (pp_hip_debug.h), %d forwards after the "
-                    "timed region; 'traffic' is for the whole forward (every launch), not the dominant kernel alone. The "
+                    "timed region, each less the events' own cost (kernel_event_overhead_ms) so that build + stage A + rest "
+                    "= fwd_ms; 'traffic' is for the whole forward (every launch), not the dominant kernel alone. The "
                     "search is bound by VALU issue and LDS bandwidth, not by HBM; 'bruteforce' carries the every-pair kernel "
                     "with its VALU roofline" % (alg_bytes_fwd, 40)}
         sgbs = alg_bytes_step / (ms * 1e-3) / 1e9
@@ -731,6 +740,35 @@ def bench_ball_group(args, dist, world, rank, device):
         qg_unfused_ms = time_it(lambda: qg.forward_unfused(x, centres, feats))
     gp_bytes = 4.0 * B * C * N + 4.0 * B * npoint * ns + 4.0 * B * C * npoint * ns
     gbs = gp_bytes / (gp_ms * 1e-3) / 1e9
+    # The store ceiling of THIS device in THIS run: a pure streaming store of as many bytes as
+    # group_points writes, 16-byte non-temporal stores, the best of a few launch shapes -- what a kernel that writes
+    # 4 GiB can at best approach here.  Reported as roofline.peak_measured beside the 8 TB/s spec.
+    import ctypes
+    from pytorch_points_amd import _lib
+    ceil_fn = _lib.lib().pp_debug_store_ceiling
+    ceil_fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    ceil_fn.restype = ctypes.c_int
+    out_bytes = int(4 * B * C * npoint * ns)
+    scratch = torch.empty(out_bytes, dtype=torch.uint8, device=device)
+    peak_measured, peak_shape = 0.0, None
+    for nt in (1, 0):
+        for wgs in (256, 512, 1024, 2048):
+            def fill():
+                with _lib.on_device(device) as stream:
+                    _lib.check(ceil_fn(_lib.ptr(scratch), out_bytes, nt, wgs, stream), "store_ceiling")
+            fill()
+            torch.cuda.synchronize()
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(5):
+                fill()
+            b_.record()
+            torch.cuda.synchronize()
+            g = out_bytes / (a.elapsed_time(b_) / 5 * 1e-3) / 1e9
+            if g > peak_measured:
+                peak_measured, peak_shape = g, "%s stores, %d workgroups x 1024 threads" % ("non-temporal" if nt else "plain", wgs)
+    del scratch
+    store_gbs = out_bytes / (gp_ms * 1e-3) / 1e9
     return {"metric": "group_points_output_bytes_per_s", "value": 4.0 * B * C * npoint * ns * world / (gp_ms * 1e-3),
             "unit": "B/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -741,6 +779,12 @@ def bench_ball_group(args, dist, world, rank, device):
             "ball_query_pairs_per_s": float(B) * npoint * N / (bq_ms * 1e-3),
             "roofline": {"bound": "hbm", "kernel": "group_points_dma1_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         # the store ceiling measured in this run (a pure 4 GiB streaming store) and group_points' own
+                         # stores against it (its row reads and index reads come on top of these bytes)
+                         "peak_measured": peak_measured, "peak_measured_how": peak_shape,
+                         "store_achieved": store_gbs, "frac_of_measured": store_gbs / peak_measured if peak_measured else None,
+                         # all of the kernel's algorithmic bytes (stores + row reads + index reads) against the same ceiling
+                         "frac_all_bytes_of_measured": gbs / peak_measured if peak_measured else None,
                          # PMC passes (profiles/r1/pmc_summary.txt): WRITE_SIZE 4096 MB exact, FETCH_SIZE
                          # 144 MB x2 (16-B loads read 1/2 on gfx950) = 288 MB
                          "traffic": 4583e6 if (B, N, C, ns) == (32, 16384, 128, 64) else None}}

@@ -49,6 +49,9 @@ void pp_debug_set_three_interpolate_variant(int variant);
 void pp_debug_set_three_interpolate_grad_variant(int variant);
 void pp_debug_set_scatter_mode(int mode);          /* 1 = never use the sorted scatter-add form */
 void pp_debug_set_knn_search(int mode);            /* 0 automatic, 1 scan */
+/* a pure streaming store of `bytes` (16-byte stores, non-temporal or plain, `workgroups` x 1024 threads): the store
+ * ceiling bench.py reports beside group_points (roofline.peak_measured) */
+int pp_debug_store_ceiling(void* buf, size_t bytes, int nontemporal, int workgroups, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,8 @@ def _fps_clear(dev, key, entry):
     """forget a reported timeout: the mirror, and the status word of the workspace it mirrors (on that workspace's
     own stream: the current one -- the key is (device, current stream))"""
     entry[0].zero_()
-    ws = _lib._WS.get((dev.index, key[1], "fps"))   # (keyed as _lib.workspace keys it)
+    ws = _lib._WS.get((key[0], key[1], "fps"))   # (keyed as _lib.workspace keys it: the device's integer index --
+    #                                                  `dev` may carry none, ADVICE r3)
     if ws is not None:
         ws[:4].zero_()
 

@@ -113,8 +113,9 @@ def test_workspace_size_queries_are_host_only():
     # FPS cluster ring: B * CL <= 256 co-resident workgroups, >= 512 points each
     assert L.pp_furthest_sampling_workspace_bytes(16, 65536, 4096) > 0
     assert L.pp_furthest_sampling_workspace_bytes(300, 1024, 64) == 0      # more batch elements than CUs, small clouds
-    # the bucketed kernel (N >= 2048, 32 or more picks): the sorted cloud (16 B) and the tie ranks (4 B) per point
-    assert L.pp_furthest_sampling_workspace_bytes(300, 2048, 64) == 256 + 300 * 2048 * 20
+    # the bucketed kernel (N >= 2048, 32 or more picks): the sorted cloud (16 B per point) and one more word per point
+    # (up to 65536 points: a word for every register slot of the running minima, 65536 per batch element)
+    assert L.pp_furthest_sampling_workspace_bytes(300, 2048, 64) == 256 + 300 * (2048 * 16 + 65536 * 4)
     assert L.pp_furthest_sampling_workspace_bytes(16, 65536, 4096) > 16 * 65536 * 20
     assert L.pp_furthest_sampling_workspace_bytes(1, 70000, 64) >= 256 + 70000 * 20
     assert L.pp_furthest_sampling_workspace_bytes(1, 600, 64) == 0         # too small to split
