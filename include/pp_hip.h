@@ -82,13 +82,23 @@ int pp_nmdistance_backward_f32(const float* xyz1, const float* xyz2, const float
 /* The same two operators for double clouds: the reference dispatches its kernels over the floating types
  * (AT_DISPATCH_FLOATING_TYPES_AND_HALF, _ext/nmdistance_cuda.cu:125,210), scalar_t = double for coordinates,
  * distances and gradients, int indices.  Every-pair scan (no workspace form); same tie rule and rounding order
- * as the reference's kernel instantiated for double.  half is not provided (the Python layer raises TypeError). */
+ * as the reference's kernel instantiated for double. */
 int pp_nmdistance_forward_f64(const double* xyz1, const double* xyz2, double* dist1, int* idx1,
                               double* dist2, int* idx2, int B, int N, int M, int C, void* stream);
 int pp_nmdistance_backward_f64(const double* xyz1, const double* xyz2, const double* graddist1,
                                const double* graddist2, const int* idx1, const int* idx2,
                                double* gradxyz1, double* gradxyz2, int B, int N, int M, int C,
                                void* stream);
+/* ... and for half clouds (scalar_t = at::Half, the third type of that dispatch): coordinates, distances and gradients
+ * are IEEE binary16 words (torch.float16; opaque pointers here), every subtraction, product and sum rounded to half
+ * separately as c10::Half's operators do (no fused operation), comparisons in half; the scattered gradient terms are
+ * added with packed half atomics, each addition rounded, in arrival order (the reference: a CAS loop on at::Half).
+ * bfloat16 is not part of the reference's dispatch and is not provided. */
+int pp_nmdistance_forward_f16(const void* xyz1, const void* xyz2, void* dist1, int* idx1, void* dist2, int* idx2,
+                              int B, int N, int M, int C, void* stream);
+int pp_nmdistance_backward_f16(const void* xyz1, const void* xyz2, const void* graddist1, const void* graddist2,
+                               const int* idx1, const int* idx2, void* gradxyz1, void* gradxyz2, int B, int N,
+                               int M, int C, void* stream);
 
 /* ---- _ext.sampling ----------------------------------------------------------------------- */
 

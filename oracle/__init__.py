@@ -123,6 +123,62 @@ def chamfer_backward_f64(xyz1, xyz2, graddist1, graddist2, idx1, idx2):
     return gx1, gx2
 
 
+def chamfer_forward_f16(xyz1, xyz2):
+    """the reference's kernel instantiated for at::Half (nmdistance_cuda.cu:7-49,125): every operator of c10::Half
+    converts to float, computes, and rounds the result back to half (c10/util/Half-inl.h) -- tmp = buf - xyz; d += tmp *
+    tmp is three separately rounded half operations per coordinate, which is what numpy's float16 arithmetic does
+    (computed in float32, rounded to float16: exact products, innocuous double rounding of sums); first minimum in
+    index order.  -> dist1 f16, idx1 i32, dist2 f16, idx2 i32.  Plain numpy, small sizes."""
+    xyz1 = np.ascontiguousarray(xyz1, dtype=np.float16)
+    xyz2 = np.ascontiguousarray(xyz2, dtype=np.float16)
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+
+    def one_way(q, r):          # q (nq, c) queries, r (nr, c) references
+        d = np.zeros((q.shape[0], r.shape[0]), np.float16)
+        for e in range(c):
+            t = (r[None, :, e] - q[:, None, e]).astype(np.float16)       # buf - xyz (:33)
+            p = (t * t).astype(np.float16)
+            d = p if e == 0 else (d + p).astype(np.float16)            # 0 + p = p exactly
+        best = d.min(axis=1) if r.shape[0] else np.zeros(q.shape[0], np.float16)
+        idx = d.argmin(axis=1).astype(np.int32) if r.shape[0] else np.zeros(q.shape[0], np.int32)   # first minimum
+        return best.astype(np.float16), idx
+
+    d1 = np.zeros((b, n), np.float16); d2 = np.zeros((b, m), np.float16)
+    i1 = np.zeros((b, n), np.int32); i2 = np.zeros((b, m), np.int32)
+    for k in range(b):
+        if n and m:
+            d1[k], i1[k] = one_way(xyz1[k], xyz2[k])
+            d2[k], i2[k] = one_way(xyz2[k], xyz1[k])
+    return d1, i1, d2, i2
+
+
+def chamfer_backward_f16_terms(xyz1, xyz2, graddist1, graddist2, idx1, idx2):
+    """the half instantiation of the backward kernel (:168-185): g = graddist * 2; v = g * (xa - xb), every operation
+    rounded to half; -> (own1 (B,N,C), own2 (B,M,C)) the own-row terms as half, and float64 sums of all terms per row
+    (gx1, gx2): the reference adds the scattered terms with half atomics in arrival order, so only a tolerance against
+    the exact sum of the half-rounded TERMS is defined."""
+    x1 = np.ascontiguousarray(xyz1, dtype=np.float16); x2 = np.ascontiguousarray(xyz2, dtype=np.float16)
+    g1 = np.ascontiguousarray(graddist1, dtype=np.float16); g2 = np.ascontiguousarray(graddist2, dtype=np.float16)
+    b, n, c = x1.shape
+    m = x2.shape[1]
+    two = np.float16(2)
+    own1 = np.zeros((b, n, c), np.float16); own2 = np.zeros((b, m, c), np.float16)
+    gx1 = np.zeros((b, n, c), np.float64); gx2 = np.zeros((b, m, c), np.float64)
+    for k in range(b):
+        ga = (g1[k] * two).astype(np.float16)
+        v = (ga[:, None] * (x1[k] - x2[k][idx1[k]]).astype(np.float16)).astype(np.float16)
+        own1[k] = v
+        gx1[k] += v.astype(np.float64)
+        np.subtract.at(gx2[k], idx1[k], v.astype(np.float64))
+        gb = (g2[k] * two).astype(np.float16)
+        w = (gb[:, None] * (x2[k] - x1[k][idx2[k]]).astype(np.float16)).astype(np.float16)
+        own2[k] = w
+        gx2[k] += w.astype(np.float64)
+        np.subtract.at(gx1[k], idx2[k], w.astype(np.float64))
+    return own1, own2, gx1, gx2
+
+
 def labeled_chamfer_forward(xyz1, xyz2, label1, label2):
     xyz1, p1 = _f(xyz1)
     xyz2, p2 = _f(xyz2)

@@ -45,16 +45,19 @@ def nmdistance_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
     _lib.require_int(*ints)
     if dist1.numel() != b * n or idx1.numel() != b * n or dist2.numel() != b * m or idx2.numel() != b * m:
         raise RuntimeError("output tensors must be (B, N) and (B, M)")
-    if dt is torch.float64:
-        _launch_f64("pp_nmdistance_forward_f64", "nmdistance_forward", dev,
+    if dt is not torch.float32:
+        _launch_f64("pp_nmdistance_forward_" + _SUFFIX[dt], "nmdistance_forward", dev,
                     xyz1, xyz2, dist1, idx1, dist2, idx2, b, n, m, c)
     else:
         _launch_forward(xyz1, xyz2, dist1, dist2, idx1, idx2, b, n, m, c, dev)
     return 1
 
 
+_SUFFIX = {torch.float64: "f64", torch.float16: "f16"}   # the every-pair scans for the reference's other two types
+
+
 def _launch_f64(symbol, what, dev, *args):
-    """double clouds (the reference's scalar_t = double instantiation, _ext/nmdistance_cuda.cu:125,210): tensors
+    """double / half clouds (the reference's scalar_t = double / at::Half instantiations, _ext/nmdistance_cuda.cu:125,210): tensors
     first (passed by address), then the four sizes; arguments already validated"""
     fn = getattr(_lib.lib(), symbol)
     with _lib.on_device(dev) as stream:
@@ -121,8 +124,8 @@ def nmdistance_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, id
     _lib.require_int(*ints)
     if gradxyz1.shape != xyz1.shape or gradxyz2.shape != xyz2.shape:
         raise RuntimeError("gradxyz tensors must have the shapes of xyz1 / xyz2")
-    if dt is torch.float64:
-        _launch_f64("pp_nmdistance_backward_f64", "nmdistance_backward", dev,
+    if dt is not torch.float32:
+        _launch_f64("pp_nmdistance_backward_" + _SUFFIX[dt], "nmdistance_backward", dev,
                     xyz1, xyz2, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, b, n, m, c)
     else:
         _launch_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2, b, n, m, c, dev)

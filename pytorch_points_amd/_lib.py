@@ -29,6 +29,8 @@ SIGNATURES = {
     "pp_nmdistance_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_nmdistance_forward_f64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_nmdistance_backward_f64": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_nmdistance_forward_f16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pp_nmdistance_backward_f16": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pp_furthest_sampling_workspace_bytes": [_I, _I, _I],
     "pp_furthest_sampling_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_furthest_sampling_gather_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _c_size_t, _P],
@@ -186,19 +188,18 @@ def require_float(*named):
 
 def require_float_or_double(*named):
     """The Chamfer operators' dtype rule: the reference dispatches them over float, double and half
-    (AT_DISPATCH_FLOATING_TYPES_AND_HALF, _ext/nmdistance_cuda.cu:125); here fp32 (tuned) and fp64 (every-pair
-    scan) are served, all floating arguments of one call in the same type.  half / bfloat16 raise TypeError:
-    not provided (the reference's half instantiation does not compile against current THC atomics either).
-    -> the common dtype"""
+    (AT_DISPATCH_FLOATING_TYPES_AND_HALF, _ext/nmdistance_cuda.cu:125); fp32 is the tuned path, fp64 and fp16 go through
+    every-pair scans with the reference's arithmetic for the type; all floating arguments of one call in the same type.
+    bfloat16 is not in that dispatch and raises TypeError.  -> the common dtype"""
     dt = named[0][1].dtype
-    if dt in (torch.float16, torch.bfloat16):
-        raise TypeError("%s is %s: the Chamfer operators serve float32 and float64 only (no half path)" % (named[0][0], dt))
-    if dt not in (torch.float32, torch.float64):
+    if dt is torch.bfloat16:
+        raise TypeError("%s is %s: the Chamfer operators serve float32, float64 and float16 (the reference's dispatch)" % (named[0][0], dt))
+    if dt not in (torch.float32, torch.float64, torch.float16):
         raise RuntimeError("%s must be a float tensor" % named[0][0])
     for name, t in named[1:]:
         if t.dtype != dt:
-            if t.dtype in (torch.float16, torch.bfloat16):
-                raise TypeError("%s is %s: the Chamfer operators serve float32 and float64 only (no half path)" % (name, t.dtype))
+            if t.dtype is torch.bfloat16:
+                raise TypeError("%s is %s: the Chamfer operators serve float32, float64 and float16" % (name, t.dtype))
             raise RuntimeError("%s must be a %s tensor like %s" % (name, "double" if dt is torch.float64 else "float", named[0][0]))
     return dt
 

@@ -1765,22 +1765,26 @@ constexpr int kPendTried = 1 << 30;
 #ifndef PP_LIST_WAVES
 #define PP_LIST_WAVES 5  // waves per SIMD the kernel and its out-of-line stages are compiled for (96 registers)
 #endif
+#ifndef PP_LIST_WG_WAVES
+#define PP_LIST_WG_WAVES 4  // waves per workgroup of the list kernel (independent waves: only the dispatch sees the difference)
+#endif
+constexpr int kListWgWaves = PP_LIST_WG_WAVES;
 template <int CAPW>
-__global__ __launch_bounds__(256, PP_LIST_WAVES) void grid_query_list_kernel(const float* __restrict__ xyz1,
+__global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_list_kernel(const float* __restrict__ xyz1,
                                                                   const float* __restrict__ xyz2,
                                                                   float* __restrict__ dist1, int* __restrict__ idx1,
                                                                   float* __restrict__ dist2, int* __restrict__ idx2,
                                                                   unsigned char* __restrict__ ws, int B, int N, int M,
                                                                   int waves_per_set, const Layout L) {
   static_assert((CAPW + 4) * 16 >= 1024 * 4, "the prefix sums of up to 1024 counts use the wave's slice");
-  __shared__ pp::f4 s_pts[4][CAPW + 4];
+  __shared__ pp::f4 s_pts[kListWgWaves][CAPW + 4];
   const int wave = pp::wave_id_uniform();
   const int lane = threadIdx.x & 63;
   // a direction's list is served on the XCD that built its grids and wrote the list (the build's and the stage-A kernel's
   // set -> XCD mapping: contiguous ranges of sets per XCD): its tables and points are in that L2 -- served from another
   // XCD every one of a query's dependent loads went to the memory side (24 -> 1x us for the whole launch at config 2).
   // Speed only: whatever the placement, the results are the same.
-  const int gw = pp::xcd_virtual_block((int)blockIdx.x, (int)(gridDim.x >> 3)) * 4 + wave;  // (the grid is a multiple of 8)
+  const int gw = pp::xcd_virtual_block((int)blockIdx.x, (int)(gridDim.x >> 3)) * kListWgWaves + wave;  // (the grid is a multiple of 8)
   const int set = gw / waves_per_set, wi = gw - set * waves_per_set;
   // (round 3, tried: a set's waves from its two ends inwards -- the rim waves are the expensive ones -- changed nothing;
   //  the XCD's sets interleaved as well spread the expensive waves over the launch -- gaussian 0.265 -> 0.243 ms, blobs8
@@ -2476,7 +2480,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
     const int sets = 2 * B;
     const int wps = ((N > M ? N : M) + 63) / 64;  // a wave for every 64 queries of a direction: as the whole-search kernel
     const long long lwaves = (long long)sets * wps;
-    grid_query_list_kernel<384><<<dim3((unsigned)(((lwaves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2,
+    grid_query_list_kernel<384><<<dim3((unsigned)(((lwaves + kListWgWaves - 1) / kListWgWaves + 7) / 8 * 8)), dim3(64 * kListWgWaves), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2,
                                                                                       ws, B, N, M, wps, lay);
   } else {
     switch (g_stage_cap) {

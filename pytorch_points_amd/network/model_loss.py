@@ -18,9 +18,12 @@ def _inputs(xyz1, xyz2, double_ok=False):
     device); the checks the reference leaves out (its launcher validates nothing, _ext/nmdistance.cpp:13-15)"""
     assert xyz1.dtype == xyz2.dtype
     xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
-    if xyz1.dtype in (torch.float16, torch.bfloat16):
-        raise TypeError("xyz1 is %s: the Chamfer operators serve float32 and float64 only (no half path)" % xyz1.dtype)
-    if xyz1.dtype is not torch.float32 and not (double_ok and xyz1.dtype is torch.float64):
+    if xyz1.dtype is torch.bfloat16:
+        raise TypeError("xyz1 is %s: the Chamfer operators serve float32, float64 and float16 (the reference's "
+                        "AT_DISPATCH_FLOATING_TYPES_AND_HALF)" % xyz1.dtype)
+    if xyz1.dtype is not torch.float32 and not (double_ok and xyz1.dtype in (torch.float64, torch.float16)):
+        if xyz1.dtype in (torch.float64, torch.float16):
+            raise TypeError("xyz1 is %s: this operator serves float32 only" % xyz1.dtype)
         raise RuntimeError("xyz1 must be a float tensor")
     if not (xyz1.is_cuda and xyz2.is_cuda):
         raise RuntimeError("%s must be a CUDA tensor" % ("xyz2" if xyz1.is_cuda else "xyz1"))
@@ -54,14 +57,14 @@ def _chamfer_backward(ctx, grad1, grad2):
     grad1 = xyz1.new_zeros(idx1.shape) if grad1 is None else grad1.contiguous()
     grad2 = xyz2.new_zeros(idx2.shape) if grad2 is None else grad2.contiguous()
     if grad1.dtype is not xyz1.dtype or grad2.dtype is not xyz1.dtype:
-        raise RuntimeError("graddist1 must be a %s tensor" % ("double" if xyz1.dtype is torch.float64 else "float"))
+        raise RuntimeError("graddist1 must be a %s tensor" % {torch.float64: "double", torch.float16: "half"}.get(xyz1.dtype, "float"))
     dev = xyz1.device
     if grad1.device != dev or grad2.device != dev:
         raise RuntimeError("graddist is on another device than xyz1 (%s)" % (dev,))
     out1, out2 = torch.empty_like(xyz1), torch.empty_like(xyz2)      # fully overwritten by the kernel
     b, n, c = xyz1.shape
-    if xyz1.dtype is torch.float64:
-        losses._launch_f64("pp_nmdistance_backward_f64", "nmdistance_backward", dev,
+    if xyz1.dtype is not torch.float32:
+        losses._launch_f64("pp_nmdistance_backward_" + losses._SUFFIX[xyz1.dtype], "nmdistance_backward", dev,
                            xyz1, xyz2, grad1, grad2, idx1, idx2, out1, out2, b, n, xyz2.shape[1], c)
     else:
         losses._launch_backward(xyz1, xyz2, out1, out2, grad1, grad2, idx1, idx2, b, n, xyz2.shape[1], c, dev)
@@ -77,8 +80,8 @@ class NmDistanceFunction(torch.autograd.Function):
     def forward(ctx, xyz1, xyz2):
         xyz1, xyz2, b, n, m, c, dev = _inputs(xyz1, xyz2, double_ok=True)
         out = _outputs(b, n, m, dev, xyz1.dtype)
-        if xyz1.dtype is torch.float64:   # the reference's scalar_t = double instantiation (nmdistance_cuda.cu:125)
-            losses._launch_f64("pp_nmdistance_forward_f64", "nmdistance_forward", dev,
+        if xyz1.dtype is not torch.float32:   # the reference's scalar_t = double / at::Half instantiations (nmdistance_cuda.cu:125)
+            losses._launch_f64("pp_nmdistance_forward_" + losses._SUFFIX[xyz1.dtype], "nmdistance_forward", dev,
                                xyz1, xyz2, out[0], out[2], out[1], out[3], b, n, m, c)
         else:
             losses._launch_forward(xyz1, xyz2, *out, b, n, m, c, dev)
@@ -92,8 +95,8 @@ class NmDistanceFunction(torch.autograd.Function):
 def nndistance(xyz1, xyz2):
     """``nndistance(xyz1 (B,N,C), xyz2 (B,M,C))`` -> ``(dist1 (B,N), dist2 (B,M), idx1, idx2)`` (reference :442:
     ``nndistance = NmDistanceFunction.apply``), through the native autograd node.  fp32 is the tuned path; double
-    clouds (the reference dispatches over the floating types, _ext/nmdistance_cuda.cu:125) go through the Python
-    node to the every-pair fp64 kernels; half raises TypeError (not provided)."""
+    and half clouds (the reference dispatches over the floating types and half, _ext/nmdistance_cuda.cu:125) go through
+    the Python node to every-pair kernels with the reference's arithmetic for the type; bfloat16 raises TypeError."""
     if xyz1.dtype is not torch.float32 and xyz1.dtype in (torch.float64, torch.float16, torch.bfloat16):
         return NmDistanceFunction.apply(xyz1, xyz2)
     return _lib.bridge().nndistance(xyz1, xyz2)

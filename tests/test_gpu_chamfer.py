@@ -216,8 +216,10 @@ def test_rejects_bad_inputs(cuda):
         losses.nmdistance_forward(x.cpu(), x, d, d, i, i)
     with pytest.raises(RuntimeError):
         losses.nmdistance_forward(x.double(), x.double(), d, d, i, i)       # mixed double / float arguments
-    with pytest.raises(TypeError, match="half"):
-        losses.nmdistance_forward(x.half(), x.half(), d.half(), d.half(), i, i)
+    with pytest.raises(TypeError, match="float16"):   # bfloat16 is not in the reference's dispatch
+        losses.nmdistance_forward(x.bfloat16(), x.bfloat16(), d.bfloat16(), d.bfloat16(), i, i)
+    with pytest.raises(RuntimeError):
+        losses.nmdistance_forward(x.half(), x.half(), d, d, i, i)            # mixed half / float arguments
     with pytest.raises(RuntimeError):
         losses.nmdistance_forward(x, x, d, d, i.long(), i)
     with pytest.raises(RuntimeError):
@@ -314,10 +316,10 @@ def test_native_autograd_nodes_equal_the_python_functions(cuda):
     x1.grad = x2.grad = None
     ml.NmDistanceFunction.apply(x1, x2)[0].sum().backward()
     assert torch.allclose(ga, x1.grad, rtol=1e-5, atol=1e-9) and torch.allclose(gb, x2.grad, rtol=1e-5, atol=1e-9)
-    with pytest.raises(TypeError, match="half"):
-        ml.nndistance(x1.half(), x2.half())
-    with pytest.raises(TypeError, match="half"):
+    with pytest.raises(TypeError, match="float16"):
         ml.nndistance(x1.bfloat16(), x2.bfloat16())
+    with pytest.raises(TypeError):   # labeled Chamfer serves float32 only
+        ml.LabeledNmdistanceFunction.apply(x1.half(), x2.half(), torch.zeros(1, 64, device=cuda), torch.zeros(1, 80, device=cuda))
     with pytest.raises(RuntimeError, match="disagree"):
         ml.nndistance(x1, torch.zeros(2, 4, 3, device=cuda))
 
@@ -411,3 +413,55 @@ def test_double_backward_and_autograd(cuda):
     z = torch.zeros(1, 0, 3, dtype=torch.float64, device=cuda)
     d1, d2, j1, j2 = ml.nndistance(z, T(x2[:1]))
     assert d1.shape == (1, 0) and (d2 == 0).all() and (j2 == 0).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 500, 3), (1, 1000, 777, 3), (2, 64, 64, 2), (1, 513, 511, 5), (1, 257, 40, 1),
+                                   (1, 130, 900, 11)])
+def test_half_clouds_match_the_half_oracle(cuda, shape):
+    """scalar_t = at::Half, the third type of the reference's dispatch (nmdistance_cuda.cu:125,210): every operation
+    rounded to half separately (c10::Half's operators), comparisons in half, first minimum in index order -- with 11
+    bits of significand EXACT TIES are everywhere, so the tie rule is what this checks.  Indices and distances bit for
+    bit against oracle.chamfer_forward_f16 (numpy float16 arithmetic); gradients: the own-row terms bit for bit where a
+    row receives nothing else, every row within half's rounding of the exact sum of the half-rounded terms (the
+    reference adds them with half atomics in no fixed order)."""
+    from pytorch_points_amd.network import model_loss as ml
+    b, n, m, c = shape
+    x1 = (S.unit_sphere(90 + n, b, n, c) * 0.75).astype(np.float16)
+    x2 = (S.unit_sphere(91 + m, b, m, c) * 0.75).astype(np.float16)
+    x2[:, : min(m, 20)] = x2[:, m - min(m, 20):]                       # exact duplicates: lowest index must win
+    e_d1, e_i1, e_d2, e_i2 = oracle.chamfer_forward_f16(x1, x2)
+    t1 = torch.from_numpy(x1).to(cuda).requires_grad_(True)
+    t2 = torch.from_numpy(x2).to(cuda).requires_grad_(True)
+    d1, d2, i1, i2 = ml.nndistance(t1, t2)
+    assert d1.dtype == torch.float16 and i1.dtype == torch.int32 and d1.requires_grad and not i1.requires_grad
+    assert np.array_equal(i1.cpu().numpy(), e_i1) and np.array_equal(i2.cpu().numpy(), e_i2)
+    assert np.array_equal(d1.detach().cpu().numpy().view(np.uint16), e_d1.view(np.uint16))
+    assert np.array_equal(d2.detach().cpu().numpy().view(np.uint16), e_d2.view(np.uint16))
+    g1 = (np.abs(S.normal(92, (b, n))) * 0.5 + 0.25).astype(np.float16)
+    g2 = (np.abs(S.normal(93, (b, m))) * 0.5 + 0.25).astype(np.float16)
+    torch.autograd.backward([d1, d2], [torch.from_numpy(g1).to(cuda), torch.from_numpy(g2).to(cuda)])
+    own1, own2, s1, s2 = oracle.chamfer_backward_f16_terms(x1, x2, g1, g2, e_i1, e_i2)
+    gx1, gx2 = t1.grad.cpu().numpy(), t2.grad.cpu().numpy()
+    assert gx1.dtype == np.float16
+    for gx, own, ssum, idx_other, nn in ((gx1, own1, s1, e_i2, n), (gx2, own2, s2, e_i1, m)):
+        for k in range(b):
+            hit = np.zeros(nn, bool)
+            hit[idx_other[k]] = True                                   # rows that also receive scattered terms
+            assert np.array_equal(gx[k][~hit].view(np.uint16), own[k][~hit].view(np.uint16))
+            cnt = np.bincount(idx_other[k], minlength=nn)[:, None] + 1   # additions per row, each rounded to half
+            tol = cnt * 2.0 ** -10 * np.maximum(np.abs(ssum[k]), np.abs(own[k].astype(np.float64))) + cnt * 1e-3
+            assert np.all(np.abs(gx[k].astype(np.float64) - ssum[k]) <= tol)
+    # the extension-module entry points take half tensors as well (the pybind functions' dispatch)
+    from pytorch_points_amd._ext import losses
+    o = (torch.empty(b, n, dtype=torch.float16, device=cuda), torch.empty(b, m, dtype=torch.float16, device=cuda),
+         torch.empty(b, n, dtype=torch.int32, device=cuda), torch.empty(b, m, dtype=torch.int32, device=cuda))
+    assert losses.nmdistance_forward(t1.detach(), t2.detach(), *o) == 1
+    assert torch.equal(o[0], d1.detach()) and torch.equal(o[2], i1)
+
+
+def test_half_empty_clouds(cuda):
+    from pytorch_points_amd.network import model_loss as ml
+    x1 = torch.zeros(2, 0, 3, dtype=torch.float16, device=cuda)
+    x2 = torch.rand(2, 5, 3, device=cuda).half()
+    d1, d2, i1, i2 = ml.nndistance(x1, x2)
+    assert d1.shape == (2, 0) and torch.count_nonzero(d2) == 0 and torch.count_nonzero(i2) == 0
