@@ -107,8 +107,13 @@ int pp_nmdistance_backward_f16(const void* xyz1, const void* xyz2, const void* g
  * xyz (B,N,3); temp (B,N) in/out running min squared distance (caller pre-fills 1e10,
  * network/geo_operations.py:33); idx (B,npoint) out, idx[:,0] = seed_idx.
  * workspace: pp_furthest_sampling_workspace_bytes(...) bytes of scratch (may be NULL if that is 0); a pure
- * host computation (an upper bound over devices).  Its first 256 bytes hold a STICKY status word: the caller
- * zeroes them once after allocating the buffer.  The fast kernel shares a batch element between workgroups
+ * host computation (an upper bound over devices).  Layout: a 256-byte status word | the ring of the cluster kernel |
+ * the scratch of the bucketed kernel (the cloud re-ordered into spatial buckets: 16 B per point + one word per point,
+ * 65536 words per batch element up to 65536 points).  With that scratch -- 2048 <= N <= 2^22 and 32 or more picks --
+ * the sampling is ONE workgroup per batch element that visits, per pick, only the buckets the pick can change (an
+ * exact test: same picks, same temp); nothing waits for another workgroup there.  Without it (or for N > 65536 when
+ * the batch leaves room) the cluster kernel runs: the first 256 bytes hold its STICKY status word, which the caller
+ * zeroes once after allocating the buffer.  That kernel shares a batch element between workgroups
  * that wait for each other; it is only launched with as many workgroups as the current device keeps resident
  * (its real CU count and the occupancy query), and every wait is bounded: if one times out (CUs held by a
  * kernel of another stream), the call leaves zeros from that step on in idx and sets the status word, which

@@ -37,7 +37,8 @@ int pp_debug_nmdistance_kernel_ms3(float* build_ms, float* stage_a_ms, float* re
 /* unlabeled grid forward: queries its stage-A kernel left to the list kernel, per direction (2 B values; synchronises) */
 int pp_debug_nmdistance_pending(const void* workspace, int B, int N, int M, unsigned* totals);
 
-void pp_debug_set_fps_v1(int on); /* 1 = one workgroup per batch element instead of the CU cluster */
+void pp_debug_set_fps_v1(int form); /* 0 = the library's choice, 1 = one workgroup per batch element over all points,
+                                      * 2 = the CU cluster over all points, 3 = the bucketed kernel */
 void pp_debug_set_gather_variant(int variant);
 void pp_debug_set_ball_query_variant(int variant); /* scan kernels: 1 = one wave per 64 centres */
 void pp_debug_set_ball_query_search(int mode);     /* 0 automatic, 1 scan, 2 grid wherever possible */
