@@ -148,6 +148,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   __syncthreads();
   float blo[3], bsc[3];
   int qmax[3];
+  bool cubic = false;  // five bits per axis: the cells are walked along a Hilbert curve instead of the Z-order
   {
     float bv[6];
     for (int a = 0; a < 6; ++a) {
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     }
     blo[0] = -bv[0]; blo[1] = -bv[1]; blo[2] = -bv[2];
     qmax[0] = n0; qmax[1] = n1; qmax[2] = n2;  // (bits per axis)
+    cubic = n0 == 5 && n1 == 5 && n2 == 5;
     // fine bins per unit length; an empty or unbounded extent puts everything into bin 0 of that axis
     bsc[0] = (ext0 > 0.0f && ext0 < INFINITY) ? (float)kBkFine / ext0 : 0.0f;
     bsc[1] = (ext1 > 0.0f && ext1 < INFINITY) ? (float)kBkFine / ext1 : 0.0f;
@@ -208,7 +210,8 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
         carry += __builtin_amdgcn_readlane(inc, 63);
         unsigned q = (unsigned)(((u64)below << nbits) / (u64)(N > 0 ? N : 1));
         q = min(q, (1u << nbits) - 1u);
-        // the cell coordinate's bits at their places in the key
+        // the cell coordinate's bits at their places in the key (a cubic plan keeps the plain coordinate: the
+        // cells are then ordered along a Hilbert curve, below)
         int left = nbits;
         unsigned val = 0;
         for (int st = 0; st < kBkBits; ++st)
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
             --left;
             val |= ((q >> left) & 1u) << (kBkBits - 1 - st);
           }
-        s_lut[a][i] = val;
+        s_lut[a][i] = cubic ? q : val;
       }
     }
   }
@@ -225,7 +228,41 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     const int qx = min(max((int)((x - blo[0]) * bsc[0]), 0), kBkFine - 1);
     const int qy = min(max((int)((y - blo[1]) * bsc[1]), 0), kBkFine - 1);
     const int qz = min(max((int)((z - blo[2]) * bsc[2]), 0), kBkFine - 1);
-    return s_lut[0][qx] | s_lut[1][qy] | s_lut[2][qz];
+    if (!cubic) return s_lut[0][qx] | s_lut[1][qy] | s_lut[2][qz];
+    // Hilbert index of the cell (Skilling's transform, 3 axes x 5 bits): consecutive cells of the curve are always
+    // neighbours in space, where the Z-order jumps -- a bucket is a run of 64 points of this order, and a run that
+    // spans a jump has a box that covers two distant patches (every pick near either visits it)
+    unsigned X0 = s_lut[0][qx], X1 = s_lut[1][qy], X2 = s_lut[2][qz];
+#pragma unroll
+    for (unsigned Q = 16u; Q > 1u; Q >>= 1) {
+      const unsigned P = Q - 1u;
+      X0 ^= (X0 & Q) ? P : 0u;
+      {
+        const unsigned hit = (X1 & Q) ? 0xFFFFFFFFu : 0u;
+        const unsigned tt = (X0 ^ X1) & P & ~hit;
+        X0 ^= (P & hit) ^ tt;
+        X1 ^= tt;
+      }
+      {
+        const unsigned hit = (X2 & Q) ? 0xFFFFFFFFu : 0u;
+        const unsigned tt = (X0 ^ X2) & P & ~hit;
+        X0 ^= (P & hit) ^ tt;
+        X2 ^= tt;
+      }
+    }
+    X1 ^= X0;
+    X2 ^= X1;
+    unsigned tg = 0u;
+#pragma unroll
+    for (unsigned Q = 16u; Q > 1u; Q >>= 1) tg ^= (X2 & Q) ? Q - 1u : 0u;
+    X0 ^= tg; X1 ^= tg; X2 ^= tg;
+    auto spread = [](unsigned v) {  // bit i -> bit 3 i
+      v = (v | (v << 8)) & 0x100Fu;
+      v = (v | (v << 4)) & 0x10C3u;
+      v = (v | (v << 2)) & 0x1249u;
+      return v;
+    };
+    return (spread(X0) << 2) | (spread(X1) << 1) | spread(X2);
   };
   if (PP_FPSB_STOP <= 2) return;
   // ---------------------------------------------------------------- C. count
