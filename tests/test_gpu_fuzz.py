@@ -160,3 +160,30 @@ def test_fuzz_far_and_offset_clouds(cuda, seed):
     for g, e, what in zip((got[0], got[2], got[1], got[3]), exp, ("dist1", "idx1", "dist2", "idx2")):
         assert np.array_equal(g.cpu().numpy(), e), "seed %d (b=%d n=%d m=%d): %s differs at %d places" % (
             seed, b, n, m, what, int((g.cpu().numpy() != e).sum()))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PP_FUZZ_SEEDS", "100")) // 2))
+def test_fuzz_furthest_sampling(cuda, seed):
+    """furthest_sampling through the operator's own choice of kernel -- the bucketed kernel from 2048 points and 32
+    picks, the cluster / single-block kernels below -- on random shapes, seeds and cloud families (ties and duplicates,
+    clusters of very different scales, thin slabs far from the origin, outliers), sometimes with a random incoming
+    temp: picks AND temp against the oracle, bit for bit"""
+    from pytorch_points_amd._ext import sampling
+    rng = np.random.default_rng(7000 + seed)
+    b = int(rng.integers(1, 4))
+    n = int(rng.choice([300, 1024, 2048, 2049, 3000, 4096, 5003, 8192, 12000, 16384, 20000]))
+    m = int(rng.choice([1, 5, 31, 32, 33, 64, 200, 513]))
+    m = min(m, n)
+    x = _cloud(rng, b, n, int(rng.integers(0, 8)))
+    start = int(rng.integers(0, n))
+    t0 = None
+    if rng.random() < 0.3:   # an incoming temp that is not the reference's 1e10 fill
+        t0 = (np.abs(rng.standard_normal((b, n))) * float(rng.choice([1e-3, 0.05, 10.0]))).astype(np.float32)
+    e_idx, e_temp = oracle.furthest_sampling(x, m, start, temp=t0)
+    idx = torch.empty(b, m, dtype=torch.int32, device=cuda)
+    temp = torch.from_numpy(t0).to(cuda) if t0 is not None else torch.full((b, n), 1e10, dtype=torch.float32, device=cuda)
+    pts = torch.empty(b, m, 3, device=cuda)
+    sampling.furthest_sampling(m, start, torch.from_numpy(x).to(cuda), temp, idx, pts, False)
+    assert np.array_equal(idx.cpu().numpy(), e_idx), (b, n, m, start)
+    assert np.array_equal(temp.cpu().numpy(), e_temp), (b, n, m, start)
+    assert np.array_equal(pts.cpu().numpy(), np.take_along_axis(x, e_idx[..., None].astype(np.int64), 1))
