@@ -105,7 +105,9 @@ int pp_nmdistance_backward_f16(const void* xyz1, const void* xyz2, const void* g
 /* Replaces sampling.furthest_sampling(m, seedIdx, input, temp, idx)
  *   (_ext/sampling.cpp:68-82 -> furthest_sampling_cuda_forward, _ext/sampling_cuda.cu:235-325).
  * xyz (B,N,3); temp (B,N) in/out running min squared distance (caller pre-fills 1e10,
- * network/geo_operations.py:33); idx (B,npoint) out, idx[:,0] = seed_idx.
+ * network/geo_operations.py:33); idx (B,npoint) out, idx[:,0] = seed_idx.  temp == NULL: every point starts at 1e10
+ * and nothing is written back (the wrapper one level up allocates temp itself and never reads it) -- served where the
+ * bucketed kernel runs, PP_ENOTSUP otherwise (the caller then passes a temp of its own).
  * workspace: pp_furthest_sampling_workspace_bytes(...) bytes of scratch (may be NULL if that is 0); a pure
  * host computation (an upper bound over devices).  Layout: a 256-byte status word | the ring of the cluster kernel |
  * the scratch of the bucketed kernel (the cloud re-ordered into spatial buckets: 16 B per point + one word per point,

@@ -73,17 +73,23 @@ def furthest_sampling_status(device):
 
 def furthest_sampling(m, seedIdx, input, temp, idx, sampled=None, channels_first=False):
     """furthest_sampling_forward (sampling.cpp:68-82): input (B,N,3), temp (B,N) in/out, idx (B,m)
-    out; returns idx.  Beyond the reference's signature: ``sampled`` (B,m,3) -- or (B,3,m) with
+    out; returns idx.  ``temp=None``: every point starts at 1e10 and nothing is kept (what the reference's wrapper does
+    with a temp of its own).  Beyond the reference's signature: ``sampled`` (B,m,3) -- or (B,3,m) with
     ``channels_first`` -- receives the picked points' coordinates in the same launch (what
     network/geo_operations.py:59-63 does with a gather_points call afterwards)."""
-    dev = _lib.require_cuda(("input", input), ("temp", temp), ("idx", idx))
-    _lib.require_contiguous(("input", input), ("temp", temp), ("idx", idx))  # CHECK_INPUT :76-77
-    _lib.require_float(("input", input), ("temp", temp))
+    if temp is None:   # (beyond the reference's signature: "a temp of the callee's own" -- see below)
+        dev = _lib.require_cuda(("input", input), ("idx", idx))
+        _lib.require_contiguous(("input", input), ("idx", idx))
+        _lib.require_float(("input", input))
+    else:
+        dev = _lib.require_cuda(("input", input), ("temp", temp), ("idx", idx))
+        _lib.require_contiguous(("input", input), ("temp", temp), ("idx", idx))  # CHECK_INPUT :76-77
+        _lib.require_float(("input", input), ("temp", temp))
     _lib.require_int(("idx", idx))
     if input.dim() != 3 or input.size(2) != 3:
         raise RuntimeError("input must be (B, N, 3)")
     b, n, _ = input.shape
-    if temp.numel() != b * n or idx.numel() != b * int(m):
+    if (temp is not None and temp.numel() != b * n) or idx.numel() != b * int(m):
         raise RuntimeError("temp must be (B, N) and idx (B, m)")
     if sampled is not None:
         _lib.require_cuda(("input", input), ("sampled", sampled))
@@ -110,10 +116,17 @@ def furthest_sampling(m, seedIdx, input, temp, idx, sampled=None, channels_first
         ws[:256].zero_()             # the sticky status word in front of the scratch (include/pp_hip.h)
         ws._pp_status_zeroed = True
     with _lib.on_device(dev) as stream:
-        _lib.check(L.pp_furthest_sampling_gather_f32(
-            _lib.ptr(input), _lib.ptr(temp), _lib.ptr(idx), _lib.ptr(sampled) if sampled is not None else None,
-            1 if channels_first else 0, b, n, int(m), int(seedIdx),
-            _lib.ptr(ws) if ws is not None else None, nbytes, stream), "furthest_sampling")
+        def call(t):
+            return L.pp_furthest_sampling_gather_f32(
+                _lib.ptr(input), _lib.ptr(t) if t is not None else None, _lib.ptr(idx),
+                _lib.ptr(sampled) if sampled is not None else None, 1 if channels_first else 0, b, n, int(m),
+                int(seedIdx), _lib.ptr(ws) if ws is not None else None, nbytes, stream)
+        code = call(temp)
+        if temp is None and code == _lib.PP_ENOTSUP:
+            # temp=None ("start at 1e10, keep nothing": network/geo_operations.py:33 fills a temp nobody reads back) is
+            # served where the bucketed kernel runs; the other kernels need a buffer
+            code = call(torch.full((b, n), 1e10, dtype=torch.float32, device=dev))
+        _lib.check(code, "furthest_sampling")
         if ws is not None and not capturing:
             if entry is None:
                 entry = _fps_status_mirror[key] = [torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event()]

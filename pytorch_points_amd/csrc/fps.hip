@@ -371,7 +371,7 @@ extern "C" int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, in
   const int cf = channels_first ? 1 : 0;
   if (B < 0 || N < 0 || npoint < 0) return PP_EINVAL;
   if (B == 0 || npoint <= 0) return PP_OK;  // ref: `if (m <= 0) return;` (sampling_cuda.cu:166)
-  if (N == 0 || !xyz || !temp || !idx) return PP_EINVAL;
+  if (N == 0 || !xyz || !idx) return PP_EINVAL;
   if (seed_idx < 0 || seed_idx >= N) return PP_EINVAL;  // the reference would read out of bounds
   hipStream_t s = (hipStream_t)stream;
   const int T = pp_opt_n_threads(N);
@@ -394,6 +394,9 @@ extern "C" int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, in
                                   (char*)workspace + kFpsErrBytes + ring_bytes(B, N), sampled, cf, s);
     if (form == 3) return PP_EINVAL;
   }
+  // temp == NULL ("start every point at 1e10 and keep nothing": what furthest_point_sample does with a temp of its own)
+  // is served by the bucketed kernel only; the caller then allocates one and calls again
+  if (!temp) return PP_ENOTSUP;
   // (the cluster kernel's per-thread tie rule assumes the reference's thread count equals its point stride)
   int cl = (form == 1 || T != kClThreads) ? 0 : pick_cluster(B, N);
   if (cl >= 2 && npoint > 1) {

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
 
   const int b = blockIdx.x;
   const float* __restrict__ p = xyz + (size_t)b * N * 3;
-  float* __restrict__ tmp = temp + (size_t)b * N;
+  float* __restrict__ tmp = temp ? temp + (size_t)b * N : nullptr;  // nullptr: every point starts at 1e10, nothing is written back
   int* __restrict__ out = idx + (size_t)b * npoint;
   f4* __restrict__ sorted = sorted_all + (size_t)b * geo.npad;
   unsigned* __restrict__ rc = aux_all + (size_t)b * geo.naux;
@@ -266,8 +266,14 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   };
   if (PP_FPSB_STOP <= 2) return;
   // ---------------------------------------------------------------- C. count
-  for (int k = t; k < N; k += kBkThreads)
-    atomicAdd(&s_hist[key_of(p[3 * (size_t)k], p[3 * (size_t)k + 1], p[3 * (size_t)k + 2])], 1u);
+  // (a point's key is computed once: it waits for the scatter in the first words of the record buffer, which nothing
+  //  else uses before the gather pass -- the Hilbert transform is a hundred instructions a point)
+  unsigned* __restrict__ keys = reinterpret_cast<unsigned*>(sorted);
+  for (int k = t; k < N; k += kBkThreads) {
+    const unsigned key = key_of(p[3 * (size_t)k], p[3 * (size_t)k + 1], p[3 * (size_t)k + 2]);
+    keys[k] = key;
+    atomicAdd(&s_hist[key], 1u);
+  }
   __syncthreads();
   if (PP_FPSB_STOP <= 3) return;
   // ---------------------------------------------------------------- D. exclusive scan (a wave per 2048 bins)
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   // (Scattering the 16-byte records themselves -- every lane of a store in a line of its own -- took 183 us of a
   //  470 us set-up; 4-byte scattered stores of the source index, then coalesced record stores, takes a third.)
   for (int k = t; k < N; k += kBkThreads) {
-    const unsigned pos = atomicAdd(&s_hist[key_of(p[3 * (size_t)k], p[3 * (size_t)k + 1], p[3 * (size_t)k + 2])], 1u);
+    const unsigned pos = atomicAdd(&s_hist[keys[k]], 1u);
     rc[pos] = (unsigned)k;
   }
   __syncthreads();
@@ -303,11 +309,12 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     const P3 v = *(const P3*)(p + 3 * (size_t)k);  // (one 12-byte load: a gathered access costs per instruction)
     f4 rec;
     rec.x = v.x; rec.y = v.y; rec.z = v.z;
+    const float t0 = tmp ? tmp[k] : 1e10f;  // (ref network/geo_operations.py:33: the caller's fill)
     if (REG) {
       rec.w = __uint_as_float(kRcMax - order.rank(k));
-      rc[pos] = __float_as_uint(tmp[k]);
+      rc[pos] = __float_as_uint(t0);
     } else {
-      rec.w = tmp[k];
+      rec.w = t0;
       rc[pos] = kRcMax - order.rank(k);
     }
     sorted[pos] = rec;
@@ -408,7 +415,32 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
 #pragma unroll
     for (int l = 0; l < 64; ++l) td_set(l, __uint_as_float(rc[first + (unsigned)(l * kBkWaves * 64)]));
   }
-  if (npoint > 1) {
+  if (REG && npoint > 1) {
+    // (one record per lane and bucket: loaded once, the next bucket's while this one is reduced)
+    const unsigned at = (unsigned)(wave * 64 + lane);
+    f4 q = sorted[at];
+    for (int l = 0; l < 64; ++l) {
+      const int bk = l * kBkWaves + wave;
+      if (bk >= geo.nb) break;  // (uniform)
+      f4 qn = q;
+      if (bk + kBkWaves < geo.nb) qn = sorted[at + (unsigned)(l + 1) * (kBkWaves * 64)];
+      const bool real = bk * 64 + lane < N;  // (the box is the box of the bucket's real points)
+      float v[6] = {real ? -q.x : -INFINITY, real ? -q.y : -INFINITY, real ? -q.z : -INFINITY,
+                    real ? q.x : -INFINITY,  real ? q.y : -INFINITY,  real ? q.z : -INFINITY};
+      pp::wave_reduce6_dpp<false, 6>(v);
+      const float b0 = rl(v[0], 63), b1 = rl(v[1], 63), b2 = rl(v[2], 63), b3 = rl(v[3], 63), b4 = rl(v[4], 63),
+                  b5 = rl(v[5], 63);
+      const float d2 = td_min(l, dist3(q.x, q.y, q.z, ox, oy, oz));
+      int src;
+      const u64 M = wave_argmax_key(__float_as_uint(d2), __float_as_uint(q.w), src);
+      const float cx = rl(q.x, src), cy = rl(q.y, src), cz = rl(q.z, src);
+      if (lane == l) {
+        lox = -b0; loy = -b1; loz = -b2; hix = b3; hiy = b4; hiz = b5;
+        bkey = M; ax = cx; ay = cy; az = cz;
+      }
+      q = qn;
+    }
+  } else if (npoint > 1) {
     for (int l = 0; l < 64; ++l) {
       const int bk = l * kBkWaves + wave;
       if (bk >= geo.nb) break;  // (uniform)
@@ -564,6 +596,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   __syncthreads();
   // ---------------------------------------------------------------- H. picks as indices; temp back in place
   for (int j = 1 + t; j < npoint; j += kBkThreads) out[j] = order.unrank(kRcMax - (unsigned)out[j]);
+  if (!tmp) return;  // (the caller keeps no running minima: furthest_point_sample's own temp, never read back)
   if (REG) {
     unsigned first = (unsigned)(wave * 64 + lane);
     asm volatile("" : "+v"(first));  // (computed afresh: sixty-four addresses kept alive across the chain spilled)

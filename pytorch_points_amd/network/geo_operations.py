@@ -17,8 +17,8 @@ class FurthestPointSampling(torch.autograd.Function):
     def forward(ctx, xyz, npoint, seedIdx):
         batch, n = xyz.shape[0], xyz.shape[1]
         picked = torch.empty((batch, npoint), dtype=torch.int32, device=xyz.device)
-        running_min = xyz.new_full((batch, n), _FAR, dtype=torch.float32)
-        sampling.furthest_sampling(npoint, seedIdx, xyz, running_min, picked)
+        # (the reference fills a temp of 1e10 here, :32-33, and never reads it back: temp=None says exactly that)
+        sampling.furthest_sampling(npoint, seedIdx, xyz, None, picked)
         ctx.mark_non_differentiable(picked)
         return picked
 
@@ -41,8 +41,7 @@ class _SampleAndGather(torch.autograd.Function):
         batch, n = points.shape[0], points.shape[1]
         picked = torch.empty((batch, npoint), dtype=torch.int32, device=points.device)
         chosen = torch.empty((batch, 3, npoint), dtype=torch.float32, device=points.device)
-        running_min = points.new_full((batch, n), _FAR, dtype=torch.float32)
-        sampling.furthest_sampling(npoint, seedIdx, points, running_min, picked, chosen, True)
+        sampling.furthest_sampling(npoint, seedIdx, points, None, picked, chosen, True)
         ctx.mark_non_differentiable(picked)
         ctx.save_for_backward(picked)
         ctx.n = n
