@@ -945,7 +945,9 @@ __global__ __launch_bounds__(1024) void group_points_grad_lds64_kernel(const flo
       pp::i4 i[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        g[u] = reinterpret_cast<const pp::f4*>(go)[e + 1024 * u];
+        // (grad_out is read once: non-temporal, so that the 4 GiB stream does not push the indices -- re-read by
+        //  every channel's workgroup -- out of the XCD's L2)
+        g[u] = __builtin_nontemporal_load(reinterpret_cast<const pp::f4*>(go) + e + 1024 * u);
         i[u] = reinterpret_cast<const pp::i4*>(ib)[e + 1024 * u];
       }
 #pragma unroll
