@@ -143,15 +143,24 @@ class PackedShardGather:
             # failure to set it up -- on any rank -- leaves the c10d path in place on all of them
             # (PP_SHARD_EXCHANGE=native asks for that path outright).
             if mode == "rccl":
-                try:
-                    rank = dist.get_rank(group)
-                    box = [bytes(type(self._native).unique_id()) if rank == 0 else None]
-                    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                    self._native.init_direct(box[0], rank)
-                    self.direct = True
-                except Exception as exc:   # noqa: BLE001 -- whatever went wrong, the c10d path still works
-                    import warnings
-                    warnings.warn("pytorch_points_amd: direct RCCL exchange not available (%s); using c10d" % (exc,))
+                # every rank takes part in every collective below whatever fails locally (a rank that skipped the
+                # broadcast because its own step raised would leave the others waiting in it)
+                import warnings
+                rank = dist.get_rank(group)
+                uid = None
+                if rank == 0:
+                    try:
+                        uid = bytes(type(self._native).unique_id())
+                    except Exception as exc:   # noqa: BLE001
+                        warnings.warn("pytorch_points_amd: no RCCL unique id (%s); using c10d" % (exc,))
+                box = [uid]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                if box[0] is not None:   # (None on every rank alike: nobody calls ncclCommInitRank, which would wait for all)
+                    try:
+                        self._native.init_direct(box[0], rank)
+                        self.direct = True
+                    except Exception as exc:   # noqa: BLE001 -- whatever went wrong, the c10d path still works
+                        warnings.warn("pytorch_points_amd: direct RCCL exchange not available (%s); using c10d" % (exc,))
                 ok = torch.tensor([1 if self.direct else 0], dtype=torch.int32, device=device)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)     # every rank takes the same path
                 if int(ok.item()) == 0 and self.direct:
