@@ -835,3 +835,20 @@ def test_config4_full_size_properties(cuda):
     for c0 in range(0, C, 16):
         ref[:, c0:c0 + 16].scatter_add_(2, flat.expand(-1, 16, -1), out[:, c0:c0 + 16].double().reshape(B, 16, -1))
     assert torch.allclose(grad.double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,m", [(300, 40), (4096, 64), (20000, 100)])
+def test_fps_without_a_temp_of_the_callers(cuda, n, m):
+    """temp=None: "every point starts at 1e10 and nothing is kept" -- what the reference's wrapper does with a temp of its
+    own that nobody reads back (network/geo_operations.py:32-33).  Served by the bucketed kernel where that runs; where it
+    does not (small clouds: PP_ENOTSUP from the C ABI) the shim passes a buffer itself.  Same picks either way."""
+    from pytorch_points_amd._ext import sampling
+    x = S.unit_sphere(50 + n, 2, n)
+    e_idx, _ = oracle.furthest_sampling(x, m, 3)
+    idx = torch.empty(2, m, dtype=torch.int32, device=cuda)
+    pts = torch.empty(2, 3, m, device=cuda)
+    sampling.furthest_sampling(m, 3, _t(x, cuda), None, idx, pts, True)
+    assert np.array_equal(idx.cpu().numpy(), e_idx)
+    assert np.array_equal(pts.cpu().numpy(), np.take_along_axis(x, e_idx[..., None].astype(np.int64), 1).transpose(0, 2, 1))
+    with pytest.raises(RuntimeError):
+        sampling.furthest_sampling(m, 3, _t(x, cuda), None, idx[:, : m - 1].contiguous())
