@@ -14,6 +14,17 @@ constexpr int kGridMax = 32;                                  // cells per axis
 constexpr int kGridCells = kGridMax * kGridMax * kGridMax;    // LDS counters: 128 KiB
 constexpr int kBuildThreads = 1024;
 
+// chamfer_slab.hip: the fused sort-and-search of config 2's size class; its per-slab verdicts
+constexpr int kSlabKernelSlabs = 8;
+constexpr unsigned kSlabServed = 0x5E12ED01u, kSlabDeclined = 0xDEC11ED0u;
+__device__ __forceinline__ bool slab_kernel_served(const unsigned* __restrict__ state, int b) {  // (uniform: scalar loads)
+  bool all = true;
+  for (int i = 0; i < kSlabKernelSlabs; ++i) all &= state[(size_t)b * kSlabKernelSlabs + i] == kSlabServed;
+  return all;
+}
+bool chamfer_slab_applies(const float* xyz1, const float* xyz2, int B, int N, int M);
+int chamfer_slab_launch(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2, int* idx2,
+                        unsigned* state, int B, int N, int M, hipStream_t s);
 constexpr int kBuildSlabs = 4;  // workgroups that share the build of one set (each owns a range of cells)
 
 // Chunk table (Chamfer's tile search): for every kChunk consecutive points of the sorted cloud, the lowest and the

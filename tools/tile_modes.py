@@ -76,7 +76,7 @@ for kind in kinds:
         tk(0)
         same = all(torch.equal(a, b) for a, b in zip(o, ref))
         pend = ""
-        if mode != -1:
+        if mode not in (-1, -2):
             tot = (ctypes.c_uint * (2 * B))()
             wsb = _lib.cached_workspaces("nmdistance")[0]
             fn = L.pp_debug_nmdistance_pending; fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]; fn.restype = ctypes.c_int
