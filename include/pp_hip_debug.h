@@ -37,6 +37,11 @@ int pp_debug_nmdistance_kernel_ms3(float* build_ms, float* stage_a_ms, float* re
 /* unlabeled grid forward: queries its stage-A kernel left to the list kernel, per direction (2 B values; synchronises) */
 int pp_debug_nmdistance_pending(const void* workspace, int B, int N, int M, unsigned* totals);
 
+/* unlabeled grid forward of config 2's size class: the fused kernel's verdict per slab (8 B values: 0 = served, 1..4 =
+ * declined -- hand-off, images too large, too many queries left by the blocks / by the cubes --, 15 = did not run);
+ * synchronises */
+int pp_debug_nmdistance_slab_state(const void* workspace, int B, int N, int M, unsigned* words);
+
 void pp_debug_set_fps_v1(int form); /* 0 = the library's choice, 1 = one workgroup per batch element over all points,
                                       * 2 = the CU cluster over all points, 3 = the bucketed kernel */
 void pp_debug_set_gather_variant(int variant);

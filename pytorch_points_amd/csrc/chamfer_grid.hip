@@ -112,7 +112,8 @@ constexpr float kBoundSlack = 0.999f;
 //   [.., +4*T)                     int pend[T]        unlabeled searches: the queries stage A left (positions in the query
 //                                  cloud's sorted order), 64 slots per wave of the stage-A kernel
 //   [.., +4*(T/64 + S + 1))        unsigned pend_cnt[...]   how many of a wave's 64 slots are filled
-//   [.., +4*B*kSlabKernelSlabs)    unsigned slab_state[B][kSlabKernelSlabs]   chamfer_slab.hip: served / declined, per slab
+//   [.., +chamfer_slab_workspace_bytes)  chamfer_slab.hip's own: unsigned slab_state[B][kSlabKernelSlabs] (served / declined,
+//                                  per slab), then its hand-off words and records (unlabeled searches of its size class only)
 struct Layout {
   size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, tile_z, layers, pend, pend_cnt, slab_state, total;
   int chunks;  // chunk-table entries per set and slab (0: sets too large for the table)
@@ -135,7 +136,7 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   L.pend = L.layers + (L.chunks ? ((4 * S * pp::kLayerWords + 255) / 256) * 256 : 0);
   L.pend_cnt = L.pend + (L.chunks ? 4 * T : 0);
   L.slab_state = L.pend_cnt + (L.chunks ? ((4 * (T / 64 + S + 1) + 255) / 256) * 256 : 0);
-  L.total = L.slab_state + (labeled ? 0 : ((4 * (size_t)B * pp::kSlabKernelSlabs + 255) / 256) * 256);
+  L.total = L.slab_state + (labeled ? 0 : (pp::chamfer_slab_workspace_bytes(B, N, M) + 255) / 256 * 256);
   return L;
 }
 // second-level arrays of set (b, dir): first table entry / first descriptor
@@ -2390,6 +2391,25 @@ extern "C" int pp_debug_nmdistance_pending(const void* workspace, int B, int N, 
   return (int)e;
 }
 
+// the fused kernel's verdicts of the most recent unlabeled forward on this workspace (chamfer_slab.hip), 8 B words:
+// 0 = served, 1..4 = declined (hand-off, images too large, too many queries left by the blocks / by the cubes),
+// 15 = the kernel did not run on this workspace's shape (synchronises the device)
+extern "C" int pp_debug_nmdistance_slab_state(const void* workspace, int B, int N, int M, unsigned* words) {
+  if (!workspace || !words || B <= 0) return PP_EINVAL;
+  const Layout L = make_layout(B, N, M, false);
+  const int n = B * pp::kSlabKernelSlabs;
+  if (pp::chamfer_slab_workspace_bytes(B, N, M) == 0) {
+    for (int i = 0; i < n; ++i) words[i] = 15u;
+    return PP_OK;
+  }
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(words, (const unsigned char*)workspace + L.slab_state, 4 * (size_t)n, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return (int)e;
+  for (int i = 0; i < n; ++i)
+    words[i] = words[i] == pp::kSlabServed ? 0u : ((words[i] & ~15u) == pp::kSlabDeclined ? (words[i] & 15u) : 15u);
+  return PP_OK;
+}
+
 static bool grid_applicable(int B, int N, int M, int C) {
   if (!(C == 3 && B > 0 && N >= 2048 && M >= 2048 && (long long)B * ((long long)N + M) < (1LL << 31) - 1)) return false;
   // the search costs ~40 us whatever the size; the brute force evaluates ~9e6 pairs per microsecond once it
@@ -2431,10 +2451,9 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   // chamfer_slab.hip first (tile == -2, for now): the batch elements it serves are skipped by the launches below
   const unsigned* served = nullptr;
   if (!LAB && tile == -2 && pp::chamfer_slab_applies(xyz1, xyz2, B, N, M)) {
-    unsigned* state = reinterpret_cast<unsigned*>(ws + lay.slab_state);
-    const int rc = pp::chamfer_slab_launch(xyz1, xyz2, dist1, idx1, dist2, idx2, state, B, N, M, s);
+    const int rc = pp::chamfer_slab_launch(xyz1, xyz2, dist1, idx1, dist2, idx2, ws + lay.slab_state, B, N, M, s);
     if (rc != PP_OK) return rc;
-    served = state;
+    served = reinterpret_cast<const unsigned*>(ws + lay.slab_state);
   }
   (vec ? grid_build_kernel<true> : grid_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(
       xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr, served);

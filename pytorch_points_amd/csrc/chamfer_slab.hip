@@ -1,28 +1,38 @@
 // chamfer_slab.hip -- nndistance forward for evenly sampled clouds of BASELINE config 2's size class, as ONE kernel
 // that sorts and searches inside the LDS (round 4; replaces the reference's NmDistanceKernel x 2,
-// _ext/nmdistance_cuda.cu:7-49,118-140, with the same outputs bit for bit).
+// _ext/nmdistance_cuda.cu:7-49,118-140, with the same outputs bit for bit).  OPT-IN (pp_debug_set_nmdistance_tile(-2) /
+// PP_NMDISTANCE_TILE=-2): measured at 62 us against the 61 us of the three launches it would replace, plus the two
+// early-exit launches behind it -- DESIGN.md 5.1f has the phase times and what they say about the three-launch search.
 //
 // The three-launch search of chamfer_grid.hip (build -> stage A by tiles -> list kernel) writes both clouds to HBM in
-// sorted order and reads them back: at config 2 it moves 3.4x the algorithmic bytes and spends most of its 61 us in
-// launch ramps, barrier-separated phases and dependent round trips, not in arithmetic.  Here a batch element is cut
-// into kSlabs slabs of grid layers along z, one 1024-thread workgroup each.  A workgroup
-//   1. reads both clouds of its batch element (L2) for their common bounding box -> a 32^3 grid of cubic cells;
-//   2. reads them again and counts, per cloud, the points of ITS layers plus one layer either side (the halo) per cell
-//      (16-bit counters packed in pairs, LDS atomics);
-//   3. scans the counters and reads the clouds a third time, scattering those points -- (x, y, z, original index) --
-//      into the LDS in cell order: two sorted images of ~3000 points, never written to memory;
-//   4. answers the queries of its own layers (both directions) from those images with the searches of
-//      chamfer_grid.hip's stage A: the 2x2x2 block of cells nearest to the query, settled if the best candidate lies
-//      strictly within what the block guarantees (`reach`, the same expression and the same 0.999 slack); else the
-//      cube of Chebyshev radius 1 (it lies inside the halo by construction); else -- a few queries in a million on a
-//      surface -- an every-pair scan of the other cloud by the whole wave.  Candidates are compared in the exact
-//      (distance, original index) order with pp::chamfer_d3, so the result is the brute force's, bit for bit.
-// Nothing is exchanged between workgroups.  A slab whose images do not fit, whose cloud is degenerate or which meets
-// too many unsettled queries (a cloud this form is not made for: volumes, clusters, far clouds) DECLINES: every
-// workgroup leaves a word saying "served" or "declined" (written unconditionally, so the words need no initialisation),
-// and the launches that follow -- chamfer_grid.hip's build and whole-search kernels -- skip the batch elements all of
-// whose slabs were served and redo the others in full.  A declined element therefore costs this kernel's first passes
-// (a few microseconds) on top of the older path; a served one costs nothing there but two early-exit launches.
+// sorted order and reads them back.  Here a batch element is cut into kSlabs slabs of grid layers along z, one
+// 1024-thread workgroup each, and nothing sorted ever leaves the chip.  A workgroup
+//   1. reads a sample of both clouds (every 16th group of four points: the same sample in all eight workgroups) for a
+//      box -> a 32^3 grid of cubic cells over it; ANY box gives a valid grid (pp::cell_coord clamps into the rim cells,
+//      every bound treats the rim as open), the workgroups only have to agree on it;
+//   2. reads ITS eighth of the two clouds, once, and hands every point to the slab that owns its layer (and to the
+//      neighbour whose halo the layer is): 16-byte records (x, y, z, index | launch tag) in its own part of that slab's
+//      hand-off area in the workspace, then the counts, tagged with the launch's nonce;
+//   3. waits (bounded) for the eight counts addressed to it, loads its ~6000 records into registers, counts them per
+//      cell (16-bit counters packed in pairs, LDS atomics), scans, and scatters them into the LDS in cell order: two
+//      sorted images of ~3000 points, its own four layers and a halo layer either side;
+//   4. answers the queries of its own layers (both directions) from those images with the walk of chamfer_grid.hip's
+//      stage A: the 2x2x2 block of cells nearest to the query, settled if the best candidate lies strictly within what
+//      the block guarantees (`reach`, the same expression and the same 0.999 slack); else the cube of Chebyshev radius 1
+//      (inside the halo by construction), a wave per query; else -- a few queries in a million on a surface -- an
+//      every-pair scan of the other cloud by the whole workgroup.  Candidates are compared in the exact (distance,
+//      original index) order with pp::chamfer_d3, so the result is the brute force's, bit for bit.
+// The hand-off is the only communication between workgroups, and correctness does not depend on how it goes: a count is
+// taken only with this launch's nonce, a record only with this launch's tag (re-read a bounded number of times), and a
+// slab that does not get what it waits for DECLINES, as does one whose images do not fit, whose clouds are degenerate
+// or non-finite, or which meets too many unsettled queries (volumes, clusters, far clouds: not what this form is for).
+// Every workgroup leaves a word saying "served" or "declined" (written unconditionally: no initialisation), and the
+// launches that follow -- chamfer_grid.hip's build and whole-search kernels -- skip the batch elements all of whose
+// slabs were served and redo the others in full.  Placement (the eight workgroups of an element on one XCD, started in
+// order) is speed only.
+#include <chrono>
+#include <random>
+
 #include "grid_common.h"
 
 // phase probe (tools/build_variant_lib.sh with SRC=chamfer_slab -DPP_SLAB_STOP=n): leave after phase n, results unwritten
@@ -50,6 +60,11 @@ constexpr int kPad = 4;                        // points that can never be taken
 constexpr int kTabWords = 3076;                // 16-bit entries 0 .. kLocCells (a sentinel) and one spare, in pairs; 16-byte multiple
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
+constexpr int kCapSrc = 640;                   // records one workgroup may hand to one slab, per cloud (an eighth of kCap, + 43 %)
+constexpr int kGroupBatch = 4;                 // groups in flight per lane in the every-pair scan
+constexpr int kSpinLimit = 1 << 14;            // polls of a hand-off word before the slab gives up (and declines): ~30 ms
+constexpr int kRereads = 64;                   // ... and of records whose tag is not this launch's yet
+constexpr int kTagShift = 15;                  // a record's index (< 2^15: N, M <= 17408) shares its word with 17 bits of the launch's tag
 constexpr int kQueue = 128;                    // queries of a workgroup their 2x2x2 block may leave unsettled
 constexpr int kMaxLeft = 16;                   // ... and the cube of radius 1 after it (every-pair scans by the workgroup)
 constexpr unsigned kServed = pp::kSlabServed, kDeclined = pp::kSlabDeclined;
@@ -90,58 +105,84 @@ __device__ __forceinline__ float min2(float a, float b) {  // (chamfer_grid.hip:
   return r;
 }
 
-// every point of the two clouds (k < N: point k of cloud 1, else point k - N of cloud 2).  A lane takes FOUR consecutive
-// points as three 16-byte loads (48 bytes; the clouds are 16-byte aligned and N, M multiples of four: the host checks):
-// a 12-byte load per lane costs the texture unit three passes of a 768-byte span each (measured: 8 us per pass over the
-// two clouds of config 2, against 2.7 for this form); kGroupBatch groups in flight per lane.
-constexpr int kGroupBatch = 4;
-template <typename F>
-__device__ __forceinline__ void for_all_points(const float* __restrict__ c1, const float* __restrict__ c2, int N, int M,
-                                               int t, F&& f) {
-  const f4* __restrict__ v1 = reinterpret_cast<const f4*>(c1);
-  const f4* __restrict__ v2 = reinterpret_cast<const f4*>(c2);
-  const int G1 = N >> 2, G = G1 + (M >> 2);
-  for (int g0 = 0; g0 < G; g0 += kGroupBatch * kThreads) {
-    f4 a[kGroupBatch][3];
-#pragma unroll
-    for (int u = 0; u < kGroupBatch; ++u) {
-      const int g = min(g0 + u * kThreads + t, G - 1);
-      const f4* __restrict__ src = g < G1 ? v1 + 3 * (size_t)g : v2 + 3 * (size_t)(g - G1);
-      a[u][0] = src[0];
-      a[u][1] = src[1];
-      a[u][2] = src[2];
-    }
-#pragma unroll
-    for (int u = 0; u < kGroupBatch; ++u) {
-      const int g = g0 + u * kThreads + t;
-      if (g < G) {
-        const int k = g < G1 ? 4 * g : N + 4 * (g - G1);
-        f(k, a[u][0].x, a[u][0].y, a[u][0].z);
-        f(k + 1, a[u][0].w, a[u][1].x, a[u][1].y);
-        f(k + 2, a[u][1].z, a[u][1].w, a[u][2].x);
-        f(k + 3, a[u][2].y, a[u][2].z, a[u][2].w);
-      }
-    }
+// A group = four consecutive points of a cloud = three 16-byte loads (the clouds are 16-byte aligned and N, M multiples
+// of four: the host checks).  A 12-byte load per lane costs the texture unit three passes of a 768-byte span each
+// (measured: 8 us per pass over the two clouds of config 2, against 2.7 for this form).
+struct Group {
+  f4 a, b, c;
+  __device__ __forceinline__ void point(int u, float& x, float& y, float& z) const {
+    if (u == 0) { x = a.x; y = a.y; z = a.z; }
+    else if (u == 1) { x = a.w; y = b.x; z = b.y; }
+    else if (u == 2) { x = b.z; y = b.w; z = c.x; }
+    else { x = c.y; y = c.z; z = c.w; }
   }
+};
+__device__ __forceinline__ Group load_group(const float* __restrict__ c1, const float* __restrict__ c2, int G1, int g) {
+  const f4* __restrict__ src = g < G1 ? reinterpret_cast<const f4*>(c1) + 3 * (size_t)g
+                                      : reinterpret_cast<const f4*>(c2) + 3 * (size_t)(g - G1);
+  return Group{src[0], src[1], src[2]};
 }
+
+// The hand-off between workgroups goes through memory with per-access coherence (sc0 sc1: a store is written through,
+// a load looks past every cache that could hold a stale copy) instead of fences: a device-scope release / acquire on
+// gfx950 writes back / invalidates the WHOLE L2 (measured here: 110 us and 30 us per workgroup hand-off), and leaving
+// the fences out would tie correctness to the eight workgroups sharing an XCD's L2, which is placement, not a promise.
+// (asm: the compiler does not count these loads -- an explicit s_waitcnt vmcnt(0) precedes every use.)
+#ifndef PP_SLAB_SCOPE
+#define PP_SLAB_SCOPE "sc1"
+#endif
+
+__device__ __forceinline__ void store16_coherent(f4* p, f4 v) {
+  // (s_nop: a store of more than eight bytes reads its data a cycle after it issues, and the hazard recogniser does not
+  //  look inside an asm statement: without it the VALU instruction that follows may overwrite the record on its way out)
+  asm volatile("global_store_dwordx4 %0, %1, off " PP_SLAB_SCOPE "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+// (four loads and the wait for them in ONE statement: the compiler takes an asm's outputs to be valid when the statement
+//  ends -- it may copy them at once --, so a load whose wait is a statement of its own is a load of garbage)
+__device__ __forceinline__ void load16x4_coherent(f4& v0, f4& v1, f4& v2, f4& v3, const f4* p0, const f4* p1, const f4* p2,
+                                                  const f4* p3) {
+  asm volatile("global_load_dwordx4 %0, %4, off " PP_SLAB_SCOPE "\n\tglobal_load_dwordx4 %1, %5, off " PP_SLAB_SCOPE
+               "\n\tglobal_load_dwordx4 %2, %6, off " PP_SLAB_SCOPE "\n\tglobal_load_dwordx4 %3, %7, off " PP_SLAB_SCOPE
+               "\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+               : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+               : "memory");
+}
+__device__ __forceinline__ void store8_coherent(unsigned long long* p, unsigned long long v) {
+  asm volatile("global_store_dwordx2 %0, %1, off " PP_SLAB_SCOPE ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned long long load8_coherent(const unsigned long long* p) {
+  unsigned long long v;
+  asm volatile("global_load_dwordx2 %0, %1, off " PP_SLAB_SCOPE "\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The workspace of the kernel: verdicts, hand-off words, hand-off records (chamfer_slab_workspace_bytes)
+__host__ __device__ inline size_t off_sync(int B) { return ((size_t)B * kSlabs * 4 + 255) / 256 * 256; }
+__host__ __device__ inline size_t off_staging(int B) { return off_sync(B) + (size_t)B * kSlabs * 2 * kSlabs * 8; }
+__host__ __device__ inline size_t ws_bytes(int B) { return off_staging(B) + (size_t)B * kSlabs * 2 * kSlabs * kCapSrc * sizeof(f4); }
 
 __global__ __launch_bounds__(kThreads) void chamfer_slab_kernel(const float* __restrict__ xyz1,
                                                                 const float* __restrict__ xyz2,
                                                                 float* __restrict__ dist1, int* __restrict__ idx1,
                                                                 float* __restrict__ dist2, int* __restrict__ idx2,
-                                                                unsigned* __restrict__ state, int B, int N, int M) {
+                                                                unsigned char* __restrict__ wsl, unsigned long long nonce,
+                                                                int B, int N, int M) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   f4* s_pts = reinterpret_cast<f4*>(s_raw);                      // [2][kCap + kPad]
   unsigned* s_tab = reinterpret_cast<unsigned*>(s_raw + kOffTab);  // [2][kTabWords]
   f4* s_queue = reinterpret_cast<f4*>(s_raw + kOffQueue);        // [kQueue]: x, y, z, original index | direction << 30
   __shared__ float s_box[kWaves][6];
-  __shared__ unsigned s_sel[2];  // points in the image of cloud 0 / 1
+  __shared__ unsigned s_cnt[2 * kSlabs];  // records handed to slab d of cloud c: [2 d + c]
+  __shared__ unsigned s_src[2 * kSlabs];  // records received from workgroup s for cloud c: [8 c + s] (0xFFFF: none, give up)
+  __shared__ unsigned s_bad;
   __shared__ unsigned s_wsum[kWaves];
   __shared__ unsigned s_qn, s_ln;
   __shared__ unsigned s_left[kMaxLeft];
   __shared__ unsigned long long s_bf[kMaxLeft];
 
-  // the slabs of a batch element share an XCD (its clouds stay in that L2): speed only
+  // the slabs of a batch element share an XCD (the records they hand to each other stay in that L2): speed only
   const int per_xcd = (B * kSlabs + 7) / 8;
   const int V = pp::xcd_virtual_block((int)blockIdx.x, per_xcd);
   if (V >= B * kSlabs) return;
@@ -150,22 +191,34 @@ __global__ __launch_bounds__(kThreads) void chamfer_slab_kernel(const float* __r
   const int wave = pp::wave_id_uniform();
   const float* __restrict__ c1 = xyz1 + (size_t)b * N * 3;
   const float* __restrict__ c2 = xyz2 + (size_t)b * M * 3;
-  unsigned* __restrict__ my_state = state + (size_t)b * kSlabs + slab;
-  auto decline = [&]() {
-    if (t == 0) *my_state = kDeclined;
+  unsigned* __restrict__ my_state = reinterpret_cast<unsigned*>(wsl) + (size_t)b * kSlabs + slab;
+  unsigned long long* __restrict__ sync = reinterpret_cast<unsigned long long*>(wsl + off_sync(B));
+  f4* __restrict__ staging = reinterpret_cast<f4*>(wsl + off_staging(B));
+  // hand-off (d, c, s): what workgroup s of this batch element found for slab d of cloud c
+  auto hand = [&](int d, int c, int sw) { return (((size_t)b * kSlabs + d) * 2 + c) * kSlabs + sw; };
+  auto decline = [&](unsigned why) {  // (the low four bits say why: pp_debug_nmdistance_slab_state)
+    if (t == 0) *my_state = kDeclined | why;
   };
   PP_SLAB_PHASE_END(9)
+  const int G1 = N >> 2, G = G1 + (M >> 2);
+  const unsigned tag = (unsigned)nonce & 0x1FFFFu;  // of this launch's records
 
-  // ---------------------------------------------------------------- 1. common bounding box
+  // ---------------------------------------------------------------- 1. a box for the grid, from a sample
+  // Any box gives a valid grid (pp::cell_coord clamps: a point outside lies in a rim cell, and every bound treats the
+  // rim as open); the eight workgroups must only agree on it, so each reads the same sample -- every 16th group of
+  // four points -- instead of the clouds.  An evenly sampled cloud loses a thousandth of its extent to the rim.
   {
     float v[6] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};  // -lo, hi
-    float bad = 0.0f;
-    for_all_points(c1, c2, N, M, t, [&](int, float x, float y, float z) {
-      v[0] = fmaxf(v[0], -x); v[1] = fmaxf(v[1], -y); v[2] = fmaxf(v[2], -z);
-      v[3] = fmaxf(v[3], x);  v[4] = fmaxf(v[4], y);  v[5] = fmaxf(v[5], z);
-      bad += (x - x) + (y - y) + (z - z);  // 0 for finite coordinates, NaN otherwise
-    });
-    if (!(bad == 0.0f)) v[3] = INFINITY;  // a non-finite coordinate anywhere: the extent below becomes unusable
+    for (int g = 16 * t; g < G; g += 16 * kThreads) {
+      const Group gr = load_group(c1, c2, G1, g);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float x, y, z;
+        gr.point(u, x, y, z);
+        v[0] = fmaxf(v[0], -x); v[1] = fmaxf(v[1], -y); v[2] = fmaxf(v[2], -z);
+        v[3] = fmaxf(v[3], x);  v[4] = fmaxf(v[4], y);  v[5] = fmaxf(v[5], z);
+      }
+    }
     pp::wave_reduce6_dpp<false, 6>(v);
     if (lane == 63)
       for (int a = 0; a < 6; ++a) s_box[wave][a] = v[a];
@@ -173,7 +226,9 @@ __global__ __launch_bounds__(kThreads) void chamfer_slab_kernel(const float* __r
   if (t == 0) {
     s_qn = 0u;
     s_ln = 0u;
+    s_bad = 0u;
   }
+  if (t < 2 * kSlabs) s_cnt[t] = 0u;
   if (t < kMaxLeft) s_bf[t] = ~0ull;
   for (int i = t; i < 2 * kTabWords; i += kThreads) s_tab[i] = 0u;
   __syncthreads();
@@ -185,31 +240,166 @@ __global__ __launch_bounds__(kThreads) void chamfer_slab_kernel(const float* __r
   }
   const float minx = -bv[0], miny = -bv[1], minz = -bv[2];
   const float ext = fmaxf(bv[3] + bv[0], fmaxf(bv[4] + bv[1], bv[5] + bv[2]));
-  if (!(ext > 0.0f && ext < INFINITY)) {  // degenerate or non-finite: not for this kernel (uniform over the workgroup)
-    decline();
-    return;
-  }
+  // (a NaN in the sample is dropped by the maxima, an infinity is not: either way the workgroups agree)
+  const bool box_ok = ext > 0.0f && ext < INFINITY;
   PP_SLAB_PHASE_END(1)
   const float h = ext * (1.0f / (float)kG) * 1.0001f, invh = 1.0f / h;
   const int zbase = slab * kOwnLayers - 1;  // the layer that is local layer 0 (the lower halo; -1 for slab 0)
-  auto local_cell = [&](float x, float y, float z, bool& mine) -> int {
-    const int cz = cell_coord(z, minz, invh, kG);
-    const int lz = cz - zbase;
-    mine = lz >= 0 && lz < kLocLayers;
-    return pp::cell_linear(cell_coord(x, minx, invh, kG), cell_coord(y, miny, invh, kG), lz, kG, kG);
-  };
 
-  // ---------------------------------------------------------------- 2. count (per cloud: 16-bit counters, two to a word)
-  for_all_points(c1, c2, N, M, t, [&](int k, float x, float y, float z) {
-    const int cl = k < N ? 0 : 1;
-    bool mine;
-    const int c = local_cell(x, y, z, mine);
-    if (mine) atomicAdd(&s_tab[cl * kTabWords + (c >> 1)], (c & 1) ? 0x10000u : 1u);
-  });
-  __syncthreads();
+  // ---------------------------------------------------------------- 2. an eighth of the points, handed to the slabs
+  // Workgroup s reads groups [s Gs, (s + 1) Gs) of the two clouds laid end to end and hands every point to the slab
+  // that owns its layer -- and to a neighbour's halo when the layer is a slab's first or last: record (x, y, z, index)
+  // at a slot of ITS part of that slab's hand-off area (slots from a counter in LDS; nothing is shared between the
+  // writers).  Then the count, tagged with this launch's nonce, is published: the reader waits for the tag, so the
+  // words need no initialisation, and a stale word (another launch, another process: the nonce is 48 random bits
+  // plus a counter) is never taken for this launch's.
+  {
+    bool bad = !box_ok;
+#pragma unroll 1
+    for (int cl = 0; cl < 2; ++cl) {  // (a cloud at a time: every lane of a wave then hands to the same counters)
+      const int Gc = cl ? G - G1 : G1;
+      const int Gs = (Gc + kSlabs - 1) / kSlabs;
+      const int gbeg = slab * Gs, gend = min(gbeg + Gs, Gc);
+      for (int g0 = gbeg; g0 < gend; g0 += kThreads) {  // (uniform)
+        const int g = g0 + t;
+        const bool valid = g < gend;
+        const Group gr = load_group(c1, c2, G1, (cl ? G1 : 0) + (valid ? g : gend - 1));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float x, y, z;
+          gr.point(u, x, y, z);
+          bad |= valid && !((x - x) + (y - y) + (z - z) == 0.0f);  // a non-finite coordinate: not for this kernel
+          const int cz = cell_coord(z, minz, invh, kG);
+          const int d = cz / kOwnLayers, r = cz % kOwnLayers;
+          const int dlo = (r == 0 && d > 0) ? d - 1 : d, dhi = (r == kOwnLayers - 1 && d < kSlabs - 1) ? d + 1 : d;
+          const f4 rec = {x, y, z, __int_as_float((4 * g + u) | (int)(tag << kTagShift))};
+          // slots: one add per slab and wave (lane `dst` adds the wave's count for slab dst), ranks from the ballots
+          unsigned mine = 0;
+#pragma unroll
+          for (int dst = 0; dst < kSlabs; ++dst) {
+            const unsigned long long m = __ballot(valid && dst >= dlo && dst <= dhi);
+            mine = lane == dst ? (unsigned)__builtin_popcountll(m) : mine;
+          }
+          unsigned basev = 0;
+          if (lane < kSlabs && mine != 0u) basev = atomicAdd(&s_cnt[2 * lane + cl], mine);
+#pragma unroll
+          for (int dst = 0; dst < kSlabs; ++dst) {
+            const unsigned long long m = __ballot(valid && dst >= dlo && dst <= dhi);
+            if (m == 0ull) continue;  // (uniform)
+            const unsigned base = (unsigned)__builtin_amdgcn_readlane((int)basev, dst);
+            const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (valid && dst >= dlo && dst <= dhi && slot < (unsigned)kCapSrc) store16_coherent(&staging[hand(dst, cl, slab) * kCapSrc + slot], rec);
+          }
+        }
+      }
+    }
+    if (bad) s_bad = 1u;
+    wait_vm();  // the records (written through), before the counts
+    __syncthreads();
+    if (t < 2 * kSlabs) {
+      const unsigned cnt = s_cnt[t];
+      const unsigned long long word = (nonce << 16) | ((s_bad != 0u || cnt > (unsigned)kCapSrc) ? 0xFFFFull : (unsigned long long)cnt);
+      store8_coherent(&sync[hand(t >> 1, t & 1, slab)], word);
+    }
+  }
   PP_SLAB_PHASE_END(2)
-  // ---------------------------------------------------------------- 3. scan: entry c := END of cell c; then scatter
-  // (thread t: twelve cells of cloud t / 512; a cloud's points number < 65536: no entry overflows)
+  // ---------------------------------------------------------------- 3. this slab's records, from the eight workgroups
+  // (a workgroup that never shows up -- it cannot happen while workgroups start in order and at least 64 of them fit
+  //  the device, but nothing here depends on that -- is waited for kSpinLimit polls; then the slab declines)
+  if (t < 2 * kSlabs) {
+    const unsigned long long* w = &sync[hand(slab, t >> 3, t & 7)];
+    unsigned got = 0xFFFFu;
+    for (int spin = 0; spin < kSpinLimit; ++spin) {
+      const unsigned long long v = load8_coherent(w);
+      if ((v >> 16) == nonce) {
+        got = (unsigned)(v & 0xFFFFull);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    s_src[t] = got;
+  }
+  __syncthreads();
+  unsigned pre[2][kSlabs + 1];
+  bool give_up = false;
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl) {
+    pre[cl][0] = 0u;
+#pragma unroll
+    for (int sw = 0; sw < kSlabs; ++sw) {
+      const unsigned n = s_src[cl * kSlabs + sw];
+      give_up |= n == 0xFFFFu;
+      pre[cl][sw + 1] = pre[cl][sw] + (n == 0xFFFFu ? 0u : n);
+    }
+  }
+  const unsigned ns0 = pre[0][kSlabs], ns1 = pre[1][kSlabs];
+  if (give_up || ns0 > (unsigned)kCap || ns1 > (unsigned)kCap) {  // (uniform) the images do not fit, a cloud has a
+    decline(give_up ? 1u : 2u);                                   // non-finite point, a hand-off overflowed or never came
+    return;
+  }
+  // records -> registers (at most four per cloud and thread), cells counted (16-bit counters, two to a word)
+  constexpr int kPer = (kCap + kThreads - 1) / kThreads;  // 4
+  f4 rec[2][kPer];
+  int cel[2][kPer];
+  auto local_cell = [&](float x, float y, float z) -> int {
+    return pp::cell_linear(cell_coord(x, minx, invh, kG), cell_coord(y, miny, invh, kG), cell_coord(z, minz, invh, kG) - zbase, kG, kG);
+  };
+  // (a record whose tag is not this launch's has not arrived yet -- the count may overtake it on its way through the
+  //  memory system --: read again, a bounded number of times; then the slab declines.  Whatever the placement of the
+  //  workgroups and the coherence of the caches between them, a record that is taken is this launch's.)
+  for (int attempt = 0;; ++attempt) {
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl) {
+      const unsigned tot = cl ? ns1 : ns0;
+      const f4* src[kPer];
+#pragma unroll
+      for (int j = 0; j < kPer; ++j) {
+        const unsigned i = (unsigned)(j * kThreads + t);
+        cel[cl][j] = -1;
+        const unsigned ii = min(i, tot ? tot - 1u : 0u);  // (a lane without a record re-reads a valid slot)
+        int sw = 0;
+#pragma unroll
+        for (int q = 1; q < kSlabs; ++q) sw += ii >= pre[cl][q] ? 1 : 0;
+        unsigned first = 0;
+#pragma unroll
+        for (int q = 1; q < kSlabs; ++q) first = ii >= pre[cl][q] ? pre[cl][q] : first;
+        src[j] = &staging[hand(slab, cl, sw) * kCapSrc + (ii - first)];
+      }
+      static_assert(kPer == 4, "load16x4_coherent");
+      load16x4_coherent(rec[cl][0], rec[cl][1], rec[cl][2], rec[cl][3], src[0], src[1], src[2], src[3]);
+    }
+    bool late = false;
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+      for (int j = 0; j < kPer; ++j)
+        late |= (unsigned)(j * kThreads + t) < (cl ? ns1 : ns0) && ((unsigned)__float_as_int(rec[cl][j].w) >> kTagShift) != tag;
+    if (!__syncthreads_or(late ? 1 : 0)) break;
+    if (attempt == kRereads) {
+      decline(5u);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) rec[cl][j].w = __int_as_float(__float_as_int(rec[cl][j].w) & ((1 << kTagShift) - 1));
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl) {
+    const unsigned tot = cl ? ns1 : ns0;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      if ((unsigned)(j * kThreads + t) < tot) {
+        const int c = local_cell(rec[cl][j].x, rec[cl][j].y, rec[cl][j].z);
+        cel[cl][j] = c;
+        atomicAdd(&s_tab[cl * kTabWords + (c >> 1)], (c & 1) ? 0x10000u : 1u);
+      }
+    }
+  }
+  __syncthreads();
+  PP_SLAB_PHASE_END(3)
+  // scan: entry c := END of cell c (thread t: twelve cells of cloud t / 512)
   {
     const int cl = t >> 9, tt = t & 511;
     unsigned* __restrict__ tab = s_tab + cl * kTabWords + tt * 6;
@@ -236,36 +426,28 @@ __global__ __launch_bounds__(kThreads) void chamfer_slab_kernel(const float* __r
       tab[i] = lo | (hi << 16);
       run = hi;
     }
-    if (tt == 511) {
-      tab[6] = run;  // the sentinel (entry kLocCells): the image's size
-      s_sel[cl] = run;
-    }
+    if (tt == 511) tab[6] = run;  // the sentinel (entry kLocCells): the image's size
   }
   __syncthreads();
-  const unsigned ns0 = s_sel[0], ns1 = s_sel[1];
-  if (ns0 > (unsigned)kCap || ns1 > (unsigned)kCap) {  // the images do not fit (uniform)
-    decline();
-    return;
-  }
   if (t < 2 * kPad) {  // the padding: points whose distance to anything is NaN
     const float qn = __builtin_nanf("");
     const f4 nanp = {qn, qn, qn, __int_as_float(0x7fffffff)};
     s_pts[(t >> 2) * (kCap + kPad) + ((t >> 2) ? ns1 : ns0) + (t & 3)] = nanp;
   }
-  // a point takes the slot below its cell's END and lowers it: afterwards entry c is the START of cell c
-  for_all_points(c1, c2, N, M, t, [&](int k, float x, float y, float z) {
-    const int cl = k < N ? 0 : 1;
-    bool mine;
-    const int c = local_cell(x, y, z, mine);
-    if (mine) {
-      const unsigned old = atomicSub(&s_tab[cl * kTabWords + (c >> 1)], (c & 1) ? 0x10000u : 1u);
-      const unsigned pos = ((c & 1) ? (old >> 16) : (old & 0xFFFFu)) - 1u;
-      const f4 rec = {x, y, z, __int_as_float(cl ? k - N : k)};
-      s_pts[cl * (kCap + kPad) + pos] = rec;
+  // a record takes the slot below its cell's END and lowers it: afterwards entry c is the START of cell c
+#pragma unroll
+  for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const int c = cel[cl][j];
+      if (c >= 0) {
+        const unsigned old = atomicSub(&s_tab[cl * kTabWords + (c >> 1)], (c & 1) ? 0x10000u : 1u);
+        const unsigned pos = ((c & 1) ? (old >> 16) : (old & 0xFFFFu)) - 1u;
+        s_pts[cl * (kCap + kPad) + pos] = rec[cl][j];
+      }
     }
-  });
   __syncthreads();
-  PP_SLAB_PHASE_END(3)
+  PP_SLAB_PHASE_END(4)
 
   // ---------------------------------------------------------------- 4. the 2x2x2 blocks, both directions
   // (chamfer_grid.hip's stage A: the same walk -- groups of four consecutive points of the block's four rows, the
@@ -274,7 +456,7 @@ __global__ __launch_bounds__(kThreads) void chamfer_slab_kernel(const float* __r
   const float inf = INFINITY;
   constexpr int g1 = kG - 1;
   for (int dir = 0; dir < 2; ++dir) {
-    if (dir == 1) { PP_SLAB_PHASE_END(4) }
+    if (dir == 1) { PP_SLAB_PHASE_END(5) }
     const f4* __restrict__ qpts = s_pts + dir * (kCap + kPad);
     const unsigned* __restrict__ qtab = s_tab + dir * kTabWords;
     const unsigned* __restrict__ rtab = s_tab + (dir ^ 1) * kTabWords;
@@ -385,12 +567,12 @@ __global__ __launch_bounds__(kThreads) void chamfer_slab_kernel(const float* __r
     }
   }
   __syncthreads();
-  PP_SLAB_PHASE_END(5)
+  PP_SLAB_PHASE_END(6)
   // ---------------------------------------------------------------- 5. what the blocks left: the cube of radius 1, a wave per query
   // (about one query in 150 on an evenly sampled surface; the cube lies inside the image by construction)
   const unsigned nqueue = s_qn;
   if (nqueue > (unsigned)kQueue) {  // not a cloud for this kernel (uniform): the batch element is redone by the launches that follow
-    decline();
+    decline(3u);
     return;
   }
   for (unsigned en = (unsigned)wave; en < nqueue; en += kWaves) {  // wave-uniform
@@ -467,25 +649,25 @@ __global__ __launch_bounds__(kThreads) void chamfer_slab_kernel(const float* __r
   // (a few queries in a million on a surface: isolated points, the ends of an open sheet)
   const unsigned nleft = s_ln;
   if (nleft > (unsigned)kMaxLeft) {
-    decline();
+    decline(4u);
     return;
   }
   for (unsigned i = 0; i < nleft; ++i) {  // (uniform)
     const f4 w = s_queue[s_left[i]];
     const int dir = (__float_as_int(w.w) >> 30) & 1;
     const f4* __restrict__ rv = reinterpret_cast<const f4*>(dir ? c1 : c2);
-    const int G = (dir ? N : M) >> 2;
+    const int Gr = (dir ? N : M) >> 2;
     unsigned long long key = ~0ull;
     auto cand = [&](int id, float x, float y, float z) {
       const float d = pp::chamfer_d3(x, y, z, w.x, w.y, w.z);
       const unsigned long long c = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)id;
       key = (d == d && c < key) ? c : key;  // (never a NaN distance)
     };
-    for (int g0 = 0; g0 < G; g0 += kGroupBatch * kThreads) {
+    for (int g0 = 0; g0 < Gr; g0 += kGroupBatch * kThreads) {
       f4 a[kGroupBatch][3];
 #pragma unroll
       for (int u = 0; u < kGroupBatch; ++u) {
-        const f4* __restrict__ src = rv + 3 * (size_t)min(g0 + u * kThreads + t, G - 1);
+        const f4* __restrict__ src = rv + 3 * (size_t)min(g0 + u * kThreads + t, Gr - 1);
         a[u][0] = src[0];
         a[u][1] = src[1];
         a[u][2] = src[2];
@@ -493,7 +675,7 @@ __global__ __launch_bounds__(kThreads) void chamfer_slab_kernel(const float* __r
 #pragma unroll
       for (int u = 0; u < kGroupBatch; ++u) {
         const int g = g0 + u * kThreads + t;
-        if (g < G) {
+        if (g < Gr) {
           cand(4 * g, a[u][0].x, a[u][0].y, a[u][0].z);
           cand(4 * g + 1, a[u][0].w, a[u][1].x, a[u][1].y);
           cand(4 * g + 2, a[u][1].z, a[u][1].w, a[u][2].x);
@@ -529,18 +711,27 @@ namespace pp {
 bool chamfer_slab_applies(const float* xyz1, const float* xyz2, int B, int N, int M) {
   // the slabs' images hold 3584 points of a cloud (4 of 32 layers + 2 halo layers of an evenly sampled cloud: 3/16 of
   // it, + 17 % of room): clouds of config 2's size class; read as 16-byte pieces, four points to a lane
-  return B >= 1 && N >= 8192 && M >= 8192 && N <= 17408 && M <= 17408 && N % 4 == 0 && M % 4 == 0 &&
-         (reinterpret_cast<uintptr_t>(xyz1) & 15) == 0 && (reinterpret_cast<uintptr_t>(xyz2) & 15) == 0;
+  return chamfer_slab_shape_ok(B, N, M) && (reinterpret_cast<uintptr_t>(xyz1) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(xyz2) & 15) == 0;
 }
 
+static_assert(ppslab::kCapSrc == pp::kSlabKernelCapSrc, "grid_common.h: chamfer_slab_workspace_bytes");
+
 int chamfer_slab_launch(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2, int* idx2,
-                        unsigned* state, int B, int N, int M, hipStream_t s) {
+                        unsigned char* ws_slab, int B, int N, int M, hipStream_t s) {
   static pp::DeviceFlags lds_ok;
   hipError_t e = pp::allow_big_lds(ppslab::chamfer_slab_kernel, (int)ppslab::kLdsBytes, lds_ok);
   if (e != hipSuccess) return (int)e;
+  // this launch's tag of the hand-off words: 48 bits, a random start (per process) plus a counter
+  static std::atomic<unsigned long long> tag{[] {
+    std::random_device rd;
+    return ((unsigned long long)rd() << 32) ^ (unsigned long long)rd() ^
+           (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+  }()};
+  const unsigned long long nonce = tag.fetch_add(1, std::memory_order_relaxed) & ((1ull << 48) - 1);
   const int grid = 8 * ((B * ppslab::kSlabs + 7) / 8);
   ppslab::chamfer_slab_kernel<<<dim3(grid), dim3(ppslab::kThreads), ppslab::kLdsBytes, s>>>(xyz1, xyz2, dist1, idx1, dist2,
-                                                                                          idx2, state, B, N, M);
+                                                                                          idx2, ws_slab, nonce, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
 }

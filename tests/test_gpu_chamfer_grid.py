@@ -375,3 +375,91 @@ def test_far_clouds_equal_oracle(cuda, name):
     got = _run(cuda, x1, x2, 2)
     for g, e, what in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
         assert np.array_equal(g, e), "%s: %s differs at %d places" % (name, what, int((g != e).sum()))
+
+
+# ---- round 4: the fused sort-and-search kernel of config 2's size class (csrc/chamfer_slab.hip; opt-in: tile knob -2).
+# Whatever it serves and whatever it declines (the build and whole-search launches behind it redo a declined batch
+# element), the four outputs are the every-pair kernel's, bit for bit.
+def _slab_cases():
+    u = lambda seed, shape: S.uniform01(seed, shape).reshape(shape).astype(np.float32)
+    n = 16384
+    c = {}
+    c["surface"] = (S.unit_sphere(700, 2, n), S.unit_sphere(701, 2, n), "served")
+    c["surface_ragged"] = (S.unit_sphere(702, 3, 12292), S.unit_sphere(703, 3, 16380), "served")
+    c["surface_smallest"] = (S.unit_sphere(704, 1, 8192), S.unit_sphere(705, 1, 12288), None)
+    same = S.unit_sphere(706, 1, n)
+    c["same_cloud"] = (same, same.copy(), "served")                     # every distance zero
+    dup = S.unit_sphere(707, 1, n)
+    dup[0, n // 2:] = dup[0, : n // 2]                                    # every point twice: exact ties across groups
+    c["duplicates"] = (S.unit_sphere(708, 1, n), dup, None)
+    lat = np.round(S.unit_sphere(709, 1, n) * 24).astype(np.float32)     # a lattice: ties everywhere
+    c["lattice"] = (lat, np.round(S.unit_sphere(710, 1, n) * 24).astype(np.float32), None)
+    zs = S.unit_sphere(711, 1, n)
+    zs = zs[:, np.argsort(zs[0, :, 2])]                                   # sorted along the slabs' axis
+    c["sorted_in_z"] = (np.ascontiguousarray(zs), S.unit_sphere(712, 1, n), None)
+    c["volume"] = (u(713, (2, n, 3)), u(714, (2, n, 3)), "declined")
+    c["gaussian"] = (S.normal(715, (1, n, 3)).astype(np.float32), S.normal(716, (1, n, 3)).astype(np.float32), None)
+    flat = u(717, (1, n, 3)).copy()
+    flat[..., 2] = 0.3
+    c["plane"] = (flat, flat[:, ::-1].copy() + np.float32(1e-3), "declined")
+    c["far_apart"] = (S.unit_sphere(718, 1, n), S.unit_sphere(719, 1, n) + np.float32(5.0), None)
+    out = S.unit_sphere(720, 1, n)
+    out[0, 5::1000] *= np.float32(30.0)                                   # outliers the sampled box does not see
+    c["outliers"] = (out, S.unit_sphere(721, 1, n), None)
+    mixed1 = np.concatenate([S.unit_sphere(722, 1, n), u(723, (1, n, 3)), S.unit_sphere(724, 1, n)])
+    mixed2 = np.concatenate([S.unit_sphere(725, 1, n), u(726, (1, n, 3)), S.unit_sphere(727, 1, n)])
+    c["mixed_batch"] = (mixed1, mixed2, "mixed")
+    nan = S.unit_sphere(728, 2, n)
+    nan[1, 777, 1] = np.nan
+    c["a_nan"] = (nan, S.unit_sphere(729, 2, n), "mixed_nan")
+    c["not_a_multiple_of_four"] = (S.unit_sphere(730, 1, 16383), S.unit_sphere(731, 1, n), "absent")
+    return c
+
+
+SLAB = _slab_cases()
+
+
+@pytest.mark.parametrize("name", sorted(SLAB))
+def test_fused_slab_kernel_equals_brute_force(cuda, name):
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd._ext import losses
+    x1, x2, expect = SLAB[name]
+    x1, x2 = np.ascontiguousarray(x1), np.ascontiguousarray(x2)
+    ref = _run(cuda, x1, x2, 1)
+    t1, t2 = torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda)
+
+    def forward():                                         # (the ctypes path: its workspace is the one read back below)
+        b, n, m = x1.shape[0], x1.shape[1], x2.shape[1]
+        o = (torch.empty(b, n, device=cuda), torch.empty(b, m, device=cuda),
+             torch.empty(b, n, dtype=torch.int32, device=cuda), torch.empty(b, m, dtype=torch.int32, device=cuda))
+        losses.nmdistance_forward(t1, t2, *o)
+        torch.cuda.synchronize()
+        return o[0].cpu().numpy(), o[2].cpu().numpy(), o[1].cpu().numpy(), o[3].cpu().numpy()
+
+    _tile_knob(-2)
+    try:
+        for rep in range(3):                               # (the hand-off areas are reused launch after launch)
+            got = forward()
+            for g, e, what in zip(got, ref, ["dist1", "idx1", "dist2", "idx2"]):
+                same = np.array_equal(g, e, equal_nan=True)
+                assert same, "%s (launch %d): %s differs at %d places" % (name, rep, what, int((g != e).sum()))
+        b, n, m = x1.shape[0], x1.shape[1], x2.shape[1]
+        words = (ctypes.c_uint * (8 * b))()
+        ws = _lib.cached_workspaces("nmdistance")[0]
+        fn = _lib.lib().pp_debug_nmdistance_slab_state
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        fn.restype = ctypes.c_int
+        assert fn(ws.data_ptr(), b, n, m, words) == 0
+        st = np.array(list(words)).reshape(b, 8)
+    finally:
+        _tile_knob(0)
+    if expect == "served":
+        assert (st == 0).all(), st
+    elif expect == "declined":
+        assert ((st != 0).any(1)).all() and (st != 15).all(), st
+    elif expect == "mixed":
+        assert (st[0] == 0).all() and (st[1] != 0).any() and (st[2] == 0).all(), st
+    elif expect == "mixed_nan":
+        assert (st[0] == 0).all() and (st[1] == 1).any(), st
+    elif expect == "absent":
+        assert (st == 15).all(), st

@@ -1,7 +1,7 @@
 #!/bin/bash
 # chamfer_slab.hip: kernel durations (rocprofv3 --kernel-trace --stats) of the variants that leave after phase n
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for n in ${VARIANTS:-9 1 2 3 4 5 full}; do
+for n in ${VARIANTS:-1 2 3 4 5 6 full}; do
   if [ $n = full ]; then unset PP_LIB; else export PP_LIB=tools/libpp_hip_slab$n.so; [ -f $PP_LIB ] || continue; fi
   rm -rf gpurun_out/slabprof_$n
   PP_TILE_MODES=-2 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/slabprof_$n -- python3 tools/tile_modes.py sphere > /dev/null 2>&1
