@@ -38,7 +38,10 @@ using pp::kGridCells;
 using pp::kBuildThreads;
 
 constexpr int kBqMaxCells = 3;   // cell-box half-extent the grid path accepts
-constexpr int kBqCap = 512;      // candidates staged per pass (8 KiB)
+#ifndef PP_BQ_CAP
+#define PP_BQ_CAP 512
+#endif
+constexpr int kBqCap = PP_BQ_CAP;  // candidates staged per pass (16 bytes each)
 constexpr int kBqMaxN = 524288;  // point bitmap <= 64 KiB
 
 struct BqLayout {
@@ -112,14 +115,17 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
   const int ncell = g.gx * g.gy * g.gz;
   const int ncw = (ncell + 31) >> 5;  // words of the cell bitmap
   const int npw = (N + 31) >> 5;      // words of the point bitmap
+  // (the cell bitmap and the list of its non-empty words live in steps 1-2, the staged candidates from step 3 on: they
+  //  share one region -- 14 KB per wave instead of 18, eleven waves per CU instead of eight)
+  static_assert(kGridCells / 8 + kGridCells / 32 * 2 <= kBqCap * 16, "the bitmap and its word list fit the staging area");
   unsigned* s_cell = reinterpret_cast<unsigned*>(s_raw);                 // [kGridCells / 32]
-  unsigned* s_pt = s_cell + kGridCells / 32;                             // [npw]
-  float* s_cx = reinterpret_cast<float*>(s_pt + ((npw + 3) & ~3));       // [kBqCap] each, 16-byte aligned
+  unsigned short* s_words = reinterpret_cast<unsigned short*>(s_cell + kGridCells / 32);  // step 2: non-empty bitmap words
+  float* s_cx = reinterpret_cast<float*>(s_raw);                         // [kBqCap] each, 16-byte aligned
   float* s_cy = s_cx + kBqCap;
   float* s_cz = s_cy + kBqCap;
   int* s_cid = reinterpret_cast<int*>(s_cz + kBqCap);
-  IT* s_rows = reinterpret_cast<IT*>(s_cid + kBqCap);                    // [G][nsample + 1]
-  unsigned short* s_words = reinterpret_cast<unsigned short*>(s_cx);     // step 2 only: non-empty bitmap words
+  unsigned* s_pt = reinterpret_cast<unsigned*>(s_cid + kBqCap);          // [npw]
+  IT* s_rows = reinterpret_cast<IT*>(s_pt + ((npw + 3) & ~3));           // [G][nsample + 1]
   __shared__ int s_rng[2];
   const int stride = nsample + 1;
 
@@ -242,9 +248,12 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
       for (int u = 0; u < 4; ++u) id[u] = s_cid[min(c + 64 * u, ncand - 1)];
       float v[4][3];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) v[u][a] = cloud[3 * (size_t)id[u] + a];
+      for (int u = 0; u < 4; ++u) {  // (one 12-byte load per candidate, not three scattered 4-byte ones)
+        typedef float f3 __attribute__((ext_vector_type(3)));
+        f3 p;
+        __builtin_memcpy(&p, cloud + 3 * (size_t)id[u], sizeof(p));
+        v[u][0] = p.x; v[u][1] = p.y; v[u][2] = p.z;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int cc = c + 64 * u;
@@ -275,8 +284,9 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
           const pp::f4 X = *reinterpret_cast<const pp::f4*>(s_cx + c0 + u);
           const pp::f4 Y = *reinterpret_cast<const pp::f4*>(s_cy + c0 + u);
           const pp::f4 Z = *reinterpret_cast<const pp::f4*>(s_cz + c0 + u);
-          const float d0 = pp::dist3(q.x, q.y, q.z, X.x, Y.x, Z.x), d1 = pp::dist3(q.x, q.y, q.z, X.y, Y.y, Z.y);
-          const float d2 = pp::dist3(q.x, q.y, q.z, X.z, Y.z, Z.z), d3 = pp::dist3(q.x, q.y, q.z, X.w, Y.w, Z.w);
+          // (two candidates per instruction: the packed forms give dist3's bits)
+          const pp::f2 dA = pp::dist3_pk(q.x, q.y, q.z, X.xy, Y.xy, Z.xy), dB = pp::dist3_pk(q.x, q.y, q.z, X.zw, Y.zw, Z.zw);
+          const float d0 = dA.x, d1 = dA.y, d2 = dB.x, d3 = dB.y;
           // hits = 2 * hits + (d < r^2), four times
           asm volatile(
               "v_cmp_lt_f32 vcc, %1, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
@@ -342,8 +352,7 @@ extern "C" void pp_debug_set_ball_query_search(int v) { g_bq_grid_mode.set(v); }
 
 static size_t bq_query_lds(int N, int nsample, int G) {
   const size_t npw = ((size_t)N + 31) / 32;
-  return (size_t)kGridCells / 8 + ((npw + 3) & ~(size_t)3) * 4 + (size_t)kBqCap * 16 +
-         (size_t)G * (nsample + 1) * (N <= 65536 ? 2 : 4);
+  return ((npw + 3) & ~(size_t)3) * 4 + (size_t)kBqCap * 16 + (size_t)G * (nsample + 1) * (N <= 65536 ? 2 : 4);
 }
 
 extern "C" size_t pp_ball_query_workspace_bytes(int B, int N, int M, int nsample) {
@@ -388,18 +397,21 @@ extern "C" int pp_ball_query_ws_f32(const float* new_xyz, const float* xyz, int*
   if (e != hipSuccess) return (int)e;
   (vec ? bq_build_kernel<true> : bq_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(xyz, new_xyz, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
-  // lanes per centre: 2 unless forced (tuning knob; 2 and 4 measure alike at config 4, 1 is 30 % slower)
-  int lpc = g_bq_lpc ? g_bq_lpc : 2;
-  while (lpc < 4 && bq_query_lds(N, nsample, 64 / lpc) > 128 * 1024) lpc *= 2;  // fewer rows per wave if the LDS is short
+  // lanes per centre: 4 unless forced (tuning knob; at config 4, with the 14 KB footprint of round 4: 1 -> 0.122 ms,
+  // 2 -> 0.115, 4 -> 0.111, 8 -> see DESIGN 5.3b)
+  int lpc = g_bq_lpc ? g_bq_lpc : 4;
+  while (lpc < 8 && bq_query_lds(N, nsample, 64 / lpc) > 128 * 1024) lpc *= 2;  // fewer rows per wave if the LDS is short
   int rc;
   if (N <= 65536)
     rc = lpc == 1 ? bq_launch_query<unsigned short, 1>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)
        : lpc == 2 ? bq_launch_query<unsigned short, 2>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)
-                  : bq_launch_query<unsigned short, 4>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s);
+       : lpc == 4 ? bq_launch_query<unsigned short, 4>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)
+                  : bq_launch_query<unsigned short, 8>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s);
   else
     rc = lpc == 1 ? bq_launch_query<unsigned, 1>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)
        : lpc == 2 ? bq_launch_query<unsigned, 2>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)
-                  : bq_launch_query<unsigned, 4>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s);
+       : lpc == 4 ? bq_launch_query<unsigned, 4>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s)
+                  : bq_launch_query<unsigned, 8>(xyz, idx, ws, B, N, M, radius2, rpad, nsample, s);
   if (rc != PP_OK) return rc;
   const BqLayout L = bq_layout(B, N, M);
   return pp::ball_query_scan_unusable(new_xyz, xyz, idx, B, N, M, radius, nsample,

@@ -75,6 +75,13 @@ __device__ __forceinline__ float dist3(float ax, float ay, float az, float bx, f
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
 }
 
+// two points b against one point a, element-wise the operations of dist3 (v_pk_add_f32 with a negated operand,
+// v_pk_mul_f32, v_pk_fma_f32: IEEE results, the same bits as the scalar form, at twice the rate)
+__device__ __forceinline__ f2 dist3_pk(float ax, float ay, float az, f2 bx, f2 by, f2 bz) {
+  const f2 dx = (f2)(ax) - bx, dy = (f2)(ay) - by, dz = (f2)(az) - bz;
+  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+}
+
 // In-place ascending sort of a[0..n) by key(a[i]) by ONE lane: insertion sort for the short lists the callers
 // normally see (a handful of entries: its cost is the number of inversions), heapsort beyond -- O(n log n) whatever
 // the arrival order, so that a degenerate input (thousands of sources sharing one destination) costs milliseconds,
