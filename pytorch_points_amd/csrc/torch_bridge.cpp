@@ -236,6 +236,9 @@ struct PackedExchange {
   c10::Device dev;
   std::vector<Tensor> send, recv;
   std::vector<std::vector<Tensor>> wide;  // int32 indices of the global batch, made on demand (widen)
+  // views made once, not per step (an as_strided per field and step was a third of the exchange's host time):
+  std::vector<std::vector<Tensor>> own;       // [slot] -> the slot's own dist1 (b, n), dist2 (b, m)
+  std::vector<std::vector<Tensor>> gathered;  // [slot] -> dist1, dist2, idx1, idx2 of every rank (wait)
   std::vector<hipEvent_t> packed, done;
   std::vector<long long> launched;
   c10::hip::HIPStreamMasqueradingAsCUDA side;
@@ -276,6 +279,18 @@ struct PackedExchange {
       done.push_back(e1);
       launched.push_back(0);
     }
+    make_views();
+  }
+  void make_views() {  // (again whenever `send` changes: init_direct, disable_direct)
+    own.clear();
+    gathered.clear();
+    for (int k = 0; k < depth; ++k) {
+      const Tensor f = send[k].view(torch::kFloat32);
+      own.push_back({f.narrow(0, 0, (int64_t)b * n).view({(int64_t)b, (int64_t)n}),
+                     f.narrow(0, (int64_t)b * n, (int64_t)b * m).view({(int64_t)b, (int64_t)m})});
+      gathered.push_back({dist_view(recv[k], world, 0), dist_view(recv[k], world, 1), idx_view(recv[k], world, 0),
+                          idx_view(recv[k], world, 1)});
+    }
   }
   ~PackedExchange() {
     // the side stream may still be writing the buffers this object is about to free
@@ -303,12 +318,22 @@ struct PackedExchange {
     const ncclResult_t rc = ncclCommInitRank(&c, world, id, rank);
     TORCH_CHECK(rc == ncclSuccess, "ncclCommInitRank failed: ", ncclGetErrorString(rc));
     comm = c;
+    // IN PLACE from here on: a slot's own part is row `rank` of its gathered buffer (the search writes its distances
+    // there, the indices are narrowed in behind them), which is what ncclAllGather takes as "sendbuff == recvbuff +
+    // rank * count": RCCL then moves the seven foreign parts and nothing else -- and on one rank nothing at all.
+    drain();
+    for (int k = 0; k < depth; ++k) send[k] = recv[k].select(0, rank);
+    make_views();
   }
   void disable_direct() {  // back to c10d (a rank failed to join: every rank must then take the same path)
     drain();
     (void)hipStreamSynchronize(side.stream());
     if (comm) (void)ncclCommDestroy(comm);
     comm = nullptr;
+    const c10::DeviceGuard guard(dev);
+    for (int k = 0; k < depth; ++k)  // c10d's call is given buffers of its own again
+      send[k] = torch::empty({nbytes_padded}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+    make_views();
   }
 
   hipStream_t current() const { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(); }
@@ -338,9 +363,19 @@ struct PackedExchange {
     const int slot = turn;
     turn = (turn + 1) % depth;
     finish(slot);
-    const Tensor f = send[slot].view(torch::kFloat32);
-    return std::make_tuple(slot, f.narrow(0, 0, (int64_t)b * n).view({(int64_t)b, (int64_t)n}),
-                           f.narrow(0, (int64_t)b * n, (int64_t)b * m).view({(int64_t)b, (int64_t)m}));
+    return std::make_tuple(slot, own[slot][0], own[slot][1]);
+  }
+
+  // begin + the search (the autograd node of nndistance, its distances written into the slot) + launch_in_place, in
+  // ONE call from Python: -> (dist1, dist2, idx1, idx2, slot)
+  std::tuple<Tensor, Tensor, Tensor, Tensor, int> forward(const Tensor& xyz1, const Tensor& xyz2) {
+    const int slot = turn;
+    turn = (turn + 1) % depth;
+    finish(slot);
+    auto r = NmDistance::apply(xyz1, xyz2, c10::optional<Tensor>(own[slot][0].detach()),
+                               c10::optional<Tensor>(own[slot][1].detach()));
+    launch_in_place(slot, r[2], r[3]);
+    return std::make_tuple(r[0], r[1], r[2], r[3], slot);
   }
 
   void issue(int slot) {  // the gather of send[slot] on the side stream, behind everything the current stream holds
@@ -406,8 +441,7 @@ struct PackedExchange {
   std::vector<Tensor> wait(int slot) {
     TORCH_CHECK(slot >= 0 && slot < depth, "PackedExchange.wait: no such slot");
     finish(slot);
-    return {dist_view(recv[slot], world, 0), dist_view(recv[slot], world, 1), idx_view(recv[slot], world, 0),
-            idx_view(recv[slot], world, 1)};
+    return gathered[slot];
   }
 
   // int32 indices of the global batch, (world * b, n) and (world * b, m), 0xFFFF -> -1: one kernel, on demand
@@ -446,6 +480,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def(pybind11::init<const c10::intrusive_ptr<c10d::ProcessGroup>&, int, int, int, const c10::Device&, int>())
       .def("begin", &PackedExchange::begin, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("launch_in_place", &PackedExchange::launch_in_place, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def("forward", &PackedExchange::forward, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("launch", &PackedExchange::launch, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("wait", &PackedExchange::wait, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("widen", &PackedExchange::widen, pybind11::call_guard<pybind11::gil_scoped_release>())

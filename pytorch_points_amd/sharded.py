@@ -214,6 +214,8 @@ class PackedShardGather:
         """nndistance of this rank's shard with the distances written straight into the exchange's slot, and the
         asynchronous gather of the shard's outputs: -> (dist1, dist2, idx1, idx2, handle).  Differentiable like
         ``nndistance``; dist1 / dist2 alias the slot (valid until it is launched again)."""
+        if self._native is not None:        # one call: begin + search + launch_in_place
+            return tuple(self._native.forward(xyz1, xyz2))
         slot, d1v, d2v = self.begin()
         if self.on_gpu:
             from . import _lib
