@@ -187,3 +187,60 @@ def test_fuzz_furthest_sampling(cuda, seed):
     assert np.array_equal(idx.cpu().numpy(), e_idx), (b, n, m, start)
     assert np.array_equal(temp.cpu().numpy(), e_temp), (b, n, m, start)
     assert np.array_equal(pts.cpu().numpy(), np.take_along_axis(x, e_idx[..., None].astype(np.int64), 1))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PP_FUZZ_SEEDS", "100")) // 4))
+def test_fuzz_fused_slab_kernel(cuda, seed):
+    """round 4: the fused sort-and-search kernel of config 2's size class (csrc/chamfer_slab.hip, opt-in) on random
+    sizes of its window and cloud families -- surfaces it serves, volumes / clusters / far clouds it declines in whole or
+    in part (the build and whole-search launches behind it redo those batch elements) -- against the every-pair kernel,
+    bit for bit; launched twice (the hand-off areas of the first launch are what the second finds in the workspace)"""
+    import ctypes
+    from pytorch_points_amd import _lib
+    from pytorch_points_amd.network.model_loss import nndistance
+    rng = np.random.default_rng(9000 + seed)
+    b = int(rng.integers(1, 4))
+    n = 4 * int(rng.integers(2048, 4353))          # [8192, 17408], multiples of four
+    m = 4 * int(rng.integers(2048, 4353))
+    def surface(k):
+        x = S.unit_sphere(int(rng.integers(1 << 30)), b, k)
+        what = int(rng.integers(0, 5))
+        if what == 1:     # an ellipsoid: layers of unequal population along z
+            x = x * np.array([1.0, 0.6, float(rng.choice([0.3, 1.7]))], np.float32)
+        elif what == 2:   # a noisy shell
+            x = x * (1 + 0.02 * rng.standard_normal((b, k, 1))).astype(np.float32)
+        elif what == 3:   # two shells
+            x[:, ::2] *= np.float32(0.55)
+        elif what == 4:   # an open sheet: half of the sphere folded onto the other half
+            x[..., 2] = np.abs(x[..., 2])
+        return np.ascontiguousarray(x, np.float32)
+    kind = int(rng.integers(0, 10))
+    if kind < 6:
+        x1, x2 = surface(n), surface(m)
+    else:                 # whatever the other fuzz tests use: mostly declined
+        x1, x2 = _cloud(rng, b, n, int(rng.integers(0, 8))), _cloud(rng, b, m, int(rng.integers(0, 8)))
+    if seed % 4 == 0:     # the second cloud a little off the first: queries in empty blocks
+        x2 = x2 + np.float32(rng.choice([0.02, 0.3]))
+    if seed % 7 == 0:     # one batch element of another family
+        x1[0] = _cloud(rng, 1, n, 1)[0]
+    x1, x2 = np.ascontiguousarray(x1, np.float32), np.ascontiguousarray(x2, np.float32)
+    t1, t2 = torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda)
+    lib = _lib.lib()
+    search, tile = lib.pp_debug_set_nmdistance_search, lib.pp_debug_set_nmdistance_tile
+    for f in (search, tile):
+        f.argtypes = [ctypes.c_int]
+        f.restype = None
+    search(1)
+    try:
+        ref = [a.cpu().numpy() for a in nndistance(t1, t2)]
+    finally:
+        search(0)
+    tile(-2)
+    try:
+        for launch in range(2):
+            got = [a.cpu().numpy() for a in nndistance(t1, t2)]
+            for g, e, what in zip(got, ref, ("dist1", "dist2", "idx1", "idx2")):
+                assert np.array_equal(g, e), "seed %d launch %d (b=%d n=%d m=%d kind %d): %s differs at %d places" % (
+                    seed, launch, b, n, m, kind, what, int((g != e).sum()))
+    finally:
+        tile(0)
