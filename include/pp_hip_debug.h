@@ -22,7 +22,10 @@ void pp_debug_set_nmdistance_variant(int variant);
 /* grid search, wave-private form of the search kernel: staged points per wave (320, 384, 512; selecting one also
  * selects that form; 0 = the default, the tile form) */
 void pp_debug_set_nmdistance_stage_cap(int points);
-/* grid search, unlabeled: queries per workgroup of the stage-A kernel (0 = 512; 256, 1024); -1 = no stage-A kernel */
+/* grid search, unlabeled: queries per workgroup of the stage-A kernel (0 = 512; 256, 1024); -1 = no stage-A kernel;
+ * -2 = the fused sort-and-search kernel (csrc/chamfer_slab.hip) first, where its shape window applies (8192 <= N, M <=
+ * 17408, multiples of 4, 16-byte aligned clouds), the build and whole-search kernels behind it for what it declines.
+ * The same values are read once from the environment variable PP_NMDISTANCE_TILE when the knob is 0. */
 void pp_debug_set_nmdistance_tile(int queries);
 /* labeled Chamfer brute force: 1 = the one-lane-per-query kernel */
 void pp_debug_set_labeled_variant(int variant);

@@ -716,6 +716,8 @@ bool chamfer_slab_applies(const float* xyz1, const float* xyz2, int B, int N, in
 }
 
 static_assert(ppslab::kCapSrc == pp::kSlabKernelCapSrc, "grid_common.h: chamfer_slab_workspace_bytes");
+static_assert(pp::kSlabKernelMaxPoints <= (1 << ppslab::kTagShift), "a record's index shares its word with the launch's tag");
+static_assert(pp::kSlabKernelMaxPoints < 65536, "16-bit cell tables, a hand-off count in 16 bits");
 
 int chamfer_slab_launch(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2, int* idx2,
                         unsigned char* ws_slab, int B, int N, int M, hipStream_t s) {

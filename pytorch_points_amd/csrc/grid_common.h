@@ -23,8 +23,10 @@ __device__ __forceinline__ bool slab_kernel_served(const unsigned* __restrict__ 
   return all;
 }
 constexpr int kSlabKernelCapSrc = 640;
+constexpr int kSlabKernelMinPoints = 8192, kSlabKernelMaxPoints = 17408;  // per cloud (an index must fit 15 bits)
 __host__ __device__ inline bool chamfer_slab_shape_ok(int B, int N, int M) {
-  return B >= 1 && N >= 8192 && M >= 8192 && N <= 17408 && M <= 17408 && N % 4 == 0 && M % 4 == 0;
+  return B >= 1 && N >= kSlabKernelMinPoints && M >= kSlabKernelMinPoints && N <= kSlabKernelMaxPoints &&
+         M <= kSlabKernelMaxPoints && N % 4 == 0 && M % 4 == 0;
 }
 // verdicts [B][8] (4 bytes), hand-off words [B][8][2][8] (8 bytes), hand-off records [B][8][2][8][kSlabKernelCapSrc] (16 bytes)
 __host__ __device__ inline size_t chamfer_slab_workspace_bytes(int B, int N, int M) {
