@@ -50,6 +50,33 @@ struct KList {
   }
 };
 
+// The same list with (distance bits << 32 | index) keys: for distances that are >= +0 and not NaN -- sums of squares --
+// the unsigned order of the keys IS the (distance, index) order, so an entry is one 64-bit compare and two 64-bit
+// selects instead of three compares, two logic operations and four selects (the grid kernel's K-list: a NaN distance
+// gets the all-ones key and never enters, as in the two-array form).
+template <int KT>
+struct KList64 {
+  unsigned long long k[KT];
+  static __device__ __forceinline__ unsigned long long key(float nd, int ni) {
+    return nd == nd ? (((unsigned long long)__float_as_uint(nd) << 32) | (unsigned)ni) : ~0ull;
+  }
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int j = 0; j < KT; ++j) k[j] = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (inf, no index)
+  }
+  __device__ __forceinline__ bool beats_last(unsigned long long nk) const { return nk < k[KT - 1]; }
+  __device__ __forceinline__ void insert(unsigned long long nk) {
+    bool lt[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) lt[j] = nk < k[j];
+#pragma unroll
+    for (int j = KT - 1; j >= 1; --j) k[j] = lt[j - 1] ? k[j - 1] : (lt[j] ? nk : k[j]);
+    k[0] = lt[0] ? nk : k[0];
+  }
+  __device__ __forceinline__ float dist(int j) const { return __uint_as_float((unsigned)(k[j] >> 32)); }
+  __device__ __forceinline__ int index(int j) const { return (int)(unsigned)k[j]; }
+};
+
 template <int KT>
 __device__ __forceinline__ void knn_store(const KList<KT>& L, float* __restrict__ od, int* __restrict__ oi, int K,
                                           int nvalid) {
@@ -274,7 +301,14 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(float* __restrict__ dist,
   const bool finite_q = __builtin_isfinite(q.x) && __builtin_isfinite(q.y) && __builtin_isfinite(q.z);
   // first box: about 2K points expected if the cloud filled its cells evenly (2 per cell), at least one cell
   float R = finite_q ? g.h * fmaxf(1.0f, 0.5f * cbrtf((float)K)) : 2.0e38f;
+#ifndef PP_KNN_KEY64
+#define PP_KNN_KEY64 1
+#endif
+#if PP_KNN_KEY64
+  KList64<KT> Lk;
+#else
   KList<KT> Lk;
+#endif
   const int kth = min(K, M) - 1;  // the entry that decides when to stop
   while (true) {
     Lk.clear();
@@ -302,17 +336,38 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(float* __restrict__ dist,
           const pp::f4 p = sorted[i];
           const float d = pp::chamfer_d3(p.x, p.y, p.z, q.x, q.y, q.z);
           const int id = __float_as_int(p.w);
+#if PP_KNN_KEY64
+          const unsigned long long nk = KList64<KT>::key(d, id);
+          if (Lk.beats_last(nk)) Lk.insert(nk);
+#else
           if (Lk.beats_last(d, id)) Lk.insert(d, id);
+#endif
         }
       }
     const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.gx - 1 && y1 == g.gy - 1 && z1 == g.gz - 1;
+#if PP_KNN_KEY64
+    float dk = Lk.dist(0);
+#pragma unroll
+    for (int j = 1; j < KT; ++j) dk = j <= kth ? Lk.dist(j) : dk;
+#else
     float dk = Lk.d[0];
 #pragma unroll
     for (int j = 1; j < KT; ++j) dk = j <= kth ? Lk.d[j] : dk;
+#endif
     if (whole || dk < 0.9999f * (reach * reach)) break;
     R *= 2.0f;
   }
+#if PP_KNN_KEY64
+  KList<KT> out;
+#pragma unroll
+  for (int j = 0; j < KT; ++j) {
+    out.d[j] = Lk.dist(j);
+    out.i[j] = Lk.index(j);
+  }
+  knn_store<KT>(out, dist + ((size_t)b * N + qorig) * K, idx + ((size_t)b * N + qorig) * K, K, M);
+#else
   knn_store<KT>(Lk, dist + ((size_t)b * N + qorig) * K, idx + ((size_t)b * N + qorig) * K, K, M);
+#endif
 }
 
 template <int KT>

@@ -73,19 +73,17 @@ __global__ __launch_bounds__(kBuildThreads) void tn_build_kernel(const float* __
                             nullptr, slab, pp::kBuildSlabs);
 }
 
-// (d, k) enters the ascending triple if it is lexicographically smaller than an entry
-__device__ __forceinline__ void insert3(float d, int k, float& b1, float& b2, float& b3, int& i1, int& i2,
-                                        int& i3) {
-  // (bitwise operators: hipcc turns the short-circuit forms into exec-mask branches)
-  const bool l1 = (d < b1) | ((d == b1) & (k < i1));
-  const bool l2 = (d < b2) | ((d == b2) & (k < i2));
-  const bool l3 = (d < b3) | ((d == b3) & (k < i3));
-  b3 = l2 ? b2 : (l3 ? d : b3);
-  i3 = l2 ? i2 : (l3 ? k : i3);
-  b2 = l1 ? b1 : (l2 ? d : b2);
-  i2 = l1 ? i1 : (l2 ? k : i2);
-  b1 = l1 ? d : b1;
-  i1 = l1 ? k : i1;
+// (d, k) enters the ascending triple if it is lexicographically smaller than an entry -- the reference's strict `<` in
+// index order.  With (distance bits << 32 | index) keys: for distances >= +0 that are not NaN the unsigned order of the
+// keys is the (distance, index) order -- three 64-bit compares instead of nine compares and six logic operations
+// (7 % of the query kernel's time at the interpolation shape).  A NaN distance gets the all-ones key and never enters.
+__device__ __forceinline__ void insert3_key(float d, int k, unsigned long long& k1, unsigned long long& k2,
+                                            unsigned long long& k3) {
+  const unsigned long long nk = d == d ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)k) : ~0ull;
+  const bool l1 = nk < k1, l2 = nk < k2, l3 = nk < k3;
+  k3 = l2 ? k2 : (l3 ? nk : k3);
+  k2 = l1 ? k1 : (l2 ? nk : k2);
+  k1 = l1 ? nk : k1;
 }
 
 __global__ __launch_bounds__(256) void tn_query_kernel(float* __restrict__ dist2, int* __restrict__ idx,
@@ -109,13 +107,11 @@ __global__ __launch_bounds__(256) void tn_query_kernel(float* __restrict__ dist2
   const pp::f4 q = (reinterpret_cast<const pp::f4*>(ws + L.qsorted) + (size_t)b * N)[n];
   const int qorig = __float_as_int(q.w);
 
-  float b1, b2, b3;
-  int i1, i2, i3;
+  unsigned long long k1, k2, k3;  // the three best (distance, index) pairs so far, as keys (insert3_key)
   const bool finite_q = __builtin_isfinite(q.x) && __builtin_isfinite(q.y) && __builtin_isfinite(q.z);
   float R = finite_q ? g.h : 2.0e38f;
   while (true) {
-    b1 = b2 = b3 = __builtin_inff();
-    i1 = i2 = i3 = 0;
+    k1 = k2 = k3 = (unsigned long long)0x7f800000u << 32;  // (inf, 0)
     const float lx = q.x - R, hx = q.x + R, ly = q.y - R, hy = q.y + R, lz = q.z - R, hz = q.z + R;
     const bool everything = !(R < 1.0e38f);  // last round (also: non-finite q): the whole grid, no questions
     const int x0 = everything ? 0 : cell_coord(lx, g.minx, g.invh, g.gx);
@@ -141,19 +137,19 @@ __global__ __launch_bounds__(256) void tn_query_kernel(float* __restrict__ dist2
         for (unsigned i = v.x; i < e; i += 2) {
           const pp::f4 p0 = sorted[i];
           const pp::f4 p1 = sorted[min(i + 1, e - 1)];
-          insert3(pp::dist3(q.x, q.y, q.z, p0.x, p0.y, p0.z), __float_as_int(p0.w), b1, b2, b3, i1, i2, i3);
-          if (i + 1 < e)
-            insert3(pp::dist3(q.x, q.y, q.z, p1.x, p1.y, p1.z), __float_as_int(p1.w), b1, b2, b3, i1, i2, i3);
+          insert3_key(pp::dist3(q.x, q.y, q.z, p0.x, p0.y, p0.z), __float_as_int(p0.w), k1, k2, k3);
+          if (i + 1 < e) insert3_key(pp::dist3(q.x, q.y, q.z, p1.x, p1.y, p1.z), __float_as_int(p1.w), k1, k2, k3);
         }
       }
     const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.gx - 1 && y1 == g.gy - 1 && z1 == g.gz - 1;
-    if (whole || b3 < 0.9999f * (reach * reach)) break;
+    if (whole || __uint_as_float((unsigned)(k3 >> 32)) < 0.9999f * (reach * reach)) break;
     R *= 2.0f;
   }
   float* od = dist2 + ((size_t)b * N + qorig) * 3;
   int* oi = idx + ((size_t)b * N + qorig) * 3;
-  od[0] = b1; od[1] = b2; od[2] = b3;
-  oi[0] = i1; oi[1] = i2; oi[2] = i3;
+  od[0] = __uint_as_float((unsigned)(k1 >> 32)); od[1] = __uint_as_float((unsigned)(k2 >> 32));
+  od[2] = __uint_as_float((unsigned)(k3 >> 32));
+  oi[0] = (int)(unsigned)k1; oi[1] = (int)(unsigned)k2; oi[2] = (int)(unsigned)k3;
 }
 
 }  // namespace

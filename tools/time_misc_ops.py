@@ -4,6 +4,9 @@ embarrassingly slow): three_nn, three_interpolate fwd/bwd, gather fwd/bwd, label
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("PP_LIB"):   # a variant of the library (tools/build_variant_lib.sh)
+    from pytorch_points_amd import _build
+    _build.LIB = os.path.abspath(os.environ["PP_LIB"]); _build.is_stale = lambda: False
 from pytorch_points_amd import synthetic as S
 from pytorch_points_amd._ext import sampling, losses
 dev = torch.device("cuda:0")
