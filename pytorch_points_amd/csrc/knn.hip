@@ -278,7 +278,8 @@ __global__ __launch_bounds__(kBuildThreads) void kn_build_kernel(const float* __
 }
 
 template <int KT>
-__global__ __launch_bounds__(256) void knn_grid_kernel(float* __restrict__ dist, int* __restrict__ idx,
+__global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                       float* __restrict__ dist, int* __restrict__ idx,
                                                        unsigned char* __restrict__ ws, int B, int N, int M, int K,
                                                        int tiles_per_b, int per_xcd) {
   const int vb = pp::xcd_virtual_block(blockIdx.x, per_xcd);  // a batch element stays on one XCD's L2
@@ -288,10 +289,24 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(float* __restrict__ dist,
   const KnLayout L = kn_layout(B, N, M);
   const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[b];
   const bool usable = !pp::grid_useless(g);
-  if (tile == 0 && threadIdx.x == 0)  // the scan kernel, launched next, skips the sets served here
-    reinterpret_cast<GridSet*>(ws + L.sets)[b].pad[0] = usable ? 1 : 0;
-  if (!usable) return;
   const int n = tile * 256 + threadIdx.x;
+  if (!usable) {
+    // A batch element without a usable grid (every point identical, a non-finite coordinate): every pair, a lane per
+    // query of the ORIGINAL order, here -- round 4; until then a second launch of the scan kernel followed every call to
+    // pick these up, 4-5 us to find, nearly always, nothing to do.
+    const int nc = min(n, N - 1);
+    const float* __restrict__ qp = p1 + ((size_t)b * N + nc) * 3;
+    const float* __restrict__ r = p2 + (size_t)b * M * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    KList<KT> Ls;
+    Ls.clear();
+    for (int k = 0; k < M; ++k) {  // r[...] is wave-uniform: scalar loads
+      const float d = pp::chamfer_d3(r[3 * (size_t)k], r[3 * (size_t)k + 1], r[3 * (size_t)k + 2], qx, qy, qz);
+      if (__any(Ls.beats_last(d, k))) Ls.insert(d, k);
+    }
+    if (n < N) knn_store<KT>(Ls, dist + ((size_t)b * N + n) * K, idx + ((size_t)b * N + n) * K, K, M);
+    return;
+  }
   if (n >= N) return;
   const unsigned* __restrict__ cell_start =
       reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1);
@@ -303,6 +318,9 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(float* __restrict__ dist,
   float R = finite_q ? g.h * fmaxf(1.0f, 0.5f * cbrtf((float)K)) : 2.0e38f;
 #ifndef PP_KNN_KEY64
 #define PP_KNN_KEY64 1
+#endif
+#ifndef PP_KNN_FLY
+#define PP_KNN_FLY 2
 #endif
 #if PP_KNN_KEY64
   KList64<KT> Lk;
@@ -332,16 +350,24 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(float* __restrict__ dist,
         const int wd = x1 + 1 - x0;
         unsigned e = wd == 1 ? v.y : (wd == 2 ? v.z : v.w);
         if (wd > 3) e = cell_start[c + x1 + 1];
-        for (unsigned i = v.x; i < e; ++i) {
-          const pp::f4 p = sorted[i];
-          const float d = pp::chamfer_d3(p.x, p.y, p.z, q.x, q.y, q.z);
-          const int id = __float_as_int(p.w);
+        constexpr int kFly = PP_KNN_FLY;  // loads in flight per lane (the tail of a row repeats its last point)
+        for (unsigned i = v.x; i < e; i += kFly) {
+          pp::f4 pf[kFly];
+#pragma unroll
+          for (int u = 0; u < kFly; ++u) pf[u] = sorted[min(i + u, e - 1)];
+#pragma unroll
+          for (int u = 0; u < kFly; ++u) {
+            const pp::f4 p = pf[u];
+            const float d = pp::chamfer_d3(p.x, p.y, p.z, q.x, q.y, q.z);
+            const int id = __float_as_int(p.w);
 #if PP_KNN_KEY64
-          const unsigned long long nk = KList64<KT>::key(d, id);
-          if (Lk.beats_last(nk)) Lk.insert(nk);
+            const unsigned long long nk = (u == 0 || i + u < e) ? KList64<KT>::key(d, id) : ~0ull;  // (~0: never enters)
+            if (Lk.beats_last(nk)) Lk.insert(nk);
 #else
-          if (Lk.beats_last(d, id)) Lk.insert(d, id);
+            if (u == 0 || i + u < e)
+              if (Lk.beats_last(d, id)) Lk.insert(d, id);
 #endif
+          }
         }
       }
     const bool whole = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.gx - 1 && y1 == g.gy - 1 && z1 == g.gz - 1;
@@ -392,11 +418,12 @@ int knn_scan_dispatch(const float* p1, const float* p2, const int* len1, const i
 }
 
 template <int KT>
-int knn_grid_launch(float* dist, int* idx, unsigned char* ws, int B, int N, int M, int K, hipStream_t s) {
+int knn_grid_launch(const float* p1, const float* p2, float* dist, int* idx, unsigned char* ws, int B, int N, int M, int K,
+                    hipStream_t s) {
   const int tiles = (N + 255) / 256;
   const long long per_xcd = ((long long)B * tiles + 7) / 8;
   if (per_xcd * 8 > 0x7fffffffLL) return PP_EINVAL;
-  knn_grid_kernel<KT><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(dist, idx, ws, B, N, M, K, tiles,
+  knn_grid_kernel<KT><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(p1, p2, dist, idx, ws, B, N, M, K, tiles,
                                                                           (int)per_xcd);
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
@@ -444,16 +471,12 @@ extern "C" int pp_knn_ws_f32(const float* p1, const float* p2, const int* length
   if (e != hipSuccess) return (int)e;
   (vec ? kn_build_kernel<true> : kn_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(p2, p1, ws, B, N, M);
   PP_RETURN_IF_LAUNCH_FAILED();
-  int rc;
-  if (K <= 1) rc = knn_grid_launch<1>(dist2, idx, ws, B, N, M, K, s);
-  else if (K <= 4) rc = knn_grid_launch<4>(dist2, idx, ws, B, N, M, K, s);
-  else if (K <= 8) rc = knn_grid_launch<8>(dist2, idx, ws, B, N, M, K, s);
-  else if (K <= 16) rc = knn_grid_launch<16>(dist2, idx, ws, B, N, M, K, s);
-  else rc = knn_grid_launch<32>(dist2, idx, ws, B, N, M, K, s);
-  if (rc != PP_OK) return rc;
-  const KnLayout L = kn_layout(B, N, M);
-  return knn_scan_dispatch(p1, p2, nullptr, nullptr, dist2, idx, B, N, M, K,
-                           reinterpret_cast<const GridSet*>(ws + L.sets), s);
+  // (batch elements whose grid is of no use are served by the same kernel, every pair: no second launch)
+  if (K <= 1) return knn_grid_launch<1>(p1, p2, dist2, idx, ws, B, N, M, K, s);
+  if (K <= 4) return knn_grid_launch<4>(p1, p2, dist2, idx, ws, B, N, M, K, s);
+  if (K <= 8) return knn_grid_launch<8>(p1, p2, dist2, idx, ws, B, N, M, K, s);
+  if (K <= 16) return knn_grid_launch<16>(p1, p2, dist2, idx, ws, B, N, M, K, s);
+  return knn_grid_launch<32>(p1, p2, dist2, idx, ws, B, N, M, K, s);
 }
 
 // pytorch3d.ops.knn_points for any point dimension D (1 <= D <= 512) and 1 <= K <= 128: brute force with the

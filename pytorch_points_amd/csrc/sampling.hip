@@ -1583,13 +1583,6 @@ extern "C" int pp_three_nn_f32(const float* unknown, const float* known, float* 
   return three_nn_launch(unknown, known, dist2, idx, B, N, M, nullptr, stream);
 }
 
-namespace pp {
-int three_nn_scan_unusable(const float* unknown, const float* known, float* dist2, int* idx, int B, int N,
-                           int M, const GridSet* sets, hipStream_t s) {
-  return three_nn_launch(unknown, known, dist2, idx, B, N, M, sets, (void*)s);
-}
-}  // namespace pp
-
 // 0 = automatic; 1 = force the global-gather kernel; 2 = no channel-group form (row-at-a-time LDS
 // form where it applies)   (tests and tuning)
 static pp::Knob g_interp_variant;

@@ -17,12 +17,6 @@
 // (that is the scan).  Batch elements whose grid is useless go to the scan kernel.
 #include "grid_common.h"
 
-namespace pp {
-// sampling.hip: the scan kernel over the batch elements whose grid set says "not usable"
-int three_nn_scan_unusable(const float* unknown, const float* known, float* dist2, int* idx, int B, int N,
-                           int M, const GridSet* sets, hipStream_t s);
-}  // namespace pp
-
 namespace {
 
 using pp::GridSet;
@@ -86,9 +80,10 @@ __device__ __forceinline__ void insert3_key(float d, int k, unsigned long long& 
   k1 = l1 ? nk : k1;
 }
 
-__global__ __launch_bounds__(256) void tn_query_kernel(float* __restrict__ dist2, int* __restrict__ idx,
-                                                       unsigned char* __restrict__ ws, int B, int N, int M,
-                                                       int tiles_per_b, int per_xcd) {
+__global__ __launch_bounds__(256) void tn_query_kernel(const float* __restrict__ unknown,
+                                                       const float* __restrict__ known, float* __restrict__ dist2,
+                                                       int* __restrict__ idx, unsigned char* __restrict__ ws, int B,
+                                                       int N, int M, int tiles_per_b, int per_xcd) {
   const int vb = pp::xcd_virtual_block(blockIdx.x, per_xcd);  // a batch element stays on one XCD's L2
   if (vb >= B * tiles_per_b) return;
   const int b = vb / tiles_per_b;
@@ -96,10 +91,37 @@ __global__ __launch_bounds__(256) void tn_query_kernel(float* __restrict__ dist2
   const TnLayout L = tn_layout(B, N, M);
   const GridSet g = reinterpret_cast<const GridSet*>(ws + L.sets)[b];
   const bool usable = !pp::grid_useless(g);
-  if (tile == 0 && threadIdx.x == 0)  // the scan kernel, launched next, skips the sets served here
-    reinterpret_cast<GridSet*>(ws + L.sets)[b].pad[0] = usable ? 1 : 0;
-  if (!usable) return;  // this batch element goes to the scan kernel
   const int n = tile * 256 + threadIdx.x;
+  if (!usable) {
+    // A batch element without a usable grid (every known point identical, a non-finite coordinate): every pair, a lane
+    // per unknown point of the ORIGINAL order, the scan kernel's loop (sampling.hip: three_nn_kernel) -- here, since
+    // round 4; until then a second launch followed every call to pick these up (4-5 us to find nothing to do).
+    const int nc = min(n, N - 1);
+    const float* __restrict__ u = unknown + ((size_t)b * N + nc) * 3;
+    const float* __restrict__ kn = known + (size_t)b * M * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int k = 0; k < M; ++k) {  // kn[...] is wave-uniform: scalar loads
+      const float d = pp::dist3(ux, uy, uz, kn[3 * (size_t)k], kn[3 * (size_t)k + 1], kn[3 * (size_t)k + 2]);
+      if (__any(d < b3)) {  // (ascending k: strict < is the (distance, index) order)
+        const bool l1 = d < b1, l2 = d < b2, l3 = d < b3;
+        b3 = l2 ? b2 : (l3 ? d : b3);
+        i3 = l2 ? i2 : (l3 ? k : i3);
+        b2 = l1 ? b1 : (l2 ? d : b2);
+        i2 = l1 ? i1 : (l2 ? k : i2);
+        b1 = l1 ? d : b1;
+        i1 = l1 ? k : i1;
+      }
+    }
+    if (n < N) {
+      float* od = dist2 + ((size_t)b * N + n) * 3;
+      int* oi = idx + ((size_t)b * N + n) * 3;
+      od[0] = b1; od[1] = b2; od[2] = b3;
+      oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    }
+    return;
+  }
   if (n >= N) return;
   const unsigned* __restrict__ cell_start =
       reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1);
@@ -183,9 +205,9 @@ extern "C" int pp_three_nn_ws_f32(const float* unknown, const float* known, floa
   const int tiles = (N + 255) / 256;
   const long long per_xcd = ((long long)B * tiles + 7) / 8;
   if (per_xcd * 8 > 0x7fffffffLL) return PP_EINVAL;
-  tn_query_kernel<<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(dist2, idx, ws, B, N, M, tiles, (int)per_xcd);
+  // (batch elements whose grid is of no use are served by the same kernel, every pair: no second launch)
+  tn_query_kernel<<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(unknown, known, dist2, idx, ws, B, N, M, tiles,
+                                                                      (int)per_xcd);
   PP_RETURN_IF_LAUNCH_FAILED();
-  const TnLayout L = tn_layout(B, N, M);
-  return pp::three_nn_scan_unusable(unknown, known, dist2, idx, B, N, M,
-                                    reinterpret_cast<const GridSet*>(ws + L.sets), s);
+  return PP_OK;
 }
