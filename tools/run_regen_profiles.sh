@@ -8,6 +8,8 @@ if [ -n "$(git status --porcelain -- pytorch_points_amd include bench.py tools o
 C=$(git rev-parse --short HEAD)
 python -c "import __graft_entry__ as g; g.build()"
 ./tools/build_fps_bucket_probes.sh > /dev/null 2>&1 || true
+rm -f tools/libpp_hip_*.so
+for n in 1 2 3 4 5 6; do SRC=chamfer_slab bash tools/build_variant_lib.sh slab$n -DPP_SLAB_STOP=$n; done
 /usr/local/graft/bin/gpurun --timeout 3000 -- "PP_COMMIT=$C bash tools/regen_profiles_r4.sh"
 mkdir -p profiles/r4
 cp gpurun_out/r4/* profiles/r4/
