@@ -27,6 +27,7 @@ The JSON line also carries
   roofline_step the whole step's algorithmic bytes / ms_per_step
   fps, ball_group   short runs of BASELINE.json configs 3 and 4, each with its own roofline
   other_distributions_fwd_ms   the forward on clouds that are not a uniform sphere
+  other_ops_ms  three_nn, three_interpolate, knn_points (K = 1, 8, 16), labeled Chamfer at the shapes of DESIGN.md 5.6
   cpu_baseline  the CPU oracle (a port of the reference semantics; the reference has no CPU
                 path) timed on this host's cores on a bounded sample of the same workload
 """
@@ -797,6 +798,49 @@ def _short(line):
     return line
 
 
+def bench_other_ops(device):
+    """the searches of the path that are not BASELINE configs, at the shapes DESIGN.md 5.6 quotes (B=32, N=16384, M=4096,
+    C=128): mean of 10 calls between two events, ms -- so that they show in the driver's line, not only in tools/"""
+    from pytorch_points_amd import synthetic as S
+    from pytorch_points_amd._ext import sampling, losses
+    from pytorch_points_amd.ops import knn_points
+    B, N, M, C = 32, 16384, 4096, 128
+
+    def t(fn, n=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n
+
+    unknown = torch.from_numpy(S.unit_sphere(0, B, N)).to(device)
+    known = torch.from_numpy(S.unit_sphere(1, B, M)).to(device)
+    d2 = torch.empty(B, N, 3, device=device)
+    idx = torch.empty(B, N, 3, dtype=torch.int32, device=device)
+    res = {"shapes": "B=32, 16384 unknown / query points, 4096 known points (knn, labeled Chamfer: 16384 both), C=128"}
+    res["three_nn"] = t(lambda: sampling.three_nn_wrapper(B, N, M, unknown, known, d2, idx))
+    feats = torch.randn(B, C, M, device=device)
+    w = torch.rand(B, N, 3, device=device)
+    w /= w.sum(-1, keepdim=True)
+    out = torch.empty(B, C, N, device=device)
+    res["three_interpolate"] = t(lambda: sampling.three_interpolate_wrapper(B, C, M, N, feats, idx, w, out))
+    x1 = torch.from_numpy(S.unit_sphere(2, B, N)).to(device)
+    x2 = torch.from_numpy(S.unit_sphere(3, B, N)).to(device)
+    for K in (1, 8, 16):
+        res["knn_points_k%d" % K] = t(lambda: knn_points(x1, x2, K=K), 5)
+    l1 = torch.randint(0, 4, (B, N), device=device).float()
+    l2 = torch.randint(0, 4, (B, N), device=device).float()
+    o = (torch.empty(B, N, device=device), torch.empty(B, N, device=device),
+         torch.empty(B, N, dtype=torch.int32, device=device), torch.empty(B, N, dtype=torch.int32, device=device))
+    res["labeled_nmdistance_forward"] = t(lambda: losses.labeled_nmdistance_forward(x1, x2, l1, l2, *o), 5)
+    return res
+
+
 def main():
     args = parse()
     if not torch.cuda.is_available():
@@ -818,6 +862,8 @@ def main():
         a4 = copy.copy(args)
         a4.steps, a4.warmup, a4.with_backward = 10, 3, True
         out["ball_group"] = _short(bench_ball_group(a4, None, 1, 0, device))
+        torch.cuda.empty_cache()
+        out["other_ops_ms"] = bench_other_ops(device)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
