@@ -532,6 +532,15 @@ def bench_chamfer(args, dist, world, rank, device):
     }
     if graph_note:
         out["config"]["launch_note"] = graph_note
+    if want == "eager" and "ext" in modes and "eager_calling_thread" in modes:
+        # The eager step under torch's default engine hands the backward to the engine's device thread and waits for it:
+        # two thread wake-ups per step.  On a box with a slow host (observed on this pool: 0.107 ms against 0.078 for
+        # the same kernels issued by the calling thread) that, not the GPU, sets `value`; say so when it happens.
+        floor = min(modes["ext"], modes["eager_calling_thread"])
+        out["host_bound"] = bool(ms > 1.10 * floor)
+        out["host_bound_note"] = ("ms_per_step is %.0f %% above the same kernels issued without the engine's thread hand-off "
+                                  "(launch_modes_ms_per_step: ext, eager_calling_thread): the host, not the GPU, bounds the "
+                                  "default-engine step on this box" % (100.0 * (ms / floor - 1.0))) if ms > 1.10 * floor else None
     if dist is not None:
         out["compute_ms"] = compute_ms
         out["exchange_ms"] = exchange_ms
