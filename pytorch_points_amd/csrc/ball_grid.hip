@@ -220,6 +220,7 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
   IT* myrow = s_rows + (size_t)ci * stride;
   int cnt = valid ? 0 : nsample;  // hits of the centre so far (same in its LPC lanes); idle lanes count as full
   const float r2v = radius2;
+  static_assert(kBqCap % (32 * LPC) == 0, "a pass is whole 32-candidate blocks for every lane of a centre");
   constexpr int NB = kBqCap / 32 / LPC;  // 32-candidate blocks a lane scans per pass, at most
   for (int base = 0; base < total; base += kBqCap) {
     const int ncand = min(kBqCap, total - base);
