@@ -2465,7 +2465,9 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   const int per_xcd = (int)((blocks + 7) / 8);
   // (PP_NMDISTANCE_TILE: the debug knob's value from the environment, read once -- benchmarks of the forms in processes
   //  that do not call the knob)
-  const bool two_stage = !LAB && tile != -1 && tile != -2 && lay.chunks > 0;
+  // (behind the fused kernel: the whole-search kernel for what it declined; tile == -2 on a shape it is not made for:
+  //  the default)
+  const bool two_stage = !LAB && tile != -1 && served == nullptr && lay.chunks > 0;
   if (two_stage) {  // stage A by tiles, then the whole-search kernel over what it left (LIST)
     const int tq = tile == 256 || tile == 1024 || tile == 513 ? tile : 512;
     const int tqq = tq == 513 ? 512 : tq;
