@@ -551,6 +551,19 @@ def bench_chamfer(args, dist, world, rank, device):
                                        else "Python: dist.all_gather_into_tensor"))
         if native is not None:
             out["exchange_issue_us"] = float(native.issue_us_per_slot())   # host time of issuing one exchange
+        # The wire model the first real 1 -> 8 run can be read against: an all-gather moves (world - 1) parts of
+        # nbytes_padded into (and, over a ring, out of) every rank; xGMI is point to point, 7 links x ~153 GB/s per GPU
+        # (MI355X guide).  ring: every part crosses ONE link per hop, (world - 1) hops back to back, so the floor is
+        # (world - 1) * part / link; direct (all-pairs, what RCCL picks on a fully connected node for messages of this
+        # size): the (world - 1) parts arrive over (world - 1) links at once, floor = part / link.
+        part = float(exchange.nbytes_padded)
+        link = 153e9
+        out["exchange_bytes_per_rank"] = {"sent": part, "received": part * (world - 1)}
+        out["wire_floor_ms"] = {"ring": (world - 1) * part / link * 1e3, "all_pairs": (part / link * 1e3) if world > 1 else 0.0,
+                                "link_GBps_assumed": link / 1e9,
+                                "note": "floors of ONE exchange at the assumed xGMI link rate (no latency term); with "
+                                        "gather_every = %d the exchange has %d step(s) of compute to hide under" % (
+                                            gather_every, gather_every)}
         out["exchange_note"] = ("compute_ms: the same steps without the exchange; exchange_ms: one step's exchange with nothing "
                                 "beside it (indices narrowed into the slot + all-gather; the distances are written into the "
                                 "slot by the search itself, the gathered buffer is read through views: no pack of "

@@ -22,9 +22,7 @@ void pp_debug_set_nmdistance_variant(int variant);
 /* grid search, wave-private form of the search kernel: staged points per wave (320, 384, 512; selecting one also
  * selects that form; 0 = the default, the tile form) */
 void pp_debug_set_nmdistance_stage_cap(int points);
-/* grid search, unlabeled: queries per workgroup of the stage-A kernel (0 = 512; 256, 1024); -1 = no stage-A kernel;
- * -2 = the fused sort-and-search kernel (csrc/chamfer_slab.hip) first, where its shape window applies (8192 <= N, M <=
- * 17408, multiples of 4, 16-byte aligned clouds), the build and whole-search kernels behind it for what it declines.
+/* grid search, unlabeled: queries per workgroup of the stage-A kernel (0 = 512; 256, 1024); -1 = no stage-A kernel.
  * The same values are read once from the environment variable PP_NMDISTANCE_TILE when the knob is 0. */
 void pp_debug_set_nmdistance_tile(int queries);
 /* labeled Chamfer brute force: 1 = the one-lane-per-query kernel */
@@ -39,11 +37,6 @@ int pp_debug_nmdistance_kernel_ms3(float* build_ms, float* stage_a_ms, float* re
 
 /* unlabeled grid forward: queries its stage-A kernel left to the list kernel, per direction (2 B values; synchronises) */
 int pp_debug_nmdistance_pending(const void* workspace, int B, int N, int M, unsigned* totals);
-
-/* unlabeled grid forward of config 2's size class: the fused kernel's verdict per slab (8 B values: 0 = served, 1..4 =
- * declined -- hand-off, images too large, too many queries left by the blocks / by the cubes --, 15 = did not run);
- * synchronises */
-int pp_debug_nmdistance_slab_state(const void* workspace, int B, int N, int M, unsigned* words);
 
 void pp_debug_set_fps_v1(int form); /* 0 = the library's choice, 1 = one workgroup per batch element over all points,
                                       * 2 = the CU cluster over all points, 3 = the bucketed kernel */

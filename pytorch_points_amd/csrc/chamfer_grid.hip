@@ -112,10 +112,8 @@ constexpr float kBoundSlack = 0.999f;
 //   [.., +4*T)                     int pend[T]        unlabeled searches: the queries stage A left (positions in the query
 //                                  cloud's sorted order), 64 slots per wave of the stage-A kernel
 //   [.., +4*(T/64 + S + 1))        unsigned pend_cnt[...]   how many of a wave's 64 slots are filled
-//   [.., +chamfer_slab_workspace_bytes)  chamfer_slab.hip's own: unsigned slab_state[B][kSlabKernelSlabs] (served / declined,
-//                                  per slab), then its hand-off words and records (unlabeled searches of its size class only)
 struct Layout {
-  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, tile_z, layers, pend, pend_cnt, slab_state, total;
+  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, tile_z, layers, pend, pend_cnt, total;
   int chunks;  // chunk-table entries per set and slab (0: sets too large for the table)
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
@@ -135,8 +133,7 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   L.layers = ((L.tile_z + 4 * S * pp::kBuildSlabs * 2 * (size_t)L.chunks + 255) / 256) * 256;
   L.pend = L.layers + (L.chunks ? ((4 * S * pp::kLayerWords + 255) / 256) * 256 : 0);
   L.pend_cnt = L.pend + (L.chunks ? 4 * T : 0);
-  L.slab_state = L.pend_cnt + (L.chunks ? ((4 * (T / 64 + S + 1) + 255) / 256) * 256 : 0);
-  L.total = L.slab_state + (labeled ? 0 : (pp::chamfer_slab_workspace_bytes(B, N, M) + 255) / 256 * 256);
+  L.total = L.pend_cnt + (L.chunks ? ((4 * (T / 64 + S + 1) + 255) / 256) * 256 : 0);
   return L;
 }
 // second-level arrays of set (b, dir): first table entry / first descriptor
@@ -166,8 +163,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
                                                                    unsigned char* __restrict__ ws, int B,
                                                                    int N, int M,
                                                                    const float* __restrict__ label1,
-                                                                   const float* __restrict__ label2,
-                                                                   const unsigned* __restrict__ served) {
+                                                                   const float* __restrict__ label2) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // pp::grid_build_lds_bytes(kBuildSlabs)
   // a set is built on the XCD that will search it (the search kernel's set -> XCD mapping): its sorted
   // points and cell table are then already in that L2
@@ -175,7 +171,6 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   if (V >= 2 * B * pp::kBuildSlabs) return;
   const int set = V / pp::kBuildSlabs, slab = V % pp::kBuildSlabs;
   const int b = set >> 1, dir = set & 1;
-  if (served && pp::slab_kernel_served(served, b)) return;  // chamfer_slab.hip has answered this batch element
   const int nr = dir ? N : M;
   const float* __restrict__ ref = (dir ? xyz1 : xyz2) + (size_t)b * nr * 3;
   const bool labeled = label1 != nullptr;
@@ -1736,13 +1731,11 @@ template <bool LAB, int CAPW>
 __global__ __launch_bounds__(256, LAB ? (CAPW > 384 ? 3 : 4) : (CAPW > 384 ? 4 : PP_WAVE_WAVES)) void grid_query_wave_kernel(
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1, int* __restrict__ idx1,
     float* __restrict__ dist2, int* __restrict__ idx2, unsigned char* __restrict__ ws, int B, int N, int M, int tiles1,
-    int tiles2, int total, int per_xcd, const float* __restrict__ label1, const float* __restrict__ label2,
-    const unsigned* __restrict__ served) {
+    int tiles2, int total, int per_xcd, const float* __restrict__ label1, const float* __restrict__ label2) {
   const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
   if (V >= total) return;
   const int per_b = tiles1 + tiles2;
   const int b = V / per_b;
-  if (served && pp::slab_kernel_served(served, b)) return;  // chamfer_slab.hip has answered this batch element
   const int r = V - b * per_b;
   const int dir = r >= tiles1 ? 1 : 0;
   const int tile = dir ? r - tiles1 : r;
@@ -2391,25 +2384,6 @@ extern "C" int pp_debug_nmdistance_pending(const void* workspace, int B, int N, 
   return (int)e;
 }
 
-// the fused kernel's verdicts of the most recent unlabeled forward on this workspace (chamfer_slab.hip), 8 B words:
-// 0 = served, 1..4 = declined (hand-off, images too large, too many queries left by the blocks / by the cubes),
-// 15 = the kernel did not run on this workspace's shape (synchronises the device)
-extern "C" int pp_debug_nmdistance_slab_state(const void* workspace, int B, int N, int M, unsigned* words) {
-  if (!workspace || !words || B <= 0) return PP_EINVAL;
-  const Layout L = make_layout(B, N, M, false);
-  const int n = B * pp::kSlabKernelSlabs;
-  if (pp::chamfer_slab_workspace_bytes(B, N, M) == 0) {
-    for (int i = 0; i < n; ++i) words[i] = 15u;
-    return PP_OK;
-  }
-  hipError_t e = hipDeviceSynchronize();
-  if (e == hipSuccess) e = hipMemcpy(words, (const unsigned char*)workspace + L.slab_state, 4 * (size_t)n, hipMemcpyDeviceToHost);
-  if (e != hipSuccess) return (int)e;
-  for (int i = 0; i < n; ++i)
-    words[i] = words[i] == pp::kSlabServed ? 0u : ((words[i] & ~15u) == pp::kSlabDeclined ? (words[i] & 15u) : 15u);
-  return PP_OK;
-}
-
 static bool grid_applicable(int B, int N, int M, int C) {
   if (!(C == 3 && B > 0 && N >= 2048 && M >= 2048 && (long long)B * ((long long)N + M) < (1LL << 31) - 1)) return false;
   // the search costs ~40 us whatever the size; the brute force evaluates ~9e6 pairs per microsecond once it
@@ -2448,15 +2422,8 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   }();
   const int tile = g_tile != 0 ? (int)g_tile : tile_env;
   const Layout lay = make_layout(B, N, M, LAB);
-  // chamfer_slab.hip first (tile == -2, for now): the batch elements it serves are skipped by the launches below
-  const unsigned* served = nullptr;
-  if (!LAB && tile == -2 && pp::chamfer_slab_applies(xyz1, xyz2, B, N, M)) {
-    const int rc = pp::chamfer_slab_launch(xyz1, xyz2, dist1, idx1, dist2, idx2, ws + lay.slab_state, B, N, M, s);
-    if (rc != PP_OK) return rc;
-    served = reinterpret_cast<const unsigned*>(ws + lay.slab_state);
-  }
   (vec ? grid_build_kernel<true> : grid_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(
-      xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr, served);
+      xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr);
   PP_RETURN_IF_LAUNCH_FAILED();
   if (timing) record_timing_event(1, s);
   const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
@@ -2465,9 +2432,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   const int per_xcd = (int)((blocks + 7) / 8);
   // (PP_NMDISTANCE_TILE: the debug knob's value from the environment, read once -- benchmarks of the forms in processes
   //  that do not call the knob)
-  // (behind the fused kernel: the whole-search kernel for what it declined; tile == -2 on a shape it is not made for:
-  //  the default)
-  const bool two_stage = !LAB && tile != -1 && served == nullptr && lay.chunks > 0;
+  const bool two_stage = !LAB && tile != -1 && lay.chunks > 0;
   if (two_stage) {  // stage A by tiles, then the whole-search kernel over what it left (LIST)
     const int tq = tile == 256 || tile == 1024 || tile == 513 ? tile : 512;
     const int tqq = tq == 513 ? 512 : tq;
@@ -2508,7 +2473,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   }
 #define PP_LAUNCH_W(CAP_)                                                                                  \
   grid_query_wave_kernel<LAB, CAP_><<<dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s>>>(                       \
-      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2, served)
+      xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, tiles1, tiles2, (int)blocks, per_xcd, label1, label2)
   if (two_stage) {
     // what stage A left: a wave for every 64 queries of a direction (as many as the whole-search kernel has, for the
     // clouds stage A cannot serve), every wave by itself

@@ -14,29 +14,6 @@ constexpr int kGridMax = 32;                                  // cells per axis
 constexpr int kGridCells = kGridMax * kGridMax * kGridMax;    // LDS counters: 128 KiB
 constexpr int kBuildThreads = 1024;
 
-// chamfer_slab.hip: the fused sort-and-search of config 2's size class; its per-slab verdicts
-constexpr int kSlabKernelSlabs = 8;
-constexpr unsigned kSlabServed = 0x5E12ED01u, kSlabDeclined = 0xDEC11ED0u;  // (declined: + a reason in the low four bits)
-__device__ __forceinline__ bool slab_kernel_served(const unsigned* __restrict__ state, int b) {  // (uniform: scalar loads)
-  bool all = true;
-  for (int i = 0; i < kSlabKernelSlabs; ++i) all &= state[(size_t)b * kSlabKernelSlabs + i] == kSlabServed;
-  return all;
-}
-constexpr int kSlabKernelCapSrc = 640;
-constexpr int kSlabKernelMinPoints = 8192, kSlabKernelMaxPoints = 17408;  // per cloud (an index must fit 15 bits)
-__host__ __device__ inline bool chamfer_slab_shape_ok(int B, int N, int M) {
-  return B >= 1 && N >= kSlabKernelMinPoints && M >= kSlabKernelMinPoints && N <= kSlabKernelMaxPoints &&
-         M <= kSlabKernelMaxPoints && N % 4 == 0 && M % 4 == 0;
-}
-// verdicts [B][8] (4 bytes), hand-off words [B][8][2][8] (8 bytes), hand-off records [B][8][2][8][kSlabKernelCapSrc] (16 bytes)
-__host__ __device__ inline size_t chamfer_slab_workspace_bytes(int B, int N, int M) {
-  if (!chamfer_slab_shape_ok(B, N, M)) return 0;
-  const size_t sync = ((size_t)B * kSlabKernelSlabs * 4 + 255) / 256 * 256;
-  return sync + (size_t)B * kSlabKernelSlabs * 2 * kSlabKernelSlabs * (8 + (size_t)kSlabKernelCapSrc * 16);
-}
-bool chamfer_slab_applies(const float* xyz1, const float* xyz2, int B, int N, int M);
-int chamfer_slab_launch(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2, int* idx2,
-                        unsigned char* ws_slab, int B, int N, int M, hipStream_t s);
 constexpr int kBuildSlabs = 4;  // workgroups that share the build of one set (each owns a range of cells)
 
 // Chunk table (Chamfer's tile search): for every kChunk consecutive points of the sorted cloud, the lowest and the

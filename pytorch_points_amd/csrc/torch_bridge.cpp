@@ -463,6 +463,27 @@ struct PackedExchange {
   void drain() {
     for (int k = 0; k < depth; ++k) finish(k);
   }
+
+  // the slot's gathered bytes, (world, nbytes_padded) uint8 (PackedShardGather's first-exchange self-check)
+  Tensor raw(int slot) {
+    TORCH_CHECK(slot >= 0 && slot < depth, "PackedExchange.raw: no such slot");
+    finish(slot);
+    return recv[slot];
+  }
+
+  // The self-check of the direct path failed somewhere: every rank is back on c10d (disable_direct) and gathers every
+  // slot it has launched again, oldest first -- a slot's own part was row `rank` of its gathered buffer, which the
+  // in-place form had the search write.
+  void reissue(int rank) {
+    TORCH_CHECK(comm == nullptr && rank >= 0 && rank < world, "PackedExchange.reissue: after disable_direct only");
+    const c10::DeviceGuard guard(dev);
+    for (int i = 0; i < depth; ++i) {
+      const int slot = (turn + i) % depth;  // `turn` is the slot launched longest ago
+      if (launched[slot] == 0) continue;
+      send[slot].copy_(recv[slot].select(0, rank));
+      issue(slot);
+    }
+  }
 };
 
 }  // namespace
@@ -485,6 +506,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("wait", &PackedExchange::wait, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("widen", &PackedExchange::widen, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("drain", &PackedExchange::drain, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def("raw", &PackedExchange::raw, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def("reissue", &PackedExchange::reissue, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def_static("unique_id", &PackedExchange::unique_id)
       .def("init_direct", &PackedExchange::init_direct, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("disable_direct", &PackedExchange::disable_direct, pybind11::call_guard<pybind11::gil_scoped_release>())

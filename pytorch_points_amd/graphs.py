@@ -1,7 +1,8 @@
 """hipGraph replay of a fixed-shape Chamfer step.
 
-At B=32, N=M=16384 the kernels of one nndistance forward + backward take about 0.14 ms, less than
-the Python / autograd / launch work that issues them, so an eager training loop is host-bound.  The
+At B=32, N=M=16384 the kernels of one nndistance forward + backward take about 0.08 ms (five launches), about
+what the Python / autograd / launch work that issues them takes on a slow host, so an eager training loop can be
+host-bound (bench.py: `host_bound`).  The
 launches of a step with fixed shapes are the same every iteration: this class records them once in
 a hipGraph (``torch.cuda.CUDAGraph`` on ROCm) and replays them with a single call.  Same kernels,
 same bits out; only the host work disappears.

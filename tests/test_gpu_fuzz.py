@@ -190,11 +190,10 @@ def test_fuzz_furthest_sampling(cuda, seed):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PP_FUZZ_SEEDS", "100")) // 4))
-def test_fuzz_fused_slab_kernel(cuda, seed):
-    """round 4: the fused sort-and-search kernel of config 2's size class (csrc/chamfer_slab.hip, opt-in) on random
-    sizes of its window and cloud families -- surfaces it serves, volumes / clusters / far clouds it declines in whole or
-    in part (the build and whole-search launches behind it redo those batch elements) -- against the every-pair kernel,
-    bit for bit; launched twice (the hand-off areas of the first launch are what the second finds in the workspace)"""
+def test_fuzz_config2_class(cuda, seed):
+    """the default search on random sizes of config 2's class (8192 .. 17408 points, multiples of four: what the build
+    sorts as one chunk) and cloud families -- surfaces (ellipsoids, noisy / double shells, open sheets), volumes, clusters,
+    far clouds -- against the every-pair kernel, bit for bit; launched twice on the same workspace"""
     import ctypes
     from pytorch_points_amd import _lib
     from pytorch_points_amd.network.model_loss import nndistance
@@ -226,21 +225,16 @@ def test_fuzz_fused_slab_kernel(cuda, seed):
     x1, x2 = np.ascontiguousarray(x1, np.float32), np.ascontiguousarray(x2, np.float32)
     t1, t2 = torch.from_numpy(x1).to(cuda), torch.from_numpy(x2).to(cuda)
     lib = _lib.lib()
-    search, tile = lib.pp_debug_set_nmdistance_search, lib.pp_debug_set_nmdistance_tile
-    for f in (search, tile):
-        f.argtypes = [ctypes.c_int]
-        f.restype = None
+    search = lib.pp_debug_set_nmdistance_search
+    search.argtypes = [ctypes.c_int]
+    search.restype = None
     search(1)
     try:
         ref = [a.cpu().numpy() for a in nndistance(t1, t2)]
     finally:
         search(0)
-    tile(-2)
-    try:
-        for launch in range(2):
-            got = [a.cpu().numpy() for a in nndistance(t1, t2)]
-            for g, e, what in zip(got, ref, ("dist1", "dist2", "idx1", "idx2")):
-                assert np.array_equal(g, e), "seed %d launch %d (b=%d n=%d m=%d kind %d): %s differs at %d places" % (
-                    seed, launch, b, n, m, kind, what, int((g != e).sum()))
-    finally:
-        tile(0)
+    for launch in range(2):
+        got = [a.cpu().numpy() for a in nndistance(t1, t2)]
+        for g, e, what in zip(got, ref, ("dist1", "dist2", "idx1", "idx2")):
+            assert np.array_equal(g, e), "seed %d launch %d (b=%d n=%d m=%d kind %d): %s differs at %d places" % (
+                seed, launch, b, n, m, kind, what, int((g != e).sum()))

@@ -74,7 +74,8 @@ dev = torch.device("cuda:0")
 B, N, M = 3, 5000, 70000                                  # M > 65536: 32-bit indices; then a 16-bit case
 for (n, m) in ((N, M), (4096, 2048)):
     ex = PackedShardGather(B, n, m, dev)
-    assert bool(getattr(ex, 'direct', False)) == (os.environ.get('PP_SHARD_EXCHANGE', 'rccl') == 'rccl'), 'exchange path'
+    assert bool(getattr(ex, 'direct', False)) == (os.environ.get('PP_SHARD_EXCHANGE', 'native') == 'rccl'), 'exchange path'
+    fail = os.environ.get('PP_SHARD_SELFCHECK_FAIL', '0') == '1'
     gen = torch.Generator(device="cpu").manual_seed(n)
     steps = []
     for s in range(5):                                     # more launches than slots: the slots are reused
@@ -87,6 +88,8 @@ for (n, m) in ((N, M), (4096, 2048)):
         torch.empty(1 << 22, device=dev).normal_()
         t = torch.ones(4, device=dev); dist.all_reduce(t)
         g = ex.wait(h)
+        if fail:                                           # the first wait found the direct path wanting: c10d from here on
+            assert not ex.direct and ex._checked
         for a, e in zip(g, (d1, d2, i1, i2)):
             assert a.dtype == e.dtype and torch.equal(a, e), (n, m, s)
         v = ex.wait_views(h)                               # the same, as views of the gathered buffer
@@ -119,21 +122,31 @@ print("exchange ok")
 """
 
 
-@pytest.mark.parametrize("path", ["native", "python", "rccl"])
+@pytest.mark.parametrize("path", ["default", "native", "python", "rccl", "rccl_selfcheck_fail"])
 def test_packed_exchange_on_one_rank_rccl_group(cuda, tmp_path, path):
     """PackedShardGather on the GPU path proper: RCCL all-gather (a one-rank group: this box has one GPU),
     slot reuse, 16- and 32-bit indices, the gathered result as contiguous tensors (wait) and as views of the gathered
     buffer (wait_views), the in-place form (forward: the search writes into the slot), a collective of the caller's
     between launch and wait.  native: the exchange as one C++ call (csrc/torch_bridge.cpp: PackedExchange over c10d);
     python: the same steps issued from Python (PP_SHARD_EXCHANGE=python); rccl: the native call with the all-gather as
-    a direct ncclAllGather on the exchange object's own communicator.  In a subprocess: the process group must not leak into the other tests."""
+    a direct ncclAllGather on the exchange object's own communicator (opt-in), its first exchange checked against c10d;
+    rccl_selfcheck_fail: that check made to fail (PP_SHARD_SELFCHECK_FAIL=1) -- every slot is gathered again over c10d and
+    the results are still the shards'; default: no variable set (= native).  In a subprocess: the process group must not
+    leak into the other tests."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "one_rank_exchange.py"
     script.write_text(_ONE_RANK_EXCHANGE)
-    env = dict(os.environ, PP_SHARD_EXCHANGE=path)
-    out = subprocess.run([sys.executable, str(script), root, {"native": "29541", "python": "29543", "rccl": "29545"}[path]], capture_output=True,
+    env = dict(os.environ)
+    env.pop("PP_SHARD_EXCHANGE", None)
+    env.pop("PP_SHARD_SELFCHECK_FAIL", None)
+    if path != "default":
+        env["PP_SHARD_EXCHANGE"] = path.split("_")[0]
+    if path == "rccl_selfcheck_fail":
+        env["PP_SHARD_SELFCHECK_FAIL"] = "1"
+    port = {"default": "29539", "native": "29541", "python": "29543", "rccl": "29545", "rccl_selfcheck_fail": "29547"}[path]
+    out = subprocess.run([sys.executable, str(script), root, port], capture_output=True,
                          text=True, timeout=600, env=env)
     assert out.returncode == 0 and "exchange ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

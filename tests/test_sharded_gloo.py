@@ -141,3 +141,67 @@ def test_packed_shard_gather_world2(n, m, compact):
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True, compact), (1, True, compact)]
+
+
+def _pipeline_worker(rank, world, port, depth, q):
+    """the control flow of the RCCL path (bench.py / PackedShardGather.forward): begin -> the search writes its
+    distances in place -> launch_in_place -> a collective of the caller's -> wait_views of the step BEFORE (the gather
+    of step k overlaps step k + 1), slots reused several times over"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, n, m = 2, 37, 53
+        ex = sharded.PackedShardGather(B, n, m, torch.device("cpu"), depth=depth)
+        ok = True
+        pending = []     # (slot, step) launched and not yet read
+        steps = 3 * depth + 1
+
+        def data(step):
+            g = torch.Generator().manual_seed(1000 + step)
+            return (torch.rand(world * B, n, generator=g), torch.rand(world * B, m, generator=g),
+                    torch.randint(-1, m, (world * B, n), generator=g, dtype=torch.int32),
+                    torch.randint(-1, n, (world * B, m), generator=g, dtype=torch.int32))
+
+        def check(slot, step):
+            D1, D2, I1, I2 = data(step)
+            w1, w2, j1, j2 = ex.wait_views(slot)
+            good = w1.shape == (world, B, n) and torch.equal(w1.reshape(world * B, n), D1)
+            good = good and torch.equal(w2.reshape(world * B, m), D2)
+            good = good and torch.equal(j1.to(torch.int32).reshape(world * B, n) & 0xFFFF, I1 & 0xFFFF)
+            good = good and torch.equal(j2.to(torch.int32).reshape(world * B, m) & 0xFFFF, I2 & 0xFFFF)
+            return good
+
+        lo, hi = rank * B, (rank + 1) * B
+        for step in range(steps):
+            D1, D2, I1, I2 = data(step)
+            slot, v1, v2 = ex.begin()
+            v1.copy_(D1[lo:hi]); v2.copy_(D2[lo:hi])          # "the search writes its distances into the slot"
+            h = ex.launch_in_place(slot, I1[lo:hi], I2[lo:hi])
+            ok = ok and h == slot
+            t = torch.ones(2) * (rank + 1)                     # the caller's own collective (e.g. a gradient all-reduce)
+            dist.all_reduce(t)
+            ok = ok and float(t[0]) == sum(range(1, world + 1))
+            pending.append((slot, step))
+            while len(pending) >= depth:                       # read a step once `depth` - 1 newer ones are in flight
+                ok = ok and check(*pending.pop(0))
+        while pending:
+            ok = ok and check(*pending.pop(0))
+        ex.drain()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,depth", [(2, 2), (2, 3), (3, 2), (3, 3)])
+def test_packed_shard_gather_pipelined(world, depth):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, depth, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(r, True) for r in range(world)]

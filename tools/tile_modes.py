@@ -76,18 +76,12 @@ for kind in kinds:
         tk(0)
         same = all(torch.equal(a, b) for a, b in zip(o, ref))
         pend = ""
-        if mode not in (-1, -2):
+        if mode != -1:
             tot = (ctypes.c_uint * (2 * B))()
             wsb = _lib.cached_workspaces("nmdistance")[0]
             fn = L.pp_debug_nmdistance_pending; fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]; fn.restype = ctypes.c_int
             if fn(wsb.data_ptr(), B, N, N, tot) == 0:
                 pend = " left %.2f%%" % (100.0 * sum(tot) / (2.0 * B * N))
-        if mode == -2:
-            wd = (ctypes.c_uint * (8 * B))()
-            wsb = _lib.cached_workspaces("nmdistance")[0]
-            fn = L.pp_debug_nmdistance_slab_state; fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]; fn.restype = ctypes.c_int
-            if fn(wsb.data_ptr(), B, N, N, wd) == 0:
-                pend = " slabs " + " ".join("%d:%d" % (v, list(wd).count(v)) for v in sorted(set(wd)))
         ok = ok and same
         line += " | %4d: fwd %.4f build %.4f stageA %.4f rest %.4f %s" % (mode, ms, np.mean(bms[1:]), np.mean(sms[1:]), np.mean(rms[1:]), ("ok" if same else "MISMATCH") + pend)
     sett(0)
