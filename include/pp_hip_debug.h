@@ -25,6 +25,9 @@ void pp_debug_set_nmdistance_stage_cap(int points);
 /* grid search, unlabeled: queries per workgroup of the stage-A kernel (0 = 512; 256, 1024); -1 = no stage-A kernel.
  * The same values are read once from the environment variable PP_NMDISTANCE_TILE when the knob is 0. */
 void pp_debug_set_nmdistance_tile(int queries);
+/* grid search, unlabeled: the build of sets of at most 16384 aligned points: 0 = sorted through the LDS, a slab owning
+ * whole z-layers (default), 1 = the general build always (tests and A/B timing) */
+void pp_debug_set_nmdistance_build(int general);
 /* labeled Chamfer brute force: 1 = the one-lane-per-query kernel */
 void pp_debug_set_labeled_variant(int variant);
 /* Chamfer backward: 1 LDS doubles, 2 CSR lists, 3 LDS fp32 columns, 4 global atomics, 5 deterministic */

@@ -27,6 +27,7 @@
 //       - labeled searches and non-finite queries keep the older forms of the last step (larger cubes by
 //         the whole wave, the occupied cells or the whole cloud a lane per query); so does every query of a
 //         set whose grid is useless (non-finite coordinates).  Two launches per forward, no list.
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 
@@ -37,7 +38,10 @@
 __device__ unsigned long long g_bphase[512][16];
 #define PP_PHASE(n)                                                                                        \
   do {                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    asm volatile("" ::: "memory");                                                                          \
     if (threadIdx.x == 0 && blockIdx.x < 512) g_bphase[blockIdx.x][n] = __builtin_amdgcn_s_memrealtime();   \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
   } while (0)
 extern "C" int pp_debug_read_build_phases(void* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bphase), sizeof(g_bphase));
@@ -163,8 +167,8 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
                                                                    unsigned char* __restrict__ ws, int B,
                                                                    int N, int M,
                                                                    const float* __restrict__ label1,
-                                                                   const float* __restrict__ label2) {
-  extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // pp::grid_build_lds_bytes(kBuildSlabs)
+                                                                   const float* __restrict__ label2, int fast) {
+  extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // max(grid_build_lds_bytes(kBuildSlabs), grid_build_fast_lds_bytes())
   // a set is built on the XCD that will search it (the search kernel's set -> XCD mapping): its sorted
   // points and cell table are then already in that L2
   const int V = pp::xcd_virtual_block(blockIdx.x, (2 * B * pp::kBuildSlabs + 7) / 8);
@@ -176,17 +180,29 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   const bool labeled = label1 != nullptr;
   const Layout L = make_layout(B, N, M, labeled);
   const float* __restrict__ lab = labeled ? (dir ? label1 : label2) + (size_t)b * nr : nullptr;
-  pp::grid_build_set_refined<VEC>(
-      ref, nr, reinterpret_cast<GridSet*>(ws + L.sets) + set,
-      reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1),
-      reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M), s_cnt, lab,
+  GridSet* gset = reinterpret_cast<GridSet*>(ws + L.sets) + set;
+  unsigned* cstart = reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
+  pp::f4* sorted = reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
+  unsigned* sub_start = reinterpret_cast<unsigned*>(ws + L.sub_start) + set_sub_start_offset(b, dir, N, M);
+  pp::SubGrid* sub_desc = reinterpret_cast<pp::SubGrid*>(ws + L.sub_desc) + set_sub_desc_offset(b, dir, N, M);
+  pp::f4* sorted2 = reinterpret_cast<pp::f4*>(ws + L.sorted2) + set_point_offset(b, dir, N, M);
+  int* tz = L.chunks ? reinterpret_cast<int*>(ws + L.tile_z) + (size_t)set * pp::kBuildSlabs * 2 * L.chunks : nullptr;
+  unsigned* layers = L.chunks ? reinterpret_cast<unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords : nullptr;
+  // round 5: unlabeled sets of config 2's class (one register chunk, aligned) are sorted through the LDS, a slab owning
+  // whole z-layers (grid_common.h: grid_build_set_fast); what that path declines takes the general one, with its plan
+  // forced where the other slabs of the set may have used it
+  pp::BuildPlan plan;
+  int how = 1;
+  if constexpr (VEC) {
+    if (!labeled && fast) how = pp::grid_build_set_fast(ref, nr, gset, cstart, sorted, s_cnt, slab, sub_start, sub_desc, sorted2, tz, L.chunks, layers, plan);
+  }
+  if (how == 0) return;
+  __syncthreads();  // (the general path reuses the LDS the fast one was using)
+  pp::grid_build_set_impl<false, VEC, true>(
+      ref, nr, gset, cstart, sorted, nullptr, s_cnt, lab,
       labeled ? reinterpret_cast<float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr, slab, pp::kBuildSlabs,
-      reinterpret_cast<unsigned*>(ws + L.sub_start) + set_sub_start_offset(b, dir, N, M),
-      reinterpret_cast<pp::SubGrid*>(ws + L.sub_desc) + set_sub_desc_offset(b, dir, N, M),
-      reinterpret_cast<pp::f4*>(ws + L.sorted2) + set_point_offset(b, dir, N, M),
-      labeled ? reinterpret_cast<float*>(ws + L.slab2) + set_point_offset(b, dir, N, M) : nullptr,
-      L.chunks ? reinterpret_cast<int*>(ws + L.tile_z) + (size_t)set * pp::kBuildSlabs * 2 * L.chunks : nullptr, L.chunks,
-      L.chunks ? reinterpret_cast<unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords : nullptr);
+      sub_start, sub_desc, sorted2, labeled ? reinterpret_cast<float*>(ws + L.slab2) + set_point_offset(b, dir, N, M) : nullptr,
+      tz, L.chunks, layers, how == 2 ? &plan : nullptr);
 }
 
 // Stages B and C (cubes of Chebyshev radius 1 and 2 around the query's cell) for the queries stage A left
@@ -2329,6 +2345,9 @@ extern "C" void pp_debug_set_nmdistance_stage_cap(int v) { g_stage_cap.set(v); }
 // kernel (round 2's two launches: the whole-search kernel serves every query)
 static pp::Knob g_tile;
 extern "C" void pp_debug_set_nmdistance_tile(int v) { g_tile.set(v); }
+// the build of config 2's class: 0 = the LDS-sorted path where it applies (default), 1 = the general path always
+static pp::Knob g_build_fast;
+extern "C" void pp_debug_set_nmdistance_build(int v) { g_build_fast.set(v); }
 
 // Per-kernel timing of the grid forward (bench.py's roofline of the dominant kernel): when switched on, HIP
 // events are recorded on the launch stream before the build, between the two kernels and after the search;
@@ -2409,7 +2428,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
                         unsigned char* ws, hipStream_t s) {
   hipError_t e;
   static pp::DeviceFlags lds_ok, lds_ok_vec;
-  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
+  const size_t lds = std::max(pp::grid_build_lds_bytes(pp::kBuildSlabs), pp::grid_build_fast_lds_bytes());
   const bool vec = pp::clouds_vec_aligned(xyz1, N, B) && pp::clouds_vec_aligned(xyz2, M, B);
   e = vec ? pp::allow_big_lds(grid_build_kernel<true>, (int)lds, lds_ok_vec)
           : pp::allow_big_lds(grid_build_kernel<false>, (int)lds, lds_ok);
@@ -2423,7 +2442,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   const int tile = g_tile != 0 ? (int)g_tile : tile_env;
   const Layout lay = make_layout(B, N, M, LAB);
   (vec ? grid_build_kernel<true> : grid_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(
-      xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr);
+      xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr, g_build_fast != 1 ? 1 : 0);
   PP_RETURN_IF_LAUNCH_FAILED();
   if (timing) record_timing_event(1, s);
   const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;

@@ -403,6 +403,16 @@ __device__ __attribute__((noinline)) void grid_refine_cells(f4* __restrict__ sor
   }
 }
 
+// What the planning phases of a build decide for a set: the box, the resolution, and the range of cells one slab owns.
+// grid_build_set_fast (below) hands it to grid_build_set_impl when a slab it cannot sort through the LDS has to take the
+// general path: that path then skips its own planning (`forced`) -- every slab of a set must sort into the SAME grid.
+struct BuildPlan {
+  float mnx, mny, mnz, h, invh;
+  int gx, gy, gz;
+  int cell_lo, cell_hi;  // this slab's cells
+  int trimmed;
+};
+
 template <bool MORTON, bool VEC, bool REFINE>
 __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ ref, int nr, GridSet* gs,
                                                unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
@@ -412,7 +422,8 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
                                                int nslab, unsigned* __restrict__ sub_start,
                                                SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
                                                float* __restrict__ payload2, int* __restrict__ tile_z = nullptr,
-                                               int tz_chunks = 0, unsigned* __restrict__ layers = nullptr) {
+                                               int tz_chunks = 0, unsigned* __restrict__ layers = nullptr,
+                                               const BuildPlan* forced = nullptr) {
   __shared__ unsigned s_part[kBuildThreads];
   __shared__ int s_tz[REFINE ? 2 * kChunkMax : 2];  // chunk table of this slab: (min, max) z keys
   const int nchunkq = (nr + kChunk - 1) / kChunk;
@@ -535,7 +546,10 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   }
   PP_PHASE(1);
   bool any_bad;
-  {  // six max-reductions (-min, max) and six sums with one barrier; a non-finite coordinate (or one whose
+  if (forced) {  // (uniform) the planning was done by the caller: same box on every slab of the set
+    mnx = forced->mnx; mny = forced->mny; mnz = forced->mnz;
+    any_bad = false;
+  } else {  // six max-reductions (-min, max) and six sums with one barrier; a non-finite coordinate (or one whose
      // square overflows: treated alike, the set goes to the brute force) shows in the sums of squares
     float v[6] = {-mnx, -mny, -mnz, mxx, mxy, mxz};
     wave_reduce6_dpp<false, 6>(v);
@@ -567,8 +581,8 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   // and every bound is stated in terms of the (monotone) cell coordinate -- so when the box reaches
   // beyond 6 sigma of the mean on some side, it is replaced by the box of the points within 4 sigma on
   // every axis.  Uniform over the workgroup; clouds without outliers skip the second pass.
-  bool trimmed = false;  // the box does not hold every point (the outliers sit in the rim cells)
-  if (!any_bad) {
+  bool trimmed = forced ? forced->trimmed != 0 : false;  // the box does not hold every point (the outliers sit in the rim cells)
+  if (!any_bad && !forced) {
     const float inv_n = 1.0f / (float)nr;
     const float mean[3] = {sm[0] * inv_n, sm[1] * inv_n, sm[2] * inv_n};
     float sig[3];
@@ -615,7 +629,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   // first guess: ~2 points per cell if the cloud filled its box; cubic cells of side h
   int g0 = (int)ceilf(cbrtf(2.0f * (float)nr));
   g0 = g0 < 1 ? 1 : (g0 > kGridMax ? kGridMax : g0);
-  const bool degenerate = any_bad || !(emax > 0.0f) || !__builtin_isfinite(emax);
+  const bool degenerate = !forced && (any_bad || !(emax > 0.0f) || !__builtin_isfinite(emax));
   float h, invh;
   int gx, gy, gz;
   auto set_resolution = [&](int g) {
@@ -631,6 +645,9 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     gz = degenerate ? 1 : cells(ez);
   };
   set_resolution(g0);
+  if (forced) {
+    h = forced->h; invh = forced->invh; gx = forced->gx; gy = forced->gy; gz = forced->gz;
+  }
   int* s_cid = reinterpret_cast<int*>(s_cnt + grid_build_counter_words(nslab));  // [KP][kBuildThreads]
   // The searches want ~4-5 points per OCCUPIED cell (then the first, smallest stage answers ~98 % of the
   // queries): the first guess is right for a surface in a cubic box, too fine for a volume (1.3 points per
@@ -651,7 +668,8 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     for (int round = 0; round < kRounds; ++round) {
       stale = false;
       const int nc = gx * gy * gz;
-      const int lo = (int)((long long)nc * slab / nslab), nl = (int)((long long)nc * (slab + 1) / nslab) - lo;
+      const int lo = forced ? forced->cell_lo : (int)((long long)nc * slab / nslab);
+      const int nl = forced ? forced->cell_hi - forced->cell_lo : (int)((long long)nc * (slab + 1) / nslab) - lo;
       const int nwords = (nc + 31) / 32;
       for (int wd = t; wd < nwords; wd += kBuildThreads) s_occ[wd] = 0;
       for (int c = t; c < nl; c += kBuildThreads) s_cnt[sk(c)] = 0;
@@ -724,7 +742,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
       const unsigned nocc = s_nocc;
       __syncthreads();
       const int gmax = max(gx, max(gy, gz));
-      if ((float)nr >= 2.5f * (float)nocc || gmax <= 4) break;
+      if (forced || (float)nr >= 2.5f * (float)nocc || gmax <= 4) break;
       // coarsen by ~1/sqrt(2) per round: x2.8 points per cell for a volume, x2 for a surface
       set_resolution(max(4, (int)((float)gmax * 0.7071f)));
       stale = true;
@@ -735,7 +753,8 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   PP_PHASE(4);
   const int ncell = MORTON ? kGridCells : gx * gy * gz;
 
-  const int cell_lo = (int)((long long)ncell * slab / nslab), cell_hi = (int)((long long)ncell * (slab + 1) / nslab);
+  const int cell_lo = forced ? forced->cell_lo : (int)((long long)ncell * slab / nslab);
+  const int cell_hi = forced ? forced->cell_hi : (int)((long long)ncell * (slab + 1) / nslab);
   const int nloc = cell_hi - cell_lo;  // this slab's cells: local index = cell - cell_lo
   auto cell_of = [&](float x, float y, float z) {
     const int cx = cell_coord(x, mnx, invh, gx), cy = cell_coord(y, mny, invh, gy), cz = cell_coord(z, mnz, invh, gz);
@@ -931,6 +950,427 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     }
   }
   PP_PHASE(10);
+}
+
+// inclusive prefix sum over the 64 lanes of a wave through DPP (row shifts inside the rows of 16, then the row
+// broadcasts): VALU-rate, where __shfl_up is six dependent ds_bpermute round trips.  Every lane must be active.
+__device__ __forceinline__ unsigned wave_scan_u32_dpp(unsigned v) {
+#define PP_SCAN_STEP(CTRL, ROWS) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false)
+  PP_SCAN_STEP(0x111, 0xf);  // row_shr:1
+  PP_SCAN_STEP(0x112, 0xf);  // row_shr:2
+  PP_SCAN_STEP(0x114, 0xf);  // row_shr:4
+  PP_SCAN_STEP(0x118, 0xf);  // row_shr:8
+  PP_SCAN_STEP(0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+  PP_SCAN_STEP(0x143, 0xc);  // row_bcast:31 -> rows 2, 3
+#undef PP_SCAN_STEP
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// grid_build_set_fast (round 5) -- the REFINE build of a set of at most 16384 points (one register chunk, 16-byte aligned,
+// a multiple of four points: BASELINE config 2's class), the same outputs as grid_build_set_impl<false, true, true>.
+// The general build's workgroup does everything to all of the set's points although it owns a quarter of the cells: cell
+// index, bitmap mark, counter slot and "is it mine" for sixteen points per thread, then again sixteen masked cursor
+// atomics in the scatter; it is bound by VALU issue.  Here only the planning looks at every point
+// (box, moments, one cell index + one bitmap mark per point: the decisions must be the set's, not the slab's); then
+//   * a slab owns whole z-LAYERS of the grid (cells are z-major: still one contiguous range of cells and of `sorted`);
+//   * the points of its layers are COMPACTED into an LDS list (wave ballots, one cursor add per wave) as 16-byte records
+//     (x, y, z, index | local cell << 16), and everything after that touches a quarter of the set: one returning counter
+//     add per own point (its rank inside its cell), the scan of the slab's counters, then position = cell start + rank --
+//     no second round of atomics -- written into the LDS list's place IN SORTED ORDER and copied out with full 16-byte
+//     coalesced stores (the general path scatters 16-byte pieces straight to memory); the chunk table comes from that
+//     copy-out, a wave reduction per 64 sorted points instead of two LDS atomics per point;
+//   * crowded cells (> kCrowd points) are refined afterwards by the general build's grid_refine_cells.
+// What it cannot do is left to the general path, with this set's plan forced on it (BuildPlan) so that every slab
+// still sorts into the same grid: a slab whose layers hold more than kFastCap points (the middle of a Gaussian), more
+// crowded cells than its list holds.
+// Flat grids (gz < kFastMinLayers) and degenerate sets are not started at all (every slab agrees: uniform data).
+// Returns 0 = done, 1 = not applicable (general path, unforced), 2 = general path with `plan` forced.
+constexpr int kFastCap = 6144;       // points per pass (16-byte records in LDS: 96 KiB, the refinement's counters afterwards)
+constexpr int kFastCells = 8192;     // cells per slab: ceil(32 / 4) layers of 32 x 32
+constexpr int kFastMinLayers = 8;
+constexpr int kFastCrowdMax = 256;   // crowded cells one slab lists (more: general path)
+constexpr int kFastMaxPoints = kBuildThreads * 16;
+static_assert((size_t)kFastCap * 16 >= (size_t)(kBuildThreads / 64) * kSubWaveCells * 4, "grid_refine_cells' counters live in the list");
+// dynamic LDS (words): counters | list (bitmap of the planning rounds inside it) | chunk table | box partials | scan partials,
+// cursor words | crowded-cell list
+constexpr int kFastLdsCnt = 0;
+constexpr int kFastLdsList = kFastLdsCnt + kFastCells + 64;
+constexpr int kFastLdsTz = kFastLdsList + (kFastCap + 64) * 4;  // (+ 64 records nobody reads: the lanes without a point of the slab)
+constexpr int kFastLdsBox = kFastLdsTz + 2 * kChunkMax;
+constexpr int kFastLdsPart = kFastLdsBox + (kBuildThreads / 64) * 16;
+constexpr int kFastLdsClist = kFastLdsPart + 64;
+constexpr int kFastLdsWords = kFastLdsClist + 2 * kFastCrowdMax;
+__host__ __device__ inline size_t grid_build_fast_lds_bytes() { return (size_t)kFastLdsWords * 4; }
+
+__device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref, int nr, GridSet* gs,
+                                                   unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
+                                                   unsigned* lds, int slab, unsigned* __restrict__ sub_start,
+                                                   SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
+                                                   int* __restrict__ tile_z, int tz_chunks,
+                                                   unsigned* __restrict__ layers, BuildPlan& plan) {
+  constexpr int KP = 16, nslab = kBuildSlabs;
+  const int nchunkq = (nr + kChunk - 1) / kChunk;
+  if (nr > kFastMaxPoints || nr < 4 * kBuildThreads || (nr & 3) != 0 || tile_z == nullptr || layers == nullptr ||
+      cell_start == nullptr || sub_start == nullptr || sub_desc == nullptr || nchunkq > tz_chunks || tz_chunks > kChunkMax)
+    return 1;  // (uniform)
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  unsigned* s_cnt = lds + kFastLdsCnt;
+  f4* s_list = reinterpret_cast<f4*>(lds + kFastLdsList);
+  unsigned* s_occ = lds + kFastLdsList;  // (planning rounds only: before the list is used)
+  int* s_tz = reinterpret_cast<int*>(lds + kFastLdsTz);
+  float* s_box = reinterpret_cast<float*>(lds + kFastLdsBox);
+  unsigned* s_part = lds + kFastLdsPart;  // [0, 16): wave totals of the scan; [32, 40): cursor, below, ncrowd, nocc, flags
+  unsigned(*s_clist)[2] = reinterpret_cast<unsigned(*)[2]>(lds + kFastLdsClist);
+  unsigned& s_below = s_part[33];
+  unsigned& s_ncrowd = s_part[34];
+
+  PP_PHASE(0);
+  // ---- the set's points: four consecutive ones per thread and group of 4096, as 16-byte loads (the general path's map)
+  float px[KP], py[KP], pz[KP];
+  bool live[KP / 4];
+#pragma unroll
+  for (int gq = 0; gq < KP / 4; ++gq) {
+    const int p0 = gq * (4 * kBuildThreads) + 4 * t;
+    live[gq] = p0 < nr;  // (nr is a multiple of four: a group is whole or absent)
+    const f4* __restrict__ src = reinterpret_cast<const f4*>(ref + 3 * (size_t)(live[gq] ? p0 : 0));
+    const f4 a = src[0], b = src[1], c = src[2];
+    px[4 * gq] = a.x; py[4 * gq] = a.y; pz[4 * gq] = a.z;
+    px[4 * gq + 1] = a.w; py[4 * gq + 1] = b.x; pz[4 * gq + 1] = b.y;
+    px[4 * gq + 2] = b.z; py[4 * gq + 2] = b.w; pz[4 * gq + 2] = c.x;
+    px[4 * gq + 3] = c.y; py[4 * gq + 3] = c.z; pz[4 * gq + 3] = c.w;
+  }
+  auto kidx = [&](int i) { return (i >> 2) * (4 * kBuildThreads) + 4 * t + (i & 3); };
+  if (t < 2 * kChunkMax) s_tz[t] = (t & 1) ? zkey(-__builtin_inff()) : zkey(__builtin_inff());
+  if (t == 0) {
+    s_ncrowd = 0u;
+    s_below = 0u;
+  }
+  // ---- planning 1: bounding box and moments (the general path's arithmetic; dead groups repeat point 0: no effect on the
+  // box, and they are kept out of the sums)
+  float mnx = __builtin_inff(), mny = mnx, mnz = mnx, mxx = -mnx, mxy = -mnx, mxz = -mnx;
+  float sm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    const float x = px[i], y = py[i], z = pz[i];
+    mnx = fminf(mnx, x); mny = fminf(mny, y); mnz = fminf(mnz, z);
+    mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y); mxz = fmaxf(mxz, z);
+    if (live[i >> 2]) {
+      sm[0] += x; sm[1] += y; sm[2] += z;
+      sm[3] = __builtin_fmaf(x, x, sm[3]); sm[4] = __builtin_fmaf(y, y, sm[4]); sm[5] = __builtin_fmaf(z, z, sm[5]);
+    }
+  }
+  PP_PHASE(1);
+  bool any_bad;
+  {
+    float v[6] = {-mnx, -mny, -mnz, mxx, mxy, mxz};
+    wave_reduce6_dpp<false, 6>(v);
+    wave_reduce6_dpp<true, 6>(sm);
+    if (lane == 63) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) s_box[wave * 16 + e] = v[e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) s_box[wave * 16 + 8 + e] = sm[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 6; ++e) v[e] = s_box[(t & 15) * 16 + e];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) sm[e] = s_box[(t & 15) * 16 + 8 + e];
+    wave_reduce6_dpp<false, 4>(v);
+    wave_reduce6_dpp<true, 4>(sm);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) v[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), 15));
+#pragma unroll
+    for (int e = 0; e < 6; ++e) sm[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm[e]), 15));
+    mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
+    any_bad = !__builtin_isfinite(sm[3] + sm[4] + sm[5]);
+  }
+  PP_PHASE(2);
+  bool trimmed = false;
+  if (!any_bad) {  // outliers: the box of the points within 4 sigma when the bounding box reaches beyond 6 (general path)
+    const float inv_n = 1.0f / (float)nr;
+    const float mean[3] = {sm[0] * inv_n, sm[1] * inv_n, sm[2] * inv_n};
+    float sig[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) sig[a] = sqrtf(fmaxf(sm[3 + a] * inv_n - mean[a] * mean[a], 0.0f));
+    const bool stretched = mxx - mean[0] > 6.0f * sig[0] || mean[0] - mnx > 6.0f * sig[0] ||
+                           mxy - mean[1] > 6.0f * sig[1] || mean[1] - mny > 6.0f * sig[1] ||
+                           mxz - mean[2] > 6.0f * sig[2] || mean[2] - mnz > 6.0f * sig[2];
+    if (stretched) {
+      float w[6] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff(),
+                    -__builtin_inff()};
+#pragma unroll
+      for (int i = 0; i < KP; ++i) {
+        const float x = px[i], y = py[i], z = pz[i];
+        const bool in = fabsf(x - mean[0]) <= 4.0f * sig[0] && fabsf(y - mean[1]) <= 4.0f * sig[1] &&
+                        fabsf(z - mean[2]) <= 4.0f * sig[2];
+        if (in) {
+          w[0] = fmaxf(w[0], -x); w[1] = fmaxf(w[1], -y); w[2] = fmaxf(w[2], -z);
+          w[3] = fmaxf(w[3], x); w[4] = fmaxf(w[4], y); w[5] = fmaxf(w[5], z);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e) w[e] = wave_reduce_dpp<false>(w[e]);
+      __syncthreads();
+      if (lane == 0)
+#pragma unroll
+        for (int e = 0; e < 6; ++e) s_box[wave * 16 + e] = w[e];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 6; ++e) w[e] = wave_reduce_dpp<false>(s_box[(t & 15) * 16 + e]);
+      if (w[3] > -w[0] || w[4] > -w[1] || w[5] > -w[2]) {
+        mnx = -w[0]; mny = -w[1]; mnz = -w[2]; mxx = w[3]; mxy = w[4]; mxz = w[5];
+        trimmed = true;
+      }
+    }
+  }
+  PP_PHASE(3);
+  const float ex = mxx - mnx, ey = mxy - mny, ez = mxz - mnz;
+  const float emax = fmaxf(ex, fmaxf(ey, ez));
+  if (any_bad || !(emax > 0.0f) || !__builtin_isfinite(emax)) return 1;  // degenerate: the general path marks it (uniform)
+  int g0 = 1;  // the general path's first guess, ceil(cbrt(2 nr)) clamped to [1, 32], on the scalar unit (cbrtf: ~200 dependent
+  while (g0 < kGridMax && g0 * g0 * g0 < 2 * nr) ++g0;  // vector instructions in every lane of a phase that is one latency chain)
+  float h, invh;
+  int gx, gy, gz;
+  auto set_resolution = [&](int g) {
+    h = emax / (float)g;
+    if (!(h > 0.0f) || !__builtin_isfinite(h)) h = 1.0f;
+    invh = 1.0f / h;
+    auto cells = [&](float e) {
+      int c = (int)(e * invh) + 1;
+      return c < 1 ? 1 : (c > kGridMax ? kGridMax : c);
+    };
+    gx = cells(ex); gy = cells(ey); gz = cells(ez);
+  };
+  set_resolution(g0);
+  // ---- planning 2 + count: the general path's rounds (about 2.5 points per occupied cell), one pass per round: a point's
+  // cell index, its mark in the bitmap of the SET's cells and -- if the cell lies in this slab's layers -- one returning
+  // add on the cell's counter: the point's rank inside its cell, kept in a register with the counter's slot.  A round
+  // that ends in "coarsen" (never for a surface) counts again.
+  unsigned key[KP];  // slot | rank << 16 of the points of this slab's layers, ~0u for the others
+  int gxy = 0, lo = 0, ncs = 0;
+  auto count_pass = [&](bool mark) {
+    float ox = mnx, oy = mny, oz = mnz;  // (hidden from the optimiser: it would keep 48 differences p - origin alive)
+    asm volatile("" : "+s"(ox), "+s"(oy), "+s"(oz));
+    unsigned nbelow = 0;
+#pragma unroll
+    for (int gq = 0; gq < KP / 4; ++gq) {
+      int c4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = 4 * gq + u;
+        c4[u] = cell_linear(cell_coord(px[i], ox, invh, gx), cell_coord(py[i], oy, invh, gy),
+                            cell_coord(pz[i], oz, invh, gz), gx, gy);
+      }
+      const bool alive = live[gq];
+      // (a thread's four consecutive points in one cell in EVERY lane, and that cell the same over the wave -- a dense
+      //  blob that is contiguous in memory -- would be 256 serial same-address atomics: one add of 256 instead)
+      const bool same4 = alive & (c4[0] == c4[1]) & (c4[1] == c4[2]) & (c4[2] == c4[3]);
+      const int lead = __builtin_amdgcn_readfirstlane(c4[0]);
+      if (__all(same4 && c4[0] == lead)) {  // (wave-uniform, rare)
+        const unsigned slot = (unsigned)(lead - lo);
+        if (mark && lane == 0) atomicOr(&s_occ[lead >> 5], 1u << (lead & 31));
+        if (lead < lo) nbelow += 256u;
+        unsigned b0 = 0u;
+        const bool mine = slot < (unsigned)ncs;
+        if (mine && lane == 0) b0 = atomicAdd(&s_cnt[slot], 256u);
+        b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)b0) + 4u * (unsigned)lane;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[4 * gq + u] = mine ? (slot | ((b0 + (unsigned)u) << 16)) : ~0u;
+      } else {
+        // (no branch per point: a lane whose point is not the slab's -- or is one of the repeats beyond nr -- adds to a
+        //  counter nobody reads, s_cnt[kFastCells + lane]; a repeat marks the cell of point 0, which is occupied)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c4[u];
+          if (mark) atomicOr(&s_occ[c >> 5], 1u << (c & 31));
+          const unsigned slot = (unsigned)(c - lo);
+          const bool mine = alive & (slot < (unsigned)ncs);
+          nbelow += (unsigned)__builtin_popcountll(__ballot(alive & (c < lo)));
+          const unsigned r = atomicAdd(&s_cnt[mine ? slot : (unsigned)(kFastCells + lane)], 1u);
+          key[4 * gq + u] = mine ? (slot | (r << 16)) : ~0u;
+        }
+      }
+    }
+    if (lane == 0 && nbelow) atomicAdd(&s_below, nbelow);
+  };
+  unsigned running = 0, own = 0;
+  {
+    constexpr int kRounds = 4;
+    for (int round = 0;; ++round) {
+      // (after the last round's "coarsen" the cloud is counted at the resolution it ended with, whatever its occupancy)
+      if (gz < kFastMinLayers) return 1;  // a flat grid: slabs of whole layers would leave workgroups idle (uniform)
+      gxy = gx * gy;
+      lo = (gz * slab / nslab) * gxy;
+      ncs = (gz * (slab + 1) / nslab) * gxy - lo;
+      const int nwords = (gxy * gz + 31) / 32;
+      if (t < nwords) s_occ[t] = 0u;  // (<= 1024 words)
+      for (int c = 4 * t; c < ((ncs + 7) & ~7); c += 4 * kBuildThreads)  // (to a multiple of eight: the scan reads whole octets)
+        *reinterpret_cast<uint4*>(&s_cnt[c]) = make_uint4(0u, 0u, 0u, 0u);
+      if (t == 0) s_below = 0u;
+      __syncthreads();
+      PP_PHASE(4);
+      count_pass(round < kRounds);
+      __syncthreads();  // the bitmap and the counters are complete
+      PP_PHASE(5);
+      // ---- one barrier serves both the occupancy of the round (popcounts of the bitmap) and the exclusive scan of the
+      // slab's counters (eight consecutive cells per thread): a wave leaves its two totals in s_part
+      unsigned v8[8];
+      const int c0 = 8 * t;
+      if (c0 < ncs) {
+        const uint4 a = *reinterpret_cast<const uint4*>(&s_cnt[c0]);
+        const uint4 b = *reinterpret_cast<const uint4*>(&s_cnt[c0 + 4]);
+        v8[0] = a.x; v8[1] = a.y; v8[2] = a.z; v8[3] = a.w; v8[4] = b.x; v8[5] = b.y; v8[6] = b.z; v8[7] = b.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = 0u;
+      }
+      unsigned sum = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v8[u];
+      const unsigned incl = wave_scan_u32_dpp(sum);
+      const unsigned occ = wave_scan_u32_dpp(round < kRounds && t < nwords ? (unsigned)__builtin_popcount(s_occ[t]) : 0u);
+      if (lane == 63) {
+        s_part[wave] = incl;
+        s_part[16 + wave] = occ;
+      }
+      __syncthreads();
+      // the sixteen wave totals: every wave scans them again in its first row of lanes and picks its own base
+      const unsigned tot16 = wave_scan_u32_dpp(s_part[lane & 15]);
+      const unsigned occ16 = wave_scan_u32_dpp(s_part[16 + (lane & 15)]);
+      const unsigned nocc = (unsigned)__builtin_amdgcn_readlane((int)occ16, 15);
+      const int gmax = max(gx, max(gy, gz));
+      if (round < kRounds && !((float)nr >= 2.5f * (float)nocc || gmax <= 4)) {  // too fine: coarsen and count again
+        set_resolution(max(4, (int)((float)gmax * 0.7071f)));
+        __syncthreads();  // (s_part, the bitmap and the counters are rewritten)
+        continue;
+      }
+      const unsigned wbase = wave == 0 ? 0u : (unsigned)__builtin_amdgcn_readlane((int)tot16, (wave - 1) & 15);
+      own = (unsigned)__builtin_amdgcn_readlane((int)tot16, 15);
+      running = s_below;  // points of the slabs below: where this slab's first cell starts
+      plan.mnx = mnx; plan.mny = mny; plan.mnz = mnz; plan.h = h; plan.invh = invh;
+      plan.gx = gx; plan.gy = gy; plan.gz = gz; plan.cell_lo = lo; plan.cell_hi = lo + ncs; plan.trimmed = trimmed ? 1 : 0;
+      if (own > (unsigned)kFastCap) return 2;  // more points than the list holds: the general path sorts this slab (uniform)
+      unsigned run = running + wbase + incl - sum;
+      if (c0 < ncs) {
+        unsigned st[8], mx8 = 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          st[u] = run;
+          run += v8[u];
+          mx8 = max(mx8, v8[u]);
+        }
+        if (mx8 > (unsigned)kCrowd) {  // (rare) crowded cells: listed for the refinement
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (v8[u] > (unsigned)kCrowd) {
+              const unsigned at = atomicAdd(&s_ncrowd, 1u);
+              if (at < (unsigned)kFastCrowdMax) {
+                s_clist[at][0] = st[u];
+                s_clist[at][1] = v8[u];
+              }
+            }
+        }
+        *reinterpret_cast<uint4*>(&s_cnt[c0]) = make_uint4(st[0], st[1], st[2], st[3]);
+        *reinterpret_cast<uint4*>(&s_cnt[c0 + 4]) = make_uint4(st[4], st[5], st[6], st[7]);
+      }
+      break;
+    }
+  }
+  const int ncell = gxy * gz;
+  const int zl = gz * slab / nslab, zh = gz * (slab + 1) / nslab;  // this slab's layers
+  __syncthreads();
+  PP_PHASE(6);
+  if (((lo | ncs) & 3) == 0 && (reinterpret_cast<uintptr_t>(cell_start) & 15) == 0) {  // (uniform) 16-byte pieces
+    for (int c = 4 * t; c < ncs; c += 4 * kBuildThreads)
+      *reinterpret_cast<uint4*>(&cell_start[lo + c]) = *reinterpret_cast<const uint4*>(&s_cnt[c]);
+  } else {
+    for (int c = t; c < ncs; c += kBuildThreads) cell_start[lo + c] = s_cnt[c];  // (coalesced)
+  }
+  if (t < zh - zl) layers[zl + t] = s_cnt[t * gxy];
+  // ---- position = cell start + rank: the slab's points into the list in sorted order
+  // (no branch per point: the other lanes' records go to 64 slots behind the list)
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    const bool mine = key[i] != ~0u;
+    const unsigned start = s_cnt[mine ? (key[i] & 0xffffu) : 0u];
+    const unsigned pos = mine ? start + (key[i] >> 16) - running : (unsigned)(kFastCap + lane);
+    f4 r = {px[i], py[i], pz[i], __int_as_float(kidx(i))};
+    s_list[pos] = r;
+  }
+  __syncthreads();
+  PP_PHASE(7);
+  // ---- copy-out: 16-byte coalesced stores, a wave per chunk of kChunk sorted positions; the chunk's pair of the chunk
+  // table from the same pass (one DPP reduction per chunk; zkey is monotone: the keys of the extreme z are the extreme keys)
+  if (own > 0u) {
+    const unsigned ch_first = running / (unsigned)kChunk, ch_last = (running + own - 1u) / (unsigned)kChunk;
+    for (unsigned ch = ch_first + (unsigned)wave; ch <= ch_last; ch += (unsigned)(kBuildThreads / 64)) {  // a wave per chunk
+      float zmax = -__builtin_inff(), nzmin = -__builtin_inff();  // max of z, max of -z
+      const unsigned p0 = ch * (unsigned)kChunk;
+      if (p0 >= running && p0 + (unsigned)kChunk <= running + own) {  // (uniform) the whole chunk is this slab's
+#pragma unroll
+        for (int q = 0; q < kChunk / 64; ++q) {
+          const unsigned pos = p0 + (unsigned)(q * 64 + lane);
+          const f4 r = s_list[pos - running];
+          sorted[pos] = r;
+          zmax = fmaxf(zmax, r.z);
+          nzmin = fmaxf(nzmin, -r.z);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < kChunk / 64; ++q) {
+          const unsigned pos = p0 + (unsigned)(q * 64 + lane);
+          const unsigned j = pos - running;  // (wraps below the range: not `have`)
+          const bool have = j < own;
+          const f4 r = s_list[have ? j : 0u];
+          if (have) {
+            sorted[pos] = r;
+            zmax = fmaxf(zmax, r.z);
+            nzmin = fmaxf(nzmin, -r.z);
+          }
+        }
+      }
+      zmax = wave_reduce_dpp<false>(zmax);
+      nzmin = wave_reduce_dpp<false>(nzmin);
+      if (lane == 0) {  // (this wave is the only writer of the slab's pair for the chunk)
+        s_tz[2 * ch] = zkey(-nzmin);
+        s_tz[2 * ch + 1] = zkey(zmax);
+      }
+    }
+  }
+  __syncthreads();  // (the epilogue reads the chunk table; the refinement reuses the counters and the list)
+  PP_PHASE(8);
+  PP_PHASE(9);
+  const unsigned ncrowd = s_ncrowd;
+  if (ncrowd > (unsigned)kFastCrowdMax) return 2;  // more crowded cells than the list holds: the general path (uniform)
+  if (t == 0 && slab == nslab - 1) {
+    cell_start[ncell] = (unsigned)nr;
+    layers[gz] = (unsigned)nr;
+  }
+  if ((t == kLayerPending || t == kLayerCursor) && slab == 0) layers[t] = 0u;
+  for (int c = t; c < 2 * tz_chunks; c += kBuildThreads) tile_z[((size_t)(c >> 1) * nslab + slab) * 2 + (c & 1)] = s_tz[c];
+  bool refined = false;
+  if (ncrowd > 0) {  // (uniform) second level: the general build's refinement of this slab's crowded cells, in place
+    __threadfence_block();  // the copy-out's stores are read back
+    __syncthreads();
+    refined = true;
+    grid_refine_cells(sorted, sorted2, nullptr, nullptr, sub_start, sub_desc, reinterpret_cast<unsigned*>(s_list), s_cnt,
+                      s_box, s_clist, ncrowd);
+  }
+  if (t == 0) {
+    gs->crowd[slab] = refined ? 2 : 0;
+    if (slab == 0) {
+      gs->minx = mnx; gs->miny = mny; gs->minz = mnz; gs->h = h; gs->invh = invh;
+      gs->gx = gx; gs->gy = gy; gs->gz = gz;
+      gs->useless = 0;
+      gs->pad[0] = 0;
+      gs->pad[1] = 1;
+      gs->pad[2] = trimmed ? 1 : 0;
+    }
+  }
+  PP_PHASE(10);
+  return 0;
 }
 
 // VEC: the cloud is 16-byte aligned (read as float4).  A compile-time choice of the calling kernel: with both
