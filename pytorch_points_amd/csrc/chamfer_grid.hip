@@ -60,6 +60,7 @@ extern "C" int pp_debug_read_build_phases(void* out) {
 constexpr int kQWaves = 1 << 17;
 __device__ unsigned long long g_qphase[8][16];
 __device__ unsigned g_qwave[kQWaves][10];
+__device__ unsigned g_qstart[kQWaves][2];    // a wave's first and last stamp (10 ns units, low 32 bits of the clock)
 __device__ unsigned long long g_qgroup[8];  // group search: calls, groups, blind groups, candidates of the row cuts, max of them in one call, rows of the
                                              // boxes, rows listed by pass 1, candidates the whole wave walked
 extern "C" int pp_debug_read_query_phases(void* out) {
@@ -76,12 +77,19 @@ extern "C" int pp_debug_read_query_group_stats(void* out, int reset) {
 extern "C" int pp_debug_read_query_wave_phases(void* out) {  // kQWaves x 10 unsigned
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qwave), sizeof(g_qwave));
 }
+extern "C" int pp_debug_read_query_wave_span(void* out) {  // kQWaves x 2 unsigned
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qstart), sizeof(g_qstart));
+}
 #define PP_QPHASE_DECL unsigned long long pp_prev = wall_clock64()
 #define PP_QPHASE(n)                                                                     \
   do {                                                                                   \
     const unsigned long long pp_now = wall_clock64();                                    \
     const unsigned pp_w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                          \
-    if ((threadIdx.x & 63) == 0 && pp_w < (unsigned)kQWaves) g_qwave[pp_w][n] = (unsigned)(pp_now - pp_prev); \
+    if ((threadIdx.x & 63) == 0 && pp_w < (unsigned)kQWaves) {                            \
+      g_qwave[pp_w][n] = (unsigned)(pp_now - pp_prev);                                   \
+      if ((n) == 0) g_qstart[pp_w][0] = (unsigned)pp_prev;                                \
+      g_qstart[pp_w][1] = (unsigned)pp_now;                                               \
+    }                                                                                    \
     pp_prev = pp_now;                                                                    \
     if (threadIdx.x == 0 && (blockIdx.x & 511) == 0 && (blockIdx.x >> 9) < 8)            \
       g_qphase[blockIdx.x >> 9][n] = pp_now;                                             \
@@ -1785,6 +1793,10 @@ constexpr int kPendTried = 1 << 30;
 #define PP_LIST_WG_WAVES 4  // waves per workgroup of the list kernel (independent waves: only the dispatch sees the difference)
 #endif
 constexpr int kListWgWaves = PP_LIST_WG_WAVES;
+#ifndef PP_LIST_RIM_UNITS
+#define PP_LIST_RIM_UNITS 2
+#endif
+constexpr int kListRimUnits = PP_LIST_RIM_UNITS;  // workgroups from either end of a set's tiles that the launch starts first
 template <int CAPW>
 __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_list_kernel(const float* __restrict__ xyz1,
                                                                   const float* __restrict__ xyz2,
@@ -1800,7 +1812,34 @@ __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_l
   // set -> XCD mapping: contiguous ranges of sets per XCD): its tables and points are in that L2 -- served from another
   // XCD every one of a query's dependent loads went to the memory side (24 -> 1x us for the whole launch at config 2).
   // Speed only: whatever the placement, the results are the same.
-  const int gw = pp::xcd_virtual_block((int)blockIdx.x, (int)(gridDim.x >> 3)) * kListWgWaves + wave;  // (the grid is a multiple of 8)
+  // Round 5: the workgroups of an XCD take its sets' RIM tiles first -- the first and the last kListRimUnits workgroups'
+  // worth of every set, i.e. the lowest and the highest z-layers of the sorted query cloud, both ends inwards, set after
+  // set -- and the rest in plain order afterwards.  Where a direction is searched in whole here (clouds stage A cannot
+  // serve), the sparse ends of a cloud hold the queries far from everything: a Gaussian's rim waves live 110-150 us
+  // against a mean of 33, and in plain order the last set's started when everybody else was done (the kernel lasted
+  // 125 us of work + 110 us of tail, tools/query_probe.py's timeline).  Only the order of the launch changes: every
+  // (set, wave) is still served exactly once.
+  int gw;
+  {
+    const int per_xcd = (int)(gridDim.x >> 3);  // (the grid is a multiple of 8)
+    const int xcd = (int)blockIdx.x & 7, u = (int)blockIdx.x >> 3;  // this workgroup: number u of its XCD
+    const int units = waves_per_set / kListWgWaves;                 // workgroups per set
+    const int nsets = units > 0 ? per_xcd / units : 0;              // whole sets per XCD
+    const bool regular = waves_per_set % kListWgWaves == 0 && nsets > 0 && nsets * units == per_xcd && units > 4 * kListRimUnits;
+    int v = u;  // the XCD's workgroup in plain order (a set's tiles in order, set after set)
+    if (regular) {
+      const int nrim = 2 * kListRimUnits * nsets;
+      if (u < nrim) {
+        const int r = u / nsets, j = u - r * nsets;  // rim rank (0: first unit, 1: last, 2: second, 3: last but one, ...), set
+        v = j * units + ((r & 1) ? units - 1 - (r >> 1) : (r >> 1));
+      } else {
+        const int w = u - nrim, inner = units - 2 * kListRimUnits;
+        const int j = w / inner;
+        v = j * units + kListRimUnits + (w - j * inner);
+      }
+    }
+    gw = (xcd * per_xcd + v) * kListWgWaves + wave;
+  }
   const int set = gw / waves_per_set, wi = gw - set * waves_per_set;
   // (round 3, tried: a set's waves from its two ends inwards -- the rim waves are the expensive ones -- changed nothing;
   //  the XCD's sets interleaved as well spread the expensive waves over the launch -- gaussian 0.265 -> 0.243 ms, blobs8
@@ -2058,6 +2097,11 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
     // (uniform over the direction) nothing of this direction is served here: its total is set to "every query" by the
     // first tile (no list is written: the list kernel then takes entry e to be query e) and the tile is done -- a
     // cloud stage A cannot serve costs this launch little more than its dispatch
+    // (round 5, measured and removed: these tiles running stage A in the wave-private form here -- search_queries cut
+    //  behind stage A, out of line, the open queries to the pending list so that the list kernel finds them compacted:
+    //  bit-identical, but this kernel then took 124 us on a filled cube and 167 on a Gaussian -- three workgroups per CU
+    //  by its image's LDS, 416 bytes of call frames -- against the 60 us stage A costs inside the list kernel, and the
+    //  list kernel gained 10-40 us: cube 0.129 -> 0.199 ms, gaussian 0.226 -> 0.374)
     if (tile == 0 && t == 0)
       (reinterpret_cast<unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords)[pp::kLayerPending] = (unsigned)nq;
     if constexpr (PERSIST) {

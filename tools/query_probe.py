@@ -48,6 +48,21 @@ for mode in [int(a) for a in sys.argv[1:]] or [0]:
     rdg = L.pp_debug_read_query_group_stats; rdg.argtypes = [ctypes.c_void_p, ctypes.c_int]; rdg.restype = ctypes.c_int
     assert rdg(gs.ctypes.data, 1) == 0
     print("   group search (all launches so far): calls %d groups %d blind %d candidates %d (max per call %d) rows %d, rows listed %d, candidates walked %d" % tuple(int(x) for x in gs[:8]))
+    sp = np.zeros((1 << 17, 2), np.uint32)
+    rds = L.pp_debug_read_query_wave_span; rds.argtypes = [ctypes.c_void_p]; rds.restype = ctypes.c_int
+    if rds(sp.ctypes.data) == 0:
+        sp = sp[:nw].astype(np.int64)
+        ok = sp[:, 1] >= sp[:, 0]
+        t0w = sp[ok, 0].min()
+        st, en = (sp[:, 0] - t0w) / 100.0, (sp[:, 1] - t0w) / 100.0
+        life = en - st
+        print("   timeline (us after the first wave's start): last start %.1f, last end %.1f; waves alive at t: " % (st[ok].max(), en[ok].max()) +
+              " ".join("%d:%d" % (tt, int(((st <= tt) & (en > tt) & ok).sum())) for tt in range(0, int(en[ok].max()) + 1, max(1, int(en[ok].max()) // 12))))
+        order = np.argsort(-life)[:12]
+        print("   longest waves: " + " ".join("w%d[%.0f-%.0f]" % (w, st[w], en[w]) for w in order))
+        # which waves end last
+        order = np.argsort(-en)[:12]
+        print("   last to end:   " + " ".join("w%d[%.0f-%.0f]" % (w, st[w], en[w]) for w in order))
     tot = wv.sum(1)
     print("   wave total: mean %.1f  p99 %.1f  max %.1f us; waves over 4x the mean: %d" % (tot.mean(), np.percentile(tot, 99), tot.max(), int((tot > 4 * tot.mean()).sum())))
     print("mode %d: fwd %.1f us" % (mode, a.elapsed_time(b) / 20 * 1e3))
