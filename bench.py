@@ -49,6 +49,10 @@ VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz fp32 lane-
 # WRITE_SIZE per launch from rocprofv3 --pmc passes of this command (tools/refresh_profiles.sh -> profiles/r4/pmc_summary.txt,
 # which names the commit it was taken at); counters cannot be collected inside the timed process
 FWD_TRAFFIC_C2 = 71565312
+# counter bytes (the same passes) of the two bandwidth-shaped kernels of the step at config 2: the build's launch
+# (2 x 6.2 MiB fetched + 24.4 MiB written) and the backward's (the algorithmic 33 554 432: PMC = algorithmic there)
+BUILD_TRAFFIC_C2 = 38600000
+BWD_TRAFFIC_C2 = 33554432
 
 
 def parse():
@@ -458,6 +462,25 @@ def bench_chamfer(args, dist, world, rank, device):
     e1.record()
     torch.cuda.synchronize()
     fwd_ms = e0.elapsed_time(e1) / nf
+    # backward duration: the backward's one launch (extension-module call on static buffers) issued back to back, same way
+    def bwd_only():
+        sx1, sx2 = dsets[counter[0] & 1]
+        counter[0] += 1
+        ext_losses.nmdistance_backward(sx1, sx2, og1, og2, g1, g2, oi1, oi2)
+    bwd_ms = None
+    try:
+        og1, og2 = torch.empty(B, N, 3, device=device), torch.empty(B, M, 3, device=device)
+        for _ in range(3):
+            bwd_only()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(nf):
+            bwd_only()
+        e1.record()
+        torch.cuda.synchronize()
+        bwd_ms = e0.elapsed_time(e1) / nf
+    except Exception as exc:   # noqa: BLE001 -- a timing extra must not take the line down
+        print("backward-only timing failed: %r" % (exc,), file=sys.stderr)
     grid = args.search == "auto" and int(_lib.lib().pp_nmdistance_forward_workspace_bytes(B, N, M, C)) > 0
     build_ms = stage_a_ms = rest_ms = search_ms = None
     raw_kernel_ms = None
@@ -585,6 +608,11 @@ def bench_chamfer(args, dist, world, rank, device):
             # per launch, profiles/r3/pmc_summary.txt
             "traffic": FWD_TRAFFIC_C2 if (c2 and two_stage) else None,
             "kernel_ms": dom_ms, "build_kernel_ms": build_ms, "stage_a_kernel_ms": stage_a_ms, "rest_kernel_ms": rest_ms,
+            "backward_kernel_ms": bwd_ms,
+            # the two bandwidth-shaped kernels of the step against the HBM roof (their counter bytes / their
+            # duration / 8 TB/s; launches issued back to back, events around the batch)
+            "build_frac_hbm": (BUILD_TRAFFIC_C2 / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (c2 and build_ms) else None,
+            "backward_frac_hbm": (BWD_TRAFFIC_C2 / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (c2 and bwd_ms) else None,
             "kernel_ms_uncorrected": raw_kernel_ms, "kernel_event_overhead_ms": event_overhead_ms,
             "traffic_source": ("recorded constant: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over the forward's launches, "
                                "profiles/r4/pmc_summary.txt (the commit is named there)") if (c2 and two_stage) else None,

@@ -246,6 +246,12 @@ size_t pp_scatter_workspace_bytes(int B, long long triples_per_batch, int destin
 int pp_group_points_grad_ws_f32(const float* grad_out, const int* idx, float* grad_points, int B, int C,
                                 int N, int npoint, int nsample, long long grad_out_batch_stride,
                                 void* workspace, size_t workspace_bytes, void* stream);
+/* The same with grad_points (B,C,N) WRITTEN instead of accumulated into: it need not be initialised (the reference's
+ * group_points_grad allocates a zero-filled tensor and adds into it, _ext/sampling.cpp:148-150 -- the fill and the read
+ * of the output are 2 x 256 MB of traffic at B=32, C=128, N=16384 that this form does not move). */
+int pp_group_points_grad_out_ws_f32(const float* grad_out, const int* idx, float* grad_points, int B, int C,
+                                    int N, int npoint, int nsample, long long grad_out_batch_stride,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 int pp_gather_backward_ws_f32(const float* grad_out, const int* idx, float* grad_points, int B, int C,
                               int N, int M, void* workspace, size_t workspace_bytes, void* stream);
 int pp_three_interpolate_grad_ws_f32(const float* grad_out, const int* idx, const float* weight,

@@ -234,14 +234,17 @@ def group_points_grad(grad_out, idx, n):
     if grad_out.dim() != 4 or idx.dim() != 3:
         raise RuntimeError("grad_out must be (B, C, npoint, nsample) and idx (B, npoint, nsample)")
     b, c, npoint, nsample = grad_out.shape
-    out = torch.zeros(b, c, int(n), dtype=torch.float32, device=dev)
+    # (the deterministic form accumulates into zeros, as the reference's does; the default form WRITES every element:
+    #  no fill in front of it, no read of the output -- pp_group_points_grad_out_ws_f32)
+    det = _lib.deterministic()
+    out = (torch.zeros if det else torch.empty)(b, c, int(n), dtype=torch.float32, device=dev)
     with _lib.on_device(dev) as stream:
         ws, nbytes = _scatter_ws(dev, b, npoint * nsample, int(n), 1, 0)
         args = (_lib.ptr(grad_out), _lib.ptr(idx), _lib.ptr(out), b, c, int(n), npoint, nsample,
                 c * npoint * nsample, _lib.ptr(ws) if ws is not None else None, nbytes, stream)
         L = _lib.lib()
-        if not (_lib.deterministic() and _lib.ordered_or_fallback(L.pp_group_points_grad_ordered_f32(*args), "group_points_grad")):
-            _lib.check(L.pp_group_points_grad_ws_f32(*args), "group_points_grad")
+        if not (det and _lib.ordered_or_fallback(L.pp_group_points_grad_ordered_f32(*args), "group_points_grad")):
+            _lib.check(L.pp_group_points_grad_out_ws_f32(*args), "group_points_grad")
     return out
 
 
@@ -278,14 +281,15 @@ def group_points_grad_from(grad_out, idx, n, channel_offset, channels):
     if channel_offset < 0 or channel_offset + channels > ctot:
         raise RuntimeError("channel slice out of range")
     p = npoint * nsample
-    out = torch.zeros(b, channels, int(n), dtype=torch.float32, device=dev)
+    det = _lib.deterministic()
+    out = (torch.zeros if det else torch.empty)(b, channels, int(n), dtype=torch.float32, device=dev)
     with _lib.on_device(dev) as stream:
         ws, nbytes = _scatter_ws(dev, b, p, int(n), 1, 0)
         args = (_lib._c_void_p(grad_out.data_ptr() + 4 * channel_offset * p), _lib.ptr(idx), _lib.ptr(out),
                 b, channels, int(n), npoint, nsample, ctot * p, _lib.ptr(ws) if ws is not None else None, nbytes, stream)
         L = _lib.lib()
-        if not (_lib.deterministic() and _lib.ordered_or_fallback(L.pp_group_points_grad_ordered_f32(*args), "group_points_grad")):
-            _lib.check(L.pp_group_points_grad_ws_f32(*args), "group_points_grad_from")
+        if not (det and _lib.ordered_or_fallback(L.pp_group_points_grad_ordered_f32(*args), "group_points_grad")):
+            _lib.check(L.pp_group_points_grad_out_ws_f32(*args), "group_points_grad_from")
     return out
 
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "pp_group_points_grad_strided_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P],
     "pp_scatter_workspace_bytes": [_I, ctypes.c_longlong, _I, _I, _I],
     "pp_group_points_grad_ws_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P, _c_size_t, _P],
+    "pp_group_points_grad_out_ws_f32": [_P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_longlong, _P, _c_size_t, _P],
     "pp_gather_backward_ws_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_three_interpolate_grad_ws_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _c_size_t, _P],
     "pp_nmdistance_backward_ordered_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -905,7 +905,7 @@ __global__ __launch_bounds__(1024) void group_points_grad_lds64_kernel(const flo
                                                                        const int* __restrict__ idx,
                                                                        float* __restrict__ grad_points,
                                                                        int B, int C, int N, long long P,
-                                                                       long long gbs, int nsplit, int W) {
+                                                                       long long gbs, int nsplit, int W, int overwrite) {
   extern __shared__ __attribute__((aligned(16))) double s_col64[];
   const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
   const int per_b = C * nsplit;
@@ -938,6 +938,68 @@ __global__ __launch_bounds__(1024) void group_points_grad_lds64_kernel(const flo
     if (!e2) add1(i.z, sz);
     if (!e3) add1(i.w, sw);
   };
+  // The same for a wave whose 64 lanes hold 64 CONSECUTIVE quads (the main loop below), with runs merged ACROSS lanes
+  // as well (round 5): the pad of a ball_query row is the row's first index repeated to the row's end --
+  // at config 4 a third of a row, six quads in six neighbouring lanes that all add to ONE address in the same wave
+  // instruction (same-address LDS atomics serialise).  A quad that is a single run and continues the run its left
+  // neighbour ends with hands its sum to the left instead of adding it: a segmented suffix sum over the lanes of a row of
+  // sixteen (DPP row shifts; 64 entries = a row of nsample = 64), in doubles, so that what is added is what the lanes would
+  // have added one by one up to the order of a sum of doubles.
+  auto add4_merged = [&](const pp::f4& g, const pp::i4& i) {
+    const bool e1 = i.y == i.x, e2 = i.z == i.y, e3 = i.w == i.z;
+    const double sw = (double)g.w;
+    const double sz = (double)g.z + (e3 ? sw : 0.0);
+    const double sy = (double)g.y + (e2 ? sz : 0.0);
+    const double sx = (double)g.x + (e1 ? sy : 0.0);
+    const bool full = e1 & e2 & e3;
+    auto shl = [](int v, auto k_c) {  // lane l <- lane l + k of its row of sixteen; 0 beyond the row
+      constexpr int K = decltype(k_c)::value;
+      return __builtin_amdgcn_update_dpp(0, v, 0x100 + K, 0xf, 0xf, false);
+    };
+    auto shl_d = [&](double v, auto k_c) {
+      const long long b = __builtin_bit_cast(long long, v);
+      const unsigned lo = (unsigned)shl((int)(unsigned)b, k_c), hi = (unsigned)shl((int)(unsigned)(b >> 32), k_c);
+      return __builtin_bit_cast(double, (long long)(((unsigned long long)hi << 32) | lo));
+    };
+    using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+    using K4 = std::integral_constant<int, 4>; using K8 = std::integral_constant<int, 8>;
+    // cont: this quad is one run and continues the run the left neighbour (same row of sixteen) ends with
+    const int left_w = __builtin_amdgcn_update_dpp(0, i.w, 0x111, 0xf, 0xf, false);  // row_shr:1
+    const bool cont = full && (threadIdx.x & 15) != 0 && i.x == left_w;
+    // A = the sums of the quads to the right for as long as they continue this lane's last run
+    // (every shift is evaluated by ALL lanes, then selected: inside `f ? shift : 0` it would run under f's mask and read
+    //  the lanes that mask switches off -- the chain's last quad -- as zero)
+    int f = shl(cont ? 1 : 0, K1{});                    // the right neighbour continues
+    const double sx_right = shl_d(sx, K1{});
+    double A = f ? sx_right : 0.0;
+    {
+      const double a2 = shl_d(A, K1{});
+      const int f2 = shl(f, K1{});
+      A += f ? a2 : 0.0;
+      f &= f2;                                          // lanes l+1, l+2 both continue
+    }
+    {
+      const double a4 = shl_d(A, K2{});
+      const int f4 = shl(f, K2{});
+      A += f ? a4 : 0.0;
+      f &= f4;                                          // lanes l+1 .. l+4
+    }
+    {
+      const double a8 = shl_d(A, K4{});
+      const int f8 = shl(f, K4{});
+      A += f ? a8 : 0.0;
+      f &= f8;                                          // lanes l+1 .. l+8
+    }
+    {
+      const double a16 = shl_d(A, K8{});
+      A += f ? a16 : 0.0;
+    }
+    // the lane's LAST run takes A along; a continuing quad adds nothing
+    if (!cont) add1(i.x, sx + (full ? A : 0.0));
+    if (!e1) add1(i.y, sy + ((e2 & e3) ? A : 0.0));
+    if (!e2) add1(i.z, sz + (e3 ? A : 0.0));
+    if (!e3) add1(i.w, sw + A);
+  };
   if constexpr (VEC) {
     long long e = t;
     for (; e + 1024 * (U - 1) < p4; e += 1024 * U) {
@@ -951,7 +1013,7 @@ __global__ __launch_bounds__(1024) void group_points_grad_lds64_kernel(const flo
         i[u] = reinterpret_cast<const pp::i4*>(ib)[e + 1024 * u];
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) add4(g[u], i[u]);
+      for (int u = 0; u < U; ++u) add4_merged(g[u], i[u]);  // (every lane is active here: the DPP shifts see whole rows)
     }
     for (; e < p4; e += 1024) add4(reinterpret_cast<const pp::f4*>(go)[e], reinterpret_cast<const pp::i4*>(ib)[e]);
     for (long long q = (p4 << 2) + t; q < P; q += 1024) add1(ib[q], (double)go[q]);
@@ -974,7 +1036,11 @@ __global__ __launch_bounds__(1024) void group_points_grad_lds64_kernel(const flo
   }
   __syncthreads();
   float* __restrict__ gp = grad_points + ((size_t)b * C + c) * N + lo;
-  for (int k = t; k < w; k += 1024) gp[k] += (float)s_col64[k];  // accumulate: the ABI's contract
+  if (overwrite) {  // (uniform) pp_group_points_grad_out_*: every element is written once, nothing is read
+    for (int k = t; k < w; k += 1024) gp[k] = (float)s_col64[k];
+  } else {
+    for (int k = t; k < w; k += 1024) gp[k] += (float)s_col64[k];  // accumulate: the reference ABI's contract
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1508,9 +1574,20 @@ extern "C" int pp_group_points_grad_f32(const float* grad_out, const int* idx, f
                                           (long long)C * npoint * nsample, stream);
 }
 
+static int group_points_grad_launch(const float* grad_out, const int* idx, float* grad_points, int B, int C, int N,
+                                    int npoint, int nsample, long long grad_out_batch_stride, void* stream,
+                                    bool overwrite);
 extern "C" int pp_group_points_grad_strided_f32(const float* grad_out, const int* idx, float* grad_points,
                                                 int B, int C, int N, int npoint, int nsample,
                                                 long long grad_out_batch_stride, void* stream) {
+  return group_points_grad_launch(grad_out, idx, grad_points, B, C, N, npoint, nsample, grad_out_batch_stride, stream,
+                                  false);
+}
+// overwrite: grad_points need not be zero on entry -- the LDS-column form writes every element once (no read of the
+// output, no fill in front of it: 2 x 256 MB less traffic at config 4); the other forms zero it themselves first
+static int group_points_grad_launch(const float* grad_out, const int* idx, float* grad_points, int B, int C, int N,
+                                    int npoint, int nsample, long long grad_out_batch_stride, void* stream,
+                                    bool overwrite) {
   if (B < 0 || C < 0 || N < 0 || npoint < 0 || nsample < 0) return PP_EINVAL;
   const long long P = (long long)npoint * nsample;
   const long long gbs = grad_out_batch_stride;
@@ -1532,16 +1609,21 @@ extern "C" int pp_group_points_grad_strided_f32(const float* grad_out, const int
         if (e != hipSuccess) return (int)e;
         group_points_grad_lds64_kernel<8, true><<<dim3((unsigned)wgs), dim3(1024), (size_t)W * sizeof(double),
                                                   (hipStream_t)stream>>>(grad_out, idx, grad_points, B, C, N, P,
-                                                                         gbs, nsplit, W);
+                                                                         gbs, nsplit, W, overwrite ? 1 : 0);
       } else {
         const hipError_t e = pp::allow_big_lds(group_points_grad_lds64_kernel<8, false>, 152 * 1024, lds64s_ok);
         if (e != hipSuccess) return (int)e;
         group_points_grad_lds64_kernel<8, false><<<dim3((unsigned)wgs), dim3(1024), (size_t)W * sizeof(double),
                                                    (hipStream_t)stream>>>(grad_out, idx, grad_points, B, C, N, P,
-                                                                          gbs, nsplit, W);
+                                                                          gbs, nsplit, W, overwrite ? 1 : 0);
       }
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
+    }
+    if (overwrite) {  // (the forms below accumulate)
+      const hipError_t e = hipMemsetAsync(grad_points, 0, (size_t)B * C * N * sizeof(float), (hipStream_t)stream);
+      if (e != hipSuccess) return (int)e;
+      overwrite = false;
     }
     if (vec && (size_t)N * sizeof(float) <= 160 * 1024) {  // fp32 column (kept for comparison: ds_add_f32 is slow)
       static pp::DeviceFlags lds_ok;
@@ -1553,6 +1635,10 @@ extern "C" int pp_group_points_grad_strided_f32(const float* grad_out, const int
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
     }
+  }
+  if (overwrite) {
+    const hipError_t e = hipMemsetAsync(grad_points, 0, (size_t)B * C * N * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
   }
   const long long cols = (P + 255) / 256;
   const int cpb = pick_c_per_block(cols, B, C);
@@ -1698,6 +1784,28 @@ extern "C" int pp_group_points_grad_ws_f32(const float* grad_out, const int* idx
                        (hipStream_t)stream, false);
   return pp_group_points_grad_strided_f32(grad_out, idx, grad_points, B, C, N, npoint, nsample,
                                           grad_out_batch_stride, stream);
+}
+
+// the same with grad_points WRITTEN, not accumulated into: the caller passes uninitialised memory (the Python shim:
+// torch.empty instead of torch.zeros)
+extern "C" int pp_group_points_grad_out_ws_f32(const float* grad_out, const int* idx, float* grad_points, int B,
+                                               int C, int N, int npoint, int nsample,
+                                               long long grad_out_batch_stride, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+  const long long P = (long long)npoint * nsample;
+  if (B < 0 || C < 0 || N < 0 || npoint < 0 || nsample < 0) return PP_EINVAL;
+  if (B == 0 || C == 0 || N == 0) return PP_OK;
+  if (!grad_points) return PP_EINVAL;
+  if (P == 0) return (int)hipMemsetAsync(grad_points, 0, (size_t)B * C * N * sizeof(float), (hipStream_t)stream);
+  if (grad_out && idx && P <= 4LL * N && grad_out_batch_stride >= (long long)C * P &&
+      scatter_ok(B, C, P, 1, N, 0, workspace, workspace_bytes)) {  // the sorted form accumulates
+    const hipError_t e = hipMemsetAsync(grad_points, 0, (size_t)B * C * N * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return pp::ssa_run(grad_out, idx, nullptr, grad_points, B, C, P, 1, N, grad_out_batch_stride, workspace,
+                       (hipStream_t)stream, false);
+  }
+  return group_points_grad_launch(grad_out, idx, grad_points, B, C, N, npoint, nsample, grad_out_batch_stride, stream,
+                                  true);
 }
 
 extern "C" int pp_gather_backward_ws_f32(const float* grad_out, const int* idx, float* grad_points, int B,
