@@ -81,10 +81,9 @@ __global__ __launch_bounds__(kBuildThreads) void bq_build_kernel(const float* __
     return;
   }
   const int b = set;
-  pp::grid_build_set<false, VEC>(xyz + (size_t)b * N * 3, N, gs,
-                            reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
-                            reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * N, nullptr, s_cnt, nullptr,
-                            nullptr, slab, pp::kBuildSlabs);
+  pp::grid_build_set_plain<VEC>(xyz + (size_t)b * N * 3, N, gs,
+                                reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
+                                reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * N, s_cnt, slab, pp::kBuildSlabs);
 }
 
 // the grid path serves this batch element (otherwise the scan kernel does): the grid exists and the
@@ -391,7 +390,8 @@ extern "C" int pp_ball_query_ws_f32(const float* new_xyz, const float* xyz, int*
   const float radius2 = radius * radius;  // fp32, as the reference (sampling_cuda.cu:354)
   const float rpad = radius * 1.00001f + 1e-30f;
   static pp::DeviceFlags lds_ok;
-  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
+  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs) > pp::grid_build_fast_lds_bytes() ? pp::grid_build_lds_bytes(pp::kBuildSlabs)
+                                                                                                 : pp::grid_build_fast_lds_bytes();
   static pp::DeviceFlags lds_ok_vec;
   const bool vec = pp::clouds_vec_aligned(xyz, N, B) && pp::clouds_vec_aligned(new_xyz, M, B);
   hipError_t e = vec ? pp::allow_big_lds(bq_build_kernel<true>, (int)lds, lds_ok_vec) : pp::allow_big_lds(bq_build_kernel<false>, (int)lds, lds_ok);

@@ -386,7 +386,25 @@ extern "C" int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, in
   const int form = g_fps_force_v1;
   // (beyond 65536 points the minima no longer fit the registers and LDS of one CU: there the CU cluster, where the
   //  batch leaves room for one, is the faster of the two -- B=4, N=262144: 11.3 against 13.7 ms)
-  const bool cluster_first = form == 0 && N > 65536 && T == kClThreads && pick_cluster(B, N) >= 2;
+  // The cluster this device can actually keep resident (a partitioned device, a CU mask -- the members of a
+  // cluster spin on each other, so never more workgroups than stay resident at once; fewer CUs -> a smaller cluster or
+  // none).  Worked out BEFORE the choice between the cluster and the bucketed kernel (decided on the nominal
+  // cluster, a device that then could not host it fell through to the single-workgroup kernel over all points although
+  // the bucketed kernel still applied).  A kernel of ANOTHER stream holding CUs can still delay members: the waits are
+  // bounded, the kernel then leaves zeros and raises the workspace's error word (pp_furthest_sampling_status).
+  // (the cluster kernel's per-thread tie rule assumes the reference's thread count equals its point stride)
+  int cl = (form == 1 || form == 3 || T != kClThreads) ? 0 : pick_cluster(B, N);
+  if (cl >= 2 && npoint > 1) {
+    auto blocks_for = [](int r) {
+      return r <= 1 ? resident_cluster_blocks<1>() : r <= 2 ? resident_cluster_blocks<2>() : r <= 4 ? resident_cluster_blocks<4>()
+           : r <= 8 ? resident_cluster_blocks<8>() : r <= 16 ? resident_cluster_blocks<16>() : resident_cluster_blocks<32>();
+    };
+    auto r_of = [&](int c) { return (((N + c - 1) / c + kClThreads - 1) / kClThreads * kClThreads) / kClThreads; };
+    const int blocks = blocks_for(r_of(cl));
+    cl = blocks > 0 ? pick_cluster(B, N, blocks) : 0;  // (a smaller cluster means more points per thread)
+    if (cl >= 2 && (long long)8 * ((B + 7) / 8) * cl > blocks_for(r_of(cl))) cl = 0;
+  }
+  const bool cluster_first = form == 0 && N > 65536 && cl >= 2 && npoint > 1 && temp != nullptr;
   if ((form == 0 || form == 3) && !cluster_first && ppfps::bucket_applies(B, N, npoint)) {
     const size_t need = pp_furthest_sampling_workspace_bytes(B, N, npoint);
     if (workspace && workspace_bytes >= need)
@@ -397,22 +415,6 @@ extern "C" int pp_furthest_sampling_gather_f32(const float* xyz, float* temp, in
   // temp == NULL ("start every point at 1e10 and keep nothing": what furthest_point_sample does with a temp of its own)
   // is served by the bucketed kernel only; the caller then allocates one and calls again
   if (!temp) return PP_ENOTSUP;
-  // (the cluster kernel's per-thread tie rule assumes the reference's thread count equals its point stride)
-  int cl = (form == 1 || T != kClThreads) ? 0 : pick_cluster(B, N);
-  if (cl >= 2 && npoint > 1) {
-    // the members of a cluster spin on each other: never launch more workgroups than this device keeps
-    // resident at once (a partitioned device, a CU mask).  Fewer CUs -> a smaller cluster or the
-    // single-workgroup kernel.  A kernel of ANOTHER stream holding CUs can still delay members: the waits are
-    // bounded, the kernel then leaves zeros and raises the workspace's error word (pp_furthest_sampling_status).
-    auto blocks_for = [](int r) {
-      return r <= 1 ? resident_cluster_blocks<1>() : r <= 2 ? resident_cluster_blocks<2>() : r <= 4 ? resident_cluster_blocks<4>()
-           : r <= 8 ? resident_cluster_blocks<8>() : r <= 16 ? resident_cluster_blocks<16>() : resident_cluster_blocks<32>();
-    };
-    auto r_of = [&](int c) { return (((N + c - 1) / c + kClThreads - 1) / kClThreads * kClThreads) / kClThreads; };
-    const int blocks = blocks_for(r_of(cl));
-    cl = blocks > 0 ? pick_cluster(B, N, blocks) : 0;  // (a smaller cluster means more points per thread)
-    if (cl >= 2 && (long long)8 * ((B + 7) / 8) * cl > blocks_for(r_of(cl))) cl = 0;
-  }
   if (cl >= 2 && npoint > 1) {
     const size_t need = kFpsErrBytes + ring_bytes(B, N);
     if (!workspace || workspace_bytes < need) return PP_EINVAL;

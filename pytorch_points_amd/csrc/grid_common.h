@@ -1003,6 +1003,7 @@ constexpr int kFastLdsClist = kFastLdsPart + 64;
 constexpr int kFastLdsWords = kFastLdsClist + 2 * kFastCrowdMax;
 __host__ __device__ inline size_t grid_build_fast_lds_bytes() { return (size_t)kFastLdsWords * 4; }
 
+template <bool REFINE = true>
 __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref, int nr, GridSet* gs,
                                                    unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
                                                    unsigned* lds, int slab, unsigned* __restrict__ sub_start,
@@ -1011,9 +1012,12 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
                                                    unsigned* __restrict__ layers, BuildPlan& plan) {
   constexpr int KP = 16, nslab = kBuildSlabs;
   const int nchunkq = (nr + kChunk - 1) / kChunk;
-  if (nr > kFastMaxPoints || nr < 4 * kBuildThreads || (nr & 3) != 0 || tile_z == nullptr || layers == nullptr ||
-      cell_start == nullptr || sub_start == nullptr || sub_desc == nullptr || nchunkq > tz_chunks || tz_chunks > kChunkMax)
-    return 1;  // (uniform)
+  // (REFINE = false: the plain build of ball_query / three_nn / knn_points -- no second level (a cell beyond 256 + nr / 32
+  //  points marks the set useless, as the general path does), no chunk and layer tables)
+  if (nr > kFastMaxPoints || nr < 4 * kBuildThreads || (nr & 3) != 0 || cell_start == nullptr) return 1;  // (uniform)
+  if (REFINE && (tile_z == nullptr || layers == nullptr || sub_start == nullptr || sub_desc == nullptr ||
+                 nchunkq > tz_chunks || tz_chunks > kChunkMax))
+    return 1;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   unsigned* s_cnt = lds + kFastLdsCnt;
   f4* s_list = reinterpret_cast<f4*>(lds + kFastLdsList);
@@ -1041,7 +1045,7 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
     px[4 * gq + 3] = c.y; py[4 * gq + 3] = c.z; pz[4 * gq + 3] = c.w;
   }
   auto kidx = [&](int i) { return (i >> 2) * (4 * kBuildThreads) + 4 * t + (i & 3); };
-  if (t < 2 * kChunkMax) s_tz[t] = (t & 1) ? zkey(-__builtin_inff()) : zkey(__builtin_inff());
+  if (REFINE && t < 2 * kChunkMax) s_tz[t] = (t & 1) ? zkey(-__builtin_inff()) : zkey(__builtin_inff());
   if (t == 0) {
     s_ncrowd = 0u;
     s_below = 0u;
@@ -1261,7 +1265,9 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
           run += v8[u];
           mx8 = max(mx8, v8[u]);
         }
-        if (mx8 > (unsigned)kCrowd) {  // (rare) crowded cells: listed for the refinement
+        if (!REFINE) {  // (no second level: a cell this full makes the grid useless, the general path's rule)
+          if ((float)mx8 > 256.0f + (float)nr * (1.0f / 32.0f)) atomicOr(&s_ncrowd, 1u);
+        } else if (mx8 > (unsigned)kCrowd) {  // (rare) crowded cells: listed for the refinement
 #pragma unroll
           for (int u = 0; u < 8; ++u)
             if (v8[u] > (unsigned)kCrowd) {
@@ -1288,7 +1294,7 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
   } else {
     for (int c = t; c < ncs; c += kBuildThreads) cell_start[lo + c] = s_cnt[c];  // (coalesced)
   }
-  if (t < zh - zl) layers[zl + t] = s_cnt[t * gxy];
+  if (REFINE && t < zh - zl) layers[zl + t] = s_cnt[t * gxy];
   // ---- position = cell start + rank: the slab's points into the list in sorted order
   // (no branch per point: the other lanes' records go to 64 slots behind the list)
 #pragma unroll
@@ -1331,6 +1337,7 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
           }
         }
       }
+      if (!REFINE) continue;  // (no chunk table)
       zmax = wave_reduce_dpp<false>(zmax);
       nzmin = wave_reduce_dpp<false>(nzmin);
       if (lane == 0) {  // (this wave is the only writer of the slab's pair for the chunk)
@@ -1343,29 +1350,31 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
   PP_PHASE(8);
   PP_PHASE(9);
   const unsigned ncrowd = s_ncrowd;
-  if (ncrowd > (unsigned)kFastCrowdMax) return 2;  // more crowded cells than the list holds: the general path (uniform)
+  if (REFINE && ncrowd > (unsigned)kFastCrowdMax) return 2;  // more crowded cells than the list holds: the general path (uniform)
   if (t == 0 && slab == nslab - 1) {
     cell_start[ncell] = (unsigned)nr;
-    layers[gz] = (unsigned)nr;
+    if (REFINE) layers[gz] = (unsigned)nr;
   }
-  if ((t == kLayerPending || t == kLayerCursor) && slab == 0) layers[t] = 0u;
-  for (int c = t; c < 2 * tz_chunks; c += kBuildThreads) tile_z[((size_t)(c >> 1) * nslab + slab) * 2 + (c & 1)] = s_tz[c];
   bool refined = false;
-  if (ncrowd > 0) {  // (uniform) second level: the general build's refinement of this slab's crowded cells, in place
-    __threadfence_block();  // the copy-out's stores are read back
-    __syncthreads();
-    refined = true;
-    grid_refine_cells(sorted, sorted2, nullptr, nullptr, sub_start, sub_desc, reinterpret_cast<unsigned*>(s_list), s_cnt,
-                      s_box, s_clist, ncrowd);
+  if constexpr (REFINE) {
+    if ((t == kLayerPending || t == kLayerCursor) && slab == 0) layers[t] = 0u;
+    for (int c = t; c < 2 * tz_chunks; c += kBuildThreads) tile_z[((size_t)(c >> 1) * nslab + slab) * 2 + (c & 1)] = s_tz[c];
+    if (ncrowd > 0) {  // (uniform) second level: the general build's refinement of this slab's crowded cells, in place
+      __threadfence_block();  // the copy-out's stores are read back
+      __syncthreads();
+      refined = true;
+      grid_refine_cells(sorted, sorted2, nullptr, nullptr, sub_start, sub_desc, reinterpret_cast<unsigned*>(s_list), s_cnt,
+                        s_box, s_clist, ncrowd);
+    }
   }
   if (t == 0) {
-    gs->crowd[slab] = refined ? 2 : 0;
+    gs->crowd[slab] = REFINE ? (refined ? 2 : 0) : (ncrowd != 0u ? 1 : 0);
     if (slab == 0) {
       gs->minx = mnx; gs->miny = mny; gs->minz = mnz; gs->h = h; gs->invh = invh;
       gs->gx = gx; gs->gy = gy; gs->gz = gz;
       gs->useless = 0;
       gs->pad[0] = 0;
-      gs->pad[1] = 1;
+      gs->pad[1] = REFINE ? 1 : 0;
       gs->pad[2] = trimmed ? 1 : 0;
     }
   }
@@ -1385,6 +1394,26 @@ __device__ __forceinline__ void grid_build_set(const float* __restrict__ ref, in
                                                int nslab = 1) {
   grid_build_set_impl<MORTON, VEC, false>(ref, nr, gs, cell_start, sorted, inv, s_cnt, payload, sorted_payload, slab,
                                           nslab, nullptr, nullptr, nullptr, nullptr);
+}
+
+// The plain (z-major, no second level) build as the searches of ball_query / three_nn / knn_points call it: the
+// LDS-sorted path where it applies, else the general one (with the fast path's plan forced where a slab declined).
+// Dynamic LDS: max(grid_build_lds_bytes(nslab), grid_build_fast_lds_bytes()).
+template <bool VEC>
+__device__ __forceinline__ void grid_build_set_plain(const float* __restrict__ ref, int nr, GridSet* gs,
+                                                     unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
+                                                     unsigned* s_cnt, int slab, int nslab) {
+  BuildPlan plan;
+  int how = 1;
+  if constexpr (VEC) {
+    if (nslab == kBuildSlabs)
+      how = grid_build_set_fast<false>(ref, nr, gs, cell_start, sorted, s_cnt, slab, nullptr, nullptr, nullptr, nullptr, 0,
+                                       nullptr, plan);
+  }
+  if (how == 0) return;
+  __syncthreads();  // (the general path reuses the LDS the fast one was using)
+  grid_build_set_impl<false, VEC, false>(ref, nr, gs, cell_start, sorted, nullptr, s_cnt, nullptr, nullptr, slab, nslab, nullptr,
+                                         nullptr, nullptr, nullptr, nullptr, 0, nullptr, how == 2 ? &plan : nullptr);
 }
 
 // the same with the second level: crowded cells refined into sub-grids (sub_start: 2 * nr + 2 entries of this

@@ -271,10 +271,9 @@ __global__ __launch_bounds__(kBuildThreads) void kn_build_kernel(const float* __
     return;
   }
   const int b = set;
-  pp::grid_build_set<false, VEC>(p2 + (size_t)b * M * 3, M, gs,
-                            reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
-                            reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * M, nullptr, s_cnt, nullptr,
-                            nullptr, slab, pp::kBuildSlabs);
+  pp::grid_build_set_plain<VEC>(p2 + (size_t)b * M * 3, M, gs,
+                                reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
+                                reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * M, s_cnt, slab, pp::kBuildSlabs);
 }
 
 template <int KT>
@@ -467,7 +466,8 @@ extern "C" int pp_knn_ws_f32(const float* p1, const float* p2, const int* length
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
   static pp::DeviceFlags lds_ok;
-  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
+  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs) > pp::grid_build_fast_lds_bytes() ? pp::grid_build_lds_bytes(pp::kBuildSlabs)
+                                                                                                 : pp::grid_build_fast_lds_bytes();
   static pp::DeviceFlags lds_ok_vec;
   const bool vec = pp::clouds_vec_aligned(p1, N, B) && pp::clouds_vec_aligned(p2, M, B);
   hipError_t e = vec ? pp::allow_big_lds(kn_build_kernel<true>, (int)lds, lds_ok_vec) : pp::allow_big_lds(kn_build_kernel<false>, (int)lds, lds_ok);

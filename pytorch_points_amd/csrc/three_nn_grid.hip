@@ -61,10 +61,9 @@ __global__ __launch_bounds__(kBuildThreads) void tn_build_kernel(const float* __
     return;
   }
   const int b = set;
-  pp::grid_build_set<false, VEC>(known + (size_t)b * M * 3, M, gs,
-                            reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
-                            reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * M, nullptr, s_cnt, nullptr,
-                            nullptr, slab, pp::kBuildSlabs);
+  pp::grid_build_set_plain<VEC>(known + (size_t)b * M * 3, M, gs,
+                                reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)b * (kGridCells + 1),
+                                reinterpret_cast<pp::f4*>(ws + L.sorted) + (size_t)b * M, s_cnt, slab, pp::kBuildSlabs);
 }
 
 // (d, k) enters the ascending triple if it is lexicographically smaller than an entry -- the reference's strict `<` in
@@ -201,7 +200,8 @@ extern "C" int pp_three_nn_ws_f32(const float* unknown, const float* known, floa
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
   static pp::DeviceFlags lds_ok;
-  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs);
+  const size_t lds = pp::grid_build_lds_bytes(pp::kBuildSlabs) > pp::grid_build_fast_lds_bytes() ? pp::grid_build_lds_bytes(pp::kBuildSlabs)
+                                                                                                 : pp::grid_build_fast_lds_bytes();
   static pp::DeviceFlags lds_ok_vec;
   const bool vec = pp::clouds_vec_aligned(unknown, N, B) && pp::clouds_vec_aligned(known, M, B);
   hipError_t e = vec ? pp::allow_big_lds(tn_build_kernel<true>, (int)lds, lds_ok_vec) : pp::allow_big_lds(tn_build_kernel<false>, (int)lds, lds_ok);
