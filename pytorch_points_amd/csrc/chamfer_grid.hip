@@ -199,10 +199,9 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   // round 5: unlabeled sets of config 2's class (one register chunk, aligned) are sorted through the LDS, a slab owning
   // whole z-layers (grid_common.h: grid_build_set_fast); what that path declines takes the general one, with its plan
   // forced where the other slabs of the set may have used it
-  pp::BuildPlan plan;
   int how = 1;
   if constexpr (VEC) {
-    if (!labeled && fast) how = pp::grid_build_set_fast(ref, nr, gset, cstart, sorted, s_cnt, slab, sub_start, sub_desc, sorted2, tz, L.chunks, layers, plan);
+    if (!labeled && fast) how = pp::grid_build_set_fast(ref, nr, gset, cstart, sorted, s_cnt, slab, sub_start, sub_desc, sorted2, tz, L.chunks, layers);
   }
   if (how == 0) return;
   __syncthreads();  // (the general path reuses the LDS the fast one was using)
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
       ref, nr, gset, cstart, sorted, nullptr, s_cnt, lab,
       labeled ? reinterpret_cast<float*>(ws + L.slab) + set_point_offset(b, dir, N, M) : nullptr, slab, pp::kBuildSlabs,
       sub_start, sub_desc, sorted2, labeled ? reinterpret_cast<float*>(ws + L.slab2) + set_point_offset(b, dir, N, M) : nullptr,
-      tz, L.chunks, layers, how == 2 ? &plan : nullptr);
+      tz, L.chunks, layers, how == 2 ? reinterpret_cast<const pp::BuildPlan*>(s_cnt + pp::kFastLdsPlan) : nullptr);
 }
 
 // Stages B and C (cubes of Chebyshev radius 1 and 2 around the query's cell) for the queries stage A left

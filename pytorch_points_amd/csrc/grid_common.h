@@ -424,6 +424,10 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
                                                float* __restrict__ payload2, int* __restrict__ tile_z = nullptr,
                                                int tz_chunks = 0, unsigned* __restrict__ layers = nullptr,
                                                const BuildPlan* forced = nullptr) {
+  // (`forced` points into LDS -- grid_build_set_fast leaves the plan there, behind everything this function uses of the
+  //  dynamic LDS -- and is read where it is used.  As a local of the calling kernel the plan lived in SCRATCH memory, its
+  //  address taken: the fast path's eleven stores to it were 11 MB of write traffic per build at config 2; by value it
+  //  cost the kernel 80 spilled registers)
   __shared__ unsigned s_part[kBuildThreads];
   __shared__ int s_tz[REFINE ? 2 * kChunkMax : 2];  // chunk table of this slab: (min, max) z keys
   const int nchunkq = (nr + kChunk - 1) / kChunk;
@@ -1000,7 +1004,9 @@ constexpr int kFastLdsTz = kFastLdsList + (kFastCap + 64) * 4;  // (+ 64 records
 constexpr int kFastLdsBox = kFastLdsTz + 2 * kChunkMax;
 constexpr int kFastLdsPart = kFastLdsBox + (kBuildThreads / 64) * 16;
 constexpr int kFastLdsClist = kFastLdsPart + 64;
-constexpr int kFastLdsWords = kFastLdsClist + 2 * kFastCrowdMax;
+constexpr int kFastLdsPlan = kFastLdsClist + 2 * kFastCrowdMax;  // a BuildPlan for the general path (return value 2)
+constexpr int kFastLdsWords = kFastLdsPlan + 16;
+static_assert(sizeof(BuildPlan) <= 16 * 4, "");
 __host__ __device__ inline size_t grid_build_fast_lds_bytes() { return (size_t)kFastLdsWords * 4; }
 
 template <bool REFINE = true>
@@ -1009,7 +1015,7 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
                                                    unsigned* lds, int slab, unsigned* __restrict__ sub_start,
                                                    SubGrid* __restrict__ sub_desc, f4* __restrict__ sorted2,
                                                    int* __restrict__ tile_z, int tz_chunks,
-                                                   unsigned* __restrict__ layers, BuildPlan& plan) {
+                                                   unsigned* __restrict__ layers) {
   constexpr int KP = 16, nslab = kBuildSlabs;
   const int nchunkq = (nr + kChunk - 1) / kChunk;
   // (REFINE = false: the plain build of ball_query / three_nn / knn_points -- no second level (a cell beyond 256 + nr / 32
@@ -1253,8 +1259,11 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
       const unsigned wbase = wave == 0 ? 0u : (unsigned)__builtin_amdgcn_readlane((int)tot16, (wave - 1) & 15);
       own = (unsigned)__builtin_amdgcn_readlane((int)tot16, 15);
       running = s_below;  // points of the slabs below: where this slab's first cell starts
-      plan.mnx = mnx; plan.mny = mny; plan.mnz = mnz; plan.h = h; plan.invh = invh;
-      plan.gx = gx; plan.gy = gy; plan.gz = gz; plan.cell_lo = lo; plan.cell_hi = lo + ncs; plan.trimmed = trimmed ? 1 : 0;
+      if (t == 0) {  // the plan, for the general path should this slab need it (LDS, behind everything that path uses)
+        BuildPlan* plan = reinterpret_cast<BuildPlan*>(lds + kFastLdsPlan);
+        plan->mnx = mnx; plan->mny = mny; plan->mnz = mnz; plan->h = h; plan->invh = invh;
+        plan->gx = gx; plan->gy = gy; plan->gz = gz; plan->cell_lo = lo; plan->cell_hi = lo + ncs; plan->trimmed = trimmed ? 1 : 0;
+      }
       if (own > (unsigned)kFastCap) return 2;  // more points than the list holds: the general path sorts this slab (uniform)
       unsigned run = running + wbase + incl - sum;
       if (c0 < ncs) {
@@ -1403,17 +1412,17 @@ template <bool VEC>
 __device__ __forceinline__ void grid_build_set_plain(const float* __restrict__ ref, int nr, GridSet* gs,
                                                      unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
                                                      unsigned* s_cnt, int slab, int nslab) {
-  BuildPlan plan;
   int how = 1;
   if constexpr (VEC) {
     if (nslab == kBuildSlabs)
       how = grid_build_set_fast<false>(ref, nr, gs, cell_start, sorted, s_cnt, slab, nullptr, nullptr, nullptr, nullptr, 0,
-                                       nullptr, plan);
+                                       nullptr);
   }
   if (how == 0) return;
-  __syncthreads();  // (the general path reuses the LDS the fast one was using)
+  __syncthreads();  // (the general path reuses the LDS the fast one was using; the plan is in place)
   grid_build_set_impl<false, VEC, false>(ref, nr, gs, cell_start, sorted, nullptr, s_cnt, nullptr, nullptr, slab, nslab, nullptr,
-                                         nullptr, nullptr, nullptr, nullptr, 0, nullptr, how == 2 ? &plan : nullptr);
+                                         nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                                         how == 2 ? reinterpret_cast<const BuildPlan*>(s_cnt + kFastLdsPlan) : nullptr);
 }
 
 // the same with the second level: crowded cells refined into sub-grids (sub_start: 2 * nr + 2 entries of this

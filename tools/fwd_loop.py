@@ -10,6 +10,9 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 L = _lib.lib()
 setq = L.pp_debug_set_nmdistance_tile; setq.argtypes = [ctypes.c_int]; setq.restype = None
 setq(mode)
+import os
+if os.environ.get('PP_BUILD_GENERAL') == '1':   # the general build instead of the LDS-sorted one (A/B of their counters)
+    sb = L.pp_debug_set_nmdistance_build; sb.argtypes = [ctypes.c_int]; sb.restype = None; sb(1)
 x1 = torch.from_numpy(S.unit_sphere(0, B, N)).to(dev); x2 = torch.from_numpy(S.unit_sphere(1, B, N)).to(dev)
 d1 = torch.empty(B, N, device=dev); d2 = torch.empty(B, N, device=dev)
 i1 = torch.empty(B, N, dtype=torch.int32, device=dev); i2 = torch.empty(B, N, dtype=torch.int32, device=dev)
