@@ -1056,6 +1056,10 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
     s_ncrowd = 0u;
     s_below = 0u;
   }
+  // the bitmap and every counter a slab can have, zeroed while the points are on their way (the first round of the count
+  // then starts without a zeroing phase and its barrier: the box's barrier lies in between)
+  s_occ[t] = 0u;
+  for (int c = 4 * t; c < kFastCells; c += 4 * kBuildThreads) *reinterpret_cast<uint4*>(&s_cnt[c]) = make_uint4(0u, 0u, 0u, 0u);
   // ---- planning 1: bounding box and moments (the general path's arithmetic; dead groups repeat point 0: no effect on the
   // box, and they are kept out of the sums)
   float mnx = __builtin_inff(), mny = mnx, mnz = mnx, mxx = -mnx, mxy = -mnx, mxz = -mnx;
@@ -1215,11 +1219,13 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
       lo = (gz * slab / nslab) * gxy;
       ncs = (gz * (slab + 1) / nslab) * gxy - lo;
       const int nwords = (gxy * gz + 31) / 32;
-      if (t < nwords) s_occ[t] = 0u;  // (<= 1024 words)
-      for (int c = 4 * t; c < ((ncs + 7) & ~7); c += 4 * kBuildThreads)  // (to a multiple of eight: the scan reads whole octets)
-        *reinterpret_cast<uint4*>(&s_cnt[c]) = make_uint4(0u, 0u, 0u, 0u);
-      if (t == 0) s_below = 0u;
-      __syncthreads();
+      if (round > 0) {  // (the first round finds the bitmap and the counters zeroed at the kernel's start, behind the box's barrier)
+        if (t < nwords) s_occ[t] = 0u;  // (<= 1024 words)
+        for (int c = 4 * t; c < ((ncs + 7) & ~7); c += 4 * kBuildThreads)  // (to a multiple of eight: the scan reads whole octets)
+          *reinterpret_cast<uint4*>(&s_cnt[c]) = make_uint4(0u, 0u, 0u, 0u);
+        if (t == 0) s_below = 0u;
+        __syncthreads();
+      }
       PP_PHASE(4);
       count_pass(round < kRounds);
       __syncthreads();  // the bitmap and the counters are complete
