@@ -108,10 +108,13 @@ using pp::kGridMax;
 using pp::kBuildThreads;
 
 constexpr float kBoundSlack = 0.999f;
+// entries between two sets' cell tables: kGridCells + 1 used, padded to a multiple of four so that every set's table is
+// 16-byte aligned (the LDS-sorted build copies a slab's 8192 entries out in 16-byte pieces)
+constexpr int kCellStride = kGridCells + 4;
 
 // Workspace layout (bytes), S = 2*B sets, T = B*(N+M) points:
 //   [0, 64*S)                      GridSet[S]
-//   [.., +4*(kGridCells+1)*S)      unsigned cell_start[S][kGridCells+1]
+//   [.., +4*kCellStride*S)         unsigned cell_start[S][kCellStride]   (kGridCells + 1 used)
 //   [.., +16*T)                    float4 sorted[T]   (x, y, z, original index bits)
 //   [.., +4*(2*T + 2*S))           unsigned sub_start[...]   second level: cell tables of the crowded cells,
 //                                  the table of the cell whose points start at `start` of set s at 2*(set offset + start) + 2*s
@@ -133,7 +136,7 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   const size_t S = (size_t)2 * B, T = (size_t)B * ((size_t)N + M);
   L.sets = 0;
   L.cell_start = L.sets + ((64 * S + 255) / 256) * 256;
-  L.sorted = L.cell_start + ((4 * (size_t)(kGridCells + 1) * S + 255) / 256) * 256;
+  L.sorted = L.cell_start + ((4 * (size_t)kCellStride * S + 255) / 256) * 256;
   L.sub_start = L.sorted + 16 * T;
   L.sub_desc = L.sub_start + ((4 * (2 * T + 2 * S) + 255) / 256) * 256;
   L.sorted2 = L.sub_desc + ((32 * (T / pp::kCrowd + 2 * S) + 255) / 256) * 256;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
   const Layout L = make_layout(B, N, M, labeled);
   const float* __restrict__ lab = labeled ? (dir ? label1 : label2) + (size_t)b * nr : nullptr;
   GridSet* gset = reinterpret_cast<GridSet*>(ws + L.sets) + set;
-  unsigned* cstart = reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
+  unsigned* cstart = reinterpret_cast<unsigned*>(ws + L.cell_start) + (size_t)set * kCellStride;
   pp::f4* sorted = reinterpret_cast<pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
   unsigned* sub_start = reinterpret_cast<unsigned*>(ws + L.sub_start) + set_sub_start_offset(b, dir, N, M);
   pp::SubGrid* sub_desc = reinterpret_cast<pp::SubGrid*>(ws + L.sub_desc) + set_sub_desc_offset(b, dir, N, M);
@@ -1327,7 +1330,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     return;
   }
   const unsigned* __restrict__ cell_start =
-      reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
+      reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * kCellStride;
   const pp::f4* __restrict__ sorted =
       reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
   const float* __restrict__ slab =
@@ -2114,7 +2117,7 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   if (lean_ok) {
     const float qx = qq.x, qy = qq.y, qz = qq.z;
     const unsigned* __restrict__ cell_start =
-        reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * (kGridCells + 1);
+        reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * kCellStride;
     const pp::f4* __restrict__ sorted = reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
     const float inf = __builtin_inff();
     const int gx1 = __builtin_amdgcn_readfirstlane(g.gx - 1), gy1 = __builtin_amdgcn_readfirstlane(g.gy - 1),

@@ -990,6 +990,9 @@ __device__ __forceinline__ unsigned wave_scan_u32_dpp(unsigned v) {
 // crowded cells than its list holds.
 // Flat grids (gz < kFastMinLayers) and degenerate sets are not started at all (every slab agrees: uniform data).
 // Returns 0 = done, 1 = not applicable (general path, unforced), 2 = general path with `plan` forced.
+#ifndef PP_BUILD_STAGE_MASKED
+#define PP_BUILD_STAGE_MASKED 1  // the staging writes under the lanes' own mask (a quarter of the lanes hold a point of the slab:
+#endif                         // 0.3 us less than every lane writing, the others to dump slots)
 constexpr int kFastCap = 6144;       // points per pass (16-byte records in LDS: 96 KiB, the refinement's counters afterwards)
 constexpr int kFastCells = 8192;     // cells per slab: ceil(32 / 4) layers of 32 x 32
 constexpr int kFastMinLayers = 8;
@@ -1315,10 +1318,18 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
 #pragma unroll
   for (int i = 0; i < KP; ++i) {
     const bool mine = key[i] != ~0u;
+#if PP_BUILD_STAGE_MASKED
+    if (mine) {
+      const unsigned pos = s_cnt[key[i] & 0xffffu] + (key[i] >> 16) - running;
+      f4 r = {px[i], py[i], pz[i], __int_as_float(kidx(i))};
+      s_list[pos] = r;
+    }
+#else
     const unsigned start = s_cnt[mine ? (key[i] & 0xffffu) : 0u];
     const unsigned pos = mine ? start + (key[i] >> 16) - running : (unsigned)(kFastCap + lane);
     f4 r = {px[i], py[i], pz[i], __int_as_float(kidx(i))};
     s_list[pos] = r;
+#endif
   }
   __syncthreads();
   PP_PHASE(7);
