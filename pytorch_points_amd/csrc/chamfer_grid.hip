@@ -2300,12 +2300,8 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
         //  extent is an estimate made from the chunk table -- leaves the query to the list kernel)
         const bool inside = __all(!rok || (rs >= tb0 && re <= tb0 + ns));
         const unsigned len = rok ? re - rs : 0u;
-        unsigned incl = len;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          const unsigned o = __shfl_up(incl, off);
-          if (lane >= off) incl += o;
-        }
+        const unsigned incl = pp::wave_scan_u32_dpp(len);  // (DPP: the shuffles were a chain of ds_bpermute round trips in a
+                                                            //  tile's tail; lanes 9.. hold no row)
         const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 15);
         const unsigned excl = incl - len, shift = (rs - tb0) - excl;  // candidate k of row r: image[k + shift_r]
         unsigned long long key = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffu;  // (+inf, no index)
@@ -2325,12 +2321,7 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
             key = cand < key ? cand : key;  // (a NaN distance -- bits above +inf -- is never taken)
           }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
-          const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-          key = o < key ? o : key;
-        }
+        key = pp::wave_min_u64_dpp(key);
         const float kbest = __uint_as_float((unsigned)(key >> 32));
         const int kidx = (int)(unsigned)key;
         const float wfx = (w.x - g.minx) * g.invh - (float)wcx, wfy = (w.y - g.miny) * g.invh - (float)wcy,

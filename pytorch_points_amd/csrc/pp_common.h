@@ -175,6 +175,31 @@ __device__ __forceinline__ void wave_reduce6_dpp(float (&v)[6]) {
     asm volatile(PP_DPP6_ROWS("v_max_f32_dpp") "s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
 }
 
+// Wave-wide minimum of an unsigned word through DPP (VALU-rate; __shfl_xor is six dependent ds_bpermute round trips):
+// the result as a wave-uniform value.  Every lane must be active.
+__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v) {
+#define PP_MIN_STEP(CTRL, ROWS)                                                                  \
+  {                                                                                               \
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xf, false); \
+    v = o < v ? o : v;                                                                            \
+  }
+  PP_MIN_STEP(0x111, 0xf)  // row_shr:1
+  PP_MIN_STEP(0x112, 0xf)  // row_shr:2
+  PP_MIN_STEP(0x114, 0xf)  // row_shr:4
+  PP_MIN_STEP(0x118, 0xf)  // row_shr:8
+  PP_MIN_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+  PP_MIN_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2, 3
+#undef PP_MIN_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// ... of 64-bit keys (high word first; the low words only decide among the lanes that hold the smallest high word)
+__device__ __forceinline__ unsigned long long wave_min_u64_dpp(unsigned long long key) {
+  const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+  const unsigned mh = wave_min_u32_dpp(hi);
+  const unsigned ml = wave_min_u32_dpp(hi == mh ? lo : 0xffffffffu);
+  return ((unsigned long long)mh << 32) | ml;
+}
+
 __device__ __forceinline__ int wave_id_uniform() {
   return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
