@@ -550,6 +550,29 @@ def test_group_points_grad_ball_rows_and_split_columns(cuda, group_grad_path, b,
     assert np.allclose(got.cpu().numpy(), e, rtol=1e-5, atol=1e-4)   # the oracle sums in fp32 too
 
 
+@pytest.mark.parametrize("b,c,n,npoint,ns", [(2, 6, 4096, 512, 64), (3, 5, 1000, 77, 9), (1, 4, 30000, 2048, 32), (2, 3, 600, 10, 4)])
+def test_group_points_grad_accumulating_and_overwriting_abi(cuda, b, c, n, npoint, ns):
+    """the two contracts of the C ABI side by side: pp_group_points_grad_ws_f32 ACCUMULATES into the caller's tensor (the
+    reference's: a zero-filled output it adds into, _ext/sampling.cpp:148-150), pp_group_points_grad_out_ws_f32 WRITES every
+    element (what the shim calls on uninitialised memory since round 5) -- on every launch path the sizes select"""
+    from pytorch_points_amd import _lib
+    idx = _t((S.uniform01(47, (b, npoint, ns)).reshape(b, npoint, ns) * n).astype(np.int32), cuda)
+    idx[:, 0, :] = n - 1                       # a run across a whole row
+    go = _t(S.normal(48, (b, c, npoint, ns)), cuda)
+    ref = torch.zeros(b, c, n, device=cuda, dtype=torch.float64)
+    ref.scatter_add_(2, idx.long().reshape(b, 1, -1).expand(-1, c, -1), go.double().reshape(b, c, -1))
+    L = _lib.lib()
+    acc = torch.full((b, c, n), 3.0, device=cuda)
+    out = torch.full((b, c, n), float("nan"), device=cuda)       # must be overwritten everywhere
+    with _lib.on_device(cuda) as stream:
+        args = lambda t: (_lib.ptr(go), _lib.ptr(idx), _lib.ptr(t), b, c, n, npoint, ns, c * npoint * ns, None, 0, stream)
+        _lib.check(L.pp_group_points_grad_ws_f32(*args(acc)), "accumulate")
+        _lib.check(L.pp_group_points_grad_out_ws_f32(*args(out)), "overwrite")
+    torch.cuda.synchronize()
+    assert torch.allclose(acc.double(), ref + 3.0, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 4, 8, 104, 108, 116, 132, 516, 616])
 @pytest.mark.parametrize("b,c,n,npoint,ns", [(9, 5, 1024, 600, 16), (2, 4, 16384, 2048, 64), (1, 7, 500, 4099, 32),
                                              (3, 9, 10000, 1024, 64), (2, 6, 20480, 512, 64), (2, 13, 4096, 2048, 32), (1, 16, 65536, 4096, 32),
