@@ -30,6 +30,20 @@ int ball_query_scan_unusable(const float* new_xyz, const float* xyz, int* idx, i
                              float radius, int nsample, const GridSet* sets, hipStream_t s);
 }  // namespace pp
 
+#ifdef PP_BQ_PROBE
+// diagnostic build only (tools/bq_phases.py): the 100 MHz clock at the step boundaries of every wave of the query kernel
+__device__ unsigned long long g_bqphase[16384][8];
+extern "C" int pp_debug_read_bq_phases(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bqphase), sizeof(g_bqphase)); }
+#define PP_BQ_MARK(n)                                                                                   \
+  do {                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_bqphase[blockIdx.x][n] = __builtin_amdgcn_s_memrealtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  } while (0)
+#else
+#define PP_BQ_MARK(n)
+#endif
+
 namespace {
 
 using pp::GridSet;
@@ -138,11 +152,13 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
   const int ci = lane & (G - 1), sub = lane / G;  // centre of the tile; which of its LPC lanes
   const int m0 = tile * G;
   const bool valid = m0 + ci < M;
+  PP_BQ_MARK(0);
   const pp::f4 q = csorted[valid ? m0 + ci : M - 1];
   const int qorig = __float_as_int(q.w);  // the centre's row in the output
 
-  for (int w = lane; w < ncw; w += 64) s_cell[w] = 0;
-  for (int w = lane; w < npw; w += 64) s_pt[w] = 0;
+  // (16-byte stores: both bitmaps start 16-byte aligned and are padded to whole quads of words)
+  for (int w = 4 * lane; w < ((ncw + 3) & ~3); w += 256) *reinterpret_cast<uint4*>(&s_cell[w]) = make_uint4(0u, 0u, 0u, 0u);
+  for (int w = 4 * lane; w < ((npw + 3) & ~3); w += 256) *reinterpret_cast<uint4*>(&s_pt[w]) = make_uint4(0u, 0u, 0u, 0u);
   if (lane == 0) {
     s_rng[0] = ncw;
     s_rng[1] = -1;
@@ -158,8 +174,9 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
     const int z0 = cell_coord(below(q.z - rpad), g.minz, g.invh, g.gz), z1 = cell_coord(above(q.z + rpad), g.minz, g.invh, g.gz);
     const unsigned long long run = (2ull << (x1 - x0)) - 1ull;  // x1 - x0 + 1 <= 8 ones
     const int ny = y1 - y0 + 1, nzy = (z1 - z0 + 1) * ny;
+    const unsigned inv_ny = 65536u / (unsigned)ny + 1u;  // t / ny for t < 64, ny <= 7 by a multiplication (exact there)
     for (int t = sub; t < nzy; t += LPC) {  // the centre's rows, dealt to its LPC lanes
-      const int zz = t / ny;
+      const int zz = (int)(((unsigned)t * inv_ny) >> 16);
       const int c = ((z0 + zz) * g.gy + y0 + (t - zz * ny)) * g.gx + x0;
       const unsigned long long bits = run << (c & 31);
       atomicOr(&s_cell[c >> 5], (unsigned)bits);
@@ -169,6 +186,7 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
     atomicMax(&s_rng[1], ((z1 * g.gy + y1) * g.gx + x1) >> 5);
   }
   __syncthreads();
+  PP_BQ_MARK(1);
   // 2. points of the marked cells.  The non-empty bitmap words are first compacted into a list so
   // that the lanes share them evenly; a run of marked cells is contiguous in `sorted`.
   int nwords = 0;
@@ -202,18 +220,25 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
+  PP_BQ_MARK(2);
   // 3. ranks: a lane owns a contiguous chunk of bitmap words
   const int per = (npw + 63) >> 6;
   const int w0 = min(npw, lane * per), w1 = min(npw, w0 + per);
-  int mine = 0;
-  for (int w = w0; w < w1; ++w) mine += __builtin_popcount(s_pt[w]);
-  int incl = mine;
+  // (round 5: a lane's words are read ONCE, all loads in flight -- up to eight of them, N <= 16384 -- and kept in
+  //  registers for the passes below; the prefix sum over the lanes through DPP instead of six ds_bpermute round trips)
+  constexpr int kPw = 8;
+  unsigned pw[kPw];
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
+  for (int i = 0; i < kPw; ++i) pw[i] = (i < per && w0 + i < w1) ? s_pt[w0 + i] : 0u;
+  int mine = 0;
+  if (per <= kPw) {  // (uniform)
+#pragma unroll
+    for (int i = 0; i < kPw; ++i) mine += __builtin_popcount(pw[i]);
+  } else {
+    for (int w = w0; w < w1; ++w) mine += __builtin_popcount(s_pt[w]);
   }
-  const int total = __shfl(incl, 63);
+  const int incl = (int)pp::wave_scan_u32_dpp((unsigned)mine);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
   const int mybase = incl - mine;
 
   IT* myrow = s_rows + (size_t)ci * stride;
@@ -225,12 +250,11 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
     const int ncand = min(kBqCap, total - base);
     // 3a. indices of the candidates of this pass, ascending
     int r = mybase;
-    for (int w = w0; w < w1 && r < base + kBqCap; ++w) {
-      unsigned bits = s_pt[w];
+    auto emit = [&](unsigned bits, int w) {
       const int pc = __builtin_popcount(bits);
       if (r + pc <= base) {
         r += pc;
-        continue;
+        return;
       }
       while (bits) {
         const int bit = __builtin_ctz(bits);
@@ -238,8 +262,16 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
         if (r >= base && r < base + kBqCap) s_cid[r - base] = w * 32 + bit;
         ++r;
       }
+    };
+    if (per <= kPw) {  // (uniform) from the registers
+#pragma unroll
+      for (int i = 0; i < kPw; ++i)
+        if (pw[i] != 0u && r < base + kBqCap) emit(pw[i], w0 + i);
+    } else {
+      for (int w = w0; w < w1 && r < base + kBqCap; ++w) emit(s_pt[w], w);
     }
     __syncthreads();
+    if (base == 0) PP_BQ_MARK(3);
     // 3b. coordinates; the tail up to a multiple of 32 gets +inf (never in radius)
     const int padded = (ncand + 31) & ~31;
     for (int c = lane; c < padded; c += 256) {
@@ -266,6 +298,7 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
       }
     }
     __syncthreads();
+    if (base == 0) PP_BQ_MARK(4);
     // 4. ordered scan.  Lane `sub` of a centre takes the sub-th segment of the staged candidates, 32
     // at a time: the in-radius flags are shifted into a mask (first candidate of the block ends up
     // in bit 31).  The hit counts of the LPC lanes give each its offset in the row; then the set
@@ -287,8 +320,9 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
           // (two candidates per instruction: the packed forms give dist3's bits)
           const pp::f2 dA = pp::dist3_pk(q.x, q.y, q.z, X.xy, Y.xy, Z.xy), dB = pp::dist3_pk(q.x, q.y, q.z, X.zw, Y.zw, Z.zw);
           const float d0 = dA.x, d1 = dA.y, d2 = dB.x, d3 = dB.y;
-          // hits = 2 * hits + (d < r^2), four times
-          asm volatile(
+          // hits = 2 * hits + (d < r^2), four times (a pure function of its operands: not volatile, so that the
+          // compiler may issue the next groups' LDS reads ahead of it)
+          asm(
               "v_cmp_lt_f32 vcc, %1, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
               "v_cmp_lt_f32 vcc, %2, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
               "v_cmp_lt_f32 vcc, %3, %5\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
@@ -323,22 +357,34 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
     __syncthreads();
   }
   __syncthreads();
+  PP_BQ_MARK(5);
   // 5. rows to the centres' original positions; slot >= count: the pad (first hit, 0 if none)
   if (!valid) cnt = 0;
   const int first = cnt > 0 ? (int)myrow[0] : 0;
   const int nrows = min(G, M - m0);
   const int total_out = nrows * nsample;
   int* __restrict__ gout = idx + (size_t)b * M * nsample;
-  for (int f0 = 0; f0 < total_out; f0 += 64) {  // uniform trip count: a shuffle needs its source lane active
+  // (round 5: a row's count, pad and destination are left in LDS by the row's first lane and read from there -- three
+  //  ds_bpermute round trips per output word before, sixteen output words per lane)
+  int* s_rowinfo = reinterpret_cast<int*>(s_raw);  // [G][3] at the start of the staging area: the candidates have been scanned
+  if (sub == 0) {
+    s_rowinfo[3 * ci] = cnt;
+    s_rowinfo[3 * ci + 1] = first;
+    s_rowinfo[3 * ci + 2] = qorig;
+  }
+  __syncthreads();
+  const bool pow2 = (nsample & (nsample - 1)) == 0;  // (uniform) a shift instead of a division per output word
+  const int lg = __builtin_ctz((unsigned)nsample);
+#pragma unroll 4
+  for (int f0 = 0; f0 < total_out; f0 += 64) {
     const int f = min(f0 + lane, total_out - 1);
-    const int row = f / nsample;
+    const int row = pow2 ? (f >> lg) : f / nsample;
     const int slot = f - row * nsample;
-    const int rc = __shfl(cnt, row);
-    const int rf = __shfl(first, row);
-    const int ro = __shfl(qorig, row);
+    const int rc = s_rowinfo[3 * row], rf = s_rowinfo[3 * row + 1], ro = s_rowinfo[3 * row + 2];
     const int v = slot < rc ? (int)s_rows[(size_t)row * stride + slot] : rf;
     if (f0 + lane < total_out) gout[(size_t)ro * nsample + slot] = v;
   }
+  PP_BQ_MARK(6);
 }
 
 }  // namespace
