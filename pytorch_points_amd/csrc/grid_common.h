@@ -1430,11 +1430,13 @@ __device__ __forceinline__ void grid_build_set_plain(const float* __restrict__ r
                                                      unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
                                                      unsigned* s_cnt, int slab, int nslab) {
   int how = 1;
+#ifndef PP_PLAIN_GENERAL  // (A/B builds: -DPP_PLAIN_GENERAL keeps the general path)
   if constexpr (VEC) {
     if (nslab == kBuildSlabs)
       how = grid_build_set_fast<false>(ref, nr, gs, cell_start, sorted, s_cnt, slab, nullptr, nullptr, nullptr, nullptr, 0,
                                        nullptr);
   }
+#endif
   if (how == 0) return;
   __syncthreads();  // (the general path reuses the LDS the fast one was using; the plan is in place)
   grid_build_set_impl<false, VEC, false>(ref, nr, gs, cell_start, sorted, nullptr, s_cnt, nullptr, nullptr, slab, nslab, nullptr,
