@@ -419,8 +419,25 @@ constexpr int kGroupBatch = 256;  // candidates per LDS batch of wave_group_sear
 #define PP_BLIND_GROUP 0.25f
 #endif
 constexpr float kBlindGroup = PP_BLIND_GROUP;
-constexpr int kSerialMax = 24;  // open lanes of a wave from which the whole-wave cubes are skipped for the group search
-constexpr int kLaneStageMin = 6;  // open lanes of a wave from which the cubes are searched a lane per query
+#ifndef PP_SERIAL_MAX
+#define PP_SERIAL_MAX 24
+#endif
+#ifndef PP_LANE_STAGE_MIN
+#define PP_LANE_STAGE_MIN 6
+#endif
+#ifndef PP_LANE_BALL
+#define PP_LANE_BALL 1
+#endif
+#ifndef PP_BALL_MIN
+#define PP_BALL_MIN 6
+#endif
+#ifndef PP_BALL_RMAX
+#define PP_BALL_RMAX 2.5f
+#endif
+constexpr float kBallRmax = PP_BALL_RMAX;  // cells: the farthest candidate whose ball is walked (a box of at most 6 x 6 rows)
+constexpr int kBallMin = PP_BALL_MIN;  // lanes with a candidate from which the ball around it is walked a lane per query
+constexpr int kSerialMax = PP_SERIAL_MAX;  // open lanes of a wave from which the whole-wave cubes are skipped for the group search
+constexpr int kLaneStageMin = PP_LANE_STAGE_MIN;  // open lanes of a wave from which the cubes are searched a lane per query
 
 // distance (in cells) from a query at position f inside cell c to the nearer face of its 2-cell block along one
 // axis that has grid beyond it (s = -1: the block is cells c-1, c; +1: c, c+1; beyond the grid there is nothing)
@@ -1255,6 +1272,103 @@ __device__ __attribute__((noinline)) Found lane_cube_search(const GridSet g, con
   return o;
 }
 
+// Round 5 -- the BALL around a query that already holds a candidate (its block was not empty, only too small to settle
+// it), a lane per query.  The cubes above know nothing of the best distance: radius 1 walks 27 cells, eight of them again,
+// and where it does not settle -- the sparse part of a cloud of mixed dimension: the points inside an object beside its
+// faces -- radius 2 walks 125, the 27 again.  A candidate at distance d makes everything beyond d irrelevant: only the
+// rows (y, z) whose slab lies within d of the query can matter, and in such a row only the cells within what is left of
+// d along x.  The rows of the box of cells around the ball, four at a time like the cubes; a row or a cell is passed
+// over by the rule that settles a query everywhere else in this file -- (its distance)^2 * kBoundSlack > best, the
+// distance to a rim cell measured as if the cell went on for ever outwards (it holds what was clamped into it) -- with
+// the best distance as it stands at that moment.  What is left when the rows are through is EXACT: no second stage.
+// A lane gives up (and is left to the stages after the cubes, with what it has found) if the box has more than
+// kBallMaxRows rows or four rows hold more than kLaneCubeMaxGroups groups.  aux: 1 settled, 2 gave up, 0 not active.
+constexpr int kBallMaxRows = 36;
+template <bool LAB, int W>
+__device__ __attribute__((noinline)) Found lane_ball_search(const GridSet g, const unsigned* __restrict__ cell_start,
+                                                            const pp::f4* __restrict__ sorted,
+                                                            const float* __restrict__ slab, float qx, float qy, float qz,
+                                                            float ql, bool active, float best_in, int bidx_in) {
+  const float px = (qx - g.minx) * g.invh, py = (qy - g.miny) * g.invh, pz = (qz - g.minz) * g.invh;  // in cells
+  const int cy = cell_coord(qy, g.miny, g.invh, g.gy), cz = cell_coord(qz, g.minz, g.invh, g.gz);
+  const float k2 = g.invh * g.invh / kBoundSlack;  // (distance in cells)^2 > best * k2: beyond the ball
+  float best = best_in;
+  int bidx = bidx_in;
+  // the box of rows: what the ball of the FIRST candidate reaches (cell_coord clamps: the rim rows stand for everything
+  // beyond them)
+  const float R = __builtin_sqrtf(best_in * k2) * 1.00001f;
+  const bool box_ok = active && R <= kBallRmax;
+  // (from the query's position in cells, as the rows' distances below: (int) saturates, the clamp stands for the rim)
+  const int gy1 = g.gy - 1, gz1 = g.gz - 1;
+  int y0 = (int)(py - R), y1 = (int)(py + R), z0 = (int)(pz - R), z1 = (int)(pz + R);
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(y0) : "v"(y0), "v"(gy1));
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(y1) : "v"(y1), "v"(gy1));
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(z0) : "v"(z0), "v"(gz1));
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(z1) : "v"(z1), "v"(gz1));
+  y0 = min(y0, cy); y1 = max(y1, cy); z0 = min(z0, cz); z1 = max(z1, cz);
+  const int ny = y1 - y0 + 1;
+  int nrows = ny * (z1 - z0 + 1);
+  bool gave_up = active && (!box_ok || nrows > kBallMaxRows);
+  if (!active || gave_up) nrows = 0;
+  const float inv_ny = 1.0f / (float)ny;
+  const int gx1 = g.gx - 1;
+  // a row's span of the sorted cloud: empty when the row, or every cell of it, is beyond the ball as it stands
+  auto row_span = [&](int r) {
+    RowSpan o;
+    o.s = 0u;
+    o.e = 0u;
+    const int zi = (int)(((float)r + 0.5f) * inv_ny);
+    const int z = z0 + zi, y = y0 + (r - zi * ny);
+    const float dy = y < cy ? py - (float)(y + 1) : (y > cy ? (float)y - py : 0.0f);
+    const float dz = z < cz ? pz - (float)(z + 1) : (z > cz ? (float)z - pz : 0.0f);
+    const float w2 = best * k2 - (dy * dy + dz * dz);
+    if (r < nrows && w2 >= 0.0f) {
+      const float w = __builtin_sqrtf(w2) * 1.00001f;
+      int x0 = (int)(px - w), x1 = (int)(px + w);  // (saturating conversions; NaN -> 0)
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x0) : "v"(x0), "v"(gx1));
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x1) : "v"(x1), "v"(gx1));
+      const int c = pp::cell_linear(0, y, z, g.gx, g.gy);
+      o.s = cell_start[c + x0];
+      o.e = cell_start[c + x1 + 1];
+    }
+    return o;
+  };
+  const int rmax = (int)pp::wave_reduce_dpp<false>((float)nrows);
+  for (int r0 = 0; r0 < rmax; r0 += 4) {  // wave-uniform
+    const RowSpan a0 = row_span(r0), a1 = row_span(r0 + 1), a2 = row_span(r0 + 2), a3 = row_span(r0 + 3);
+    unsigned t0 = (a0.e - a0.s + 3) >> 2, t1 = (a1.e - a1.s + 3) >> 2, t2 = (a2.e - a2.s + 3) >> 2,
+             t3 = (a3.e - a3.s + 3) >> 2;
+    if (t0 + t1 + t2 + t3 > (unsigned)kLaneCubeMaxGroups) {  // rows through a crowded region: the whole wave's work
+      gave_up = true;
+      nrows = 0;
+      t0 = t1 = t2 = t3 = 0u;
+    }
+    const unsigned T1 = t0, T2 = T1 + t1, T3 = T2 + t2, T4 = T3 + t3;
+    const unsigned adj0 = a0.s, adj1 = a1.s - 4 * T1, adj2 = a2.s - 4 * T2, adj3 = a3.s - 4 * T3;
+    const unsigned last0 = a0.e - 1, last1 = a1.e - 1, last2 = a2.e - 1, last3 = a3.e - 1;
+    pp::f4 pa[4], pb[4];
+    float la[4] = {0.0f, 0.0f, 0.0f, 0.0f}, lb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    stage_a_fetch<LAB>(0, T1, T2, T3, T4, adj0, adj1, adj2, adj3, last0, last1, last2, last3, sorted, slab, pa, la);
+    for (unsigned k = 0; __any(k < T4); k += 2) {
+      stage_a_fetch<LAB>(k + 1, T1, T2, T3, T4, adj0, adj1, adj2, adj3, last0, last1, last2, last3, sorted, slab, pb, lb);
+      if (k < T4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) take_candidate<LAB>(pa[u], la[u], qx, qy, qz, ql, best, bidx);
+      }
+      stage_a_fetch<LAB>(k + 2, T1, T2, T3, T4, adj0, adj1, adj2, adj3, last0, last1, last2, last3, sorted, slab, pa, la);
+      if (k + 1 < T4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) take_candidate<LAB>(pb[u], lb[u], qx, qy, qz, ql, best, bidx);
+      }
+    }
+  }
+  Found o;
+  o.best = active ? best : best_in;
+  o.bidx = active ? bidx : bidx_in;
+  o.aux = !active ? 0.0f : (gave_up ? 2.0f : 1.0f);
+  return o;
+}
+
 // first staged position of group k of a lane's sequence (by value: see stage_a_fetch)
 __device__ __forceinline__ unsigned stage_first(unsigned k, unsigned T1, unsigned T2, unsigned T3, unsigned T4,
                                                 unsigned adj0, unsigned adj1, unsigned adj2, unsigned adj3) {
@@ -1665,8 +1779,25 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     open_lane = true;
     pend = false;
   }
-  if (__builtin_popcountll(__ballot(pend && !deferred)) >= kLaneStageMin) {
-    const bool mine = pend && !deferred;
+  // (round 5) lanes that hold a candidate: the ball around it, exact in one stage (lane_ball_search)
+  bool ball_left = false;  // the ball gave up (rows through a crowded region): not for the lane cubes either
+  {
+    // (a candidate further than kBallRmax cells: a box of rows larger than the cubes' -- those lanes stay with the cubes)
+    const bool ball = PP_LANE_BALL && pend && !deferred && best * (g.invh * g.invh) <= kBallRmax * kBallRmax * kBoundSlack * 0.9999f;
+    if (__builtin_popcountll(__ballot(ball)) >= kBallMin) {
+      const Found f = lane_ball_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, ball, best, bidx);
+      best = f.best;
+      bidx = f.bidx;
+      if (f.aux == 1.0f) {
+        od[j] = best;
+        oi[j] = bidx;
+        pend = false;
+      }
+      ball_left = f.aux == 2.0f;
+    }
+  }
+  if (__builtin_popcountll(__ballot(pend && !deferred && !ball_left)) >= kLaneStageMin) {
+    const bool mine = pend && !deferred && !ball_left;
     Found f = lane_cube_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, 1, mine, best, bidx);
     best = f.best;
     bidx = f.bidx;
