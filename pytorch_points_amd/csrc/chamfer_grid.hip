@@ -435,6 +435,13 @@ constexpr float kBlindGroup = PP_BLIND_GROUP;
 #define PP_BALL_RMAX 2.5f
 #endif
 constexpr float kBallRmax = PP_BALL_RMAX;  // cells: the farthest candidate whose ball is walked (a box of at most 6 x 6 rows)
+#ifndef PP_POOLED_BALL
+#define PP_POOLED_BALL 1
+#endif
+#ifndef PP_POOL_MIN
+#define PP_POOL_MIN 1
+#endif
+constexpr int kPoolMin = PP_POOL_MIN;  // ... pooled over the wave (unlabeled searches)
 constexpr int kBallMin = PP_BALL_MIN;  // lanes with a candidate from which the ball around it is walked a lane per query
 constexpr int kSerialMax = PP_SERIAL_MAX;  // open lanes of a wave from which the whole-wave cubes are skipped for the group search
 constexpr int kLaneStageMin = PP_LANE_STAGE_MIN;  // open lanes of a wave from which the cubes are searched a lane per query
@@ -1369,6 +1376,183 @@ __device__ __attribute__((noinline)) Found lane_ball_search(const GridSet g, con
   return o;
 }
 
+// Round 5 -- the same balls, POOLED over the wave (unlabeled searches).  A lane per query wastes the wave where few lanes
+// are open (a tenth of a wave's queries in the sparse part of a cloud of mixed dimension) and every step waits for the
+// lane with the longest rows; here the open queries' work is laid out flat, twice:
+//   * the (query, row) pairs of every open query's box, 64 at a time: a lane works out ONE row's span inside the ball
+//     (two table entries: the only dependent trip besides the points themselves) and appends it, if not empty, to a list
+//     of pieces in LDS with the number of the piece's first group of four points;
+//   * the (piece, group) pairs, 64 at a time: a lane fetches ONE group of four points of some piece, measures them
+//     against that piece's query and lowers the query's 64-bit (distance bits, index) key in LDS with ds_min_u64 -- the
+//     exact (distance, index) order, whoever comes first.
+// Which piece a group belongs to, and which query a row belongs to, is found without a search: the pieces (queries) that
+// START inside the current window of 64 groups (rows) mark their first position in a 64-entry window of LDS; a ballot
+// of the marks and two popcounts give every lane its piece.  Every step is full width whatever the number of open
+// lanes, and the chain is two trips to memory for the whole wave instead of two per four rows of the slowest lane.
+// The ball is that of the candidate the query came with (it does not shrink on the way).  A row of more than
+// kPoolMaxGroups groups (a crowded region) makes its query give up (aux 2), as in the lane form.
+// LDS (the wave's slice, free after stage A): see the offsets below; <= 6208 bytes (CAPW = 384).
+constexpr int kPoolItems = 256;       // pieces per flush
+constexpr int kPoolMaxGroups = 48;    // groups of a row before its query gives up
+typedef unsigned __attribute__((address_space(3))) * lds_u_wptr;
+typedef unsigned long long __attribute__((address_space(3))) * lds_u64_wptr;
+template <int W>
+__device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet g, const unsigned* __restrict__ cell_start,
+                                                                   const pp::f4* __restrict__ sorted, float qx, float qy,
+                                                                   float qz, bool active, float best_in, int bidx_in,
+                                                                   lds_f4_wptr slice) {
+  const int lane = threadIdx.x & 63;
+  // ---- the slice, in bytes: queries (x, y, z, best * k2) | keys | boxes | first row of a query | pieces: start, first
+  // group, (points << 8 | query) | the window | the mask of the queries that gave up
+  const lds_f4_wptr s_q = slice;                                   // 64 x 16
+  const lds_u64_wptr s_key = (lds_u64_wptr)(slice + 64);           // 64 x 8
+  const lds_u_wptr s_box = (lds_u_wptr)(slice + 96);               // 64 x 4
+  const lds_u_wptr s_rowp = s_box + 64;                            // 65 x 4 (+ pad to 68)
+  const lds_u_wptr s_start = s_rowp + 68;                          // kPoolItems x 4
+  const lds_u_wptr s_first = s_start + kPoolItems;                 // (kPoolItems + 64) x 4: read up to 64 past the list
+  const lds_u_wptr s_meta = s_first + kPoolItems + 64;             // kPoolItems x 4
+  const lds_u_wptr s_win = s_meta + kPoolItems;                    // 64 x 4
+  const lds_u_wptr s_gave = s_win + 64;                            // 2 x 4
+  static_assert(96 * 16 + (64 + 68 + kPoolItems * 3 + 64 + 64 + 2) * 4 <= (384 + 4) * 16, "the wave's slice");
+  auto lds_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  const float k2 = g.invh * g.invh / kBoundSlack;
+  const float py = (qy - g.miny) * g.invh, pz = (qz - g.minz) * g.invh;
+  const int cy = cell_coord(qy, g.miny, g.invh, g.gy), cz = cell_coord(qz, g.minz, g.invh, g.gz);
+  const int gx1 = g.gx - 1, gy1 = g.gy - 1, gz1 = g.gz - 1;
+  // ---- the open queries, compacted: query k = the k-th active lane
+  const unsigned long long am = __ballot(active);
+  const int nq = __builtin_popcountll(am);
+  const int k = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
+  const float R = __builtin_sqrtf(best_in * k2) * 1.00001f;
+  int y0 = (int)(py - R), y1 = (int)(py + R), z0 = (int)(pz - R), z1 = (int)(pz + R);
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(y0) : "v"(y0), "v"(gy1));
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(y1) : "v"(y1), "v"(gy1));
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(z0) : "v"(z0), "v"(gz1));
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(z1) : "v"(z1), "v"(gz1));
+  y0 = min(y0, cy); y1 = max(y1, cy); z0 = min(z0, cz); z1 = max(z1, cz);
+  const int ny = y1 - y0 + 1;
+  const unsigned nrows = active ? (unsigned)(ny * (z1 - z0 + 1)) : 0u;  // (<= 36: R <= kBallRmax)
+  const unsigned rincl = pp::wave_scan_u32_dpp(nrows);
+  const unsigned rtotal = (unsigned)__builtin_amdgcn_readlane((int)rincl, 63);
+  if (active) {
+    s_q[k] = pp::f4{qx, qy, qz, best_in * k2};
+    s_key[k] = ((unsigned long long)__float_as_uint(best_in) << 32) | (unsigned)bidx_in;
+    s_box[k] = (unsigned)y0 | ((unsigned)z0 << 8) | ((unsigned)ny << 16);
+    s_rowp[k] = rincl - nrows;
+  }
+  if (lane == 0) {
+    s_rowp[nq] = rtotal;
+    s_gave[0] = 0u;
+    s_gave[1] = 0u;
+  }
+  lds_sync();
+  // One window step of the "which one am I in" search: `first` is an ascending list of n first positions (rows of a
+  // query, groups of a piece; every entry owns at least one position), `cur` of them start before position c0; returns
+  // the index of the entry that holds position c0 + lane and moves cur past the entries that start in this window.
+  auto locate = [&](const lds_u_wptr first, int n, unsigned c0, int& cur) {
+    s_win[lane] = 0u;
+    const int cand = cur + lane;
+    const unsigned fpos = first[min(cand, n)];  // (entry n: the total -- beyond every window that is looked at)
+    lds_sync();
+    if (cand < n && fpos - c0 < 64u) s_win[fpos - c0] = 1u;
+    lds_sync();
+    const unsigned long long m = __ballot(s_win[lane] != 0u);
+    const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const int idx = cur + __builtin_popcountll(m & le) - 1;
+    cur += __builtin_popcountll(m);
+    lds_sync();
+    return idx;
+  };
+  int nitems = 0;       // pieces in the list
+  unsigned ctotal = 0;  // groups in the list
+  // ---- the groups of the listed pieces, 64 at a time
+  auto flush = [&]() {
+    if (lane == 0) s_first[nitems] = ctotal;
+    lds_sync();
+    int cur = 0;
+    for (unsigned c0 = 0; c0 < ctotal; c0 += 64) {  // wave-uniform
+      const int it = max(locate(s_first, nitems, c0, cur), 0);
+      const unsigned c = min(c0 + (unsigned)lane, ctotal - 1);  // (a lane past the end repeats the last group: harmless)
+      const int itc = c0 + (unsigned)lane < ctotal ? it : nitems - 1;
+      const unsigned st = s_start[itc], fs = s_first[itc], meta = s_meta[itc];
+      const unsigned npts = meta >> 8, kq = meta & 63u;
+      const pp::f4 q = s_q[kq];
+      const unsigned o4 = (c - fs) << 2;
+      pp::f4 p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = sorted[st + min(o4 + (unsigned)u, npts - 1)];
+      unsigned long long key = ~0ull;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, q.x, q.y, q.z);
+        const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w);
+        key = cand < key ? cand : key;  // (a NaN distance -- bits above +inf -- never beats a real candidate)
+      }
+      __hip_atomic_fetch_min(s_key + kq, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    lds_sync();
+    nitems = 0;
+    ctotal = 0;
+  };
+  // ---- the rows of the open queries' boxes, 64 at a time
+  int curq = 0;
+  for (unsigned j0 = 0; j0 < rtotal; j0 += 64) {  // wave-uniform
+    const int kq0 = locate(s_rowp, nq, j0, curq);
+    const bool live = j0 + (unsigned)lane < rtotal;
+    const int kq = live ? max(kq0, 0) : 0;
+    const pp::f4 q = s_q[kq];
+    const unsigned box = s_box[kq];
+    const int r = (int)(j0 + (unsigned)lane - s_rowp[kq]);
+    const int by0 = (int)(box & 255u), bz0 = (int)((box >> 8) & 255u), bny = (int)(box >> 16);
+    const int zi = (int)(((float)r + 0.5f) * (1.0f / (float)bny));
+    const int z = bz0 + zi, y = by0 + (r - zi * bny);
+    const float wpx = (q.x - g.minx) * g.invh, wpy = (q.y - g.miny) * g.invh, wpz = (q.z - g.minz) * g.invh;
+    const int wcy = cell_coord(q.y, g.miny, g.invh, g.gy), wcz = cell_coord(q.z, g.minz, g.invh, g.gz);
+    const float dy = y < wcy ? wpy - (float)(y + 1) : (y > wcy ? (float)y - wpy : 0.0f);
+    const float dz = z < wcz ? wpz - (float)(z + 1) : (z > wcz ? (float)z - wpz : 0.0f);
+    const float w2 = q.w - (dy * dy + dz * dz);
+    unsigned rs = 0u, re = 0u;
+    if (live && w2 >= 0.0f) {
+      const float w = __builtin_sqrtf(w2) * 1.00001f;
+      int x0 = (int)(wpx - w), x1 = (int)(wpx + w);
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x0) : "v"(x0), "v"(gx1));
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x1) : "v"(x1), "v"(gx1));
+      const int c = pp::cell_linear(0, y, z, g.gx, g.gy);
+      rs = cell_start[c + x0];
+      re = cell_start[c + x1 + 1];
+    }
+    unsigned t = (re - rs + 3u) >> 2;
+    if (t > (unsigned)kPoolMaxGroups) {  // a crowded region: the query is the whole wave's (what it has found stays valid)
+      atomicOr((unsigned*)(s_gave + (kq >> 5)), 1u << (kq & 31));
+      t = 0u;
+    }
+    const unsigned long long nm = __ballot(t > 0u);
+    const int slot = nitems + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(nm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm, 0u));
+    const unsigned tincl = pp::wave_scan_u32_dpp(t);
+    if (t > 0u) {
+      s_start[slot] = rs;
+      s_first[slot] = ctotal + tincl - t;
+      s_meta[slot] = ((re - rs) << 8) | (unsigned)kq;
+    }
+    nitems += __builtin_popcountll(nm);
+    ctotal += (unsigned)__builtin_amdgcn_readlane((int)tincl, 63);
+    if (nitems > kPoolItems - 64) flush();  // (the next 64 rows would not fit for sure)
+  }
+  if (nitems > 0) flush();
+  lds_sync();
+  const unsigned long long key = active ? s_key[k] : 0ull;
+  const bool gave = active && ((s_gave[k >> 5] >> (k & 31)) & 1u) != 0u;
+  lds_sync();
+  Found o;
+  o.best = active ? __uint_as_float((unsigned)(key >> 32)) : best_in;
+  o.bidx = active ? (int)(unsigned)key : bidx_in;
+  o.aux = !active ? 0.0f : (gave ? 2.0f : 1.0f);
+  return o;
+}
+
 // first staged position of group k of a lane's sequence (by value: see stage_a_fetch)
 __device__ __forceinline__ unsigned stage_first(unsigned k, unsigned T1, unsigned T2, unsigned T3, unsigned T4,
                                                 unsigned adj0, unsigned adj1, unsigned adj2, unsigned adj3) {
@@ -1784,8 +1968,13 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
   {
     // (a candidate further than kBallRmax cells: a box of rows larger than the cubes' -- those lanes stay with the cubes)
     const bool ball = PP_LANE_BALL && pend && !deferred && best * (g.invh * g.invh) <= kBallRmax * kBallRmax * kBoundSlack * 0.9999f;
-    if (__builtin_popcountll(__ballot(ball)) >= kBallMin) {
-      const Found f = lane_ball_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, ball, best, bidx);
+    constexpr bool kPooled = PP_POOLED_BALL && !LAB && CAPW >= 384;  // (the pooled form's lists need the slice of CAPW = 384)
+    if (__builtin_popcountll(__ballot(ball)) >= (kPooled ? kPoolMin : kBallMin)) {
+      Found f;
+      if constexpr (kPooled)
+        f = wave_pooled_ball_search<W>(g, cell_start, sorted, qx, qy, qz, ball, best, bidx, s_pts_w);
+      else
+        f = lane_ball_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, ball, best, bidx);
       best = f.best;
       bidx = f.bidx;
       if (f.aux == 1.0f) {
