@@ -63,6 +63,22 @@ __device__ unsigned g_qwave[kQWaves][10];
 __device__ unsigned g_qstart[kQWaves][2];    // a wave's first and last stamp (10 ns units, low 32 bits of the clock)
 __device__ unsigned long long g_qgroup[8];  // group search: calls, groups, blind groups, candidates of the row cuts, max of them in one call, rows of the
                                              // boxes, rows listed by pass 1, candidates the whole wave walked
+__device__ unsigned long long g_qgt[8];      // group search: time (10 ns) in sampling, grouping, row listing, row cuts + spans, candidate fetch + sift, walk
+extern "C" int pp_debug_read_query_group_times(void* out, int reset) {
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qgt), sizeof(g_qgt));
+  if (reset) {
+    unsigned long long z[8] = {0};
+    rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_qgt), z, sizeof(z));
+  }
+  return rc;
+}
+#define PP_GT_DECL unsigned long long pp_gtp = wall_clock64(), pp_gt[6] = {0, 0, 0, 0, 0, 0}
+#define PP_GT(i)                                   \
+  do {                                             \
+    const unsigned long long pp_n = wall_clock64(); \
+    pp_gt[i] += pp_n - pp_gtp;                     \
+    pp_gtp = pp_n;                                 \
+  } while (0)
 extern "C" int pp_debug_read_query_phases(void* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qphase), sizeof(g_qphase));
 }
@@ -97,6 +113,8 @@ extern "C" int pp_debug_read_query_wave_span(void* out) {  // kQWaves x 2 unsign
 #else
 #define PP_QPHASE_DECL
 #define PP_QPHASE(n)
+#define PP_GT_DECL
+#define PP_GT(i)
 #endif
 
 namespace {
@@ -108,6 +126,9 @@ using pp::kGridMax;
 using pp::kBuildThreads;
 
 constexpr float kBoundSlack = 0.999f;
+// v_sqrt_f32 (one ulp; sqrtf is the correctly rounded sequence of a dozen instructions): only where the result is
+// widened by a slack factor of 1e-5 or more right after -- bounds of searches, never a distance that is returned
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 // entries between two sets' cell tables: kGridCells + 1 used, padded to a multiple of four so that every set's table is
 // 16-byte aligned (the LDS-sorted build copies a slab's 8192 entries out in 16-byte pieces)
 constexpr int kCellStride = kGridCells + 4;
@@ -237,13 +258,8 @@ __device__ __forceinline__ unsigned long long wave_scan_rows(int nrows, unsigned
                                                              bool& skipped) {
   const int lane = threadIdx.x & 63;
   const unsigned len = lane < nrows ? re - rs : 0u;
-  unsigned incl = len;  // nrows <= 32: five steps
-#pragma unroll
-  for (int off = 1; off < 32; off <<= 1) {
-    const unsigned o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
-  }
-  const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 31);
+  const unsigned incl = pp::wave_scan_u32_dpp(len);  // (DPP: __shfl_up was five dependent ds_bpermute round trips)
+  const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
   const unsigned excl = incl - len;
   const unsigned shift = rs - excl;  // candidate c of row r sits at sorted[c + shift_r]
   if (!PIPE && total > kScanInline) {  // wave-uniform
@@ -299,14 +315,7 @@ __device__ __forceinline__ unsigned long long wave_scan_rows(int nrows, unsigned
       }
     }
   }
-  // wave-wide minimum
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned lo = __shfl_xor((unsigned)key, off), hi = __shfl_xor((unsigned)(key >> 32), off);
-    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-    key = o < key ? o : key;
-  }
-  return key;
+  return pp::wave_min_u64_dpp(key);  // wave-wide minimum (DPP)
 }
 
 // The wide stages for one query, executed by a whole wave (every lane active, all arguments wave-uniform):
@@ -774,6 +783,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
 #ifdef PP_QUERY_PROBE
   unsigned long long pp_ngroups = 0, pp_nblind = 0, pp_ncand = 0, pp_nrows = 0, pp_nwalk = 0, pp_nlist = 0;
 #endif
+  PP_GT_DECL;
   while (open) {
     const int seed = (int)__builtin_ctzll(open);
     const float sx = rl(qx, seed), sy = rl(qy, seed), sz = rl(qz, seed);
@@ -821,8 +831,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         }
       }
       const float mine = u1;
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) u1 = fminf(u1, __shfl_xor(u1, off));
+      u1 = -pp::wave_reduce_dpp<false>(-u1);  // (min; DPP)
       us = fminf(us, u1 * 1.0001f);
       // the nearest sample itself (a real point of the cloud, of the seed's label): every query that joins the group
       // has a neighbour within ITS OWN distance to it -- a far tighter bound for the members than the triangle
@@ -835,6 +844,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         spz = rl(smz, wl);
       }
     }
+    PP_GT(0);
     // The seed takes along the open queries within r of it, r = a quarter of the distance of its candidate.  Where
     // the seed knew a candidate: at least two cells, and only queries whose own candidate is no more than twice as
     // far (the group's bound is the largest of them).  Where it did not (the bound is the sample's, a crude one):
@@ -885,23 +895,19 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
       for (int k = 0; k < kSub; ++k) {
         const bool in = member && mypiece == k;
         float a = in ? -qx : -inf, b2 = in ? qx : -inf, c = in ? ub : -1.0f;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          a = fmaxf(a, __shfl_xor(a, off));
-          b2 = fmaxf(b2, __shfl_xor(b2, off));
-          c = fmaxf(c, __shfl_xor(c, off));
-        }
+        a = pp::wave_reduce_dpp<false>(a);
+        b2 = pp::wave_reduce_dpp<false>(b2);
+        c = pp::wave_reduce_dpp<false>(c);
         sbl[k] = -a;
         sbh[k] = b2;
         su[k] = c >= 0.0f ? c * 1.0001f : -1.0f;  // (a piece without members cuts nothing)
       }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) ub = fmaxf(ub, __shfl_xor(ub, off));
+    ub = pp::wave_reduce_dpp<false>(ub);
     float U = ub * 1.0001f;
     // the rows within sqrt(U) of the box (cell coordinates are monotonic in the coordinate: exact)
     const bool bounded = U < inf;
-    const float R = bounded ? sqrtf(U) * 1.0001f + slack : 0.0f;
+    const float R = bounded ? fast_sqrt(U) * 1.0001f + slack : 0.0f;
     const int y0 = bounded ? cell_coord(bly - R, g.miny, g.invh, g.gy) : 0;
     const int y1 = bounded ? cell_coord(bhy + R, g.miny, g.invh, g.gy) : g.gy - 1;
     const int z0 = bounded ? cell_coord(blz - R, g.minz, g.invh, g.gz) : 0;
@@ -928,13 +934,14 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
 #pragma unroll
       for (int k = 0; k < kSub; ++k) {
         const float remk = su[k] - gyz;
-        const float rxk = sqrtf(fmaxf(remk, 0.0f)) * 1.0001f + slack;
+        const float rxk = fast_sqrt(fmaxf(remk, 0.0f)) * 1.0001f + slack;
         const float lo = sbl[k] - rxk, hi = sbh[k] + rxk;
         const bool ok = remk >= 0.0f && (rim_open || (hi >= box_x0 && lo <= box_x1));
         xlo = ok ? fminf(xlo, lo) : xlo;
         xhi = ok ? fmaxf(xhi, hi) : xhi;
       }
     };
+    PP_GT(1);
     // Pass 1 (round 3): the rows the pieces' cuts leave, packed into a list in the wave's slice behind the candidate
     // batch (<= 1024 rows, two bytes each).  Between far clouds that is a tenth of the rows of the box around the
     // group; the member-by-member cut below is then paid for full blocks of rows that have a chance.
@@ -967,7 +974,9 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     pp_nlist += (unsigned long long)nq;
 #endif
     bool dirty = false;
+    PP_GT(2);
     for (int r0 = 0; r0 < nq; r0 += 64) {  // wave-uniform
+      PP_GT(5);
       if (dirty) {  // (wave-uniform) candidates have been examined since the bound was last taken
         // the bound follows what the members have found in the rows examined so far: the rows still to come are cut
         // by the candidates already seen (a member's own best is always a valid bound for it)
@@ -983,7 +992,10 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
       unsigned cs = 0u, len = 0u;
       float xlo, xhi;  // the row's cut along x
       piece_cut(rr, cy, cz, xlo, xhi);
-      if (__ballot(xlo <= xhi) == 0ull) continue;  // wave-uniform: no row of these within the group's bound
+      if (__ballot(xlo <= xhi) == 0ull) {  // wave-uniform: no row of these within the group's bound
+        PP_GT(3);
+        continue;
+      }
       auto load_span = [&]() {
         cs = 0u;
         len = 0u;
@@ -996,9 +1008,8 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         }
       };
       load_span();
-      unsigned box_total = len;  // candidates of the pieces' cuts in these rows
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) box_total += (unsigned)__shfl_xor((int)box_total, off);
+      // candidates of the pieces' cuts in these rows
+      const unsigned box_total = (unsigned)__builtin_amdgcn_readlane((int)pp::wave_scan_u32_dpp(len), 63);
       // (the member-by-member cut costs the wave ~30 instructions per member: it pays when the cut above left more
       //  candidates than that buys examined by every lane)
       if (bounded && box_total > 8u * (unsigned)__builtin_popcountll(members) && members != (1ull << seed)) {  // (wave-uniform)
@@ -1018,7 +1029,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
           const float gy_ = fmaxf(fmaxf(ylo - my, my - yhi), 0.0f), gz_ = fmaxf(fmaxf(zlo - mz, mz - zhi), 0.0f);
           const float remm = mu - __builtin_fmaf(gz_, gz_, gy_ * gy_) * 0.9999f;
           // (a member out of reach of the row: a cut of -inf width leaves the hull alone)
-          const float rxm = remm >= 0.0f ? sqrtf(remm) * 1.0001f + slack : -inf;
+          const float rxm = remm >= 0.0f ? fast_sqrt(remm) * 1.0001f + slack : -inf;
           mlo = fminf(mlo, mx - rxm);
           mhi = fmaxf(mhi, mx + rxm);
         }
@@ -1027,21 +1038,21 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         if (!rim_open && (xhi < box_x0 || xlo > box_x1)) xhi = -inf;  // (no member reaches the box in this row)
         load_span();
       }
-      if (__ballot(len != 0u) == 0ull) continue;  // wave-uniform: nothing in these rows
-      dirty = true;
-      unsigned incl = len;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
+      if (__ballot(len != 0u) == 0ull) {  // wave-uniform: nothing in these rows
+        PP_GT(3);
+        continue;
       }
+      dirty = true;
+      const unsigned incl = pp::wave_scan_u32_dpp(len);
       const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
       const unsigned excl = incl - len;
       const unsigned shift = cs - excl;  // candidate c of this lane's row sits at sorted[c + shift]
 #ifdef PP_QUERY_PROBE
       pp_ncand += total;
 #endif
+      PP_GT(3);
       for (unsigned t0 = 0; t0 < total; t0 += kGroupBatch) {  // wave-uniform
+        PP_GT(5);
         if (t0 != 0u) {
           // the bound follows the batches too (round 3): a crowded cell is a thousand candidates, and after the first
           // few hundred of them the members know their neighbour to within a little -- the test below then drops most
@@ -1114,6 +1125,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
 #ifdef PP_QUERY_PROBE
         pp_nwalk += n;
 #endif
+        PP_GT(4);
         if (n == 0u) continue;  // (wave-uniform)
         // Every lane, every candidate (uniform address: LDS broadcast), trimmed for VALU issue like the staged walk of
         // stage A: per group of four only the running minimum (v_min3 + v_min) and the group that last lowered it;
@@ -1185,6 +1197,8 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     atomicAdd(&g_qgroup[5], pp_nrows);
     atomicAdd(&g_qgroup[6], pp_nlist);
     atomicAdd(&g_qgroup[7], pp_nwalk);
+    PP_GT(5);
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_qgt[i], pp_gt[i]);
   }
 #endif
   Found o;
@@ -1303,7 +1317,7 @@ __device__ __attribute__((noinline)) Found lane_ball_search(const GridSet g, con
   int bidx = bidx_in;
   // the box of rows: what the ball of the FIRST candidate reaches (cell_coord clamps: the rim rows stand for everything
   // beyond them)
-  const float R = __builtin_sqrtf(best_in * k2) * 1.00001f;
+  const float R = fast_sqrt(best_in * k2) * 1.00001f;
   const bool box_ok = active && R <= kBallRmax;
   // (from the query's position in cells, as the rows' distances below: (int) saturates, the clamp stands for the rim)
   const int gy1 = g.gy - 1, gz1 = g.gz - 1;
@@ -1330,7 +1344,7 @@ __device__ __attribute__((noinline)) Found lane_ball_search(const GridSet g, con
     const float dz = z < cz ? pz - (float)(z + 1) : (z > cz ? (float)z - pz : 0.0f);
     const float w2 = best * k2 - (dy * dy + dz * dz);
     if (r < nrows && w2 >= 0.0f) {
-      const float w = __builtin_sqrtf(w2) * 1.00001f;
+      const float w = fast_sqrt(w2) * 1.00001f;
       int x0 = (int)(px - w), x1 = (int)(px + w);  // (saturating conversions; NaN -> 0)
       asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x0) : "v"(x0), "v"(gx1));
       asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x1) : "v"(x1), "v"(gx1));
@@ -1426,7 +1440,7 @@ __device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet
   const unsigned long long am = __ballot(active);
   const int nq = __builtin_popcountll(am);
   const int k = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u));
-  const float R = __builtin_sqrtf(best_in * k2) * 1.00001f;
+  const float R = fast_sqrt(best_in * k2) * 1.00001f;
   int y0 = (int)(py - R), y1 = (int)(py + R), z0 = (int)(pz - R), z1 = (int)(pz + R);
   asm("v_med3_i32 %0, %1, 0, %2" : "=v"(y0) : "v"(y0), "v"(gy1));
   asm("v_med3_i32 %0, %1, 0, %2" : "=v"(y1) : "v"(y1), "v"(gy1));
@@ -1516,7 +1530,7 @@ __device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet
     const float w2 = q.w - (dy * dy + dz * dz);
     unsigned rs = 0u, re = 0u;
     if (live && w2 >= 0.0f) {
-      const float w = __builtin_sqrtf(w2) * 1.00001f;
+      const float w = fast_sqrt(w2) * 1.00001f;
       int x0 = (int)(wpx - w), x1 = (int)(wpx + w);
       asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x0) : "v"(x0), "v"(gx1));
       asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x1) : "v"(x1), "v"(gx1));
@@ -2163,6 +2177,9 @@ __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_l
     gw = (xcd * per_xcd + v) * kListWgWaves + wave;
   }
   const int set = gw / waves_per_set, wi = gw - set * waves_per_set;
+  // (round 5, measured and removed: every rim workgroup launched 2 / 4 / 8 times, each copy serving a part of its waves'
+  //  lanes -- a Gaussian's first waves live the whole launch -- made every cloud slower: gaussian 0.210 -> 0.212 / 0.221 /
+  //  0.231, blobs8 0.70 -> 0.71 / 0.75 / 0.78: a rim wave's life is not in proportion to its open queries)
   // (round 3, tried: a set's waves from its two ends inwards -- the rim waves are the expensive ones -- changed nothing;
   //  the XCD's sets interleaved as well spread the expensive waves over the launch -- gaussian 0.265 -> 0.243 ms, blobs8
   //  0.83 -> 0.78 -- but cost the clouds whose neighbouring waves share cells their cache hits: two_scales 0.316 -> 0.335,

@@ -48,6 +48,11 @@ for mode in [int(a) for a in sys.argv[1:]] or [0]:
     rdg = L.pp_debug_read_query_group_stats; rdg.argtypes = [ctypes.c_void_p, ctypes.c_int]; rdg.restype = ctypes.c_int
     assert rdg(gs.ctypes.data, 1) == 0
     print("   group search (all launches so far): calls %d groups %d blind %d candidates %d (max per call %d) rows %d, rows listed %d, candidates walked %d" % tuple(int(x) for x in gs[:8]))
+    if hasattr(L, "pp_debug_read_query_group_times"):
+        gt = np.zeros(8, np.uint64)
+        rgt = L.pp_debug_read_query_group_times; rgt.argtypes = [ctypes.c_void_p, ctypes.c_int]; rgt.restype = ctypes.c_int
+        if rgt(gt.ctypes.data, 1) == 0 and gs[0] > 0:
+            print("   group search, us per call: sampling %.1f grouping %.1f row list %.1f row cuts+spans %.1f fetch+sift %.1f walk %.1f" % tuple(float(x) / 100.0 / float(gs[0]) for x in gt[:6]))
     sp = np.zeros((1 << 17, 2), np.uint32)
     rds = L.pp_debug_read_query_wave_span; rds.argtypes = [ctypes.c_void_p]; rds.restype = ctypes.c_int
     if rds(sp.ctypes.data) == 0:
