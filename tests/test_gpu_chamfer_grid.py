@@ -429,3 +429,61 @@ def test_config2_class_clouds_equal_brute_force(cuda, name):
         for g, e, what in zip(got, ref, ["dist1", "idx1", "dist2", "idx2"]):
             same = np.array_equal(g, e, equal_nan=True)
             assert same, "%s (launch %d): %s differs at %d places" % (name, rep, what, int((g != e).sum()))
+
+
+# ---- round 5: the balls behind stage A (lane_ball_search, wave_pooled_ball_search): clouds of mixed dimension -- thin
+# faces with a sparse interior, where a query's block holds a candidate too far to settle it -- at several sizes, far
+# from the origin (the ball is measured in cells from the query's own cell coordinates), with outliers clamped into the
+# rim cells the balls reach, with ties; unlabeled (the pooled form) and labeled (the lane form): the every-pair kernel's
+# outputs, bit for bit.
+def _object_like(seed, b, n, offset=0.0, scale=1.0):
+    u = _u(seed, (b, n, 3)) - np.float32(0.5)
+    q = n // 4
+    u[:, :q, 2] = -0.5                                              # a face in the lowest layer
+    u[:, q:2 * q, 0] = 0.2                                          # a wall
+    th = _u(seed + 1, (b, q)) * np.float32(6.283)
+    u[:, 2 * q:3 * q, 0] = np.float32(0.3) * np.cos(th)
+    u[:, 2 * q:3 * q, 1] = np.float32(0.3) * np.sin(th)             # a cylinder; the last quarter fills the volume
+    return (u * np.float32(scale) + np.float32(offset)).astype(np.float32)
+
+
+def _ball_cases():
+    c = {}
+    c["object_16384"] = (_object_like(800, 2, 16384), _object_like(802, 2, 16384))
+    c["object_ragged"] = (_object_like(804, 2, 9001), _object_like(806, 2, 12345))
+    c["object_small"] = (_object_like(808, 3, 3000), _object_like(810, 3, 4096))
+    c["object_far_from_origin"] = (_object_like(812, 1, 16384, offset=1000.0), _object_like(814, 1, 16384, offset=1000.0))
+    c["object_tiny_scale"] = (_object_like(816, 1, 16384, scale=1e-3), _object_like(818, 1, 16384, scale=1e-3))
+    out = _object_like(820, 1, 16384)
+    out[0, 3::500] *= np.float32(40.0)                               # outliers: clamped into the rim cells
+    c["object_with_outliers"] = (_object_like(822, 1, 16384), out)
+    c["queries_beside_the_box"] = (_object_like(824, 1, 8192) + np.float32([0.6, 0.0, 0.0]), _object_like(826, 1, 16384))
+    lat = np.round(_object_like(828, 1, 16384) * 20).astype(np.float32)
+    c["object_on_a_lattice"] = (lat, np.round(_object_like(830, 1, 16384) * 20).astype(np.float32))
+    vol = _u(832, (2, 16384, 3))
+    c["volume_vs_object"] = (vol - np.float32(0.5), _object_like(834, 2, 16384))
+    sparse = _u(836, (1, 2048, 3)) - np.float32(0.5)
+    c["sparse_queries_dense_object"] = (sparse, _object_like(838, 1, 16384))
+    return c
+
+
+BALL = _ball_cases()
+
+
+@pytest.mark.parametrize("name", sorted(BALL))
+def test_ball_stage_clouds_equal_brute_force(cuda, name):
+    x1, x2 = (np.ascontiguousarray(a) for a in BALL[name])
+    ref = _run(cuda, x1, x2, 1)
+    got = _run(cuda, x1, x2, 2)
+    for g, e, what in zip(got, ref, ["dist1", "idx1", "dist2", "idx2"]):
+        assert np.array_equal(g, e, equal_nan=True), "%s: %s differs at %d places" % (name, what, int((g != e).sum()))
+
+
+@pytest.mark.parametrize("name", ["object_ragged", "object_with_outliers", "object_on_a_lattice", "volume_vs_object"])
+def test_ball_stage_clouds_labeled_equal_oracle(cuda, name):
+    x1, x2 = (np.ascontiguousarray(a[:1, :6000]) for a in BALL[name])
+    l1, l2 = _labels(60, x1.shape[:2], 3), _labels(61, x2.shape[:2], 3)
+    exp = oracle.labeled_chamfer_forward(x1, x2, l1, l2)
+    got = _run_labeled(cuda, x1, x2, l1, l2, 2)
+    for g, e, what in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
+        assert np.array_equal(g, e), "%s: %s differs at %d places" % (name, what, int((g != e).sum()))
