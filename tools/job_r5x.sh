@@ -1,3 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_chamfer_grid.py -x -q -m gpu -k "ball_stage" 2>&1 | tail -5
+export PP_TILE_MODES=512
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cube -- python3 tools/tile_modes.py cube > /tmp/cube.log 2>&1
+grep -v amdgpu.ids /tmp/cube.log | grep "cube"
+f=$(find /tmp/prof_cube -name "*kernel_stats.csv" | head -1); head -8 $f | cut -c1-220
