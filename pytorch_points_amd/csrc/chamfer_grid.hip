@@ -2229,6 +2229,10 @@ __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_l
   const unsigned per_wave = min(64u, max(1u, (total + (unsigned)waves_per_set - 1) / (unsigned)waves_per_set));
   // ONE piece of per_wave entries per wave (the launch has a wave for every 64 queries of a direction, so a list of
   // every query still fits; no loop: state that lives across the search costs this kernel registers it does not have)
+  // (round 5, measured and removed: a persistent launch -- 4 / 5 / 8 workgroups per CU, each wave on to the piece of
+  //  virtual workgroup w + k gridDim.x: the hardware's dispatch of the next waiting workgroup to whichever CU has room
+  //  balances the long pieces better than a fixed stride: gaussian 0.198 -> 0.264 / 0.232 / 0.213 ms, blobs8 0.65 ->
+  //  0.81 / 0.71 / 0.73, and the sphere's 7 us did not move; 97 spilled scalar registers on top)
   const bool everything = total == (unsigned)nq;  // the stage-A kernel served nothing of this direction (sets with
                                                   // crowded cells, degenerate sets): entry e is query e, no table needed
   {
