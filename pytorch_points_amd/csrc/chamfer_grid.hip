@@ -428,6 +428,9 @@ constexpr int kGroupBatch = 256;  // candidates per LDS batch of wave_group_sear
 #define PP_BLIND_GROUP 0.25f
 #endif
 constexpr float kBlindGroup = PP_BLIND_GROUP;
+#ifndef PP_MEMBER_CUT_MIN
+#define PP_MEMBER_CUT_MIN 2  // (round 5: 2, was 8 -- disjoint clouds 0.225 -> 0.203 ms) candidates per member the pieces' cuts must leave in a block of rows for the member-by-member cut
+#endif
 #ifndef PP_SERIAL_MAX
 #define PP_SERIAL_MAX 24
 #endif
@@ -1012,7 +1015,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
       const unsigned box_total = (unsigned)__builtin_amdgcn_readlane((int)pp::wave_scan_u32_dpp(len), 63);
       // (the member-by-member cut costs the wave ~30 instructions per member: it pays when the cut above left more
       //  candidates than that buys examined by every lane)
-      if (bounded && box_total > 8u * (unsigned)__builtin_popcountll(members) && members != (1ull << seed)) {  // (wave-uniform)
+      if (bounded && box_total > (unsigned)(PP_MEMBER_CUT_MIN) * (unsigned)__builtin_popcountll(members) && members != (1ull << seed)) {  // (wave-uniform)
         // Member by member (round 3): the cut above measures from the BOX (its nearest face) with the LARGEST bound of
         // a piece -- between far clouds that is the box's diagonal too generous, thousands of candidates where every
         // member's own ball holds a handful.  A candidate of this row matters only if it lies within SOME member's own
