@@ -450,6 +450,12 @@ constexpr float kBallRmax = PP_BALL_RMAX;  // cells: the farthest candidate whos
 #ifndef PP_POOLED_BALL
 #define PP_POOLED_BALL 1
 #endif
+#ifndef PP_BALL_AFTER_CUBE
+#define PP_BALL_AFTER_CUBE 1
+#endif
+#ifndef PP_POOLED_LAB
+#define PP_POOLED_LAB 1  // labeled searches too (0: a lane per query, lane_ball_search)
+#endif
 #ifndef PP_POOL_MIN
 #define PP_POOL_MIN 1
 #endif
@@ -1400,7 +1406,7 @@ __device__ __attribute__((noinline)) Found lane_ball_search(const GridSet g, con
   return o;
 }
 
-// Round 5 -- the same balls, POOLED over the wave (unlabeled searches).  A lane per query wastes the wave where few lanes
+// Round 5 -- the same balls, POOLED over the wave.  A lane per query wastes the wave where few lanes
 // are open (a tenth of a wave's queries in the sparse part of a cloud of mixed dimension) and every step waits for the
 // lane with the longest rows; here the open queries' work is laid out flat, twice:
 //   * the (query, row) pairs of every open query's box, 64 at a time: a lane works out ONE row's span inside the ball
@@ -1420,11 +1426,12 @@ constexpr int kPoolItems = 256;       // pieces per flush
 constexpr int kPoolMaxGroups = 48;    // groups of a row before its query gives up
 typedef unsigned __attribute__((address_space(3))) * lds_u_wptr;
 typedef unsigned long long __attribute__((address_space(3))) * lds_u64_wptr;
-template <int W>
+template <bool LAB, int W>
 __device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet g, const unsigned* __restrict__ cell_start,
-                                                                   const pp::f4* __restrict__ sorted, float qx, float qy,
-                                                                   float qz, bool active, float best_in, int bidx_in,
-                                                                   lds_f4_wptr slice) {
+                                                                   const pp::f4* __restrict__ sorted,
+                                                                   const float* __restrict__ slab, float qx, float qy,
+                                                                   float qz, float ql, bool active, float best_in,
+                                                                   int bidx_in, lds_f4_wptr slice) {
   const int lane = threadIdx.x & 63;
   // ---- the slice, in bytes: queries (x, y, z, best * k2) | keys | boxes | first row of a query | pieces: start, first
   // group, (points << 8 | query) | the window | the mask of the queries that gave up
@@ -1436,8 +1443,9 @@ __device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet
   const lds_u_wptr s_first = s_start + kPoolItems;                 // (kPoolItems + 64) x 4: read up to 64 past the list
   const lds_u_wptr s_meta = s_first + kPoolItems + 64;             // kPoolItems x 4
   const lds_u_wptr s_win = s_meta + kPoolItems;                    // 64 x 4
-  const lds_u_wptr s_gave = s_win + 64;                            // 2 x 4
-  static_assert(96 * 16 + (64 + 68 + kPoolItems * 3 + 64 + 64 + 2) * 4 <= (384 + 4) * 16, "the wave's slice");
+  const lds_u_wptr s_gave = s_win + 64;                            // 2 x 4 (+ 2 pad)
+  const lds_f_wptr s_ql = (lds_f_wptr)(s_gave + 4);                // 64 x 4: the queries' labels (labeled searches)
+  static_assert(96 * 16 + (64 + 68 + kPoolItems * 3 + 64 + 64 + 4 + 64) * 4 <= (384 + 4) * 16, "the wave's slice");
   auto lds_sync = [] {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1464,6 +1472,7 @@ __device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet
   if (active) {
     s_q[k] = pp::f4{qx, qy, qz, best_in * k2};
     s_key[k] = ((unsigned long long)__float_as_uint(best_in) << 32) | (unsigned)bidx_in;
+    if (LAB) s_ql[k] = ql;
     s_box[k] = (unsigned)y0 | ((unsigned)z0 << 8) | ((unsigned)ny << 16);
     s_rowp[k] = rincl - nrows;
   }
@@ -1506,14 +1515,21 @@ __device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet
       const pp::f4 q = s_q[kq];
       const unsigned o4 = (c - fs) << 2;
       pp::f4 p[4];
+      float pl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int u = 0; u < 4; ++u) p[u] = sorted[st + min(o4 + (unsigned)u, npts - 1)];
+      for (int u = 0; u < 4; ++u) {
+        const unsigned at = st + min(o4 + (unsigned)u, npts - 1);
+        p[u] = sorted[at];
+        if (LAB) pl[u] = slab[at];
+      }
+      const float wl = LAB ? s_ql[kq] : 0.0f;
       unsigned long long key = ~0ull;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float d = pp::chamfer_d3(p[u].x, p[u].y, p[u].z, q.x, q.y, q.z);
         const unsigned long long cand = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w);
-        key = cand < key ? cand : key;  // (a NaN distance -- bits above +inf -- never beats a real candidate)
+        // (a NaN distance -- bits above +inf -- never beats a real candidate; labeled: a candidate of the query's label only)
+        key = ((!LAB || pl[u] == wl) && cand < key) ? cand : key;
       }
       __hip_atomic_fetch_min(s_key + kq, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     }
@@ -1982,16 +1998,19 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     open_lane = true;
     pend = false;
   }
-  // (round 5) lanes that hold a candidate: the ball around it, exact in one stage (lane_ball_search)
+  // (round 5) lanes that hold a candidate: the ball around it, exact in one stage (wave_pooled_ball_search / lane_ball_search);
+  // once for the candidates of the blocks, once more behind the cubes of radius 1 for the lanes those gave their first
+  // candidate (an empty block in the sparse part of a cloud; labeled searches, where a block seldom holds the query's label)
   bool ball_left = false;  // the ball gave up (rows through a crowded region): not for the lane cubes either
-  {
+  auto ball_stage = [&]() {
     // (a candidate further than kBallRmax cells: a box of rows larger than the cubes' -- those lanes stay with the cubes)
-    const bool ball = PP_LANE_BALL && pend && !deferred && best * (g.invh * g.invh) <= kBallRmax * kBallRmax * kBoundSlack * 0.9999f;
-    constexpr bool kPooled = PP_POOLED_BALL && !LAB && CAPW >= 384;  // (the pooled form's lists need the slice of CAPW = 384)
+    const bool ball = PP_LANE_BALL && pend && !deferred && !ball_left &&
+                      best * (g.invh * g.invh) <= kBallRmax * kBallRmax * kBoundSlack * 0.9999f;
+    constexpr bool kPooled = PP_POOLED_BALL && (PP_POOLED_LAB || !LAB) && CAPW >= 384;  // (the pooled form's lists need the slice of CAPW = 384)
     if (__builtin_popcountll(__ballot(ball)) >= (kPooled ? kPoolMin : kBallMin)) {
       Found f;
       if constexpr (kPooled)
-        f = wave_pooled_ball_search<W>(g, cell_start, sorted, qx, qy, qz, ball, best, bidx, s_pts_w);
+        f = wave_pooled_ball_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, ball, best, bidx, s_pts_w);
       else
         f = lane_ball_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, ball, best, bidx);
       best = f.best;
@@ -2001,9 +2020,10 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
         oi[j] = bidx;
         pend = false;
       }
-      ball_left = f.aux == 2.0f;
+      ball_left = ball_left || f.aux == 2.0f;
     }
-  }
+  };
+  ball_stage();
   if (__builtin_popcountll(__ballot(pend && !deferred && !ball_left)) >= kLaneStageMin) {
     const bool mine = pend && !deferred && !ball_left;
     Found f = lane_cube_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, 1, mine, best, bidx);
@@ -2021,7 +2041,8 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
       open_lane = true;
       pend = false;
     }
-    const bool mine2 = pend && !deferred && f.aux != 2.0f;
+    if (PP_BALL_AFTER_CUBE) ball_stage();
+    const bool mine2 = pend && !deferred && !ball_left && f.aux != 2.0f;
     if (__builtin_popcountll(__ballot(mine2)) >= kLaneStageMin) {
       f = lane_cube_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, 2, mine2, best, bidx);
       best = f.best;
