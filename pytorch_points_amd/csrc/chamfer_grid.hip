@@ -450,6 +450,13 @@ constexpr float kBallRmax = PP_BALL_RMAX;  // cells: the farthest candidate whos
 #ifndef PP_POOLED_BALL
 #define PP_POOLED_BALL 1
 #endif
+#ifndef PP_POOLED_CUBE
+#define PP_POOLED_CUBE 1
+#endif
+#ifndef PP_POOL_CUBE_MIN
+#define PP_POOL_CUBE_MIN 1
+#endif
+constexpr int kPoolCubeMin = PP_POOL_CUBE_MIN;
 #ifndef PP_BALL_AFTER_CUBE
 #define PP_BALL_AFTER_CUBE 1
 #endif
@@ -1431,7 +1438,10 @@ __device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet
                                                                    const pp::f4* __restrict__ sorted,
                                                                    const float* __restrict__ slab, float qx, float qy,
                                                                    float qz, float ql, bool active, float best_in,
-                                                                   int bidx_in, lds_f4_wptr slice) {
+                                                                   int bidx_in, lds_f4_wptr slice, int rho) {
+  // rho > 0 (wave-uniform): not the ball but the CUBE of Chebyshev radius rho around the query's cell, for the lanes that
+  // hold no candidate yet (lane_cube_search's job, pooled): every row of the cube, the cells cx - rho .. cx + rho of each;
+  // settled (aux 1) if the best found lies below what the cube guarantees, else aux 0 with what was found.
   const int lane = threadIdx.x & 63;
   // ---- the slice, in bytes: queries (x, y, z, best * k2) | keys | boxes | first row of a query | pieces: start, first
   // group, (points << 8 | query) | the window | the mask of the queries that gave up
@@ -1465,12 +1475,15 @@ __device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet
   asm("v_med3_i32 %0, %1, 0, %2" : "=v"(z0) : "v"(z0), "v"(gz1));
   asm("v_med3_i32 %0, %1, 0, %2" : "=v"(z1) : "v"(z1), "v"(gz1));
   y0 = min(y0, cy); y1 = max(y1, cy); z0 = min(z0, cz); z1 = max(z1, cz);
+  if (rho > 0) {
+    y0 = max(cy - rho, 0); y1 = min(cy + rho, gy1); z0 = max(cz - rho, 0); z1 = min(cz + rho, gz1);
+  }
   const int ny = y1 - y0 + 1;
-  const unsigned nrows = active ? (unsigned)(ny * (z1 - z0 + 1)) : 0u;  // (<= 36: R <= kBallRmax)
+  const unsigned nrows = active ? (unsigned)(ny * (z1 - z0 + 1)) : 0u;  // (<= 36: R <= kBallRmax, rho <= 2)
   const unsigned rincl = pp::wave_scan_u32_dpp(nrows);
   const unsigned rtotal = (unsigned)__builtin_amdgcn_readlane((int)rincl, 63);
   if (active) {
-    s_q[k] = pp::f4{qx, qy, qz, best_in * k2};
+    s_q[k] = pp::f4{qx, qy, qz, rho > 0 ? __builtin_inff() : best_in * k2};  // (a cube: every row, nothing is cut by a distance)
     s_key[k] = ((unsigned long long)__float_as_uint(best_in) << 32) | (unsigned)bidx_in;
     if (LAB) s_ql[k] = ql;
     s_box[k] = (unsigned)y0 | ((unsigned)z0 << 8) | ((unsigned)ny << 16);
@@ -1560,6 +1573,11 @@ __device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet
       int x0 = (int)(wpx - w), x1 = (int)(wpx + w);
       asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x0) : "v"(x0), "v"(gx1));
       asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x1) : "v"(x1), "v"(gx1));
+      if (rho > 0) {
+        const int wcx = cell_coord(q.x, g.minx, g.invh, g.gx);
+        x0 = max(wcx - rho, 0);
+        x1 = min(wcx + rho, gx1);
+      }
       const int c = pp::cell_linear(0, y, z, g.gx, g.gy);
       rs = cell_start[c + x0];
       re = cell_start[c + x1 + 1];
@@ -1590,6 +1608,23 @@ __device__ __attribute__((noinline)) Found wave_pooled_ball_search(const GridSet
   o.best = active ? __uint_as_float((unsigned)(key >> 32)) : best_in;
   o.bidx = active ? (int)(unsigned)key : bidx_in;
   o.aux = !active ? 0.0f : (gave ? 2.0f : 1.0f);
+  if (rho > 0) {  // (uniform) what the cube guarantees: lane_cube_search's rule
+    const int cx = cell_coord(qx, g.minx, g.invh, g.gx);
+    const float fx = (qx - g.minx) * g.invh - (float)cx, fy = py - (float)cy, fz = pz - (float)cz;
+    auto axis = [&](float f, int c, int gdim) {
+      const float lo = c - rho >= 1 ? (float)rho + f : __builtin_inff();
+      const float hi = c + rho <= gdim - 2 ? (float)(rho + 1) - f : __builtin_inff();
+      return fminf(lo, hi);
+    };
+    const float reach = g.h * fminf(axis(fx, cx, g.gx), fminf(axis(fy, cy, g.gy), axis(fz, cz, g.gz)));
+    const bool all = cz - rho <= 0 && cz + rho >= gz1 && cy - rho <= 0 && cy + rho >= gy1 && cx - rho <= 0 && cx + rho >= gx1;
+    const bool settled = all ? (LAB || o.bidx != 0x7fffffff) : (o.best < reach * reach * kBoundSlack);
+    if (LAB && active && settled && !gave && o.bidx == 0x7fffffff) {  // whole grid examined, nobody carries this label
+      o.best = 0.0f;                                                  // (ref nmdistance_cuda.cu:110-113)
+      o.bidx = -1;
+    }
+    o.aux = !active ? 0.0f : (gave ? 2.0f : (settled ? 1.0f : 0.0f));
+  }
   return o;
 }
 
@@ -2010,7 +2045,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     if (__builtin_popcountll(__ballot(ball)) >= (kPooled ? kPoolMin : kBallMin)) {
       Found f;
       if constexpr (kPooled)
-        f = wave_pooled_ball_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, ball, best, bidx, s_pts_w);
+        f = wave_pooled_ball_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, ball, best, bidx, s_pts_w, 0);
       else
         f = lane_ball_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, ball, best, bidx);
       best = f.best;
@@ -2024,9 +2059,19 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     }
   };
   ball_stage();
-  if (__builtin_popcountll(__ballot(pend && !deferred && !ball_left)) >= kLaneStageMin) {
+  // the cubes of radius 1 and 2 for the lanes without a candidate: pooled over the wave like the balls (from kPoolCubeMin
+  // lanes on), or a lane per query (from kLaneStageMin on)
+  constexpr bool kPooledCube = PP_POOLED_CUBE && PP_POOLED_BALL && (PP_POOLED_LAB || !LAB) && CAPW >= 384;
+  constexpr int kCubeMin = kPooledCube ? kPoolCubeMin : kLaneStageMin;
+  auto cube_stage = [&](int rho, bool mine) {
+    if constexpr (kPooledCube)
+      return wave_pooled_ball_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, mine, best, bidx, s_pts_w, rho);
+    else
+      return lane_cube_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, rho, mine, best, bidx);
+  };
+  if (__builtin_popcountll(__ballot(pend && !deferred && !ball_left)) >= kCubeMin) {
     const bool mine = pend && !deferred && !ball_left;
-    Found f = lane_cube_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, 1, mine, best, bidx);
+    Found f = cube_stage(1, mine);
     best = f.best;
     bidx = f.bidx;
     if (f.aux == 1.0f) {
@@ -2043,8 +2088,8 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     }
     if (PP_BALL_AFTER_CUBE) ball_stage();
     const bool mine2 = pend && !deferred && !ball_left && f.aux != 2.0f;
-    if (__builtin_popcountll(__ballot(mine2)) >= kLaneStageMin) {
-      f = lane_cube_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, 2, mine2, best, bidx);
+    if (__builtin_popcountll(__ballot(mine2)) >= kCubeMin) {
+      f = cube_stage(2, mine2);
       best = f.best;
       bidx = f.bidx;
       if (f.aux == 1.0f) {
