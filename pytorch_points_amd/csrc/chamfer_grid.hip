@@ -665,6 +665,9 @@ __device__ __attribute__((noinline)) OpenMask serve_long_scans(const GridSet* __
     float wbest;
     int widx;
     bool skipped = false;
+    // (round 5, measured and removed: for a query that comes with a candidate, the rows of the BALL around it in one exact
+    //  scan instead of the cubes of radius 1 and 2 -- two_scales 0.295 -> 0.305 / 0.358 / 0.415 / 0.437 ms for balls of up
+    //  to 0.5 / 1 / 1.5 / 2.5 cells: the scan's row lookup is unrolled for the cubes' 9 and 25 rows and a loop for a ball's)
     if (wide_stages_wave<LAB, true>(wx, wy, wz, wl, g, cell_start, sorted, slab, wbest, widx, skipped)) {
       if (lane == 0) {
         od[wj] = wbest;
