@@ -990,6 +990,9 @@ __device__ __forceinline__ unsigned wave_scan_u32_dpp(unsigned v) {
 // crowded cells than its list holds.
 // Flat grids (gz < kFastMinLayers) and degenerate sets are not started at all (every slab agrees: uniform data).
 // Returns 0 = done, 1 = not applicable (general path, unforced), 2 = general path with `plan` forced.
+#ifndef PP_BUILD_BALANCE
+#define PP_BUILD_BALANCE 1  // the slabs' layers dealt by a histogram where the cloud is not spread evenly along z
+#endif
 #ifndef PP_BUILD_STAGE_MASKED
 #define PP_BUILD_STAGE_MASKED 1  // the staging writes under the lanes' own mask (a quarter of the lanes hold a point of the slab:
 #endif                         // 0.3 us less than every lane writing, the others to dump slots)
@@ -1105,12 +1108,15 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
   }
   PP_PHASE(2);
   bool trimmed = false;
+  float zmean = 0.0f, zsig = 0.0f;  // (for the slabs' balance below)
   if (!any_bad) {  // outliers: the box of the points within 4 sigma when the bounding box reaches beyond 6 (general path)
     const float inv_n = 1.0f / (float)nr;
     const float mean[3] = {sm[0] * inv_n, sm[1] * inv_n, sm[2] * inv_n};
     float sig[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) sig[a] = sqrtf(fmaxf(sm[3 + a] * inv_n - mean[a] * mean[a], 0.0f));
+    zmean = mean[2];
+    zsig = sig[2];
     const bool stretched = mxx - mean[0] > 6.0f * sig[0] || mean[0] - mnx > 6.0f * sig[0] ||
                            mxy - mean[1] > 6.0f * sig[1] || mean[1] - mny > 6.0f * sig[1] ||
                            mxz - mean[2] > 6.0f * sig[2] || mean[2] - mnz > 6.0f * sig[2];
@@ -1213,14 +1219,56 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
     if (lane == 0 && nbelow) atomicAdd(&s_below, nbelow);
   };
   unsigned running = 0, own = 0;
+#if PP_BUILD_BALANCE
+  const bool balance_z = fabsf(zsig - 0.2887f * ez) > 0.03f * ez || fabsf(zmean - (mnz + 0.5f * ez)) > 0.06f * ez;
+#endif
   {
     constexpr int kRounds = 4;
     for (int round = 0;; ++round) {
       // (after the last round's "coarsen" the cloud is counted at the resolution it ended with, whatever its occupancy)
       if (gz < kFastMinLayers) return 1;  // a flat grid: slabs of whole layers would leave workgroups idle (uniform)
       gxy = gx * gy;
-      lo = (gz * slab / nslab) * gxy;
-      ncs = (gz * (slab + 1) / nslab) * gxy - lo;
+      int zl = gz * slab / nslab, zh = gz * (slab + 1) / nslab;  // this slab's layers: an equal share ...
+#if PP_BUILD_BALANCE
+      // ... unless the cloud is not spread evenly along z (its moments say so: an even spread has sigma = extent /
+      // sqrt(12) about the middle -- every surface of revolution about z, every filled box; a Gaussian, an object
+      // with a face in its lowest layer have not): then the layers are dealt by a HISTOGRAM of a quarter of the points
+      // (one LDS add per thread and group), a quarter of the cloud to each slab as nearly as whole layers allow -- an
+      // equal share of layers gave the middle slabs of a Gaussian, or the slab with the face, more points than the LDS
+      // list holds, and that slab took the general path (35-40 us for the launch instead of 25).  Every slab of the set
+      // computes the same moments and the same histogram from the same points: they agree without meeting.
+      if (balance_z) {  // (uniform)
+        unsigned* s_hist = reinterpret_cast<unsigned*>(s_box);  // (the box partials are done with)
+        if (t < 32) s_hist[t] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int gq = 0; gq < KP / 4; ++gq)
+          if (live[gq]) atomicAdd(&s_hist[cell_coord(pz[4 * gq], mnz, invh, gz)], 1u);
+        __syncthreads();
+        const unsigned cum = wave_scan_u32_dpp(lane < gz ? s_hist[lane] : 0u);  // (gz <= 32)
+        const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)cum, 63);
+        int zb[nslab + 1];
+        zb[0] = 0;
+        zb[nslab] = gz;
+#pragma unroll
+        for (int k = 1; k < nslab; ++k)  // the layers that lie wholly within the first k quarters; a layer at least per slab
+          zb[k] = min(max((int)__builtin_popcountll(__ballot(lane < gz && (unsigned)nslab * cum <= (unsigned)k * tot)), zb[k - 1] + 1),
+                      gz - (nslab - k));
+        bool fits = true;  // (a slab's counters hold kFastCells cells)
+#pragma unroll
+        for (int k = 0; k < nslab; ++k) fits = fits && (zb[k + 1] - zb[k]) * gxy <= kFastCells;
+        if (fits) {
+#pragma unroll
+          for (int k = 0; k < nslab; ++k)
+            if (k == slab) {
+              zl = zb[k];
+              zh = zb[k + 1];
+            }
+        }
+      }
+#endif
+      lo = zl * gxy;
+      ncs = (zh - zl) * gxy;
       const int nwords = (gxy * gz + 31) / 32;
       if (round > 0) {  // (the first round finds the bitmap and the counters zeroed at the kernel's start, behind the box's barrier)
         if (t < nwords) s_occ[t] = 0u;  // (<= 1024 words)
@@ -1303,7 +1351,7 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
     }
   }
   const int ncell = gxy * gz;
-  const int zl = gz * slab / nslab, zh = gz * (slab + 1) / nslab;  // this slab's layers
+  const int zl = lo / gxy, zh = (lo + ncs) / gxy;  // this slab's layers (as the last round dealt them)
   __syncthreads();
   PP_PHASE(6);
   if (((lo | ncs) & 3) == 0 && (reinterpret_cast<uintptr_t>(cell_start) & 15) == 0) {  // (uniform) 16-byte pieces

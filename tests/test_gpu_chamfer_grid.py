@@ -413,6 +413,23 @@ def _class2_cases():
     nan[1, 777, 1] = np.nan
     c["a_nan"] = (nan, S.unit_sphere(729, 2, n), "mixed_nan")
     c["not_a_multiple_of_four"] = (S.unit_sphere(730, 1, 16383), S.unit_sphere(731, 1, n), "absent")
+    # surfaces that are NOT spread evenly along z (round 5: the build then deals the slabs' layers by a histogram, and
+    # stage A's tiles read the layer table those slabs write): three quarters of a sphere's points in its lower cap; a
+    # cone (its layers grow with z)
+    def uneven(seed):
+        p = S.unit_sphere(seed, 2, n).copy()
+        low = p[:, : 3 * n // 4]
+        low[..., 2] = -np.abs(low[..., 2]) * np.float32(0.5) - np.float32(0.5)
+        low[..., :2] *= np.sqrt(np.maximum(1.0 - low[..., 2:3] ** 2, 0.0)).astype(np.float32) / np.maximum(
+            np.linalg.norm(low[..., :2], axis=-1, keepdims=True), 1e-6).astype(np.float32)
+        return np.ascontiguousarray(p.astype(np.float32))
+    c["surface_uneven_in_z"] = (uneven(732), uneven(733), None)
+    def cone(seed):
+        u = S.uniform01(seed, (2, n, 2)).reshape(2, n, 2).astype(np.float32)
+        zz = np.sqrt(u[..., 0])                                            # area-uniform on the cone
+        th = u[..., 1] * np.float32(6.2831853)
+        return np.ascontiguousarray(np.stack([zz * np.cos(th), zz * np.sin(th), zz], -1).astype(np.float32))
+    c["cone"] = (cone(734), cone(735), None)
     return c
 
 
