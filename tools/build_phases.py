@@ -16,6 +16,9 @@ rd = L.pp_debug_read_build_phases; rd.argtypes = [ctypes.c_void_p]; rd.restype =
 for kind in sys.argv[1:] or ["sphere", "two_scales", "blobs8"]:
     if kind == "sphere":
         x1, x2 = S.unit_sphere(0, B, N), S.unit_sphere(1, B, N)
+    elif kind == "cube":
+        r = np.random.default_rng(0)
+        x1, x2 = r.random((B, N, 3), dtype=np.float32), r.random((B, N, 3), dtype=np.float32)
     else:
         x1, x2 = bench._distribution(kind, 0, B, N), bench._distribution(kind, 1, B, N)
     x1, x2 = torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev)

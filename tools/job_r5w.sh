@@ -1,3 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-timeout 300 python3 tools/build_phases.py sphere two_scales blobs8 gaussian shapenet_like 2>&1 | grep -v amdgpu.ids
+timeout 300 python3 tools/build_phases.py cube 2>&1 | grep -v amdgpu.ids
+for v in "" nojump; do echo "== variant '$v'"
+  if [ -n "$v" ]; then export PP_LIB=tools/libpp_hip_$v.so; else unset PP_LIB; fi
+  PP_TILE_MODES=512 timeout 600 python3 tools/tile_modes.py cube gaussian shapenet_like two_scales 2>&1 | grep -v amdgpu.ids
+done

@@ -1,3 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_chamfer_grid.py -x -q -m gpu -k "config2_class" 2>&1 | tail -4
+timeout 2500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 300 python3 tools/dist_probe.py 2>&1 | grep -v amdgpu.ids
