@@ -990,6 +990,9 @@ __device__ __forceinline__ unsigned wave_scan_u32_dpp(unsigned v) {
 // crowded cells than its list holds.
 // Flat grids (gz < kFastMinLayers) and degenerate sets are not started at all (every slab agrees: uniform data).
 // Returns 0 = done, 1 = not applicable (general path, unforced), 2 = general path with `plan` forced.
+#ifndef PP_BUILD_SPILL
+#define PP_BUILD_SPILL PP_BUILD_STAGE_MASKED  // a slab beyond the list's capacity scatters from its registers (0: general path)
+#endif
 #ifndef PP_BUILD_JUMP
 #define PP_BUILD_JUMP 1  // a coarsening step sized by the occupancy (a volume needs more than the surface's step)
 #endif
@@ -1338,7 +1341,9 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
         plan->mnx = mnx; plan->mny = mny; plan->mnz = mnz; plan->h = h; plan->invh = invh;
         plan->gx = gx; plan->gy = gy; plan->gz = gz; plan->cell_lo = lo; plan->cell_hi = lo + ncs; plan->trimmed = trimmed ? 1 : 0;
       }
+#if !PP_BUILD_SPILL
       if (own > (unsigned)kFastCap) return 2;  // more points than the list holds: the general path sorts this slab (uniform)
+#endif
       unsigned run = running + wbase + incl - sum;
       if (c0 < ncs) {
         unsigned st[8], mx8 = 0u;
@@ -1380,6 +1385,11 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
   if (REFINE && t < zh - zl) layers[zl + t] = s_cnt[t * gxy];
   // ---- position = cell start + rank: the slab's points into the list in sorted order
   // (no branch per point: the other lanes' records go to 64 slots behind the list)
+  // (round 5) a slab with more points than the list holds -- the middle slabs of a Gaussian at 32 layers, which the
+  // histogram cannot deal more evenly: a slab's counters hold eight such layers -- no longer leaves for the general path
+  // (a second sort of the slab from scratch: 15-20 us more for the launch): its points go from the registers STRAIGHT to
+  // their places (scattered 16-byte stores, the general path's way) and its chunk table through two LDS atomics per point.
+  const bool spill = PP_BUILD_SPILL && own > (unsigned)kFastCap;  // (uniform)
 #pragma unroll
   for (int i = 0; i < KP; ++i) {
     const bool mine = key[i] != ~0u;
@@ -1387,7 +1397,16 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
     if (mine) {
       const unsigned pos = s_cnt[key[i] & 0xffffu] + (key[i] >> 16) - running;
       f4 r = {px[i], py[i], pz[i], __int_as_float(kidx(i))};
-      s_list[pos] = r;
+      if (spill) {
+        sorted[pos + running] = r;
+        if (REFINE) {
+          const unsigned ch = (pos + running) / (unsigned)kChunk;
+          atomicMin(&s_tz[2 * ch], zkey(pz[i]));
+          atomicMax(&s_tz[2 * ch + 1], zkey(pz[i]));
+        }
+      } else {
+        s_list[pos] = r;
+      }
     }
 #else
     const unsigned start = s_cnt[mine ? (key[i] & 0xffffu) : 0u];
@@ -1400,7 +1419,7 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
   PP_PHASE(7);
   // ---- copy-out: 16-byte coalesced stores, a wave per chunk of kChunk sorted positions; the chunk's pair of the chunk
   // table from the same pass (one DPP reduction per chunk; zkey is monotone: the keys of the extreme z are the extreme keys)
-  if (own > 0u) {
+  if (own > 0u && !spill) {
     const unsigned ch_first = running / (unsigned)kChunk, ch_last = (running + own - 1u) / (unsigned)kChunk;
     for (unsigned ch = ch_first + (unsigned)wave; ch <= ch_last; ch += (unsigned)(kBuildThreads / 64)) {  // a wave per chunk
       float zmax = -__builtin_inff(), nzmin = -__builtin_inff();  // max of z, max of -z

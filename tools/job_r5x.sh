@@ -1,4 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-timeout 2500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout 300 python3 tools/dist_probe.py 2>&1 | grep -v amdgpu.ids
+timeout 1500 python -m pytest tests/test_gpu_chamfer_grid.py tests/test_gpu_fuzz.py tests/test_gpu_chamfer.py tests/test_gpu_golden.py -x -q -m gpu 2>&1 | tail -3
+for v in "" nospill; do echo "== variant '$v'"
+  if [ -n "$v" ]; then export PP_LIB=tools/libpp_hip_$v.so; else unset PP_LIB; fi
+  PP_TILE_MODES=512 timeout 600 python3 tools/tile_modes.py sphere cube gaussian shapenet_like two_scales blobs8 plane 2>&1 | grep -v amdgpu.ids
+done
