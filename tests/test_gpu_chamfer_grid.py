@@ -504,3 +504,28 @@ def test_ball_stage_clouds_labeled_equal_oracle(cuda, name):
     got = _run_labeled(cuda, x1, x2, l1, l2, 2)
     for g, e, what in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
         assert np.array_equal(g, e), "%s: %s differs at %d places" % (name, what, int((g != e).sum()))
+
+
+@pytest.mark.parametrize("nlab", [16, 64])
+@pytest.mark.parametrize("name", ["object_ragged", "volume_vs_object"])
+def test_ball_stage_many_labels_equal_oracle(cuda, name, nlab):
+    """many labels: a block seldom holds the query's label, nearly every lane of a wave is open and the pooled stages
+    flush their piece lists several times per wave"""
+    x1, x2 = (np.ascontiguousarray(a[:1, :5000]) for a in BALL[name])
+    l1, l2 = _labels(62, x1.shape[:2], nlab), _labels(63, x2.shape[:2], nlab)
+    exp = oracle.labeled_chamfer_forward(x1, x2, l1, l2)
+    got = _run_labeled(cuda, x1, x2, l1, l2, 2)
+    for g, e, what in zip(got, exp, ["dist1", "idx1", "dist2", "idx2"]):
+        assert np.array_equal(g, e), "%s/%d: %s differs at %d places" % (name, nlab, what, int((g != e).sum()))
+
+
+@pytest.mark.parametrize("n,m", [(16384, 2048), (2048, 16384), (12000, 3000)])
+def test_ball_stage_sparse_reference_equal_brute_force(cuda, n, m):
+    """a dense query cloud against a sparse reference (and the reverse): every query's block is nearly empty, the balls
+    and the cubes of radius 1 and 2 carry the search"""
+    x1 = _u(840, (2, n, 3)) - np.float32(0.5)
+    x2 = _object_like(842, 2, m)
+    ref = _run(cuda, x1, x2, 1)
+    got = _run(cuda, x1, x2, 2)
+    for g, e, what in zip(got, ref, ["dist1", "idx1", "dist2", "idx2"]):
+        assert np.array_equal(g, e, equal_nan=True), "%d/%d: %s differs at %d places" % (n, m, what, int((g != e).sum()))
