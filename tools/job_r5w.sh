@@ -1,7 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-timeout 300 python3 tools/build_phases.py cube 2>&1 | grep -v amdgpu.ids
-for v in "" nojump; do echo "== variant '$v'"
-  if [ -n "$v" ]; then export PP_LIB=tools/libpp_hip_$v.so; else unset PP_LIB; fi
-  PP_TILE_MODES=512 timeout 600 python3 tools/tile_modes.py cube gaussian shapenet_like two_scales 2>&1 | grep -v amdgpu.ids
-done
+for k in shapenet_like gaussian two_scales; do echo "== $k"; PP_PROBE_KIND=$k timeout 300 python3 tools/query_probe.py 512 2>&1 | grep -v amdgpu.ids | grep "stage A inside\|per wave\|mode"; done
