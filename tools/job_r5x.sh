@@ -1,3 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_chamfer_grid.py -x -q -m gpu -k "ball_stage" 2>&1 | tail -4
+for v in "" r30 r40 r60; do echo "== variant '$v'"
+  if [ -n "$v" ]; then export PP_LIB=tools/libpp_hip_$v.so; else unset PP_LIB; fi
+  PP_TILE_MODES=512 timeout 600 python3 tools/tile_modes.py cube gaussian shapenet_like two_scales blobs8 disjoint 2>&1 | grep -v amdgpu.ids
+done
