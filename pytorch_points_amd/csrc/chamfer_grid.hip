@@ -442,6 +442,9 @@ constexpr int kGroupBatch = 256;  // candidates per LDS batch of wave_group_sear
 #define PP_BLIND_GROUP 0.25f
 #endif
 constexpr float kBlindGroup = PP_BLIND_GROUP;
+// (the macros below are A/B switches of the stages behind stage A: tools/build_variant_lib.sh <tag> -D<macro>=<value> builds a
+//  library with one of them changed, tools/job_r5ab.sh runs them all against the shipped values --
+//  profiles/r5/near_field_stages_ab.txt; the shipped library is compiled with the defaults written here)
 #ifndef PP_MEMBER_CUT_MIN
 #define PP_MEMBER_CUT_MIN 2  // (round 5: 2, was 8 -- disjoint clouds 0.225 -> 0.203 ms) candidates per member the pieces' cuts must leave in a block of rows for the member-by-member cut
 #endif
