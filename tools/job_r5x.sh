@@ -1,5 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -3
-timeout 2500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-timeout 600 python bench.py --steps 20 --warmup 5 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-400
+PP_NMDISTANCE_TILE=256 timeout 1500 python -m pytest tests/test_gpu_chamfer_grid.py tests/test_gpu_fuzz.py tests/test_gpu_chamfer.py tests/test_gpu_golden.py -q -m gpu --deselect tests/test_gpu_chamfer_grid.py::test_stage_a_serves_an_evenly_sampled_surface 2>&1 | tail -3
