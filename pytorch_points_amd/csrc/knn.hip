@@ -318,6 +318,9 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
 #ifndef PP_KNN_KEY64
 #define PP_KNN_KEY64 1
 #endif
+#ifndef PP_KNN_BALL
+#define PP_KNN_BALL 1  // rounds after the first walk the ball of the K-th best found, not its box (0: the box)
+#endif
 #ifndef PP_KNN_FLY
 #define PP_KNN_FLY 2
 #endif
@@ -327,6 +330,11 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
   KList<KT> Lk;
 #endif
   const int kth = min(K, M) - 1;  // the entry that decides when to stop
+  // (round 5) from the second round on only the BALL of the K-th best of the round before can matter, not its box: rows
+  // beyond it are passed over, the others cut along x (three_nn_grid.hip / chamfer_grid.hip's ball stages: same rule)
+  const float px = (q.x - g.minx) * g.invh, py = (q.y - g.miny) * g.invh, pz = (q.z - g.minz) * g.invh;
+  const int cy = cell_coord(q.y, g.miny, g.invh, g.gy), cz = cell_coord(q.z, g.minz, g.invh, g.gz);
+  float bk2 = __builtin_inff();
   while (true) {
     Lk.clear();
     const float lx = q.x - R, hx = q.x + R, ly = q.y - R, hy = q.y + R, lz = q.z - R, hz = q.z + R;
@@ -342,13 +350,28 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
     for (int z = z0; z <= z1; ++z)
       for (int y = y0; y <= y1; ++y) {
         const int c = (z * g.gy + y) * g.gx;
+        int xa = x0, xb = x1;
+#if PP_KNN_BALL
+        {
+          const float dy = y < cy ? py - (float)(y + 1) : (y > cy ? (float)y - py : 0.0f);
+          const float dz = z < cz ? pz - (float)(z + 1) : (z > cz ? (float)z - pz : 0.0f);
+          const float w2 = bk2 - (dy * dy + dz * dz);
+          if (!everything && w2 < 0.0f) continue;  // the row lies beyond the ball
+          if (!everything) {
+            const float w = __builtin_amdgcn_sqrtf(w2) * 1.00001f;
+            xa = max(xa, max(min((int)(px - w), g.gx - 1), 0));
+            xb = min(xb, max(min((int)(px + w), g.gx - 1), 0));
+            if (xa > xb) continue;
+          }
+        }
+#endif
         // (one 16-byte load for both bounds of a row up to three cells wide: see three_nn_grid.hip)
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         u4 v;
-        __builtin_memcpy(&v, cell_start + c + x0, sizeof(v));
-        const int wd = x1 + 1 - x0;
+        __builtin_memcpy(&v, cell_start + c + xa, sizeof(v));
+        const int wd = xb + 1 - xa;
         unsigned e = wd == 1 ? v.y : (wd == 2 ? v.z : v.w);
-        if (wd > 3) e = cell_start[c + x1 + 1];
+        if (wd > 3) e = cell_start[c + xb + 1];
         constexpr int kFly = PP_KNN_FLY;  // loads in flight per lane (the tail of a row repeats its last point)
         for (unsigned i = v.x; i < e; i += kFly) {
           pp::f4 pf[kFly];
@@ -384,6 +407,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(const float* __restrict__
     // search -- doubling blindly walked 125 cells where a few dozen do (three_nn_grid.hip: the same); at least 25 %
     // wider than the last one; fewer than K points found: double
     R = dk < 3.0e38f ? fmaxf(sqrtf(dk) * 1.0005f, 1.25f * R) : 2.0f * R;
+    bk2 = dk < 3.0e38f ? dk * (g.invh * g.invh) * (1.0f / 0.999f) : __builtin_inff();
   }
 #if PP_KNN_KEY64
   KList<KT> out;

@@ -17,6 +17,10 @@
 // (that is the scan).  Batch elements whose grid is useless go to the scan kernel.
 #include "grid_common.h"
 
+#ifndef PP_TN_BALL
+#define PP_TN_BALL 1  // rounds after the first walk the ball of the third best found, not its box (0: the box)
+#endif
+
 namespace {
 
 using pp::GridSet;
@@ -131,6 +135,14 @@ __global__ __launch_bounds__(256) void tn_query_kernel(const float* __restrict__
   unsigned long long k1, k2, k3;  // the three best (distance, index) pairs so far, as keys (insert3_key)
   const bool finite_q = __builtin_isfinite(q.x) && __builtin_isfinite(q.y) && __builtin_isfinite(q.z);
   float R = finite_q ? g.h : 2.0e38f;
+  // (round 5) from the second round on the third best of the round before bounds the answer: of the box only the BALL of
+  // that radius can matter -- a cell row (y, z) whose slab lies beyond it is passed over, the others are cut to the cells
+  // within what is left of the radius along x (the rule and the arithmetic of chamfer_grid.hip's ball stages: distances
+  // in cells from the query's own cell coordinates, a factor 0.999 of slack on the squares, rim cells open outwards).
+  // bk2 = that bound in cells^2 (+inf in the first round: every row, whole width).
+  const float px = (q.x - g.minx) * g.invh, py = (q.y - g.miny) * g.invh, pz = (q.z - g.minz) * g.invh;
+  const int cy = cell_coord(q.y, g.miny, g.invh, g.gy), cz = cell_coord(q.z, g.minz, g.invh, g.gz);
+  float bk2 = __builtin_inff();
   while (true) {
     k1 = k2 = k3 = (unsigned long long)0x7f800000u << 32;  // (inf, 0)
     const float lx = q.x - R, hx = q.x + R, ly = q.y - R, hy = q.y + R, lz = q.z - R, hz = q.z + R;
@@ -146,15 +158,30 @@ __global__ __launch_bounds__(256) void tn_query_kernel(const float* __restrict__
     for (int z = z0; z <= z1; ++z)
       for (int y = y0; y <= y1; ++y) {
         const int c = (z * g.gy + y) * g.gx;
+        int xa = x0, xb = x1;
+#if PP_TN_BALL
+        {
+          const float dy = y < cy ? py - (float)(y + 1) : (y > cy ? (float)y - py : 0.0f);
+          const float dz = z < cz ? pz - (float)(z + 1) : (z > cz ? (float)z - pz : 0.0f);
+          const float w2 = bk2 - (dy * dy + dz * dz);
+          if (!everything && w2 < 0.0f) continue;  // the row lies beyond the ball
+          if (!everything) {
+            const float w = __builtin_amdgcn_sqrtf(w2) * 1.00001f;
+            xa = max(xa, max(min((int)(px - w), g.gx - 1), 0));
+            xb = min(xb, max(min((int)(px + w), g.gx - 1), 0));
+            if (xa > xb) continue;
+          }
+        }
+#endif
         // a row's two bounds are a few table entries apart: up to three cells wide (the usual first round)
         // ONE 16-byte load fetches both (the entries after a set's table are the next set's or the sorted
         // cloud: valid memory); this kernel is bound by the L1's handling of scattered loads
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         u4 v;
-        __builtin_memcpy(&v, cell_start + c + x0, sizeof(v));
-        const int wd = x1 + 1 - x0;
+        __builtin_memcpy(&v, cell_start + c + xa, sizeof(v));
+        const int wd = xb + 1 - xa;
         unsigned e = wd == 1 ? v.y : (wd == 2 ? v.z : v.w);
-        if (wd > 3) e = cell_start[c + x1 + 1];
+        if (wd > 3) e = cell_start[c + xb + 1];
         for (unsigned i = v.x; i < e; i += 2) {
           const pp::f4 p0 = sorted[i];
           const pp::f4 p1 = sorted[min(i + 1, e - 1)];
@@ -171,6 +198,7 @@ __global__ __launch_bounds__(256) void tn_query_kernel(const float* __restrict__
     // wider than the last one (coordinates far from the origin round the box's reach down); fewer than three points
     // found: double.
     R = d3 < 3.0e38f ? fmaxf(sqrtf(d3) * 1.0005f, 1.25f * R) : 2.0f * R;
+    bk2 = d3 < 3.0e38f ? d3 * (g.invh * g.invh) * (1.0f / 0.999f) : __builtin_inff();
   }
   float* od = dist2 + ((size_t)b * N + qorig) * 3;
   int* oi = idx + ((size_t)b * N + qorig) * 3;

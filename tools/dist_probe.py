@@ -1,6 +1,10 @@
 """forward time of the search operators on point distributions other than the uniform sphere"""
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, ".")
+if os.environ.get("PP_LIB"):   # a variant of the library (tools/build_variant_lib.sh)
+    from pytorch_points_amd import _build
+    _build.LIB = os.path.abspath(os.environ["PP_LIB"])
+    _build.is_stale = lambda: False
 from pytorch_points_amd import synthetic as S
 from pytorch_points_amd._ext import losses, sampling
 from pytorch_points_amd.ops import knn_points
