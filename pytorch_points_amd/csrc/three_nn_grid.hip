@@ -161,11 +161,11 @@ __global__ __launch_bounds__(256) void tn_query_kernel(const float* __restrict__
         int xa = x0, xb = x1;
 #if PP_TN_BALL
         {
-          const float dy = y < cy ? py - (float)(y + 1) : (y > cy ? (float)y - py : 0.0f);
-          const float dz = z < cz ? pz - (float)(z + 1) : (z > cz ? (float)z - pz : 0.0f);
-          const float w2 = bk2 - (dy * dy + dz * dz);
-          if (!everything && w2 < 0.0f) continue;  // the row lies beyond the ball
-          if (!everything) {
+          if (bk2 < 3.0e38f && !everything) {  // (a lane in its first round has no bound yet: nothing of this for it)
+            const float dy = y < cy ? py - (float)(y + 1) : (y > cy ? (float)y - py : 0.0f);
+            const float dz = z < cz ? pz - (float)(z + 1) : (z > cz ? (float)z - pz : 0.0f);
+            const float w2 = bk2 - (dy * dy + dz * dz);
+            if (w2 < 0.0f) continue;  // the row lies beyond the ball
             const float w = __builtin_amdgcn_sqrtf(w2) * 1.00001f;
             xa = max(xa, max(min((int)(px - w), g.gx - 1), 0));
             xb = min(xb, max(min((int)(px + w), g.gx - 1), 0));
