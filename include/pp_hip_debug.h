@@ -43,6 +43,9 @@ int pp_debug_nmdistance_pending(const void* workspace, int B, int N, int M, unsi
 
 void pp_debug_set_fps_v1(int form); /* 0 = the library's choice, 1 = one workgroup per batch element over all points,
                                       * 2 = the CU cluster over all points, 3 = the bucketed kernel */
+/* the bucketed FPS kernel's serial chain (N <= 65536): 0 = several mutually independent picks per barrier round
+ * (default), 1 = one pick per round (the round-4 chain; A/B timing and tests) */
+void pp_debug_set_fps_bucket_chain(int form);
 void pp_debug_set_gather_variant(int variant);
 void pp_debug_set_ball_query_variant(int variant); /* scan kernels: 1 = one wave per 64 centres */
 void pp_debug_set_ball_query_search(int mode);     /* 0 automatic, 1 scan, 2 grid wherever possible */

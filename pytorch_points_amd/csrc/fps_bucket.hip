@@ -42,6 +42,7 @@
 #define PP_FPSB_PROBE_DECL
 #define PP_FPSB_MARK(n)
 #define PP_FPSB_TOUCHED(mask)
+#define PP_FPSB_PICKS(k)
 #define PP_FPSB_END()
 #endif
 
@@ -103,6 +104,34 @@ __device__ __forceinline__ u64 wave_argmax_key(unsigned hi, unsigned lo, int& sr
   return ((u64)mh << 32) | ml;
 }
 
+// Wave-wide largest and second largest (as a multiset: equal when two lanes hold the largest) of 32-bit unsigned
+// values.  One chain of six steps over the pair (x, y) = (largest, second largest so far): t = min(x, x'), x = max(x, x'),
+// y = max(y, y', t).  bound_ctrl:0 makes a lane without a source read 0 -- the identity of both max and of the
+// min's contribution; the order of the four operations leaves two instructions between every VALU write and the DPP
+// read of the same register (the two wait states DPP needs): no s_nop inside the chain.  In the row_bcast steps the
+// rows outside the row mask keep a stale t, which their y has already absorbed (t <= y after every step): harmless,
+// and only lane 63 is read.
+__device__ __forceinline__ void wave_max2_u32(unsigned x, unsigned& m1, unsigned& m2) {
+  unsigned y = 0u, t = 0u;
+#define PP_MAX2_STEP(CTRL, RM)                                                                \
+  "v_min_u32_dpp %2, %0, %0 " CTRL " row_mask:" RM " bank_mask:0xf bound_ctrl:0\n\t"          \
+  "v_max_u32_dpp %0, %0, %0 " CTRL " row_mask:" RM " bank_mask:0xf\n\t"                       \
+  "v_max_u32_dpp %1, %1, %1 " CTRL " row_mask:" RM " bank_mask:0xf\n\t"                       \
+  "v_max_u32 %1, %1, %2\n\t"
+  asm volatile("s_nop 1\n\t"
+               PP_MAX2_STEP("row_shr:1", "0xf")
+               PP_MAX2_STEP("row_shr:2", "0xf")
+               PP_MAX2_STEP("row_shr:4", "0xf")
+               PP_MAX2_STEP("row_shr:8", "0xf")
+               PP_MAX2_STEP("row_bcast:15", "0xa")
+               PP_MAX2_STEP("row_bcast:31", "0xc")
+               "s_nop 1"
+               : "+v"(x), "+v"(y), "+v"(t));
+#undef PP_MAX2_STEP
+  m1 = (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+  m2 = (unsigned)__builtin_amdgcn_readlane((int)y, 63);
+}
+
 constexpr unsigned kRcMax = 0x0FFFFFFFu;  // ~tie rank in 28 bits (rank < N + 512 <= 2^22 + 2^9); four bits below it
                                           // carry the wave number in the workgroup-wide maximum
 
@@ -111,7 +140,7 @@ constexpr unsigned kRcMax = 0x0FFFFFFFu;  // ~tie rank in 28 bits (rank < N + 51
 // one 16-byte load per lane (x, y, z, ~tie rank) and no store at all: nothing in the chain waits for a write to be
 // acknowledged.  Otherwise (larger clouds) temp travels in the record's fourth word and ~tie rank in an array of its
 // own (`aux`); with REG `aux` holds the incoming temp in sorted order, read once.
-template <bool REG>
+template <bool REG, bool BATCH>
 __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     const float* __restrict__ xyz, float* __restrict__ temp, int* __restrict__ idx, int N, int npoint,
     int seed, TieOrder order, BucketGeom geo, f4* __restrict__ sorted_all, unsigned* __restrict__ aux_all,
@@ -122,6 +151,19 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   __shared__ unsigned s_lut[3][kBkFine];
   __shared__ u64 s_g[3];
   __shared__ float s_c[3][kBkWaves][4];
+  // BATCH: the candidate table of a round -- two per wave (slot 2 w, 2 w + 1): key, then (x, y, z, second-largest
+  // temp of the candidate's bucket) -- the largest of the second candidates and the largest failing candidate;
+  // two deep (two barriers per round)
+  __shared__ u64 s_key[2][2 * kBkWaves];
+  __shared__ f4 s_rec[2][2 * kBkWaves];
+  __shared__ u64 s_bound[2], s_fail[2];
+  // BATCH: "super-box" l = the sixteen buckets 16 l .. 16 l + 15 (1024 consecutive points of the curve: a compact
+  // patch), i.e. lane l of EVERY wave.  Their union boxes (ordered-integer images of -lo, hi: LDS integer maxima), the
+  // largest temp inside each (raised by every wave before the round's first barrier) and, per super-box, the candidate
+  // slots whose pick can reach it (set by each candidate's OWN wave) -- the last two two deep, like the tables above.
+  __shared__ int s_sbox[64][6];
+  __shared__ unsigned s_sbmax[2][64];
+  __shared__ unsigned s_cover[2][64];
 
   const int b = blockIdx.x;
   const float* __restrict__ p = xyz + (size_t)b * N * 3;
@@ -332,6 +374,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   // ---------------------------------------------------------------- F. bucket summaries + the seed's step
   // thread (wave w, lane l) owns bucket l * 16 + w: neighbouring buckets live in different waves, so the
   // handful of buckets a pick touches are re-evaluated side by side.
+  auto slot_bucket = [&](int l) -> int { return l * kBkWaves + wave; };
   const int m = geo.m;
   const int bsize = 64 * m;
   float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
@@ -411,19 +454,21 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     wlo = (unsigned)wk;
   };
   if (REG) {  // (`aux` has 65536 entries per batch element in this form; behind the last point: zeros)
-    unsigned first = (unsigned)(wave * 64 + lane);
 #pragma unroll
-    for (int l = 0; l < 64; ++l) td_set(l, __uint_as_float(rc[first + (unsigned)(l * kBkWaves * 64)]));
+    for (int l = 0; l < 64; ++l) td_set(l, __uint_as_float(rc[(unsigned)(slot_bucket(l) * 64 + lane)]));
   }
   if (REG && npoint > 1) {
     // (one record per lane and bucket: loaded once, the next bucket's while this one is reduced)
-    const unsigned at = (unsigned)(wave * 64 + lane);
-    f4 q = sorted[at];
+    f4 q = sorted[(unsigned)(slot_bucket(0) * 64 + lane)];  // (inside the padded buffer for every wave: nb >= 32)
     for (int l = 0; l < 64; ++l) {
-      const int bk = l * kBkWaves + wave;
-      if (bk >= geo.nb) break;  // (uniform)
+      const int bk = slot_bucket(l);
+      const int bkn = l < 63 ? slot_bucket(l + 1) : geo.nb;
       f4 qn = q;
-      if (bk + kBkWaves < geo.nb) qn = sorted[at + (unsigned)(l + 1) * (kBkWaves * 64)];
+      if (bkn < geo.nb) qn = sorted[(unsigned)(bkn * 64 + lane)];
+      if (bk >= geo.nb) {  // (uniform; an empty slot keeps the empty box and the zero key)
+        q = qn;
+        continue;
+      }
       const bool real = bk * 64 + lane < N;  // (the box is the box of the bucket's real points)
       float v[6] = {real ? -q.x : -INFINITY, real ? -q.y : -INFINITY, real ? -q.z : -INFINITY,
                     real ? q.x : -INFINITY,  real ? q.y : -INFINITY,  real ? q.z : -INFINITY};
@@ -471,126 +516,350 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   }
 
   if (PP_FPSB_STOP <= 6) return;
-  // ---------------------------------------------------------------- G. the chain
-  // Keys only ever fall (temp = min(...)), so a wave's best bucket stays its best until that very bucket is
-  // re-evaluated: only then is the wave's maximum taken again.  The workgroup's maximum is ONE LDS atomic per wave
-  // (ds_max_u64 on a word of a three-deep ring, the wave's number in the key's low bits), one barrier, one read.
-  u64 wkey = 0ull;
-  int wl = 0;  // the lane whose bucket holds wkey
-  float wcx = 0.0f, wcy = 0.0f, wcz = 0.0f;
-  bool redo = true;
-  int buf = 1;  // j % 3
   PP_FPSB_PROBE_DECL
-  for (int j = 1; j < npoint; ++j) {
-    PP_FPSB_MARK(0);
-    if (redo) {  // this wave's best bucket
-      wkey = wave_argmax_key((unsigned)(bkey >> 32), (unsigned)bkey, wl);
-      wcx = rl(ax, wl); wcy = rl(ay, wl); wcz = rl(az, wl);
+  if constexpr (REG && BATCH) {
+    // -------------------------------------------------------------- G'. the chain, several picks per round
+    // Keys only ever fall, and a pick only lowers the keys of points it is closer to than every earlier pick.  So if
+    // c1 > c2 > ... are the largest keys of the cloud, c2 is the pick after c1 provided (i) c1 does not lower c2's own
+    // key: !(dist3(c2, c1) < temp[c2]), and (ii) nothing that c1 leaves behind can overtake c2.  Everything outside
+    // c1's bucket keeps or lowers a key that was below c2's already; inside c1's bucket every other point's temp is
+    // at most the bucket's SECOND-largest temp (`sec`, taken from the bucket's running minima when it is posted), so
+    // temp[c2] > sec(c1) settles (ii).  By induction a whole prefix c1 .. ck of the sorted candidates is the next k
+    // picks when every c_j passes (i) and (ii) against every c_i before it -- the very picks, in the very order, of
+    // one-at-a-time sampling: the reference's tie rule is the 64-bit key order, which the test never leaves.  min
+    // commutes exactly, so applying the k picks to the buckets they touch in one visit gives the same temp.
+    //
+    // Candidates: every wave posts its two best bucket keys K1 > K2 (with coordinates and sec).  Whatever a wave did
+    // not post is below its K2, so the sorted list of ALL bucket keys is known down to BOUND = the largest K2, that
+    // one included: the candidates are the keys >= BOUND (at most 17).  Round:
+    //   post -> barrier -> every wave with an eligible candidate tests ITS OWN against the others (a lane per other
+    //   candidate: one pair per lane, no loop, no sort), raises FAIL = the largest candidate key that fails (i) or
+    //   (ii) against an eligible larger one (LDS atomic max), and marks the super-boxes its pick can reach
+    //   -> barrier -> the picks are the candidates above FAIL, a pick's position is the number of eligible keys above
+    //   it; box tests, one visit per touched bucket.
+    // Box tests: 1024 buckets x k picks is what a round would cost with a pass over the wave's buckets per pick (the
+    // whole kernel is bound by instruction issue -- sixteen waves, one instruction per wave every four cycles).  The
+    // super-box masks are the same for every wave (super-box l = lane l of each), so a lane only tests ITS bucket
+    // against the picks that reach ITS super-box: each lane fetches its own pick (ds_bpermute), one pass serves
+    // every pick of the round (a second only where two picks reach one super-box).
+    // The last picks are taken one per round (every candidate but the largest fails), so that the round that takes
+    // pick npoint-1 is known: temp ends as the minimum over every pick but the last (ref :203-205).
+    u64 wk1 = 0ull, wk2 = 0ull;  // this wave's best two bucket keys
+    int wl1 = 0, wl2 = 0;        // and the lanes that own them
+    float w1x = 0.0f, w1y = 0.0f, w1z = 0.0f, w2x = 0.0f, w2y = 0.0f, w2z = 0.0f;
+    unsigned w1s = 0u;
+    bool redo = true;
+    int buf = 0;
+    auto okey_of = [](float v) -> int {  // order-preserving integer image of a float (an involution on the bits)
+      const int b = (int)__float_as_uint(v);
+      return b ^ ((b >> 31) & 0x7fffffff);
+    };
+    if (t < 2) { s_bound[t] = 0ull; s_fail[t] = 0ull; }
+    if (t < 64) {
+      for (int a = 0; a < 6; ++a) s_sbox[t][a] = (int)0x80000000;
+      s_sbmax[0][t] = 0u; s_sbmax[1][t] = 0u;
+      s_cover[0][t] = 0u; s_cover[1][t] = 0u;
     }
-    if (lane == 0) {
-      s_c[buf][wave][0] = wcx; s_c[buf][wave][1] = wcy; s_c[buf][wave][2] = wcz;
-      __hip_atomic_fetch_max(&s_g[buf], (wkey & 0xFFFFFFFF00000000ull) | ((wkey & (u64)kRcMax) << 4) | (u64)wave,
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    {  // (an empty slot's box is (+inf, -inf): the identity)
+      const float v[6] = {-lox, -loy, -loz, hix, hiy, hiz};
+      for (int a = 0; a < 6; ++a) atomicMax(&s_sbox[lane][a], okey_of(v[a]));
     }
-    PP_FPSB_MARK(1);
-    // LDS only: what the loop writes to global memory (temp, the picks) is read back by the SAME wave (a bucket is
-    // always visited by its owner's wave) or after the loop's closing __syncthreads -- no store's acknowledgement is
-    // waited for here
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (PP_FPSB_DOUBLE & 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    PP_FPSB_MARK(2);
-    const u64 G = s_g[buf];
-    const int wv = (int)(G & 15ull);
-    ox = s_c[buf][wv][0]; oy = s_c[buf][wv][1]; oz = s_c[buf][wv][2];
-    // the pick, as its ~tie rank (turned into the index after the loop: a division, off the chain); one wave per
-    // step stores, in turn; and the ring word of the step after the next is cleared (nobody reads it any more)
-    const int nbuf = buf == 2 ? 0 : buf + 1;
-    if (t == ((j & (kBkWaves - 1)) << 6)) {
-      out[j] = (int)((unsigned)(G >> 4) & kRcMax);
-      if (smp) put(j, ox, oy, oz);
-      s_g[nbuf == 2 ? 0 : nbuf + 1] = 0ull;
+    __syncthreads();
+    float sb[6];  // -lo, hi of super-box `lane`
+    for (int a = 0; a < 6; ++a) {
+      const int k = s_sbox[lane][a];
+      sb[a] = __uint_as_float((unsigned)(k ^ ((k >> 31) & 0x7fffffff)));
     }
-    buf = nbuf;
-    if (j == npoint - 1) break;  // (ref: temp ends as the minimum over every pick but the last)
-    PP_FPSB_MARK(3);
-    // which of my buckets can this pick change?
-    const float gx = fmaxf(fmaxf(lox - ox, ox - hix), 0.0f);
-    const float gy = fmaxf(fmaxf(loy - oy, oy - hiy), 0.0f);
-    const float gz = fmaxf(fmaxf(loz - oz, oz - hiz), 0.0f);
-    const float bd = __builtin_fmaf(gz, gz, __builtin_fmaf(gx, gx, gy * gy));
-    const float bmax = __uint_as_float((unsigned)(bkey >> 32));
-    u64 mask = __ballot(!(bd >= bmax));
-    if (PP_FPSB_DOUBLE & 16) {  // the box test and its ballot once more, dependent on the first
-      float gx2 = fmaxf(fmaxf(lox - ox, ox - hix), __uint_as_float((unsigned)mask & 0u));
-      asm volatile("" : "+v"(gx2));
-      const float bd2 = __builtin_fmaf(gz, gz, __builtin_fmaf(gx2, gx2, gy * gy));
-      mask = __ballot(!(bd2 >= bmax));
-    }
-    if (PP_FPSB_DOUBLE & 32) mask = 0;  // no visits at all (WRONG picks: the cost of a step without its visits)
-    redo = (mask >> wl) & 1ull;
-    PP_FPSB_TOUCHED(mask);
-    PP_FPSB_MARK(4);
-    if (REG) {
-      // A step lasts as long as its busiest wave (one step in nine has a wave with two or more buckets to visit):
-      // the next bucket's record is loaded before this one is evaluated, so every visit after the first costs its
-      // arithmetic only.
-      const unsigned at = (unsigned)(wave * 64 + lane);
-      int l = 0;
-      f4 q;
-      float told = 0.0f;
-      if (mask) {
-        l = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        q = sorted[at + (unsigned)l * (kBkWaves * 64)];
-        told = td_get(l);
-      } else {
-        l = -1;
+    const float sblox = -sb[0], sbloy = -sb[1], sbloz = -sb[2], sbhix = sb[3], sbhiy = sb[4], sbhiz = sb[5];
+    int j = 1;
+    while (j < npoint) {
+      PP_FPSB_MARK(0);
+      if (redo) {
+        const unsigned khi = (unsigned)(bkey >> 32), klo = (unsigned)bkey;
+        wk1 = wave_argmax_key(khi, klo, wl1);
+        const bool rest = lane != wl1;
+        wk2 = wave_argmax_key(rest ? khi : 0u, rest ? klo : 0u, wl2);
+        w1x = rl(ax, wl1); w1y = rl(ay, wl1); w1z = rl(az, wl1);
+        w2x = rl(ax, wl2); w2y = rl(ay, wl2); w2z = rl(az, wl2);
+        // the second-largest temp of K1's bucket, from the running minima themselves (only a posted bucket needs
+        // it: kept per bucket it cost every visit a second reduction; K2 is only ever eligible as BOUND, the last
+        // of the sorted candidates: nothing is tested against its bucket)
+        unsigned top;
+        wave_max2_u32(__float_as_uint(td_get(wl1)), top, w1s);
       }
-      while (l >= 0) {
-        int ln = -1;
-        f4 qn = q;
-        float tn = 0.0f;
+      if (lane < 2) {
+        f4 r;
+        r.x = lane ? w2x : w1x; r.y = lane ? w2y : w1y; r.z = lane ? w2z : w1z;
+        r.w = __uint_as_float(lane ? 0xFFFFFFFFu : w1s);
+        s_key[buf][2 * wave + lane] = lane ? wk2 : wk1;
+        s_rec[buf][2 * wave + lane] = r;
+        if (lane) __hip_atomic_fetch_max(&s_bound[buf], wk2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      // the largest temp of every super-box (lane l of the sixteen waves)
+      __hip_atomic_fetch_max(&s_sbmax[buf][lane], (unsigned)(bkey >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      PP_FPSB_MARK(1);
+      // LDS only (see the one-pick chain below): no store's acknowledgement is waited for
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      PP_FPSB_MARK(2);
+      const bool single = npoint - j < 2 * kBkWaves + 2;
+      const int slot = lane & (2 * kBkWaves - 1);
+      const u64 okey = s_key[buf][slot];
+      const f4 orec = s_rec[buf][slot];
+      const u64 bound = s_bound[buf];
+      if (t < 64) {  // (the other half of the tables: read for the last time before this round's first barrier)
+        if (t == 0) s_fail[buf ^ 1] = 0ull;
+        s_sbmax[buf ^ 1][t] = 0u;
+        s_cover[buf ^ 1][t] = 0u;
+      }
+      const bool o_el = okey >= bound && okey != 0ull;
+      const bool el1 = wk1 >= bound && wk1 != 0ull, el2 = wk2 >= bound && wk2 != 0ull;
+      int rank1 = 0, rank2 = 0;
+      if (el1 || el2) {  // (a wave without an eligible candidate has nothing to test)
+        const bool second = lane >= 2 * kBkWaves;  // the upper half of the wave tests K2, the lower K1
+        const u64 mkey = second ? wk2 : wk1;
+        const float mx = second ? w2x : w1x, my = second ? w2y : w1y, mz = second ? w2z : w1z;
+        const unsigned mhi = (unsigned)(mkey >> 32);
+        const bool gt = o_el && okey > mkey;
+        const float dd = dist3(mx, my, mz, orec.x, orec.y, orec.z);
+        const bool bad = gt && (single || dd < __uint_as_float(mhi) || !(mhi > __float_as_uint(orec.w)));
+        const u64 gtm = __ballot(gt), badm = __ballot(bad);
+        rank1 = __builtin_popcount((unsigned)gtm);
+        rank2 = __builtin_popcount((unsigned)(gtm >> 32));
+        u64 f = 0ull;
+        if (el1 && (unsigned)badm != 0u) f = wk1;
+        if (el2 && (unsigned)(badm >> 32) != 0u && wk2 > f) f = wk2;
+        if (f != 0ull && lane == 0)
+          __hip_atomic_fetch_max(&s_fail[buf], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // the super-boxes an eligible candidate's pick can reach: the box test with the super-box's box and its
+        // largest temp (>= every member's: the test only ever says "visit" more often), a lane per super-box
+        const float sbm = __uint_as_float(s_sbmax[buf][lane]);
+        auto reach = [&](float px, float py, float pz, unsigned bit) {
+          const float gx = fmaxf(fmaxf(sblox - px, px - sbhix), 0.0f);
+          const float gy = fmaxf(fmaxf(sbloy - py, py - sbhiy), 0.0f);
+          const float gz = fmaxf(fmaxf(sbloz - pz, pz - sbhiz), 0.0f);
+          const float bd = __builtin_fmaf(gz, gz, __builtin_fmaf(gx, gx, gy * gy));
+          if (!(bd >= sbm)) atomicOr(&s_cover[buf][lane], bit);
+        };
+        if (el1) reach(w1x, w1y, w1z, 1u << (2 * wave));
+        if (el2) reach(w2x, w2y, w2z, 2u << (2 * wave));
+      }
+      PP_FPSB_MARK(3);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      PP_FPSB_MARK(4);
+      const u64 fail = s_fail[buf];
+      unsigned cover = s_cover[buf][lane];
+      if (t == 0) s_bound[buf] = 0ull;  // (read for the last time before the barrier above)
+      const u64 accm = __ballot(lane < 2 * kBkWaves && o_el && okey > fail);
+      const int k = __builtin_popcountll(accm);
+      PP_FPSB_PICKS(k);
+      // this wave's own candidates among the picks: stored at their positions (as ~tie rank: turned into the index
+      // after the loop)
+      if (lane == 0) {
+        if (el1 && wk1 > fail) {
+          out[j + rank1] = (int)((unsigned)wk1 & kRcMax);
+          if (smp) put(j + rank1, w1x, w1y, w1z);
+        }
+        if (el2 && wk2 > fail) {
+          out[j + rank2] = (int)((unsigned)wk2 & kRcMax);
+          if (smp) put(j + rank2, w2x, w2y, w2z);
+        }
+      }
+      j += k;
+      buf ^= 1;
+      if (j >= npoint || k == 0) break;  // (a single round: its pick is the last one, never applied)
+      // Which of my buckets can these picks change?  (Against the bucket's largest temp BEFORE the round: the test only
+      // ever says "visit" more often than one pick at a time would.)  ... and does one of them lower the bucket's
+      // BEST point?  Only then does the bucket's key change (every other temp only falls): a visit that leaves the
+      // best point alone updates the running minima and nothing else -- no reduction, no new key.
+      const float bmax = __uint_as_float((unsigned)(bkey >> 32));
+      cover &= (unsigned)accm;  // the picks (by candidate slot) that reach this lane's super-box
+      unsigned tm = 0u;         // ... and this lane's bucket
+      bool chg = false;
+      while (__ballot(cover != 0u)) {
+        const bool on = cover != 0u;
+        const int sl = on ? __builtin_ctz(cover) : 0;
+        cover &= cover - 1u;  // (0 stays 0)
+        const float px = __int_as_float(__builtin_amdgcn_ds_bpermute(sl << 2, __float_as_int(orec.x)));
+        const float py = __int_as_float(__builtin_amdgcn_ds_bpermute(sl << 2, __float_as_int(orec.y)));
+        const float pz = __int_as_float(__builtin_amdgcn_ds_bpermute(sl << 2, __float_as_int(orec.z)));
+        const float gx = fmaxf(fmaxf(lox - px, px - hix), 0.0f);
+        const float gy = fmaxf(fmaxf(loy - py, py - hiy), 0.0f);
+        const float gz = fmaxf(fmaxf(loz - pz, pz - hiz), 0.0f);
+        const float bd = __builtin_fmaf(gz, gz, __builtin_fmaf(gx, gx, gy * gy));
+        const bool hit = on && !(bd >= bmax);
+        tm |= hit ? 1u << sl : 0u;
+        chg |= hit && dist3(ax, ay, az, px, py, pz) < bmax;  // (the visit's own arithmetic)
+      }
+      u64 mask = __ballot(tm != 0u);
+      const u64 chgm = __ballot(chg);
+      redo = ((chgm >> wl1) | (chgm >> wl2)) & 1ull;
+      PP_FPSB_TOUCHED(mask);
+      PP_FPSB_MARK(5);
+      {
+        int l = -1;
+        f4 q;
+        q.x = q.y = q.z = q.w = 0.0f;
+        float told = 0.0f;
         if (mask) {
-          ln = __builtin_ctzll(mask);
+          l = __builtin_ctzll(mask);
           mask &= mask - 1;
-          qn = sorted[at + (unsigned)ln * (kBkWaves * 64)];
-          tn = td_get(ln);
+          q = sorted[(unsigned)(slot_bucket(l) * 64 + lane)];
+          told = td_get(l);
         }
-        if (PP_FPSB_DOUBLE & 1) {  // a second, dependent load of the same record
-          const unsigned zero = __float_as_uint(q.x) & 0u;
-          asm volatile("" ::: "memory");
-          q = sorted[at + (unsigned)l * (kBkWaves * 64) + zero];
+        while (l >= 0) {
+          int ln = -1;
+          f4 qn = q;
+          float tn = 0.0f;
+          if (mask) {  // (the next bucket's record is on its way while this one is evaluated)
+            ln = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            qn = sorted[(unsigned)(slot_bucket(ln) * 64 + lane)];
+            tn = td_get(ln);
+          }
+          unsigned tml = (unsigned)__builtin_amdgcn_readlane((int)tm, l);
+          float d2 = told;
+          while (tml) {
+            const int sl = __builtin_ctz(tml);
+            tml &= tml - 1;
+            const float px = rl(orec.x, sl), py = rl(orec.y, sl), pz = rl(orec.z, sl);
+            d2 = __builtin_fminf(dist3(q.x, q.y, q.z, px, py, pz), d2);
+          }
+          td_set(l, d2);
+          if ((chgm >> l) & 1ull) {  // (uniform)
+            int src;
+            const u64 M = wave_argmax_key(__float_as_uint(d2), __float_as_uint(q.w), src);
+            const float cx = rl(q.x, src), cy = rl(q.y, src), cz = rl(q.z, src);
+            if (lane == l) { bkey = M; ax = cx; ay = cy; az = cz; }
+          }
+          l = ln;
+          q = qn;
+          told = tn;
         }
-        if (PP_FPSB_DOUBLE & 2) td_set(l, __builtin_fminf(INFINITY, td_get(l)));
-        const float d2 = __builtin_fminf(dist3(q.x, q.y, q.z, ox, oy, oz), told);
-        td_set(l, d2);
-        const unsigned whi = __float_as_uint(d2);
-        int src;
-        if (PP_FPSB_DOUBLE & 4) {
-          u64 M0 = wave_argmax_key(whi, __float_as_uint(q.w), src);
-          asm volatile("" : "+s"(src), "+s"(M0));
-        }
-        const u64 M = wave_argmax_key(whi, __float_as_uint(q.w), src);
-        const float cx = rl(q.x, src), cy = rl(q.y, src), cz = rl(q.z, src);
-        if (lane == l) { bkey = M; ax = cx; ay = cy; az = cz; }
-        l = ln;
-        q = qn;
-        told = tn;
       }
-    } else {
-      while (mask) {
-        const int l = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        unsigned whi, wlo;
-        float wx, wy, wz;
-        visit(l, l * kBkWaves + wave, whi, wlo, wx, wy, wz);
-        int src;
-        const u64 M = wave_argmax_key(whi, wlo, src);
-        const float cx = rl(wx, src), cy = rl(wy, src), cz = rl(wz, src);
-        if (lane == l) { bkey = M; ax = cx; ay = cy; az = cz; }
-      }
+      PP_FPSB_MARK(6);
     }
-    PP_FPSB_MARK(5);
+  } else {
+    // ---------------------------------------------------------------- G. the chain
+    // Keys only ever fall (temp = min(...)), so a wave's best bucket stays its best until that very bucket is
+    // re-evaluated: only then is the wave's maximum taken again.  The workgroup's maximum is ONE LDS atomic per wave
+    // (ds_max_u64 on a word of a three-deep ring, the wave's number in the key's low bits), one barrier, one read.
+    u64 wkey = 0ull;
+    int wl = 0;  // the lane whose bucket holds wkey
+    float wcx = 0.0f, wcy = 0.0f, wcz = 0.0f;
+    bool redo = true;
+    int buf = 1;  // j % 3
+    for (int j = 1; j < npoint; ++j) {
+      PP_FPSB_MARK(0);
+      if (redo) {  // this wave's best bucket
+        wkey = wave_argmax_key((unsigned)(bkey >> 32), (unsigned)bkey, wl);
+        wcx = rl(ax, wl); wcy = rl(ay, wl); wcz = rl(az, wl);
+      }
+      if (lane == 0) {
+        s_c[buf][wave][0] = wcx; s_c[buf][wave][1] = wcy; s_c[buf][wave][2] = wcz;
+        __hip_atomic_fetch_max(&s_g[buf], (wkey & 0xFFFFFFFF00000000ull) | ((wkey & (u64)kRcMax) << 4) | (u64)wave,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      PP_FPSB_MARK(1);
+      // LDS only: what the loop writes to global memory (temp, the picks) is read back by the SAME wave (a bucket is
+      // always visited by its owner's wave) or after the loop's closing __syncthreads -- no store's acknowledgement is
+      // waited for here
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (PP_FPSB_DOUBLE & 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      PP_FPSB_MARK(2);
+      const u64 G = s_g[buf];
+      const int wv = (int)(G & 15ull);
+      ox = s_c[buf][wv][0]; oy = s_c[buf][wv][1]; oz = s_c[buf][wv][2];
+      // the pick, as its ~tie rank (turned into the index after the loop: a division, off the chain); one wave per
+      // step stores, in turn; and the ring word of the step after the next is cleared (nobody reads it any more)
+      const int nbuf = buf == 2 ? 0 : buf + 1;
+      if (t == ((j & (kBkWaves - 1)) << 6)) {
+        out[j] = (int)((unsigned)(G >> 4) & kRcMax);
+        if (smp) put(j, ox, oy, oz);
+        s_g[nbuf == 2 ? 0 : nbuf + 1] = 0ull;
+      }
+      buf = nbuf;
+      if (j == npoint - 1) break;  // (ref: temp ends as the minimum over every pick but the last)
+      PP_FPSB_MARK(3);
+      // which of my buckets can this pick change?
+      const float gx = fmaxf(fmaxf(lox - ox, ox - hix), 0.0f);
+      const float gy = fmaxf(fmaxf(loy - oy, oy - hiy), 0.0f);
+      const float gz = fmaxf(fmaxf(loz - oz, oz - hiz), 0.0f);
+      const float bd = __builtin_fmaf(gz, gz, __builtin_fmaf(gx, gx, gy * gy));
+      const float bmax = __uint_as_float((unsigned)(bkey >> 32));
+      u64 mask = __ballot(!(bd >= bmax));
+      if (PP_FPSB_DOUBLE & 16) {  // the box test and its ballot once more, dependent on the first
+        float gx2 = fmaxf(fmaxf(lox - ox, ox - hix), __uint_as_float((unsigned)mask & 0u));
+        asm volatile("" : "+v"(gx2));
+        const float bd2 = __builtin_fmaf(gz, gz, __builtin_fmaf(gx2, gx2, gy * gy));
+        mask = __ballot(!(bd2 >= bmax));
+      }
+      if (PP_FPSB_DOUBLE & 32) mask = 0;  // no visits at all (WRONG picks: the cost of a step without its visits)
+      redo = (mask >> wl) & 1ull;
+      PP_FPSB_TOUCHED(mask);
+      PP_FPSB_MARK(4);
+      if (REG) {
+        // A step lasts as long as its busiest wave (one step in nine has a wave with two or more buckets to visit):
+        // the next bucket's record is loaded before this one is evaluated, so every visit after the first costs its
+        // arithmetic only.
+        const unsigned at = (unsigned)(wave * 64 + lane);
+        int l = 0;
+        f4 q;
+        float told = 0.0f;
+        if (mask) {
+          l = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          q = sorted[at + (unsigned)l * (kBkWaves * 64)];
+          told = td_get(l);
+        } else {
+          l = -1;
+        }
+        while (l >= 0) {
+          int ln = -1;
+          f4 qn = q;
+          float tn = 0.0f;
+          if (mask) {
+            ln = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            qn = sorted[at + (unsigned)ln * (kBkWaves * 64)];
+            tn = td_get(ln);
+          }
+          if (PP_FPSB_DOUBLE & 1) {  // a second, dependent load of the same record
+            const unsigned zero = __float_as_uint(q.x) & 0u;
+            asm volatile("" ::: "memory");
+            q = sorted[at + (unsigned)l * (kBkWaves * 64) + zero];
+          }
+          if (PP_FPSB_DOUBLE & 2) td_set(l, __builtin_fminf(INFINITY, td_get(l)));
+          const float d2 = __builtin_fminf(dist3(q.x, q.y, q.z, ox, oy, oz), told);
+          td_set(l, d2);
+          const unsigned whi = __float_as_uint(d2);
+          int src;
+          if (PP_FPSB_DOUBLE & 4) {
+            u64 M0 = wave_argmax_key(whi, __float_as_uint(q.w), src);
+            asm volatile("" : "+s"(src), "+s"(M0));
+          }
+          const u64 M = wave_argmax_key(whi, __float_as_uint(q.w), src);
+          const float cx = rl(q.x, src), cy = rl(q.y, src), cz = rl(q.z, src);
+          if (lane == l) { bkey = M; ax = cx; ay = cy; az = cz; }
+          l = ln;
+          q = qn;
+          told = tn;
+        }
+      } else {
+        while (mask) {
+          const int l = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          unsigned whi, wlo;
+          float wx, wy, wz;
+          visit(l, l * kBkWaves + wave, whi, wlo, wx, wy, wz);
+          int src;
+          const u64 M = wave_argmax_key(whi, wlo, src);
+          const float cx = rl(wx, src), cy = rl(wy, src), cz = rl(wz, src);
+          if (lane == l) { bkey = M; ax = cx; ay = cy; az = cz; }
+        }
+      }
+      PP_FPSB_MARK(5);
+    }
   }
   PP_FPSB_END();
   __syncthreads();
@@ -598,11 +867,11 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   for (int j = 1 + t; j < npoint; j += kBkThreads) out[j] = order.unrank(kRcMax - (unsigned)out[j]);
   if (!tmp) return;  // (the caller keeps no running minima: furthest_point_sample's own temp, never read back)
   if (REG) {
-    unsigned first = (unsigned)(wave * 64 + lane);
+    unsigned first = (unsigned)lane;
     asm volatile("" : "+v"(first));  // (computed afresh: sixty-four addresses kept alive across the chain spilled)
 #pragma unroll
     for (int l = 0; l < 64; ++l) {
-      const unsigned pos = first + (unsigned)(l * kBkWaves * 64);
+      const unsigned pos = first + (unsigned)(slot_bucket(l) * 64);
       if (pos < (unsigned)N) tmp[order.unrank(kRcMax - __float_as_uint(sorted[pos].w))] = td_get(l);
     }
   } else {
@@ -610,7 +879,8 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   }
 }
 
-pp::DeviceFlags g_bucket_lds[2];
+pp::DeviceFlags g_bucket_lds[3];
+pp::Knob g_bucket_chain;  // 1: one pick per round (the round-4 chain)
 
 }  // namespace
 
@@ -643,19 +913,26 @@ int bucket_launch(const float* xyz, float* temp, int* idx, int B, int N, int npo
   const BucketGeom g = bucket_geom(N);
   f4* sorted = (f4*)ws;
   unsigned* aux = (unsigned*)((char*)ws + (size_t)B * g.npad * sizeof(f4));
-  if (g.m == 1) {
-    hipError_t e = pp::allow_big_lds(fps_bucket_kernel<true>, kBkLdsBytes, g_bucket_lds[0]);
+  if (g.m == 1 && (int)g_bucket_chain != 1) {
+    hipError_t e = pp::allow_big_lds(fps_bucket_kernel<true, true>, kBkLdsBytes, g_bucket_lds[2]);
     if (e != hipSuccess) return (int)e;
-    fps_bucket_kernel<true><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed, order, g,
-                                                                          sorted, aux, sampled, cf);
+    fps_bucket_kernel<true, true><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed,
+                                                                                order, g, sorted, aux, sampled, cf);
+  } else if (g.m == 1) {
+    hipError_t e = pp::allow_big_lds(fps_bucket_kernel<true, false>, kBkLdsBytes, g_bucket_lds[0]);
+    if (e != hipSuccess) return (int)e;
+    fps_bucket_kernel<true, false><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed,
+                                                                                 order, g, sorted, aux, sampled, cf);
   } else {
-    hipError_t e = pp::allow_big_lds(fps_bucket_kernel<false>, kBkLdsBytes, g_bucket_lds[1]);
+    hipError_t e = pp::allow_big_lds(fps_bucket_kernel<false, false>, kBkLdsBytes, g_bucket_lds[1]);
     if (e != hipSuccess) return (int)e;
-    fps_bucket_kernel<false><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed, order, g,
-                                                                           sorted, aux, sampled, cf);
+    fps_bucket_kernel<false, false><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed,
+                                                                                  order, g, sorted, aux, sampled, cf);
   }
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
 }
 
 }  // namespace ppfps
+
+extern "C" void pp_debug_set_fps_bucket_chain(int form) { g_bucket_chain.set(form); }

@@ -246,6 +246,11 @@ struct PackedExchange {
   // Direct mode (init_direct): the all-gather is ONE ncclAllGather on a communicator of this object's own instead of a
   // c10d call (which wraps the same RCCL enqueue in a Work object, two events and a stream wait).  nullptr: c10d.
   ncclComm_t comm = nullptr;
+  // p2p mode (set_p2p): the all-gather as ONE grouped set of world - 1 sends and world - 1 receives, in place between
+  // the rows of the gathered buffers -- every part crosses the direct xGMI link between its two GPUs instead of
+  // whatever ring or tree the library's all-gather picks (one link per hop, world - 1 hops back to back)
+  bool p2p = false;
+  int rank = 0;
   double issue_ns = 0.0;  // host time spent issuing exchanges (collective + events), and how many
   long long issue_slots = 0;
 
@@ -261,6 +266,7 @@ struct PackedExchange {
       : pg(group), world(group->getSize()), b(b_local), n(n_), m(m_), depth(depth_), dev(with_index(device)),
         side(c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, with_index(device).index())) {
     TORCH_CHECK(dev.is_cuda() && depth >= 1, "PackedExchange needs a GPU device and depth >= 1");
+    rank = group->getRank();
     compact = std::max(n, m) <= 65535 ? 1 : 0;
     const int64_t isz = compact ? 2 : 4;
     const int64_t nbytes = (int64_t)4 * b * (n + m) + isz * b * (n + m);
@@ -325,14 +331,31 @@ struct PackedExchange {
     for (int k = 0; k < depth; ++k) send[k] = recv[k].select(0, rank);
     make_views();
   }
-  void disable_direct() {  // back to c10d (a rank failed to join: every rank must then take the same path)
+  // The grouped send / receive form, in place like the direct form: a slot's own part is row `rank` of its gathered
+  // buffer.  Over c10d's communicator (coalesced send / recv), or over the object's own after init_direct.  A
+  // collective decision: every rank, before the first launch.
+  void set_p2p() {
+    drain();
+    const c10::DeviceGuard guard(dev);
+    for (int k = 0; k < depth; ++k) send[k] = recv[k].select(0, rank);
+    make_views();
+    p2p = true;
+  }
+  // back to c10d's all-gather (a rank failed to join, or the first exchange's self-check failed: every rank must then
+  // take the same path).  EVERY slot's own part -- launched or only begun: the search may have written its distances
+  // into the in-place row already -- moves into the send buffer the c10d call is given again.
+  void disable_direct() {
     drain();
     (void)hipStreamSynchronize(side.stream());
     if (comm) (void)ncclCommDestroy(comm);
     comm = nullptr;
+    const bool in_place = depth > 0 && send[0].data_ptr() == recv[0].select(0, rank).data_ptr();
+    p2p = false;
     const c10::DeviceGuard guard(dev);
-    for (int k = 0; k < depth; ++k)  // c10d's call is given buffers of its own again
+    for (int k = 0; k < depth; ++k) {
       send[k] = torch::empty({nbytes_padded}, torch::TensorOptions().dtype(torch::kUInt8).device(dev));
+      if (in_place) send[k].copy_(recv[k].select(0, rank));
+    }
     make_views();
   }
 
@@ -384,7 +407,34 @@ struct PackedExchange {
     const hipStream_t cur = current();
     TORCH_CHECK(hipEventRecord(packed[slot], cur) == hipSuccess, "hipEventRecord failed");
     TORCH_CHECK(hipStreamWaitEvent(side.stream(), packed[slot], 0) == hipSuccess, "hipStreamWaitEvent failed");
-    if (comm) {
+    if (p2p && world == 1) {
+      // (nothing to move: the own part is in place)
+    } else if (p2p && comm) {
+      ncclResult_t rc = ncclGroupStart();
+      for (int d = 1; d < world && rc == ncclSuccess; ++d) {
+        const int to = (rank + d) % world, from = (rank - d + world) % world;
+        rc = ncclSend(send[slot].data_ptr(), (size_t)nbytes_padded, ncclChar, to, comm, side.stream());
+        if (rc == ncclSuccess)
+          rc = ncclRecv(recv[slot].select(0, from).data_ptr(), (size_t)nbytes_padded, ncclChar, from, comm, side.stream());
+      }
+      const ncclResult_t rc_end = ncclGroupEnd();
+      TORCH_CHECK(rc == ncclSuccess && rc_end == ncclSuccess, "grouped ncclSend/ncclRecv failed: ",
+                  ncclGetErrorString(rc != ncclSuccess ? rc : rc_end));
+    } else if (p2p) {
+      // c10d: the sends and receives coalesced into ONE group on the process group's communicator, ordered behind
+      // the side stream like the all-gather below
+      const c10::hip::HIPStreamGuardMasqueradingAsCUDA on_side(side);
+      pg->startCoalescing(c10::DeviceType::CUDA);
+      for (int d = 1; d < world; ++d) {
+        const int to = (rank + d) % world, from = (rank - d + world) % world;
+        std::vector<Tensor> out{send[slot]};
+        std::vector<Tensor> in{recv[slot].select(0, from)};
+        pg->send(out, to, 0);
+        pg->recv(in, from, 0);
+      }
+      c10::intrusive_ptr<c10d::Work> work = pg->endCoalescing(c10::DeviceType::CUDA);
+      if (work) work->wait();  // (the side stream waits for the group's end, no host block)
+    } else if (comm) {
       const ncclResult_t rc = ncclAllGather(send[slot].data_ptr(), recv[slot].data_ptr(), (size_t)nbytes_padded, ncclChar, comm,
                                             side.stream());
       TORCH_CHECK(rc == ncclSuccess, "ncclAllGather failed: ", ncclGetErrorString(rc));
@@ -511,6 +561,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def_static("unique_id", &PackedExchange::unique_id)
       .def("init_direct", &PackedExchange::init_direct, pybind11::call_guard<pybind11::gil_scoped_release>())
       .def("disable_direct", &PackedExchange::disable_direct, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def("set_p2p", &PackedExchange::set_p2p, pybind11::call_guard<pybind11::gil_scoped_release>())
+      .def_readonly("p2p", &PackedExchange::p2p)
       .def("issue_us_per_slot", [](PackedExchange& e) { return e.issue_slots ? e.issue_ns / 1e3 / (double)e.issue_slots : 0.0; })
       .def_readonly("compact", &PackedExchange::compact)
       .def_readonly("nbytes_padded", &PackedExchange::nbytes_padded);

@@ -105,7 +105,7 @@ class PackedShardGather:
     (``depth`` launches later).
     """
 
-    def __init__(self, b_local, n, m, device, group=None, depth=2):
+    def __init__(self, b_local, n, m, device, group=None, depth=2, exchange=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.b, self.n, self.m = int(b_local), int(n), int(m)
@@ -133,8 +133,22 @@ class PackedShardGather:
         # direct ncclAllGather, in place, on a communicator of the object's own (opt-in: it has run on one rank only,
         # where RCCL moves nothing -- VERDICT r4 #3; its first exchange is verified against c10d, below);
         # "python" = the Python-issued exchange.
-        mode = os.environ.get("PP_SHARD_EXCHANGE", "native")
-        if self.on_gpu and self._nccl and mode != "python":
+        # "p2p" (round 6) = the all-gather as ONE grouped set of world - 1 sends and world - 1 receives, in place between
+        # the rows of the gathered buffers, on c10d's communicator: each 6 MiB part crosses the direct xGMI link
+        # between its two GPUs (floor: one part over one link, 0.04 ms at config 2) where a ring all-gather pays
+        # world - 1 hops back to back (0.29 ms); "rccl_p2p" = the same group on the direct communicator.  ``exchange``
+        # (the constructor's argument) overrides the environment variable.
+        mode = exchange if exchange is not None else os.environ.get("PP_SHARD_EXCHANGE", "native")
+        if mode not in ("native", "rccl", "python", "p2p", "rccl_p2p", "python_p2p"):
+            raise ValueError("PP_SHARD_EXCHANGE: unknown exchange mode %r" % (mode,))
+        self.mode = mode
+        self.rank = dist.get_rank(group)
+        self.p2p = False
+        if mode in ("p2p", "python_p2p") and not (self.on_gpu and self._nccl and mode == "p2p"):
+            # the Python path (gloo in the CPU tests, or asked for): isend / irecv between the rows, in place
+            self.p2p = True
+            self.send = [self.recv[k][self.rank] for k in range(depth)]
+        if self.on_gpu and self._nccl and mode not in ("python", "python_p2p"):
             from . import _lib
             pg = group if group is not None else dist.distributed_c10d._get_default_group()
             self._native = _lib.bridge().PackedExchange(pg, self.b, self.n, self.m, torch.device(device), depth)
@@ -150,7 +164,11 @@ class PackedShardGather:
             # not the default until a multi-rank run with a concurrent c10d collective has passed.  Any failure to
             # set it up -- on any rank -- leaves the c10d path in place on all of them, and the first exchange is
             # checked against c10d (_self_check).
-            if mode == "rccl":
+            if mode == "p2p":
+                self._native.set_p2p()
+                self.p2p = True
+                self._checked = self.world == 1     # (its first exchange is verified against c10d's all-gather)
+            if mode in ("rccl", "rccl_p2p"):
                 # every rank takes part in every collective below whatever fails locally (a rank that skipped the
                 # broadcast because its own step raised would leave the others waiting in it)
                 import warnings
@@ -174,6 +192,9 @@ class PackedShardGather:
                 if int(ok.item()) == 0 and self.direct:
                     self._native.disable_direct()
                     self.direct = False
+                if self.direct and mode == "rccl_p2p":
+                    self._native.set_p2p()
+                    self.p2p = True
                 self._checked = not self.direct
 
     # ------------------------------------------------------------------ layout helpers (the Python / CPU path)
@@ -261,7 +282,21 @@ class PackedShardGather:
             v[2].copy_(i1.reshape(-1))            # int32 -> int16 keeps the low 16 bits
             v[3].copy_(i2.reshape(-1))
 
+    def _peer(self, r):
+        """rank ``r`` of the exchange's group as the global rank isend / irecv address"""
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
     def _gather(self, slot):
+        if self.p2p:
+            # one send of the own row to every other rank and one receive into that rank's row (batched: one group on
+            # RCCL); tag = slot, so that two slots in flight between the same pair cannot be confused
+            ops = []
+            for d in range(1, self.world):
+                to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+                ops.append(dist.P2POp(dist.isend, self.send[slot], self._peer(to), self.group, slot))
+                ops.append(dist.P2POp(dist.irecv, self.recv[slot][frm], self._peer(frm), self.group, slot))
+            self.inflight[slot] = dist.batch_isend_irecv(ops) if ops else None
+            return slot
         if self._nccl:
             work = dist.all_gather_into_tensor(self.recv[slot], self.send[slot], group=self.group, async_op=True)
         else:                                 # gloo (CPU tests)
@@ -275,7 +310,8 @@ class PackedShardGather:
         h = self.inflight[slot]
         if h is None:
             return
-        h.wait()
+        for w in (h if isinstance(h, (list, tuple)) else [h]):
+            w.wait()
         self.inflight[slot] = None
 
     def _self_check(self, slot):
@@ -285,6 +321,9 @@ class PackedShardGather:
         the slot again and warns.  (PP_SHARD_SELFCHECK_FAIL=1 makes the check fail: the test of the fall-back.)"""
         self._checked = True
         rank = dist.get_rank(self.group)
+        # every exchange in flight first: the check's c10d collectives must not run beside the direct communicator's
+        # kernels (two communicators whose kernels start in different orders on different ranks can deadlock, ADVICE r5)
+        self._native.drain()
         r = self._native.raw(slot)                                            # (world, nbytes_padded) uint8
         sums = r.view(torch.int32).to(torch.int64).sum(1)                     # one checksum per gathered row
         theirs = torch.empty(self.world, dtype=torch.int64, device=r.device)
@@ -297,8 +336,9 @@ class PackedShardGather:
         import warnings
         warnings.warn("pytorch_points_amd: the direct RCCL exchange did not reproduce the shards (rank %d: %s); "
                       "every rank falls back to c10d" % (rank, "mismatch here" if not good else "mismatch elsewhere"))
-        self._native.disable_direct()        # (drains; from here on the slots have send buffers of their own again)
-        self.direct = False
+        self._native.disable_direct()        # (drains; from here on the slots have send buffers of their own again,
+        self.direct = False                  #  every slot's own row copied into them -- also a slot only begun)
+        self.p2p = False
         self._native.reissue(rank)           # every launched slot once more, over c10d, from its own row
 
     # ------------------------------------------------------------------ consuming side

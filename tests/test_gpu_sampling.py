@@ -28,6 +28,24 @@ def _fps_form(name):
     setter(_FPS_FORMS[name])
 
 
+def _fps_chain(form):
+    import ctypes
+    from pytorch_points_amd import _lib
+    setter = _lib.lib().pp_debug_set_fps_bucket_chain
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter(form)
+
+
+@pytest.fixture(params=["batched", "one_pick"])
+def bucket_chain(request):
+    """the bucketed kernel's two chains: several independent picks per barrier round (default) and one pick per
+    round -- the same picks and temp from both"""
+    _fps_chain({"batched": 0, "one_pick": 1}[request.param])
+    yield request.param
+    _fps_chain(0)
+
+
 @pytest.fixture(params=["default", "cluster", "single_block"])
 def fps_path(request, cuda):
     """Run every FPS test on the three decompositions: the operator's own choice (the bucketed kernel where it
@@ -101,7 +119,7 @@ def _fps_clouds(n):
 
 
 @pytest.mark.parametrize("n,m,seed", [(2048, 64, 0), (5000, 300, 7), (4099, 4099, 4098), (16384, 700, 3)])
-def test_fps_bucketed_kernel_on_hard_clouds(cuda, n, m, seed):
+def test_fps_bucketed_kernel_on_hard_clouds(cuda, bucket_chain, n, m, seed):
     """The bucketed kernel (every step only visits the buckets the pick can change) against the oracle: picks AND
     temp, on clouds with exact ties, duplicates, degenerate extents, clusters and outliers."""
     from pytorch_points_amd._ext import sampling
@@ -124,7 +142,7 @@ def test_fps_bucketed_kernel_on_hard_clouds(cuda, n, m, seed):
     assert np.array_equal(pts.cpu().numpy(), np.take_along_axis(x, e_idx[..., None].astype(np.int64), 1))
 
 
-def test_fps_bucketed_kernel_honours_the_incoming_temp(cuda):
+def test_fps_bucketed_kernel_honours_the_incoming_temp(cuda, bucket_chain):
     """temp is an in/out argument (ref sampling_cuda.cu:190,204-205): whatever the caller passes bounds every
     point's distance from the start -- also for the bucket maxima the pruning relies on"""
     from pytorch_points_amd._ext import sampling

@@ -1,20 +1,28 @@
-// tools/fps_bucket_probe.hip -- where a pick of the bucketed FPS kernel spends its time: fps_bucket.hip compiled with
-// phase marks (shader clock, accumulated per wave of workgroup 0 over all steps) and touched-bucket counts at config 3.
-// Intervals per step:  0->1 this wave's best bucket (DPP reduction if one of its buckets changed) + LDS write
-//   1->2 barrier   2->3 16-value reduction, winner's coordinates from LDS, pick stored   3->4 box test + ballot
-//   4->5 touched buckets re-evaluated (loads, update, reduction each)
+// tools/fps_bucket_probe.hip -- where a round of the bucketed FPS kernel spends its time: fps_bucket.hip compiled with
+// phase marks (shader clock, accumulated per wave of workgroup 0 over all rounds), touched-bucket counts and the
+// picks-per-round histogram at config 3.  Intervals per round of the batched chain (round 6):
+//   0->1 this wave's two best buckets (two reductions if one of them was visited) + the post to LDS
+//   1->2 barrier   2->3 own candidates against the others (a pair per lane), FAIL raised   3->4 barrier
+//   4->5 picks read, own picks stored, box tests of every pick + ballot   5->6 touched buckets re-evaluated
+// (the one-pick chain, PP_PROBE_CHAIN=1: 0->1 best bucket + post, 1->2 barrier, 2->3 pick read, 3->4 box test, 4->5 visits)
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Iinclude -Ipytorch_points_amd/csrc tools/fps_bucket_probe.hip -o tools/fps_bucket_probe
 #include <hip/hip_runtime.h>
-__device__ unsigned long long g_probe[16][16];
+__device__ unsigned long long g_probe[16][32];
 #ifdef PP_FPSB_NOMARKS  // timing only (with -DPP_FPSB_DOUBLE=<bits>: what one more copy of a link of the chain costs)
 #define PP_FPSB_PROBE_DECL
 #define PP_FPSB_MARK(n)
 #define PP_FPSB_TOUCHED(mask)
+#define PP_FPSB_PICKS(k)
 #define PP_FPSB_END()
 #else
+// pr_acc: 0..5 phase clocks, 6 touched buckets, 12 rounds; pr_hist (LDS: indexed by a run-time value -- a register
+// array would go to scratch memory, whose vmcnt(0) waits would be charged to the phase): 0..4 rounds with 0/1/2/3/4+
+// touched buckets, 8..25 rounds with k picks
 #define PP_FPSB_PROBE_DECL                                   \
-  unsigned long long pr_t[6] = {0, 0, 0, 0, 0, 0};           \
-  unsigned long long pr_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pr_t[7] = {0, 0, 0, 0, 0, 0, 0};        \
+  unsigned long long pr_acc[13] = {0};                       \
+  __shared__ unsigned pr_hist[16][32];                       \
+  if (lane < 32) pr_hist[wave][lane] = 0u;
 #define PP_FPSB_MARK(n)                                                            \
   do {                                                                             \
     pr_t[n] = __builtin_amdgcn_s_memtime();                                        \
@@ -24,12 +32,18 @@ __device__ unsigned long long g_probe[16][16];
   do {                                                       \
     const int c__ = __builtin_popcountll(mask);              \
     pr_acc[6] += c__;                                        \
-    pr_acc[7 + (c__ > 4 ? 4 : c__)] += 1;                    \
+    if (lane == 0) pr_hist[wave][c__ > 4 ? 4 : c__] += 1u;   \
+    pr_acc[12] += 1;                                         \
   } while (0)
+#define PP_FPSB_PICKS(k) do { if (lane == 0) pr_hist[wave][8 + ((k) > 17 ? 17 : (k))] += 1u; } while (0)
 #define PP_FPSB_END()                                                         \
   do {                                                                        \
-    if (blockIdx.x == 0 && lane == 0)                                         \
-      for (int i__ = 0; i__ < 12; ++i__) g_probe[wave][i__] = pr_acc[i__];    \
+    if (blockIdx.x == 0 && lane == 0) {                                       \
+      for (int i__ = 0; i__ < 7; ++i__) g_probe[wave][i__] = pr_acc[i__];     \
+      g_probe[wave][12] = pr_acc[12];                                         \
+      for (int i__ = 0; i__ < 5; ++i__) g_probe[wave][7 + i__] = pr_hist[wave][i__];   \
+      for (int i__ = 0; i__ < 18; ++i__) g_probe[wave][13 + i__] = pr_hist[wave][8 + i__]; \
+    }                                                                         \
   } while (0)
 #endif
 #include "../pytorch_points_amd/csrc/fps_bucket.hip"
@@ -59,6 +73,7 @@ int main(int argc, char** argv) {
   hipMalloc(&x, h.size() * 4); hipMalloc(&temp, big.size() * 4); hipMalloc(&idx, (size_t)B * npoint * 4); hipMalloc(&ws, wsb + 256);
   hipMemset(ws, 0, 256);
   hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  if (getenv("PP_PROBE_CHAIN")) pp_debug_set_fps_bucket_chain(atoi(getenv("PP_PROBE_CHAIN")));
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int it = 0; it < 3; ++it) {
     hipMemcpy(temp, big.data(), big.size() * 4, hipMemcpyHostToDevice);
@@ -66,20 +81,25 @@ int main(int argc, char** argv) {
     const int rc = pp_furthest_sampling_f32(x, temp, idx, B, N, npoint, 0, ws, wsb, nullptr);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
-    unsigned long long pr[16][16];
+    unsigned long long pr[16][32];
     hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr));
     printf("rc %d: %.3f ms = %.3f us/pick (events)\n", rc, ms, ms * 1e3 / (npoint - 1));
 #ifdef PP_FPSB_NOMARKS
     continue;
 #endif
     if (it < 2) continue;
-    const double steps = npoint - 2;
+    const double rounds = (double)pr[0][12];
+    printf(" %.0f rounds for %d picks: %.2f picks per round; rounds with k picks:", rounds, npoint - 1, (npoint - 1) / rounds);
+    for (int k = 0; k <= 17; ++k)
+      if (pr[0][13 + k]) printf(" %d:%llu", k, pr[0][13 + k]);
+    printf("\n");
     for (int w = 0; w < 16; ++w) {
-      printf(" wave %2d cycles/step:", w);
+      printf(" wave %2d cycles/round:", w);
       double tot = 0;
-      for (int k = 0; k < 5; ++k) { printf(" p%d %6.0f", k, pr[w][k] / steps); tot += pr[w][k] / steps; }
-      printf("  sum %6.0f | touched/step %.2f; steps with 0/1/2/3/4+ touched: %.3f %.3f %.3f %.3f %.3f\n", tot, pr[w][6] / steps,
-             pr[w][7] / steps, pr[w][8] / steps, pr[w][9] / steps, pr[w][10] / steps, pr[w][11] / steps);
+      for (int k = 0; k < 6; ++k) { printf(" p%d %6.0f", k, pr[w][k] / rounds); tot += pr[w][k] / rounds; }
+      printf("  sum %6.0f | touched/round %.2f; rounds with 0/1/2/3/4+ touched: %.3f %.3f %.3f %.3f %.3f\n", tot,
+             pr[w][6] / rounds, pr[w][7] / rounds, pr[w][8] / rounds, pr[w][9] / rounds, pr[w][10] / rounds,
+             pr[w][11] / rounds);
     }
   }
   return 0;

@@ -21,6 +21,14 @@ def form(name):
     f(FORMS[name])
 
 
+def chain(one_pick):
+    """the bucketed kernel's chain: 0 = several independent picks per round (default), 1 = one pick per round"""
+    f = _lib.lib().pp_debug_set_fps_bucket_chain
+    f.argtypes = [ctypes.c_int]
+    f.restype = None
+    f(1 if one_pick else 0)
+
+
 def clouds(B, N):
     rng = np.random.default_rng(5)
     out = {"sphere": S.unit_sphere(0, B, N)}
@@ -49,7 +57,9 @@ def time_it(x, m, reps=3):
 
 def main():
     dev = torch.device("cuda:0")
-    for (B, N, m) in [(16, 65536, 4096), (16, 16384, 1024), (32, 8192, 512), (64, 4096, 1024), (1, 65536, 4096), (4, 262144, 4096)]:
+    quick = len(sys.argv) > 1 and sys.argv[1] == "quick"   # the bucketed kernel's two chains at config 3 only
+    shapes = [(16, 65536, 4096), (16, 16384, 1024), (32, 8192, 512), (64, 4096, 1024), (1, 65536, 4096), (4, 262144, 4096)]
+    for (B, N, m) in shapes[:1] if quick else shapes:
         cl = clouds(B, N)
         for name, x in cl.items():
             if name != "sphere" and (B, N) != (16, 65536):
@@ -57,12 +67,13 @@ def main():
             xt = torch.from_numpy(np.ascontiguousarray(x.astype(np.float32))).to(dev)
             row = {}
             ref = None
-            for f in ("bucket", "cluster", "single_block"):
-                if f == "single_block" and N * B > 16 * 65536:
+            for f in ("bucket", "bucket_one_pick") if quick else ("bucket", "bucket_one_pick", "cluster", "single_block"):
+                if f == "single_block" and (N * B > 16 * 65536 or (name != "sphere")):
                     continue
-                form(f)
+                form("bucket" if f == "bucket_one_pick" else f)
+                chain(f == "bucket_one_pick")
                 try:
-                    row[f] = time_it(xt, m, reps=2 if f != "bucket" else 5)
+                    row[f] = time_it(xt, m, reps=5 if f.startswith("bucket") else 2)
                     idx = furthest_point_sample(xt, m, NCHW=False)[0]
                     if ref is None:
                         ref = idx
@@ -70,6 +81,7 @@ def main():
                         assert torch.equal(ref, idx), (name, f)
                 finally:
                     form("default")
+                    chain(False)
             print("B=%d N=%d m=%d %-10s " % (B, N, m, name) +
                   "  ".join("%s %.3f ms (%.3f us/pick)" % (k, v, v * 1e3 / (m - 1)) for k, v in row.items()), flush=True)
 
