@@ -132,6 +132,55 @@ __device__ __forceinline__ void wave_max2_u32(unsigned x, unsigned& m1, unsigned
   m2 = (unsigned)__builtin_amdgcn_readlane((int)y, 63);
 }
 
+// wave_argmax_key, and the second largest high word beside it (what every other lane's key is bounded by)
+__device__ __forceinline__ u64 wave_argmax_key2(unsigned hi, unsigned lo, int& src, unsigned& hi2) {
+  unsigned mh;
+  wave_max2_u32(hi, mh, hi2);
+  u64 tied = __ballot(hi == mh);
+  unsigned ml;
+  if (__builtin_popcountll(tied) > 1) {
+    ml = wave_max_u32<6>(hi == mh ? lo : 0u);
+    tied = __ballot(hi == mh && lo == ml);
+    src = __builtin_ctzll(tied);
+  } else {
+    src = __builtin_ctzll(tied);
+    ml = (unsigned)__builtin_amdgcn_readlane((int)lo, src);
+  }
+  return ((u64)mh << 32) | ml;
+}
+
+// The same over each DPP row of sixteen lanes, the results in EVERY lane of the row: four rotations (row_ror:1, 2, 4,
+// 8) -- lane i gathers the cyclic window of 2, 4, 8, 16 lanes that ends at i, and the window it merges in is always
+// the disjoint one before its own, so the pair stays an exact multiset pair.
+__device__ __forceinline__ void row_max2_u32(unsigned x, unsigned& m1, unsigned& m2) {
+  unsigned y = 0u, t = 0u;
+#define PP_RMAX2_STEP(CTRL)                                                  \
+  "v_min_u32_dpp %2, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"          \
+  "v_max_u32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"          \
+  "v_max_u32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"          \
+  "v_max_u32 %1, %1, %2\n\t"
+  asm volatile("s_nop 1\n\t"
+               PP_RMAX2_STEP("row_ror:1")
+               PP_RMAX2_STEP("row_ror:2")
+               PP_RMAX2_STEP("row_ror:4")
+               PP_RMAX2_STEP("row_ror:8")
+               "s_nop 1"
+               : "+v"(x), "+v"(y), "+v"(t));
+#undef PP_RMAX2_STEP
+  m1 = x;
+  m2 = y;
+}
+__device__ __forceinline__ unsigned row_max_u32(unsigned x) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+      : "+v"(x));
+  return x;
+}
+
 constexpr unsigned kRcMax = 0x0FFFFFFFu;  // ~tie rank in 28 bits (rank < N + 512 <= 2^22 + 2^9); four bits below it
                                           // carry the wave number in the workgroup-wide maximum
 
@@ -151,19 +200,20 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   __shared__ unsigned s_lut[3][kBkFine];
   __shared__ u64 s_g[3];
   __shared__ float s_c[3][kBkWaves][4];
-  // BATCH: the candidate table of a round -- two per wave (slot 2 w, 2 w + 1): key, then (x, y, z, second-largest
-  // temp of the candidate's bucket) -- the largest of the second candidates and the largest failing candidate;
-  // two deep (two barriers per round)
-  __shared__ u64 s_key[2][2 * kBkWaves];
-  __shared__ f4 s_rec[2][2 * kBkWaves];
-  __shared__ u64 s_bound[2], s_fail[2];
+  // BATCH: the candidate table of a round -- one per DPP row of every wave (slot 4 w + row): key, then (x, y, z, the bound
+  // of the other temps of its bucket) -- the largest second-best temp of any row (BOUND) and the largest failing
+  // candidate key (FAIL); two deep (two barriers per round)
+  __shared__ u64 s_key[2][4 * kBkWaves];
+  __shared__ f4 s_rec[2][4 * kBkWaves];
+  __shared__ unsigned s_bound[2];
+  __shared__ u64 s_fail[2];
   // BATCH: "super-box" l = the sixteen buckets 16 l .. 16 l + 15 (1024 consecutive points of the curve: a compact
   // patch), i.e. lane l of EVERY wave.  Their union boxes (ordered-integer images of -lo, hi: LDS integer maxima), the
   // largest temp inside each (raised by every wave before the round's first barrier) and, per super-box, the candidate
   // slots whose pick can reach it (set by each candidate's OWN wave) -- the last two two deep, like the tables above.
   __shared__ int s_sbox[64][6];
   __shared__ unsigned s_sbmax[2][64];
-  __shared__ unsigned s_cover[2][64];
+  __shared__ u64 s_cover[2][64];
 
   const int b = blockIdx.x;
   const float* __restrict__ p = xyz + (size_t)b * N * 3;
@@ -379,6 +429,9 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   const int bsize = 64 * m;
   float lox = INFINITY, loy = INFINITY, loz = INFINITY, hix = -INFINITY, hiy = -INFINITY, hiz = -INFINITY;
   u64 bkey = 0ull;
+  // (BATCH) an upper bound of every temp of the bucket but its best point's: the second-largest temp when the key was
+  // last reduced (the others only fall)
+  unsigned bsec = 0u;
   float ax = 0.0f, ay = 0.0f, az = 0.0f;
   float ox = p[3 * (size_t)seed], oy = p[3 * (size_t)seed + 1], oz = p[3 * (size_t)seed + 2];
   ox = rl(ox, 0); oy = rl(oy, 0); oz = rl(oz, 0);
@@ -477,11 +530,13 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
                   b5 = rl(v[5], 63);
       const float d2 = td_min(l, dist3(q.x, q.y, q.z, ox, oy, oz));
       int src;
-      const u64 M = wave_argmax_key(__float_as_uint(d2), __float_as_uint(q.w), src);
+      unsigned sec = 0u;
+      const u64 M = BATCH ? wave_argmax_key2(__float_as_uint(d2), __float_as_uint(q.w), src, sec)
+                          : wave_argmax_key(__float_as_uint(d2), __float_as_uint(q.w), src);
       const float cx = rl(q.x, src), cy = rl(q.y, src), cz = rl(q.z, src);
       if (lane == l) {
         lox = -b0; loy = -b1; loz = -b2; hix = b3; hiy = b4; hiz = b5;
-        bkey = M; ax = cx; ay = cy; az = cz;
+        bkey = M; ax = cx; ay = cy; az = cz; bsec = sec;
       }
       q = qn;
     }
@@ -523,20 +578,21 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     // c1 > c2 > ... are the largest keys of the cloud, c2 is the pick after c1 provided (i) c1 does not lower c2's own
     // key: !(dist3(c2, c1) < temp[c2]), and (ii) nothing that c1 leaves behind can overtake c2.  Everything outside
     // c1's bucket keeps or lowers a key that was below c2's already; inside c1's bucket every other point's temp is
-    // at most the bucket's SECOND-largest temp (`sec`, taken from the bucket's running minima when it is posted), so
-    // temp[c2] > sec(c1) settles (ii).  By induction a whole prefix c1 .. ck of the sorted candidates is the next k
-    // picks when every c_j passes (i) and (ii) against every c_i before it -- the very picks, in the very order, of
-    // one-at-a-time sampling: the reference's tie rule is the 64-bit key order, which the test never leaves.  min
-    // commutes exactly, so applying the k picks to the buckets they touch in one visit gives the same temp.
+    // at most the bucket's SECOND-largest temp (`sec`, taken from the bucket's running minima), so temp[c2] > sec(c1)
+    // settles (ii).  By induction a whole prefix c1 .. ck of the sorted candidates is the next k picks when every c_j
+    // passes (i) and (ii) against every c_i before it -- the very picks, in the very order, of one-at-a-time sampling:
+    // the reference's tie rule is the 64-bit key order, which the test never leaves.  min commutes exactly, so
+    // applying the k picks to the buckets they touch in one visit gives the same temp.
     //
-    // Candidates: every wave posts its two best bucket keys K1 > K2 (with coordinates and sec).  Whatever a wave did
-    // not post is below its K2, so the sorted list of ALL bucket keys is known down to BOUND = the largest K2, that
-    // one included: the candidates are the keys >= BOUND (at most 17).  Round:
-    //   post -> barrier -> every wave with an eligible candidate tests ITS OWN against the others (a lane per other
-    //   candidate: one pair per lane, no loop, no sort), raises FAIL = the largest candidate key that fails (i) or
-    //   (ii) against an eligible larger one (LDS atomic max), and marks the super-boxes its pick can reach
-    //   -> barrier -> the picks are the candidates above FAIL, a pick's position is the number of eligible keys above
-    //   it; box tests, one visit per touched bucket.
+    // Candidates: the best bucket key of every DPP row (sixteen buckets) of every wave, 64 in all, posted by the lanes
+    // that hold them.  What a row did not post has a temp of at most the row's second-largest, so with BOUND = the
+    // largest of those over all rows, a candidate whose temp is above BOUND is above every unposted key: the sorted
+    // candidates above BOUND are the top of the sorted list of ALL keys.  (The largest candidate, TOP, is the next pick
+    // whatever BOUND says.)  Round:
+    //   post -> barrier -> a wave tests each ELIGIBLE candidate of its own against the lower ones (a lane per other
+    //   candidate: one pair per lane, no sort): a lower one that fails (i) or (ii) raises FAIL (LDS atomic max); it
+    //   also marks the super-boxes its pick can reach -> barrier -> the picks are the eligible candidates above FAIL,
+    //   a pick's position is the number of eligible keys above it; box tests, one visit per touched bucket.
     // Box tests: 1024 buckets x k picks is what a round would cost with a pass over the wave's buckets per pick (the
     // whole kernel is bound by instruction issue -- sixteen waves, one instruction per wave every four cycles).  The
     // super-box masks are the same for every wave (super-box l = lane l of each), so a lane only tests ITS bucket
@@ -544,21 +600,19 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     // every pick of the round (a second only where two picks reach one super-box).
     // The last picks are taken one per round (every candidate but the largest fails), so that the round that takes
     // pick npoint-1 is known: temp ends as the minimum over every pick but the last (ref :203-205).
-    u64 wk1 = 0ull, wk2 = 0ull;  // this wave's best two bucket keys
-    int wl1 = 0, wl2 = 0;        // and the lanes that own them
-    float w1x = 0.0f, w1y = 0.0f, w1z = 0.0f, w2x = 0.0f, w2y = 0.0f, w2z = 0.0f;
-    unsigned w1s = 0u;
+    bool win = false;    // this lane's bucket is its row's candidate
+    unsigned rsec = 0u;  // the row's second-largest temp
     bool redo = true;
     int buf = 0;
     auto okey_of = [](float v) -> int {  // order-preserving integer image of a float (an involution on the bits)
       const int b = (int)__float_as_uint(v);
       return b ^ ((b >> 31) & 0x7fffffff);
     };
-    if (t < 2) { s_bound[t] = 0ull; s_fail[t] = 0ull; }
+    if (t < 2) { s_bound[t] = 0u; s_fail[t] = 0ull; }
     if (t < 64) {
       for (int a = 0; a < 6; ++a) s_sbox[t][a] = (int)0x80000000;
       s_sbmax[0][t] = 0u; s_sbmax[1][t] = 0u;
-      s_cover[0][t] = 0u; s_cover[1][t] = 0u;
+      s_cover[0][t] = 0ull; s_cover[1][t] = 0ull;
     }
     __syncthreads();
     {  // (an empty slot's box is (+inf, -inf): the identity)
@@ -572,97 +626,100 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       sb[a] = __uint_as_float((unsigned)(k ^ ((k >> 31) & 0x7fffffff)));
     }
     const float sblox = -sb[0], sbloy = -sb[1], sbloz = -sb[2], sbhix = sb[3], sbhiy = sb[4], sbhiz = sb[5];
+    const int myslot = 4 * wave + (lane >> 4);
     int j = 1;
     while (j < npoint) {
       PP_FPSB_MARK(0);
-      if (redo) {
-        const unsigned khi = (unsigned)(bkey >> 32), klo = (unsigned)bkey;
-        wk1 = wave_argmax_key(khi, klo, wl1);
-        const bool rest = lane != wl1;
-        wk2 = wave_argmax_key(rest ? khi : 0u, rest ? klo : 0u, wl2);
-        w1x = rl(ax, wl1); w1y = rl(ay, wl1); w1z = rl(az, wl1);
-        w2x = rl(ax, wl2); w2y = rl(ay, wl2); w2z = rl(az, wl2);
-        // the second-largest temp of K1's bucket, from the running minima themselves (only a posted bucket needs
-        // it: kept per bucket it cost every visit a second reduction; K2 is only ever eligible as BOUND, the last
-        // of the sorted candidates: nothing is tested against its bucket)
+      const unsigned khi = (unsigned)(bkey >> 32), klo = (unsigned)bkey;
+      if (redo) {  // (a key of this wave changed)
         unsigned top;
-        wave_max2_u32(__float_as_uint(td_get(wl1)), top, w1s);
+        row_max2_u32(khi, top, rsec);
+        const unsigned ml = row_max_u32(khi == top ? klo : 0u);  // (exact ties of the temp: the tie rank decides)
+        win = khi == top && klo == ml;  // one lane per row (every lane of a row of empty slots: they post the same zeros)
       }
-      if (lane < 2) {
+      if (win) {
         f4 r;
-        r.x = lane ? w2x : w1x; r.y = lane ? w2y : w1y; r.z = lane ? w2z : w1z;
-        r.w = __uint_as_float(lane ? 0xFFFFFFFFu : w1s);
-        s_key[buf][2 * wave + lane] = lane ? wk2 : wk1;
-        s_rec[buf][2 * wave + lane] = r;
-        if (lane) __hip_atomic_fetch_max(&s_bound[buf], wk2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        r.x = ax; r.y = ay; r.z = az; r.w = __uint_as_float(bsec);
+        s_key[buf][myslot] = bkey;
+        s_rec[buf][myslot] = r;
+      }
+      {  // BOUND: one atomic per wave (the rows' values meet in lane 63)
+        unsigned wsec = rsec;
+        asm volatile("s_nop 1\n\t"
+                     "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                     "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                     : "+v"(wsec));
+        if (lane == 63) __hip_atomic_fetch_max(&s_bound[buf], wsec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       // the largest temp of every super-box (lane l of the sixteen waves)
-      __hip_atomic_fetch_max(&s_sbmax[buf][lane], (unsigned)(bkey >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_max(&s_sbmax[buf][lane], khi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       PP_FPSB_MARK(1);
       // LDS only (see the one-pick chain below): no store's acknowledgement is waited for
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       PP_FPSB_MARK(2);
-      const bool single = npoint - j < 2 * kBkWaves + 2;
-      const int slot = lane & (2 * kBkWaves - 1);
-      const u64 okey = s_key[buf][slot];
-      const f4 orec = s_rec[buf][slot];
-      const u64 bound = s_bound[buf];
+      const bool single = npoint - j < 4 * kBkWaves + 2;
+      const u64 okey = s_key[buf][lane];  // a lane per candidate slot
+      const f4 orec = s_rec[buf][lane];
+      const unsigned bound = s_bound[buf];
       if (t < 64) {  // (the other half of the tables: read for the last time before this round's first barrier)
         if (t == 0) s_fail[buf ^ 1] = 0ull;
         s_sbmax[buf ^ 1][t] = 0u;
-        s_cover[buf ^ 1][t] = 0u;
+        s_cover[buf ^ 1][t] = 0ull;
       }
-      const bool o_el = okey >= bound && okey != 0ull;
-      const bool el1 = wk1 >= bound && wk1 != 0ull, el2 = wk2 >= bound && wk2 != 0ull;
-      int rank1 = 0, rank2 = 0;
-      if (el1 || el2) {  // (a wave without an eligible candidate has nothing to test)
-        const bool second = lane >= 2 * kBkWaves;  // the upper half of the wave tests K2, the lower K1
-        const u64 mkey = second ? wk2 : wk1;
-        const float mx = second ? w2x : w1x, my = second ? w2y : w1y, mz = second ? w2z : w1z;
-        const unsigned mhi = (unsigned)(mkey >> 32);
-        const bool gt = o_el && okey > mkey;
-        const float dd = dist3(mx, my, mz, orec.x, orec.y, orec.z);
-        const bool bad = gt && (single || dd < __uint_as_float(mhi) || !(mhi > __float_as_uint(orec.w)));
-        const u64 gtm = __ballot(gt), badm = __ballot(bad);
-        rank1 = __builtin_popcount((unsigned)gtm);
-        rank2 = __builtin_popcount((unsigned)(gtm >> 32));
-        u64 f = 0ull;
-        if (el1 && (unsigned)badm != 0u) f = wk1;
-        if (el2 && (unsigned)(badm >> 32) != 0u && wk2 > f) f = wk2;
-        if (f != 0ull && lane == 0)
-          __hip_atomic_fetch_max(&s_fail[buf], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // the super-boxes an eligible candidate's pick can reach: the box test with the super-box's box and its
-        // largest temp (>= every member's: the test only ever says "visit" more often), a lane per super-box
+      const unsigned ohi = (unsigned)(okey >> 32);
+      bool o_el = okey != 0ull && ohi > bound;
+      u64 elm = __ballot(o_el);
+      if (elm == 0ull) {  // (the largest temp is shared: the largest KEY is the next pick, alone)
+        const u64 topk = wave_max_u64(okey);  // (every lane active: not behind the && below)
+        o_el = okey != 0ull && okey == topk;
+        elm = __ballot(o_el);
+      }
+      // the eligible candidates are dealt to the waves in turn (any wave can test any of them: everything is in the
+      // tables): a wave tests the lower candidates against its own, a lane per other candidate
+      u64 mym = __ballot(o_el && ((int)__builtin_amdgcn_mbcnt_hi((unsigned)(elm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)elm, 0u)) & (kBkWaves - 1)) == wave);
+      if (mym) {
         const float sbm = __uint_as_float(s_sbmax[buf][lane]);
-        auto reach = [&](float px, float py, float pz, unsigned bit) {
-          const float gx = fmaxf(fmaxf(sblox - px, px - sbhix), 0.0f);
-          const float gy = fmaxf(fmaxf(sbloy - py, py - sbhiy), 0.0f);
-          const float gz = fmaxf(fmaxf(sbloz - pz, pz - sbhiz), 0.0f);
+        while (mym) {
+          const int ms = __builtin_ctzll(mym);
+          mym &= mym - 1ull;
+          const u64 mkey = ((u64)(unsigned)__builtin_amdgcn_readlane((int)ohi, ms) << 32) |
+                           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)okey, ms);
+          const float mx = rl(orec.x, ms), my = rl(orec.y, ms), mz = rl(orec.z, ms);
+          const unsigned msec = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(orec.w), ms);
+          // a lower eligible candidate fails against this one if this pick lowers its key, or if something this
+          // pick leaves behind in its own bucket could still be above it
+          const bool lower = o_el && okey < mkey;
+          const float dd = dist3(orec.x, orec.y, orec.z, mx, my, mz);
+          if (lower && (single || dd < __uint_as_float(ohi) || !(ohi > msec)))
+            __hip_atomic_fetch_max(&s_fail[buf], okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // the super-boxes the pick can reach: the box test with the super-box's box and its largest temp (>= every
+          // member's: the test only ever says "visit" more often), a lane per super-box
+          const float gx = fmaxf(fmaxf(sblox - mx, mx - sbhix), 0.0f);
+          const float gy = fmaxf(fmaxf(sbloy - my, my - sbhiy), 0.0f);
+          const float gz = fmaxf(fmaxf(sbloz - mz, mz - sbhiz), 0.0f);
           const float bd = __builtin_fmaf(gz, gz, __builtin_fmaf(gx, gx, gy * gy));
-          if (!(bd >= sbm)) atomicOr(&s_cover[buf][lane], bit);
-        };
-        if (el1) reach(w1x, w1y, w1z, 1u << (2 * wave));
-        if (el2) reach(w2x, w2y, w2z, 2u << (2 * wave));
+          if (!(bd >= sbm)) atomicOr(&s_cover[buf][lane], 1ull << ms);
+        }
       }
       PP_FPSB_MARK(3);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       PP_FPSB_MARK(4);
       const u64 fail = s_fail[buf];
-      unsigned cover = s_cover[buf][lane];
-      if (t == 0) s_bound[buf] = 0ull;  // (read for the last time before the barrier above)
-      const u64 accm = __ballot(lane < 2 * kBkWaves && o_el && okey > fail);
+      u64 cover = s_cover[buf][lane];
+      if (t == 0) s_bound[buf] = 0u;  // (read for the last time before the barrier above)
+      const u64 accm = __ballot(o_el && okey > fail);
       const int k = __builtin_popcountll(accm);
       PP_FPSB_PICKS(k);
-      // this wave's own candidates among the picks: stored at their positions (as ~tie rank: turned into the index
-      // after the loop)
-      if (lane == 0) {
-        if (el1 && wk1 > fail) {
-          out[j + rank1] = (int)((unsigned)wk1 & kRcMax);
-          if (smp) put(j + rank1, w1x, w1y, w1z);
-        }
-        if (el2 && wk2 > fail) {
-          out[j + rank2] = (int)((unsigned)wk2 & kRcMax);
-          if (smp) put(j + rank2, w2x, w2y, w2z);
+      // this wave's own candidates among the picks: stored at their positions -- the number of eligible keys above --
+      // as ~tie rank (turned into the index after the loop)
+      for (unsigned own = (unsigned)(accm >> (4 * wave)) & 15u; own; own &= own - 1u) {
+        const int ms = 4 * wave + __builtin_ctz(own);
+        const u64 mkey = ((u64)(unsigned)__builtin_amdgcn_readlane((int)ohi, ms) << 32) |
+                         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)okey, ms);
+        const int rank = __builtin_popcountll(__ballot(o_el && okey > mkey));
+        if (lane == 0) {
+          out[j + rank] = (int)((unsigned)mkey & kRcMax);
+          if (smp) put(j + rank, rl(orec.x, ms), rl(orec.y, ms), rl(orec.z, ms));
         }
       }
       j += k;
@@ -672,14 +729,14 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       // ever says "visit" more often than one pick at a time would.)  ... and does one of them lower the bucket's
       // BEST point?  Only then does the bucket's key change (every other temp only falls): a visit that leaves the
       // best point alone updates the running minima and nothing else -- no reduction, no new key.
-      const float bmax = __uint_as_float((unsigned)(bkey >> 32));
-      cover &= (unsigned)accm;  // the picks (by candidate slot) that reach this lane's super-box
-      unsigned tm = 0u;         // ... and this lane's bucket
+      const float bmax = __uint_as_float(khi);
+      cover &= accm;    // the picks (by candidate slot) that reach this lane's super-box
+      u64 tm = 0ull;    // ... and this lane's bucket
       bool chg = false;
-      while (__ballot(cover != 0u)) {
-        const bool on = cover != 0u;
-        const int sl = on ? __builtin_ctz(cover) : 0;
-        cover &= cover - 1u;  // (0 stays 0)
+      while (__ballot(cover != 0ull)) {
+        const bool on = cover != 0ull;
+        const int sl = on ? __builtin_ctzll(cover) : 0;
+        cover &= cover - 1ull;  // (0 stays 0)
         const float px = __int_as_float(__builtin_amdgcn_ds_bpermute(sl << 2, __float_as_int(orec.x)));
         const float py = __int_as_float(__builtin_amdgcn_ds_bpermute(sl << 2, __float_as_int(orec.y)));
         const float pz = __int_as_float(__builtin_amdgcn_ds_bpermute(sl << 2, __float_as_int(orec.z)));
@@ -688,12 +745,12 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
         const float gz = fmaxf(fmaxf(loz - pz, pz - hiz), 0.0f);
         const float bd = __builtin_fmaf(gz, gz, __builtin_fmaf(gx, gx, gy * gy));
         const bool hit = on && !(bd >= bmax);
-        tm |= hit ? 1u << sl : 0u;
+        tm |= hit ? 1ull << sl : 0ull;
         chg |= hit && dist3(ax, ay, az, px, py, pz) < bmax;  // (the visit's own arithmetic)
       }
-      u64 mask = __ballot(tm != 0u);
+      u64 mask = __ballot(tm != 0ull);
       const u64 chgm = __ballot(chg);
-      redo = ((chgm >> wl1) | (chgm >> wl2)) & 1ull;
+      redo = chgm != 0ull;
       PP_FPSB_TOUCHED(mask);
       PP_FPSB_MARK(5);
       {
@@ -717,10 +774,11 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
             qn = sorted[(unsigned)(slot_bucket(ln) * 64 + lane)];
             tn = td_get(ln);
           }
-          unsigned tml = (unsigned)__builtin_amdgcn_readlane((int)tm, l);
+          u64 tml = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(tm >> 32), l) << 32) |
+                    (unsigned)__builtin_amdgcn_readlane((int)(unsigned)tm, l);
           float d2 = told;
           while (tml) {
-            const int sl = __builtin_ctz(tml);
+            const int sl = __builtin_ctzll(tml);
             tml &= tml - 1;
             const float px = rl(orec.x, sl), py = rl(orec.y, sl), pz = rl(orec.z, sl);
             d2 = __builtin_fminf(dist3(q.x, q.y, q.z, px, py, pz), d2);
@@ -728,9 +786,10 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
           td_set(l, d2);
           if ((chgm >> l) & 1ull) {  // (uniform)
             int src;
-            const u64 M = wave_argmax_key(__float_as_uint(d2), __float_as_uint(q.w), src);
+            unsigned sec;
+            const u64 M = wave_argmax_key2(__float_as_uint(d2), __float_as_uint(q.w), src, sec);
             const float cx = rl(q.x, src), cy = rl(q.y, src), cz = rl(q.z, src);
-            if (lane == l) { bkey = M; ax = cx; ay = cy; az = cz; }
+            if (lane == l) { bkey = M; ax = cx; ay = cy; az = cz; bsec = sec; }
           }
           l = ln;
           q = qn;
