@@ -43,9 +43,12 @@ int pp_debug_nmdistance_pending(const void* workspace, int B, int N, int M, unsi
 
 void pp_debug_set_fps_v1(int form); /* 0 = the library's choice, 1 = one workgroup per batch element over all points,
                                       * 2 = the CU cluster over all points, 3 = the bucketed kernel */
-/* the bucketed FPS kernel's serial chain (N <= 65536): 0 = several mutually independent picks per barrier round
- * (default), 1 = one pick per round (the round-4 chain; A/B timing and tests) */
+/* the bucketed FPS kernel's serial chain (N <= 65536): 0 = the library's choice (several mutually independent picks
+ * per barrier round from 32768 points, one pick per round below), 1 = one pick per round, 2 = several per round */
 void pp_debug_set_fps_bucket_chain(int form);
+/* the bucketed FPS kernel's sort: 0 = by the whole chip from 32768 points (six short launches in front of the kernel),
+ * else inside the kernel by its one workgroup; 1 = always inside the kernel, 2 = always by the chip */
+void pp_debug_set_fps_bucket_sort(int mode);
 void pp_debug_set_gather_variant(int variant);
 void pp_debug_set_ball_query_variant(int variant); /* scan kernels: 1 = one wave per 64 centres */
 void pp_debug_set_ball_query_search(int mode);     /* 0 automatic, 1 scan, 2 grid wherever possible */

@@ -181,6 +181,114 @@ __device__ __forceinline__ unsigned row_max_u32(unsigned x) {
   return x;
 }
 
+// ---- the sort's key plan, shared by the one-workgroup set-up of fps_bucket_kernel and the pre-sort kernels ----
+struct KeyPlan {
+  float blo[3], bsc[3];  // box origin; fine bins per unit length
+  int nbits[3];          // key bits per axis
+  unsigned plan;         // the axis of every key bit, two bits per step, first step in the low bits
+  int cubic;             // five bits per axis: the cells are walked along a Hilbert curve instead of the Z-order
+};
+// 15 bits dealt to the axes greedily (always halve the axis whose cells are longest); bv = (-lo, hi) of the cloud
+__device__ __forceinline__ KeyPlan make_key_plan(const float (&bv)[6]) {
+  KeyPlan kp;
+  float e0 = bv[3] + bv[0], e1 = bv[4] + bv[1], e2 = bv[5] + bv[2];  // extents (hi - lo)
+  const float ext0 = e0, ext1 = e1, ext2 = e2;
+  int n0 = 0, n1 = 0, n2 = 0;
+  unsigned plan = 0;
+  for (int s = 0; s < kBkBits; ++s) {
+    const float c0 = n0 < kBkAxisBits ? e0 : -INFINITY, c1 = n1 < kBkAxisBits ? e1 : -INFINITY,
+                c2 = n2 < kBkAxisBits ? e2 : -INFINITY;
+    int a = 0;
+    float best = c0;
+    if (c1 > best) { a = 1; best = c1; }
+    if (c2 > best) { a = 2; best = c2; }
+    // (nothing compares greater when no axis has a finite extent: take the first axis with room)
+    if (a == 0 && n0 >= kBkAxisBits) a = n1 < kBkAxisBits ? 1 : 2;
+    plan |= (unsigned)a << (2 * s);
+    if (a == 0) { ++n0; e0 *= 0.5f; } else if (a == 1) { ++n1; e1 *= 0.5f; } else { ++n2; e2 *= 0.5f; }
+  }
+  kp.blo[0] = -bv[0]; kp.blo[1] = -bv[1]; kp.blo[2] = -bv[2];
+  kp.nbits[0] = n0; kp.nbits[1] = n1; kp.nbits[2] = n2;
+  kp.plan = plan;
+  kp.cubic = n0 == 5 && n1 == 5 && n2 == 5;
+  // fine bins per unit length; an empty or unbounded extent puts everything into bin 0 of that axis
+  kp.bsc[0] = (ext0 > 0.0f && ext0 < INFINITY) ? (float)kBkFine / ext0 : 0.0f;
+  kp.bsc[1] = (ext1 > 0.0f && ext1 < INFINITY) ? (float)kBkFine / ext1 : 0.0f;
+  kp.bsc[2] = (ext2 > 0.0f && ext2 < INFINITY) ? (float)kBkFine / ext2 : 0.0f;
+  return kp;
+}
+__device__ __forceinline__ int fine_bin(const KeyPlan& kp, float v, int a) {
+  return min(max((int)((v - kp.blo[a]) * kp.bsc[a]), 0), kBkFine - 1);
+}
+// Cells of equal COUNT along an axis: a wave turns the axis' 1024-bin histogram `cnt` into the table `lut` (cell =
+// floor(2^n * (points below the bin's middle) / N), its bits at their places in the key; a cubic plan keeps the plain
+// coordinate).  `cnt` and `lut` may be the same array.  Every lane of the wave.
+__device__ __forceinline__ void axis_lut(const KeyPlan& kp, int a, int N, const unsigned* cnt, unsigned* lut, int lane) {
+  const int nbits = kp.nbits[a];
+  int carry = 0;
+  for (int r = 0; r < kBkFine / 64; ++r) {
+    const int i = 64 * r + lane;
+    const int c = (int)cnt[i];
+    const int inc = wave_scan_incl(c);
+    const unsigned below = (unsigned)(carry + inc - c) + (unsigned)c / 2u;
+    carry += __builtin_amdgcn_readlane(inc, 63);
+    unsigned q = (unsigned)(((u64)below << nbits) / (u64)(N > 0 ? N : 1));
+    q = min(q, (1u << nbits) - 1u);
+    int left = nbits;
+    unsigned val = 0;
+    for (int st = 0; st < kBkBits; ++st)
+      if ((int)((kp.plan >> (2 * st)) & 3u) == a) {
+        --left;
+        val |= ((q >> left) & 1u) << (kBkBits - 1 - st);
+      }
+    lut[i] = kp.cubic ? q : val;
+  }
+}
+// the 15-bit cell key of a point; lut = the three axis tables, [3][kBkFine]
+__device__ __forceinline__ unsigned cell_key(const KeyPlan& kp, const unsigned (*lut)[kBkFine], float x, float y, float z) {
+  const int qx = fine_bin(kp, x, 0), qy = fine_bin(kp, y, 1), qz = fine_bin(kp, z, 2);
+  if (!kp.cubic) return lut[0][qx] | lut[1][qy] | lut[2][qz];
+  // Hilbert index of the cell (Skilling's transform, 3 axes x 5 bits): consecutive cells of the curve are always
+  // neighbours in space, where the Z-order jumps -- a bucket is a run of 64 points of this order, and a run that
+  // spans a jump has a box that covers two distant patches (every pick near either visits it)
+  unsigned X0 = lut[0][qx], X1 = lut[1][qy], X2 = lut[2][qz];
+#pragma unroll
+  for (unsigned Q = 16u; Q > 1u; Q >>= 1) {
+    const unsigned P = Q - 1u;
+    X0 ^= (X0 & Q) ? P : 0u;
+    {
+      const unsigned hit = (X1 & Q) ? 0xFFFFFFFFu : 0u;
+      const unsigned tt = (X0 ^ X1) & P & ~hit;
+      X0 ^= (P & hit) ^ tt;
+      X1 ^= tt;
+    }
+    {
+      const unsigned hit = (X2 & Q) ? 0xFFFFFFFFu : 0u;
+      const unsigned tt = (X0 ^ X2) & P & ~hit;
+      X0 ^= (P & hit) ^ tt;
+      X2 ^= tt;
+    }
+  }
+  X1 ^= X0;
+  X2 ^= X1;
+  unsigned tg = 0u;
+#pragma unroll
+  for (unsigned Q = 16u; Q > 1u; Q >>= 1) tg ^= (X2 & Q) ? Q - 1u : 0u;
+  X0 ^= tg; X1 ^= tg; X2 ^= tg;
+  auto spread = [](unsigned v) {  // bit i -> bit 3 i
+    v = (v | (v << 8)) & 0x100Fu;
+    v = (v | (v << 4)) & 0x10C3u;
+    v = (v | (v << 2)) & 0x1249u;
+    return v;
+  };
+  return (spread(X0) << 2) | (spread(X1) << 1) | spread(X2);
+}
+__device__ __forceinline__ int ordered_int(float v) {  // order-preserving integer image of a float (an involution on the bits)
+  const int b = (int)__float_as_uint(v);
+  return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float ordered_float(int k) { return __uint_as_float((unsigned)(k ^ ((k >> 31) & 0x7fffffff))); }
+
 constexpr unsigned kRcMax = 0x0FFFFFFFu;  // ~tie rank in 28 bits (rank < N + 512 <= 2^22 + 2^9); four bits below it
                                           // carry the wave number in the workgroup-wide maximum
 
@@ -193,7 +301,7 @@ template <bool REG, bool BATCH>
 __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     const float* __restrict__ xyz, float* __restrict__ temp, int* __restrict__ idx, int N, int npoint,
     int seed, TieOrder order, BucketGeom geo, f4* __restrict__ sorted_all, unsigned* __restrict__ aux_all,
-    float* __restrict__ sampled, int cf) {
+    float* __restrict__ sampled, int cf, int presorted) {
   extern __shared__ unsigned s_hist[];  // kBkBins counters, then cursors (the sort only)
   __shared__ float s_box[kBkWaves][6];
   __shared__ int s_wsum[kBkWaves];
@@ -225,6 +333,8 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   const int lane = t & 63;
   const int wave = pp::wave_id_uniform();
 
+  if (t < 3) s_g[t] = 0ull;  // (the one-pick chain's ring: read after the barriers below)
+  if (!presorted) {  // (else the pre-sort kernels below have filled `sorted` / `aux`: the chip sorts, not one CU)
   // ---------------------------------------------------------------- A. bounding box of the cloud
   {
     float v[6] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};  // -lo, hi
@@ -238,9 +348,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       for (int a = 0; a < 6; ++a) s_box[wave][a] = v[a];
   }
   __syncthreads();
-  float blo[3], bsc[3];
-  int qmax[3];
-  bool cubic = false;  // five bits per axis: the cells are walked along a Hilbert curve instead of the Z-order
+  KeyPlan kp;
   {
     float bv[6];
     for (int a = 0; a < 6; ++a) {
@@ -249,32 +357,9 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       bv[a] = m;
     }
     // ---------------------------------------------------------------- B. key plan: 15 bits dealt to the axes
-    float e0 = bv[3] + bv[0], e1 = bv[4] + bv[1], e2 = bv[5] + bv[2];  // extents (hi - lo)
-    const float ext0 = e0, ext1 = e1, ext2 = e2;
-    int n0 = 0, n1 = 0, n2 = 0;
-    unsigned plan = 0;  // two bits per step, first step in the low bits
-    for (int s = 0; s < kBkBits; ++s) {
-      const float c0 = n0 < kBkAxisBits ? e0 : -INFINITY, c1 = n1 < kBkAxisBits ? e1 : -INFINITY,
-                  c2 = n2 < kBkAxisBits ? e2 : -INFINITY;
-      int a = 0;
-      float best = c0;
-      if (c1 > best) { a = 1; best = c1; }
-      if (c2 > best) { a = 2; best = c2; }
-      // (nothing compares greater when no axis has a finite extent: take the first axis with room)
-      if (a == 0 && n0 >= kBkAxisBits) a = n1 < kBkAxisBits ? 1 : 2;
-      plan |= (unsigned)a << (2 * s);
-      if (a == 0) { ++n0; e0 *= 0.5f; } else if (a == 1) { ++n1; e1 *= 0.5f; } else { ++n2; e2 *= 0.5f; }
-    }
-    blo[0] = -bv[0]; blo[1] = -bv[1]; blo[2] = -bv[2];
-    qmax[0] = n0; qmax[1] = n1; qmax[2] = n2;  // (bits per axis)
-    cubic = n0 == 5 && n1 == 5 && n2 == 5;
-    // fine bins per unit length; an empty or unbounded extent puts everything into bin 0 of that axis
-    bsc[0] = (ext0 > 0.0f && ext0 < INFINITY) ? (float)kBkFine / ext0 : 0.0f;
-    bsc[1] = (ext1 > 0.0f && ext1 < INFINITY) ? (float)kBkFine / ext1 : 0.0f;
-    bsc[2] = (ext2 > 0.0f && ext2 < INFINITY) ? (float)kBkFine / ext2 : 0.0f;
+    kp = make_key_plan(bv);
     for (int i = t; i < 3 * kBkFine; i += kBkThreads) (&s_lut[0][0])[i] = 0u;
     for (int i = t; i < kBkBins; i += kBkThreads) s_hist[i] = 0u;
-    if (t < 3) s_g[t] = 0ull;
     __syncthreads();
     if (PP_FPSB_STOP <= 1) return;
     // ---------------------------------------------------------------- B2. cells of equal COUNT along every axis
@@ -283,79 +368,16 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     // are: a 1024-bin histogram per axis, its running sum, cell = floor(2^n * (points below the bin's middle) / N).
     // A separable approximation of a k-d split, built in one extra pass; an evenly sampled cloud gets the uniform
     // grid back.
-    auto bin_of = [&](float v, int a) -> int { return min(max((int)((v - blo[a]) * bsc[a]), 0), kBkFine - 1); };
     for (int k = t; k < N; k += kBkThreads) {
-      atomicAdd(&s_lut[0][bin_of(p[3 * (size_t)k], 0)], 1u);
-      atomicAdd(&s_lut[1][bin_of(p[3 * (size_t)k + 1], 1)], 1u);
-      atomicAdd(&s_lut[2][bin_of(p[3 * (size_t)k + 2], 2)], 1u);
+      atomicAdd(&s_lut[0][fine_bin(kp, p[3 * (size_t)k], 0)], 1u);
+      atomicAdd(&s_lut[1][fine_bin(kp, p[3 * (size_t)k + 1], 1)], 1u);
+      atomicAdd(&s_lut[2][fine_bin(kp, p[3 * (size_t)k + 2], 2)], 1u);
     }
     __syncthreads();
-    if (wave < 3) {
-      const int a = wave;
-      const int nbits = qmax[a];
-      int carry = 0;
-      for (int r = 0; r < kBkFine / 64; ++r) {
-        const int i = 64 * r + lane;
-        const int c = (int)s_lut[a][i];
-        const int inc = wave_scan_incl(c);
-        const unsigned below = (unsigned)(carry + inc - c) + (unsigned)c / 2u;
-        carry += __builtin_amdgcn_readlane(inc, 63);
-        unsigned q = (unsigned)(((u64)below << nbits) / (u64)(N > 0 ? N : 1));
-        q = min(q, (1u << nbits) - 1u);
-        // the cell coordinate's bits at their places in the key (a cubic plan keeps the plain coordinate: the
-        // cells are then ordered along a Hilbert curve, below)
-        int left = nbits;
-        unsigned val = 0;
-        for (int st = 0; st < kBkBits; ++st)
-          if ((int)((plan >> (2 * st)) & 3u) == a) {
-            --left;
-            val |= ((q >> left) & 1u) << (kBkBits - 1 - st);
-          }
-        s_lut[a][i] = cubic ? q : val;
-      }
-    }
+    if (wave < 3) axis_lut(kp, wave, N, s_lut[wave], s_lut[wave], lane);
   }
   __syncthreads();
-  auto key_of = [&](float x, float y, float z) -> unsigned {
-    const int qx = min(max((int)((x - blo[0]) * bsc[0]), 0), kBkFine - 1);
-    const int qy = min(max((int)((y - blo[1]) * bsc[1]), 0), kBkFine - 1);
-    const int qz = min(max((int)((z - blo[2]) * bsc[2]), 0), kBkFine - 1);
-    if (!cubic) return s_lut[0][qx] | s_lut[1][qy] | s_lut[2][qz];
-    // Hilbert index of the cell (Skilling's transform, 3 axes x 5 bits): consecutive cells of the curve are always
-    // neighbours in space, where the Z-order jumps -- a bucket is a run of 64 points of this order, and a run that
-    // spans a jump has a box that covers two distant patches (every pick near either visits it)
-    unsigned X0 = s_lut[0][qx], X1 = s_lut[1][qy], X2 = s_lut[2][qz];
-#pragma unroll
-    for (unsigned Q = 16u; Q > 1u; Q >>= 1) {
-      const unsigned P = Q - 1u;
-      X0 ^= (X0 & Q) ? P : 0u;
-      {
-        const unsigned hit = (X1 & Q) ? 0xFFFFFFFFu : 0u;
-        const unsigned tt = (X0 ^ X1) & P & ~hit;
-        X0 ^= (P & hit) ^ tt;
-        X1 ^= tt;
-      }
-      {
-        const unsigned hit = (X2 & Q) ? 0xFFFFFFFFu : 0u;
-        const unsigned tt = (X0 ^ X2) & P & ~hit;
-        X0 ^= (P & hit) ^ tt;
-        X2 ^= tt;
-      }
-    }
-    X1 ^= X0;
-    X2 ^= X1;
-    unsigned tg = 0u;
-#pragma unroll
-    for (unsigned Q = 16u; Q > 1u; Q >>= 1) tg ^= (X2 & Q) ? Q - 1u : 0u;
-    X0 ^= tg; X1 ^= tg; X2 ^= tg;
-    auto spread = [](unsigned v) {  // bit i -> bit 3 i
-      v = (v | (v << 8)) & 0x100Fu;
-      v = (v | (v << 4)) & 0x10C3u;
-      v = (v | (v << 2)) & 0x1249u;
-      return v;
-    };
-    return (spread(X0) << 2) | (spread(X1) << 1) | spread(X2);
-  };
+  auto key_of = [&](float x, float y, float z) -> unsigned { return cell_key(kp, s_lut, x, y, z); };
   if (PP_FPSB_STOP <= 2) return;
   // ---------------------------------------------------------------- C. count
   // (a point's key is computed once: it waits for the scatter in the first words of the record buffer, which nothing
@@ -390,12 +412,17 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   // ---------------------------------------------------------------- E. scatter, as a permutation + a gather
   // (Scattering the 16-byte records themselves -- every lane of a store in a line of its own -- took 183 us of a
   //  470 us set-up; 4-byte scattered stores of the source index, then coalesced record stores, takes a third.)
+#ifndef PP_FPSB_E_UNROLL
+#define PP_FPSB_E_UNROLL 4
+#endif
+#pragma unroll PP_FPSB_E_UNROLL
   for (int k = t; k < N; k += kBkThreads) {
     const unsigned pos = atomicAdd(&s_hist[keys[k]], 1u);
     rc[pos] = (unsigned)k;
   }
   __syncthreads();
-#pragma unroll 4
+  if (PP_FPSB_STOP == 45) return;
+#pragma unroll PP_FPSB_E_UNROLL
   for (int pos = t; pos < N; pos += kBkThreads) {
     const int k = (int)rc[pos];
     const P3 v = *(const P3*)(p + 3 * (size_t)k);  // (one 12-byte load: a gathered access costs per instruction)
@@ -419,6 +446,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   }
   for (int pos = N + t; pos < geo.naux; pos += kBkThreads) rc[pos] = 0u;
   __syncthreads();  // (the stores are drained before the barrier; one CU, one L1: visible to every wave)
+  }  // !presorted
 
   if (PP_FPSB_STOP <= 5) return;
   // ---------------------------------------------------------------- F. bucket summaries + the seed's step
@@ -604,10 +632,6 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     unsigned rsec = 0u;  // the row's second-largest temp
     bool redo = true;
     int buf = 0;
-    auto okey_of = [](float v) -> int {  // order-preserving integer image of a float (an involution on the bits)
-      const int b = (int)__float_as_uint(v);
-      return b ^ ((b >> 31) & 0x7fffffff);
-    };
     if (t < 2) { s_bound[t] = 0u; s_fail[t] = 0ull; }
     if (t < 64) {
       for (int a = 0; a < 6; ++a) s_sbox[t][a] = (int)0x80000000;
@@ -617,14 +641,11 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     __syncthreads();
     {  // (an empty slot's box is (+inf, -inf): the identity)
       const float v[6] = {-lox, -loy, -loz, hix, hiy, hiz};
-      for (int a = 0; a < 6; ++a) atomicMax(&s_sbox[lane][a], okey_of(v[a]));
+      for (int a = 0; a < 6; ++a) atomicMax(&s_sbox[lane][a], ordered_int(v[a]));
     }
     __syncthreads();
     float sb[6];  // -lo, hi of super-box `lane`
-    for (int a = 0; a < 6; ++a) {
-      const int k = s_sbox[lane][a];
-      sb[a] = __uint_as_float((unsigned)(k ^ ((k >> 31) & 0x7fffffff)));
-    }
+    for (int a = 0; a < 6; ++a) sb[a] = ordered_float(s_sbox[lane][a]);
     const float sblox = -sb[0], sbloy = -sb[1], sbloz = -sb[2], sbhix = sb[3], sbhiy = sb[4], sbhiz = sb[5];
     const int myslot = 4 * wave + (lane >> 4);
     int j = 1;
@@ -803,6 +824,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     // Keys only ever fall (temp = min(...)), so a wave's best bucket stays its best until that very bucket is
     // re-evaluated: only then is the wave's maximum taken again.  The workgroup's maximum is ONE LDS atomic per wave
     // (ds_max_u64 on a word of a three-deep ring, the wave's number in the key's low bits), one barrier, one read.
+    __syncthreads();  // (the ring's words were cleared at the top: no barrier in between when the chip sorted)
     u64 wkey = 0ull;
     int wl = 0;  // the lane whose bucket holds wkey
     float wcx = 0.0f, wcy = 0.0f, wcz = 0.0f;
@@ -938,8 +960,167 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The sort by the whole chip (clouds of 16384 points and more): the one-workgroup set-up above spends 0.28 ms of a
+// 2.9 ms call at config 3 sorting 65536 points on ONE CU (gathered loads, one line per lane) while 240 CUs idle.  The
+// same counting sort -- same plan, same cell tables, same keys -- as six short launches of kPre workgroups per
+// batch element, its tables in the workspace:
+//   box (a part per workgroup) -> per-axis fine histograms -> cell tables -> cell counts -> scan -> scatter.
+// The order of the points INSIDE a cell is whatever the atomics make it (it was in the one-workgroup form, too): any
+// order is correct, the boxes are computed from the points.
+constexpr int kPre = 16;
+constexpr int kPreThreads = 1024;
+struct PreTables {  // per batch element
+  float part[kPre][8];             // (-lo, hi) of every workgroup's share of the points
+  unsigned fine[3][kBkFine];       // per-axis histograms
+  unsigned cell[kBkBins];          // cell counts, then cursors
+};
+
+__device__ __forceinline__ void pre_range(int N, int& k0, int& k1) {
+  const int per = (N + kPre - 1) / kPre;
+  k0 = min(N, (int)blockIdx.x * per);
+  k1 = min(N, k0 + per);
+}
+__device__ __forceinline__ KeyPlan pre_plan(const PreTables* tb) {  // (every thread of the workgroup)
+  __shared__ float s_bv[6];
+  if (threadIdx.x < 6) {
+    float m = tb->part[0][threadIdx.x];
+    for (int c = 1; c < kPre; ++c) m = fmaxf(m, tb->part[c][threadIdx.x]);
+    s_bv[threadIdx.x] = m;
+  }
+  __syncthreads();
+  float bv[6];
+  for (int a = 0; a < 6; ++a) bv[a] = s_bv[a];
+  return make_key_plan(bv);
+}
+
+__global__ __launch_bounds__(kPreThreads) void fps_pre_box_kernel(const float* __restrict__ xyz, int N, PreTables* tabs) {
+  __shared__ float s_part[kPreThreads / 64][6];
+  PreTables* tb = tabs + blockIdx.y;
+  const float* __restrict__ p = xyz + (size_t)blockIdx.y * N * 3;
+  const int t = threadIdx.x, lane = t & 63;
+  // (this element's tables of the later passes are cleared here: nothing reads them before the next launch)
+  for (int i = blockIdx.x * kPreThreads + t; i < 3 * kBkFine + kBkBins; i += kPre * kPreThreads) (&tb->fine[0][0])[i] = 0u;
+  int k0, k1;
+  pre_range(N, k0, k1);
+  float v[6] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};  // -lo, hi
+  for (int k = k0 + t; k < k1; k += kPreThreads) {
+    const float x = p[3 * (size_t)k], y = p[3 * (size_t)k + 1], z = p[3 * (size_t)k + 2];
+    v[0] = fmaxf(v[0], -x); v[1] = fmaxf(v[1], -y); v[2] = fmaxf(v[2], -z);
+    v[3] = fmaxf(v[3], x);  v[4] = fmaxf(v[4], y);  v[5] = fmaxf(v[5], z);
+  }
+  pp::wave_reduce6_dpp<false, 6>(v);
+  if (lane == 63)
+    for (int a = 0; a < 6; ++a) s_part[t >> 6][a] = v[a];
+  __syncthreads();
+  if (t < 6) {
+    float m = s_part[0][t];
+    for (int w = 1; w < kPreThreads / 64; ++w) m = fmaxf(m, s_part[w][t]);
+    tb->part[blockIdx.x][t] = m;
+  }
+}
+
+__global__ __launch_bounds__(kPreThreads) void fps_pre_fine_kernel(const float* __restrict__ xyz, int N, PreTables* tabs) {
+  __shared__ unsigned s_fine[3][kBkFine];
+  PreTables* tb = tabs + blockIdx.y;
+  const float* __restrict__ p = xyz + (size_t)blockIdx.y * N * 3;
+  const int t = threadIdx.x;
+  const KeyPlan kp = pre_plan(tb);
+  for (int i = t; i < 3 * kBkFine; i += kPreThreads) (&s_fine[0][0])[i] = 0u;
+  __syncthreads();
+  int k0, k1;
+  pre_range(N, k0, k1);
+  for (int k = k0 + t; k < k1; k += kPreThreads) {
+    atomicAdd(&s_fine[0][fine_bin(kp, p[3 * (size_t)k], 0)], 1u);
+    atomicAdd(&s_fine[1][fine_bin(kp, p[3 * (size_t)k + 1], 1)], 1u);
+    atomicAdd(&s_fine[2][fine_bin(kp, p[3 * (size_t)k + 2], 2)], 1u);
+  }
+  __syncthreads();
+  for (int i = t; i < 3 * kBkFine; i += kPreThreads) {
+    const unsigned c = (&s_fine[0][0])[i];
+    if (c) atomicAdd(&(&tb->fine[0][0])[i], c);
+  }
+}
+
+// the per-axis histograms to cell tables, in place (a wave per axis: sixteen dependent scans, once per element)
+__global__ __launch_bounds__(192) void fps_pre_lut_kernel(int N, PreTables* tabs) {
+  PreTables* tb = tabs + blockIdx.x;
+  const KeyPlan kp = pre_plan(tb);
+  const int lane = threadIdx.x & 63, wave = pp::wave_id_uniform();
+  axis_lut(kp, wave, N, tb->fine[wave], tb->fine[wave], lane);
+}
+
+// SCATTER = false: cell counts; true: the records to their places (after the scan)
+template <bool SCATTER, bool REG>
+__global__ __launch_bounds__(kPreThreads) void fps_pre_cell_kernel(const float* __restrict__ xyz, const float* __restrict__ temp,
+                                                                   int N, TieOrder order, BucketGeom geo, PreTables* tabs,
+                                                                   f4* __restrict__ sorted_all, unsigned* __restrict__ aux_all) {
+  __shared__ unsigned s_lut[3][kBkFine];
+  PreTables* tb = tabs + blockIdx.y;
+  const float* __restrict__ p = xyz + (size_t)blockIdx.y * N * 3;
+  const int t = threadIdx.x;
+  const KeyPlan kp = pre_plan(tb);
+  for (int i = t; i < 3 * kBkFine; i += kPreThreads) (&s_lut[0][0])[i] = (&tb->fine[0][0])[i];
+  __syncthreads();
+  int k0, k1;
+  pre_range(N, k0, k1);
+  if (!SCATTER) {
+    for (int k = k0 + t; k < k1; k += kPreThreads)
+      atomicAdd(&tb->cell[cell_key(kp, s_lut, p[3 * (size_t)k], p[3 * (size_t)k + 1], p[3 * (size_t)k + 2])], 1u);
+    return;
+  }
+  f4* __restrict__ sorted = sorted_all + (size_t)blockIdx.y * geo.npad;
+  unsigned* __restrict__ rc = aux_all + (size_t)blockIdx.y * geo.naux;
+  const float* __restrict__ tmp = temp ? temp + (size_t)blockIdx.y * N : nullptr;
+  for (int k = k0 + t; k < k1; k += kPreThreads) {
+    f4 rec;
+    rec.x = p[3 * (size_t)k]; rec.y = p[3 * (size_t)k + 1]; rec.z = p[3 * (size_t)k + 2];
+    const unsigned pos = atomicAdd(&tb->cell[cell_key(kp, s_lut, rec.x, rec.y, rec.z)], 1u);
+    const float t0 = tmp ? tmp[k] : 1e10f;  // (ref network/geo_operations.py:33: the caller's fill)
+    if (REG) {
+      rec.w = __uint_as_float(kRcMax - order.rank(k));
+      rc[pos] = __float_as_uint(t0);
+    } else {
+      rec.w = t0;
+      rc[pos] = kRcMax - order.rank(k);
+    }
+    sorted[pos] = rec;
+  }
+  if (blockIdx.x == 0) {  // padding behind the last point: temp 0 and the lowest key -- never picked, never rewritten
+    for (int pos = N + t; pos < geo.npad; pos += kPreThreads) {
+      f4 rec;
+      rec.x = 0.0f; rec.y = 0.0f; rec.z = 0.0f; rec.w = 0.0f;
+      sorted[pos] = rec;
+    }
+    for (int pos = N + t; pos < geo.naux; pos += kPreThreads) rc[pos] = 0u;
+  }
+}
+
+// exclusive scan of an element's cell counts, in place (a wave per 2048 bins)
+__global__ __launch_bounds__(kBkThreads) void fps_pre_scan_kernel(PreTables* tabs) {
+  __shared__ int s_wsum[kBkWaves];
+  unsigned* __restrict__ h = tabs[blockIdx.x].cell;
+  const int lane = threadIdx.x & 63, wave = pp::wave_id_uniform();
+  constexpr int kRows = kBkBins / kBkWaves / 64;
+  int loc[kRows];
+  int carry = 0;
+  for (int r = 0; r < kRows; ++r) {
+    const int c = (int)h[wave * (kBkBins / kBkWaves) + 64 * r + lane];
+    const int inc = wave_scan_incl(c);
+    loc[r] = carry + inc - c;
+    carry += __builtin_amdgcn_readlane(inc, 63);
+  }
+  if (lane == 0) s_wsum[wave] = carry;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_wsum[w];
+  for (int r = 0; r < kRows; ++r) h[wave * (kBkBins / kBkWaves) + 64 * r + lane] = (unsigned)(loc[r] + base);
+}
+
+
 pp::DeviceFlags g_bucket_lds[3];
 pp::Knob g_bucket_chain;  // 1: one pick per round (the round-4 chain)
+pp::Knob g_bucket_sort;   // 1: always the one-workgroup sort, 2: always the chip-wide sort
 
 }  // namespace
 
@@ -962,9 +1143,16 @@ bool bucket_applies(int B, int N, int npoint) {
   return N >= 2048 && N <= (1 << 22) && npoint >= 32;
 }
 
+// the sort by the whole chip pays from 32768 points (the one-workgroup set-up of a smaller cloud is a few dozen us)
+static bool presort_applies(int N) {
+  const int mode = (int)g_bucket_sort;
+  return mode == 2 || (mode != 1 && N >= 32768);
+}
+
 size_t bucket_workspace_bytes(int B, int N) {
   const BucketGeom g = bucket_geom(N);
-  return (size_t)B * ((size_t)g.npad * sizeof(f4) + (size_t)g.naux * sizeof(unsigned));
+  // (the pre-sort's tables whatever the knob says: the size must not depend on a debug switch)
+  return (size_t)B * ((size_t)g.npad * sizeof(f4) + (size_t)g.naux * sizeof(unsigned) + sizeof(PreTables));
 }
 
 int bucket_launch(const float* xyz, float* temp, int* idx, int B, int N, int npoint, int seed, TieOrder order,
@@ -972,21 +1160,37 @@ int bucket_launch(const float* xyz, float* temp, int* idx, int B, int N, int npo
   const BucketGeom g = bucket_geom(N);
   f4* sorted = (f4*)ws;
   unsigned* aux = (unsigned*)((char*)ws + (size_t)B * g.npad * sizeof(f4));
-  if (g.m == 1 && (int)g_bucket_chain != 1) {
+  PreTables* tabs = (PreTables*)((char*)aux + (size_t)B * g.naux * sizeof(unsigned));
+  const int pre = presort_applies(N) ? 1 : 0;
+  if (pre) {
+    const dim3 grid(kPre, B);  // (the first launch clears the tables of the later ones: no memset)
+    fps_pre_box_kernel<<<grid, dim3(kPreThreads), 0, s>>>(xyz, N, tabs);
+    fps_pre_fine_kernel<<<grid, dim3(kPreThreads), 0, s>>>(xyz, N, tabs);
+    fps_pre_lut_kernel<<<dim3(B), dim3(192), 0, s>>>(N, tabs);
+    if (g.m == 1) fps_pre_cell_kernel<false, true><<<grid, dim3(kPreThreads), 0, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
+    else fps_pre_cell_kernel<false, false><<<grid, dim3(kPreThreads), 0, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
+    fps_pre_scan_kernel<<<dim3(B), dim3(kBkThreads), 0, s>>>(tabs);
+    if (g.m == 1) fps_pre_cell_kernel<true, true><<<grid, dim3(kPreThreads), 0, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
+    else fps_pre_cell_kernel<true, false><<<grid, dim3(kPreThreads), 0, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
+  }
+  // several picks per round from 32768 points (measured: 0.96 against 0.93 ms at 16 x 16384 -> 1024, 0.58 against 0.49
+  // at 32 x 8192 -> 512: few buckets per lane, and the first hundred picks of any call come one per round)
+  const int chain = (int)g_bucket_chain;
+  if (g.m == 1 && (chain == 2 || (chain == 0 && N >= 32768))) {
     hipError_t e = pp::allow_big_lds(fps_bucket_kernel<true, true>, kBkLdsBytes, g_bucket_lds[2]);
     if (e != hipSuccess) return (int)e;
     fps_bucket_kernel<true, true><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed,
-                                                                                order, g, sorted, aux, sampled, cf);
+                                                                                order, g, sorted, aux, sampled, cf, pre);
   } else if (g.m == 1) {
     hipError_t e = pp::allow_big_lds(fps_bucket_kernel<true, false>, kBkLdsBytes, g_bucket_lds[0]);
     if (e != hipSuccess) return (int)e;
     fps_bucket_kernel<true, false><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed,
-                                                                                 order, g, sorted, aux, sampled, cf);
+                                                                                 order, g, sorted, aux, sampled, cf, pre);
   } else {
     hipError_t e = pp::allow_big_lds(fps_bucket_kernel<false, false>, kBkLdsBytes, g_bucket_lds[1]);
     if (e != hipSuccess) return (int)e;
     fps_bucket_kernel<false, false><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed,
-                                                                                  order, g, sorted, aux, sampled, cf);
+                                                                                  order, g, sorted, aux, sampled, cf, pre);
   }
   PP_RETURN_IF_LAUNCH_FAILED();
   return PP_OK;
@@ -995,3 +1199,4 @@ int bucket_launch(const float* xyz, float* temp, int* idx, int B, int N, int npo
 }  // namespace ppfps
 
 extern "C" void pp_debug_set_fps_bucket_chain(int form) { g_bucket_chain.set(form); }
+extern "C" void pp_debug_set_fps_bucket_sort(int mode) { g_bucket_sort.set(mode); }

@@ -41,9 +41,23 @@ def _fps_chain(form):
 def bucket_chain(request):
     """the bucketed kernel's two chains: several independent picks per barrier round (default) and one pick per
     round -- the same picks and temp from both"""
-    _fps_chain({"batched": 0, "one_pick": 1}[request.param])
+    _fps_chain({"batched": 2, "one_pick": 1}[request.param])
     yield request.param
     _fps_chain(0)
+
+
+@pytest.fixture(params=["auto", "in_kernel", "chip"])
+def bucket_sort(request):
+    """where the bucketed kernel's counting sort runs: inside the kernel (its one workgroup), or as five short launches
+    over the whole chip in front of it (the library's choice from 32768 points) -- any order inside a cell is correct"""
+    import ctypes
+    from pytorch_points_amd import _lib
+    setter = _lib.lib().pp_debug_set_fps_bucket_sort
+    setter.argtypes = [ctypes.c_int]
+    setter.restype = None
+    setter({"auto": 0, "in_kernel": 1, "chip": 2}[request.param])
+    yield request.param
+    setter(0)
 
 
 @pytest.fixture(params=["default", "cluster", "single_block"])
@@ -118,8 +132,8 @@ def _fps_clouds(n):
     return out
 
 
-@pytest.mark.parametrize("n,m,seed", [(2048, 64, 0), (5000, 300, 7), (4099, 4099, 4098), (16384, 700, 3)])
-def test_fps_bucketed_kernel_on_hard_clouds(cuda, bucket_chain, n, m, seed):
+@pytest.mark.parametrize("n,m,seed", [(2048, 64, 0), (5000, 300, 7), (4099, 4099, 4098), (16384, 700, 3), (40000, 1500, 1)])
+def test_fps_bucketed_kernel_on_hard_clouds(cuda, bucket_chain, bucket_sort, n, m, seed):
     """The bucketed kernel (every step only visits the buckets the pick can change) against the oracle: picks AND
     temp, on clouds with exact ties, duplicates, degenerate extents, clusters and outliers."""
     from pytorch_points_amd._ext import sampling
@@ -163,7 +177,7 @@ def test_fps_bucketed_kernel_honours_the_incoming_temp(cuda, bucket_chain):
     assert np.array_equal(temp.cpu().numpy(), e_temp)
 
 
-def test_fps_bucketed_kernel_beyond_65536_points(cuda):
+def test_fps_bucketed_kernel_beyond_65536_points(cuda, bucket_sort):
     """N > 65536: buckets of 128 or more points (at most 1024 buckets, one per thread)"""
     from pytorch_points_amd._ext import sampling
     for n, m in [(70000, 40), (200001, 33)]:

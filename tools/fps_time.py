@@ -22,11 +22,11 @@ def form(name):
 
 
 def chain(one_pick):
-    """the bucketed kernel's chain: 0 = several independent picks per round (default), 1 = one pick per round"""
+    """the bucketed kernel's chain: 2 = several independent picks per round, 1 = one pick per round"""
     f = _lib.lib().pp_debug_set_fps_bucket_chain
     f.argtypes = [ctypes.c_int]
     f.restype = None
-    f(1 if one_pick else 0)
+    f(1 if one_pick else 2)
 
 
 def clouds(B, N):
@@ -81,7 +81,7 @@ def main():
                         assert torch.equal(ref, idx), (name, f)
                 finally:
                     form("default")
-                    chain(False)
+                    _lib.lib().pp_debug_set_fps_bucket_chain(0)
             print("B=%d N=%d m=%d %-10s " % (B, N, m, name) +
                   "  ".join("%s %.3f ms (%.3f us/pick)" % (k, v, v * 1e3 / (m - 1)) for k, v in row.items()), flush=True)
 
