@@ -261,9 +261,11 @@ def bench_chamfer(args, dist, world, rank, device):
         # one asynchronous collective per gathered step: (dist1 | dist2 | idx1 | idx2) of the shard, packed (idx as
         # 16-bit words: 6 MiB per rank at B=32, N=M=16384), double-buffered (pytorch_points_amd/sharded.py)
         from pytorch_points_amd.sharded import PackedShardGather
-        # PP_SHARD_EXCHANGE: native (default: c10d's _allgather_base issued from C++ by the calling thread), rccl (one
-        # direct ncclAllGather on a communicator of the object's own -- opt-in: it could only be exercised with one
-        # rank here), python (the Python-issued exchange)
+        # PP_SHARD_EXCHANGE: native (c10d's _allgather_base issued from C++ by the calling thread), p2p (round 6: ONE
+        # grouped set of world - 1 sends and receives between the rows of the gathered buffer: every part over its own
+        # xGMI link), rccl / rccl_p2p (the same two on a communicator of the object's own -- opt-in: they could only be
+        # exercised with one rank here), python (the Python-issued exchange).  With several ranks and no variable set
+        # the native and the p2p form are both timed below and the headline runs on the faster.
         exchange = PackedShardGather(B, N, M, device)
     pending = []        # slot of the previous gathered step
     counter = [0]
@@ -390,6 +392,34 @@ def bench_chamfer(args, dist, world, rank, device):
     if want == "graph" and gstep is None:
         want = "eager"
     timed_fn = {"graph": graph_step, "ext": ext_step, "eager": eager_step}[want]
+    # ---- which exchange?  (several ranks, nothing asked for: 20 steps of the timed function on each form after a
+    # warm-up, the headline on the faster; every rank takes the same decision: run_timed returns the MAX over ranks)
+    exchange_modes_ms, exchange_mode = None, None
+    if exchange is not None:
+        exchange_mode = exchange.mode
+        if world > 1 and os.environ.get("PP_SHARD_EXCHANGE") is None:
+            from pytorch_points_amd.sharded import PackedShardGather
+            exchange_modes_ms = {}
+            objs = {exchange.mode: exchange}
+            for mode in ("p2p",):
+                ok = 1
+                try:
+                    objs[mode] = PackedShardGather(B, N, M, device, exchange=mode)
+                except Exception as exc:   # noqa: BLE001
+                    ok = 0
+                    sys.stderr.write("bench: exchange mode %s not available (%s: %s)\n" % (mode, type(exc).__name__, exc))
+                flag = torch.tensor([ok], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)       # (every rank takes the same path)
+                if int(flag.item()) == 0:
+                    objs.pop(mode, None)
+            for mode, obj in objs.items():
+                exchange = obj
+                exchange_modes_ms[mode] = run_timed(timed_fn, 5, 20) / 20 * 1e3
+            exchange_mode = min(exchange_modes_ms, key=exchange_modes_ms.get)
+            exchange = objs[exchange_mode]
+            for mode in list(objs):
+                if mode != exchange_mode:
+                    objs.pop(mode).drain()
     dt = run_timed(timed_fn, args.warmup, args.steps)
     ms = dt / args.steps * 1e3
 
@@ -570,10 +600,15 @@ def bench_chamfer(args, dist, world, rank, device):
         out["compute_ms"] = compute_ms
         out["exchange_ms"] = exchange_ms
         out["exchange_gpu_us"] = exchange_gpu_us
+        out["exchange_mode"] = exchange_mode
+        out["exchange_modes_ms"] = exchange_modes_ms     # ms per step of the timed function on every form tried (20 steps each)
         native = getattr(exchange, "_native", None)
-        out["exchange_issue"] = ("direct ncclAllGather issued by the calling thread" if getattr(exchange, "direct", False)
-                                 else ("c10d _allgather_base issued by the calling thread (C++)" if native is not None
-                                       else "Python: dist.all_gather_into_tensor"))
+        p2p = bool(getattr(exchange, "p2p", False))
+        out["exchange_issue"] = (("grouped ncclSend / ncclRecv, one per peer" if p2p else "direct ncclAllGather") +
+                                 " issued by the calling thread" if getattr(exchange, "direct", False)
+                                 else (("c10d coalesced send / recv, one per peer," if p2p else "c10d _allgather_base") +
+                                       " issued by the calling thread (C++)" if native is not None
+                                       else ("Python: dist.batch_isend_irecv" if p2p else "Python: dist.all_gather_into_tensor")))
         if native is not None:
             out["exchange_issue_us"] = float(native.issue_us_per_slot())   # host time of issuing one exchange
         # The wire model the first real 1 -> 8 run can be read against: an all-gather moves (world - 1) parts of
@@ -589,6 +624,13 @@ def bench_chamfer(args, dist, world, rank, device):
                                 "note": "floors of ONE exchange at the assumed xGMI link rate (no latency term); with "
                                         "gather_every = %d the exchange has %d step(s) of compute to hide under" % (
                                             gather_every, gather_every)}
+        # measured step against what the model allows: the longer of the compute leg and the wire floor of the form
+        # that ran (ring for the library's all-gather, all-pairs for the grouped sends / receives); 1.0 = at the model
+        floor_ms = out["wire_floor_ms"]["all_pairs" if p2p else "ring"] / gather_every
+        out["scaling_vs_model"] = {"value": ms / max(compute_ms, floor_ms) if max(compute_ms, floor_ms) > 0 else None,
+                                   "compute_ms": compute_ms, "wire_floor_ms": floor_ms,
+                                   "floor": "all_pairs" if p2p else "ring",
+                                   "note": "ms_per_step / max(compute_ms, wire floor of the exchange form that ran)"}
         out["exchange_note"] = ("compute_ms: the same steps without the exchange; exchange_ms: one step's exchange with nothing "
                                 "beside it (indices narrowed into the slot + all-gather; the distances are written into the "
                                 "slot by the search itself, the gathered buffer is read through views: no pack of "

@@ -47,7 +47,7 @@ void pp_debug_set_fps_v1(int form); /* 0 = the library's choice, 1 = one workgro
  * per barrier round from 32768 points, one pick per round below), 1 = one pick per round, 2 = several per round */
 void pp_debug_set_fps_bucket_chain(int form);
 /* the bucketed FPS kernel's sort: 0 = by the whole chip from 32768 points (six short launches in front of the kernel),
- * else inside the kernel by its one workgroup; 1 = always inside the kernel, 2 = always by the chip */
+ * below that inside the kernel by its one workgroup; 1 = always inside the kernel */
 void pp_debug_set_fps_bucket_sort(int mode);
 void pp_debug_set_gather_variant(int variant);
 void pp_debug_set_ball_query_variant(int variant); /* scan kernels: 1 = one wave per 64 centres */

@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_pre_scan_kernel(PreTables* tab
 
 pp::DeviceFlags g_bucket_lds[3];
 pp::Knob g_bucket_chain;  // 1: one pick per round (the round-4 chain)
-pp::Knob g_bucket_sort;   // 1: always the one-workgroup sort, 2: always the chip-wide sort
+pp::Knob g_bucket_sort;   // 1: always the one-workgroup sort
 
 }  // namespace
 
@@ -1144,15 +1144,14 @@ bool bucket_applies(int B, int N, int npoint) {
 }
 
 // the sort by the whole chip pays from 32768 points (the one-workgroup set-up of a smaller cloud is a few dozen us)
-static bool presort_applies(int N) {
-  const int mode = (int)g_bucket_sort;
-  return mode == 2 || (mode != 1 && N >= 32768);
-}
+static bool presort_sizes(int N) { return N >= 32768; }
+static bool presort_applies(int N) { return presort_sizes(N) && (int)g_bucket_sort != 1; }
 
 size_t bucket_workspace_bytes(int B, int N) {
   const BucketGeom g = bucket_geom(N);
-  // (the pre-sort's tables whatever the knob says: the size must not depend on a debug switch)
-  return (size_t)B * ((size_t)g.npad * sizeof(f4) + (size_t)g.naux * sizeof(unsigned) + sizeof(PreTables));
+  // (the pre-sort's tables wherever it can run, whatever the knob says: the size must not depend on a debug switch)
+  return (size_t)B * ((size_t)g.npad * sizeof(f4) + (size_t)g.naux * sizeof(unsigned) +
+                      (presort_sizes(N) ? sizeof(PreTables) : 0));
 }
 
 int bucket_launch(const float* xyz, float* temp, int* idx, int B, int N, int npoint, int seed, TieOrder order,

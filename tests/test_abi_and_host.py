@@ -116,7 +116,9 @@ def test_workspace_size_queries_are_host_only():
     # the bucketed kernel (N >= 2048, 32 or more picks): the sorted cloud (16 B per point) and one more word per point
     # (up to 65536 points: a word for every register slot of the running minima, 65536 per batch element)
     assert L.pp_furthest_sampling_workspace_bytes(300, 2048, 64) == 256 + 300 * (2048 * 16 + 65536 * 4)
-    assert L.pp_furthest_sampling_workspace_bytes(16, 65536, 4096) > 16 * 65536 * 20
+    # from 32768 points the counting sort runs as launches of their own: its tables (box parts, three 1024-bin axis
+    # histograms, 32768 cell counters) per batch element
+    assert L.pp_furthest_sampling_workspace_bytes(16, 65536, 4096) > 16 * (65536 * 20 + 32768 * 4 + 3 * 1024 * 4)
     assert L.pp_furthest_sampling_workspace_bytes(1, 70000, 64) >= 256 + 70000 * 20
     assert L.pp_furthest_sampling_workspace_bytes(1, 600, 64) == 0         # too small to split
     # argument validation happens before anything touches a device

@@ -82,3 +82,35 @@ def test_default_line_is_the_autograd_operator_and_carries_configs_3_and_4(cuda)
         assert "workload" in sub["config"]
     od = d["other_distributions_fwd_ms"]
     assert all(od[k] > 0 for k in ("gaussian", "blobs8", "two_scales", "shapenet_like", "disjoint"))
+
+
+def test_distributed_line_times_the_exchange_forms(cuda):
+    """N > 1 (VERDICT r5 #2c): with no PP_SHARD_EXCHANGE the line times the native all-gather and the grouped
+    send / receive form, runs the headline on the faster and reports the step against the wire model.  Two ranks on this
+    box's one GPU over gloo (PP_BENCH_DEBUG_GLOO=1: a logic check of the control flow, not a measurement), then one rank
+    over RCCL with the p2p form asked for."""
+    env = dict(os.environ, PP_BENCH_DEBUG_GLOO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PP_SHARD_EXCHANGE", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--points", "4096",
+                          "--launch", "eager", "--no-extras", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert set(d["exchange_modes_ms"]) == {"native", "p2p"} and d["exchange_mode"] in d["exchange_modes_ms"]
+    assert all(v > 0 for v in d["exchange_modes_ms"].values())
+    m = d["scaling_vs_model"]
+    assert m["floor"] == ("all_pairs" if d["exchange_mode"] == "p2p" else "ring") and m["value"] > 0
+    assert abs(d["value"] - 2 * 2.0 * 4 * 4096 * 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    env = dict(os.environ, PP_BENCH_FORCE_DIST="1", PP_SHARD_EXCHANGE="p2p", MASTER_ADDR="127.0.0.1", MASTER_PORT="29573",
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "4",
+                          "--points", "4096", "--launch", "eager", "--no-extras", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["exchange_mode"] == "p2p" and d["exchange_modes_ms"] is None and "coalesced send / recv" in d["exchange_issue"]

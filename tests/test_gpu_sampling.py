@@ -46,7 +46,7 @@ def bucket_chain(request):
     _fps_chain(0)
 
 
-@pytest.fixture(params=["auto", "in_kernel", "chip"])
+@pytest.fixture(params=["auto", "in_kernel"])
 def bucket_sort(request):
     """where the bucketed kernel's counting sort runs: inside the kernel (its one workgroup), or as five short launches
     over the whole chip in front of it (the library's choice from 32768 points) -- any order inside a cell is correct"""
@@ -55,7 +55,7 @@ def bucket_sort(request):
     setter = _lib.lib().pp_debug_set_fps_bucket_sort
     setter.argtypes = [ctypes.c_int]
     setter.restype = None
-    setter({"auto": 0, "in_kernel": 1, "chip": 2}[request.param])
+    setter({"auto": 0, "in_kernel": 1}[request.param])
     yield request.param
     setter(0)
 

@@ -74,7 +74,9 @@ dev = torch.device("cuda:0")
 B, N, M = 3, 5000, 70000                                  # M > 65536: 32-bit indices; then a 16-bit case
 for (n, m) in ((N, M), (4096, 2048)):
     ex = PackedShardGather(B, n, m, dev)
-    assert bool(getattr(ex, 'direct', False)) == (os.environ.get('PP_SHARD_EXCHANGE', 'native') == 'rccl'), 'exchange path'
+    mode = os.environ.get('PP_SHARD_EXCHANGE', 'native')
+    assert bool(getattr(ex, 'direct', False)) == (mode in ('rccl', 'rccl_p2p')), 'exchange path'
+    assert bool(ex.p2p) == (mode in ('p2p', 'rccl_p2p', 'python_p2p')), 'exchange path (p2p)'
     fail = os.environ.get('PP_SHARD_SELFCHECK_FAIL', '0') == '1'
     gen = torch.Generator(device="cpu").manual_seed(n)
     steps = []
@@ -89,7 +91,7 @@ for (n, m) in ((N, M), (4096, 2048)):
         t = torch.ones(4, device=dev); dist.all_reduce(t)
         g = ex.wait(h)
         if fail:                                           # the first wait found the direct path wanting: c10d from here on
-            assert not ex.direct and ex._checked
+            assert not ex.direct and not ex.p2p and ex._checked
         for a, e in zip(g, (d1, d2, i1, i2)):
             assert a.dtype == e.dtype and torch.equal(a, e), (n, m, s)
         v = ex.wait_views(h)                               # the same, as views of the gathered buffer
@@ -122,7 +124,13 @@ print("exchange ok")
 """
 
 
-@pytest.mark.parametrize("path", ["default", "native", "python", "rccl", "rccl_selfcheck_fail"])
+_EXCHANGE_PATHS = {"default": (None, "29539"), "native": ("native", "29541"), "python": ("python", "29543"),
+                   "rccl": ("rccl", "29545"), "rccl_selfcheck_fail": ("rccl", "29547"), "p2p": ("p2p", "29549"),
+                   "p2p_selfcheck_fail": ("p2p", "29551"), "rccl_p2p": ("rccl_p2p", "29553"),
+                   "python_p2p": ("python_p2p", "29555")}
+
+
+@pytest.mark.parametrize("path", list(_EXCHANGE_PATHS))
 def test_packed_exchange_on_one_rank_rccl_group(cuda, tmp_path, path):
     """PackedShardGather on the GPU path proper: RCCL all-gather (a one-rank group: this box has one GPU),
     slot reuse, 16- and 32-bit indices, the gathered result as contiguous tensors (wait) and as views of the gathered
@@ -131,7 +139,10 @@ def test_packed_exchange_on_one_rank_rccl_group(cuda, tmp_path, path):
     python: the same steps issued from Python (PP_SHARD_EXCHANGE=python); rccl: the native call with the all-gather as
     a direct ncclAllGather on the exchange object's own communicator (opt-in), its first exchange checked against c10d;
     rccl_selfcheck_fail: that check made to fail (PP_SHARD_SELFCHECK_FAIL=1) -- every slot is gathered again over c10d and
-    the results are still the shards'; default: no variable set (= native).  In a subprocess: the process group must not
+    the results are still the shards'; p2p (round 6): the all-gather as one grouped set of sends and receives between
+    the rows, in place (on one rank: nothing moves, the own row is where the search wrote it), over c10d's communicator,
+    over the object's own (rccl_p2p) or issued from Python (python_p2p), and its self-check made to fail; default: no
+    variable set (= native).  In a subprocess: the process group must not
     leak into the other tests."""
     import os
     import subprocess
@@ -142,11 +153,11 @@ def test_packed_exchange_on_one_rank_rccl_group(cuda, tmp_path, path):
     env = dict(os.environ)
     env.pop("PP_SHARD_EXCHANGE", None)
     env.pop("PP_SHARD_SELFCHECK_FAIL", None)
-    if path != "default":
-        env["PP_SHARD_EXCHANGE"] = path.split("_")[0]
-    if path == "rccl_selfcheck_fail":
+    mode, port = _EXCHANGE_PATHS[path]
+    if mode is not None:
+        env["PP_SHARD_EXCHANGE"] = mode
+    if path.endswith("_selfcheck_fail"):
         env["PP_SHARD_SELFCHECK_FAIL"] = "1"
-    port = {"default": "29539", "native": "29541", "python": "29543", "rccl": "29545", "rccl_selfcheck_fail": "29547"}[path]
     out = subprocess.run([sys.executable, str(script), root, port], capture_output=True,
                          text=True, timeout=600, env=env)
     assert out.returncode == 0 and "exchange ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])

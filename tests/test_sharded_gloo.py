@@ -143,7 +143,7 @@ def test_packed_shard_gather_world2(n, m, compact):
     assert sorted(res) == [(0, True, compact), (1, True, compact)]
 
 
-def _pipeline_worker(rank, world, port, depth, q):
+def _pipeline_worker(rank, world, port, depth, q, exchange=None):
     """the control flow of the RCCL path (bench.py / PackedShardGather.forward): begin -> the search writes its
     distances in place -> launch_in_place -> a collective of the caller's -> wait_views of the step BEFORE (the gather
     of step k overlaps step k + 1), slots reused several times over"""
@@ -152,8 +152,8 @@ def _pipeline_worker(rank, world, port, depth, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         B, n, m = 2, 37, 53
-        ex = sharded.PackedShardGather(B, n, m, torch.device("cpu"), depth=depth)
-        ok = True
+        ex = sharded.PackedShardGather(B, n, m, torch.device("cpu"), depth=depth, exchange=exchange)
+        ok = exchange is None or (ex.p2p == (exchange == "p2p"))
         pending = []     # (slot, step) launched and not yet read
         steps = 3 * depth + 1
 
@@ -193,12 +193,15 @@ def _pipeline_worker(rank, world, port, depth, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", [None, "p2p"])
 @pytest.mark.parametrize("world,depth", [(2, 2), (2, 3), (3, 2), (3, 3)])
-def test_packed_shard_gather_pipelined(world, depth):
+def test_packed_shard_gather_pipelined(world, depth, exchange):
+    """exchange="p2p": the all-gather as world - 1 sends of the own row and world - 1 receives into the other rows,
+    in place (the control flow of PP_SHARD_EXCHANGE=p2p over RCCL: one grouped set per step)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, depth, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, depth, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
