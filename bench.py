@@ -45,14 +45,36 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md chip table)
 VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz fp32 lane-ops/s (same table)
-# bytes per forward at config 2, all three launches -- a RECORDED constant, not measured by this run: 2 x FETCH_SIZE +
-# WRITE_SIZE per launch from rocprofv3 --pmc passes of this command (tools/refresh_profiles.sh -> profiles/r4/pmc_summary.txt,
-# which names the commit it was taken at); counters cannot be collected inside the timed process
-FWD_TRAFFIC_C2 = 71565312
-# counter bytes (the same passes) of the two bandwidth-shaped kernels of the step at config 2: the build's launch
-# (2 x 6.2 MiB fetched + 24.4 MiB written) and the backward's (the algorithmic 33 554 432: PMC = algorithmic there)
-BUILD_TRAFFIC_C2 = 38600000
-BWD_TRAFFIC_C2 = 33554432
+
+
+def _pmc_traffic_c2():
+    """HBM-side bytes per launch of the config-2 step's kernels, from the rocprofv3 --pmc passes of THIS command that
+    tools/regen_profiles.sh wrote last (profiles/r<N>/pmc_summary.txt, the newest round in the tree; counters cannot be
+    collected inside the timed process): 2 x FETCH_SIZE (16-byte loads count half on gfx950, MI355X_MICROARCH.md) +
+    WRITE_SIZE, in bytes.  -> ({kernel prefix: bytes}, source line) or ({}, None) when no summary travels with the tree."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.txt")),
+                   key=lambda f: int(re.search(r"r(\d+)", os.path.basename(os.path.dirname(f))).group(1)))
+    if not files:
+        return {}, None
+    path = files[-1]
+    fetch, write, section, head = {}, {}, None, ""
+    for ln in open(path):
+        if ln.startswith("#"):
+            head = head or ln.strip("# \n")
+            continue
+        if not ln.startswith(" "):
+            section = ln.strip()
+            continue
+        m = re.match(r"\s+(\S+).*?(FETCH_SIZE|WRITE_SIZE) launches=\d+ mean=(\d+) KB", ln)
+        if m and section in ("ch_FETCH_SIZE", "ch_WRITE_SIZE"):
+            name = m.group(1).split("<")[0]
+            (fetch if m.group(2) == "FETCH_SIZE" else write)[name] = float(m.group(3)) * 1024.0
+    out = {k: 2.0 * fetch.get(k, 0.0) + write.get(k, 0.0) for k in set(fetch) | set(write)}
+    return out, "%s (%s)" % (os.path.relpath(path, ROOT), head)
+
+
 
 
 def parse():
@@ -183,24 +205,31 @@ def _search_kernel_ms(fwd, n=40):
     read = L.pp_debug_nmdistance_kernel_ms3
     read.argtypes = [ctypes.POINTER(ctypes.c_float)] * 3
     read.restype = ctypes.c_int
+    own = L.pp_debug_nmdistance_kernel_own_ms      # the build's and the stage-A kernel's own begin / end stamps
+    own.argtypes = [ctypes.POINTER(ctypes.c_float)] * 2
+    own.restype = ctypes.c_int
     on = _knob("pp_debug_set_nmdistance_kernel_timing")
     on(1)
     try:
         for _ in range(3):
             fwd()
         torch.cuda.synchronize()
-        bs, aa, rr = [], [], []
+        bs, aa, rr, ob, oa = [], [], [], [], []
         for _ in range(n):
             fwd()
             bm, am, rm = ctypes.c_float(0), ctypes.c_float(0), ctypes.c_float(0)
             if read(ctypes.byref(bm), ctypes.byref(am), ctypes.byref(rm)) != 0:
-                return None, None, None
+                return None, None, None, None
             bs.append(bm.value)
             aa.append(am.value)
             rr.append(rm.value)
+            if own(ctypes.byref(bm), ctypes.byref(am)) == 0:
+                ob.append(bm.value)
+                oa.append(am.value)
     finally:
         on(0)
-    return float(np.mean(bs)), float(np.mean(aa)), float(np.mean(rr))
+    own_ms = {"build": float(np.mean(ob)), "stage_a": float(np.mean(oa))} if len(oa) == n else None
+    return float(np.mean(bs)), float(np.mean(aa)), float(np.mean(rr)), own_ms
 
 
 def _distribution(kind, seed, B, N):
@@ -517,8 +546,9 @@ def bench_chamfer(args, dist, world, rank, device):
     build_ms = stage_a_ms = rest_ms = search_ms = None
     raw_kernel_ms = None
     event_overhead_ms = None
+    own_kernel_ms = None
     if grid:
-        build_ms, stage_a_ms, rest_ms = _search_kernel_ms(fwd_only)
+        build_ms, stage_a_ms, rest_ms, own_kernel_ms = _search_kernel_ms(fwd_only)
         search_ms = (stage_a_ms + rest_ms) if build_ms is not None else None
         if build_ms is not None:
             # Each figure is the time between two HIP events around ONE launch, which adds a recorded event's own
@@ -640,32 +670,45 @@ def bench_chamfer(args, dist, world, rank, device):
         # the dominant kernel of the step: the stage-A kernel of the unlabeled search (round 3: the search is two launches,
         # stage A by tiles + the kernel over what it leaves); the whole-search kernel where there is no stage-A kernel
         two_stage = bool(stage_a_ms)
-        dom_ms = stage_a_ms if two_stage else (rest_ms if rest_ms else fwd_ms)
+        # roofline.kernel_ms is the dominant kernel's OWN duration -- its launch's begin / end stamps, what rocprofv3's
+        # kernel trace reports for the dispatch (profiles/r<N>/chamfer_kernel_stats.csv) -- where the library can
+        # stamp the launch (the stage-A kernel, the build); the durations between events recorded on the stream around
+        # each launch, and those less the events' own cost, stay beside it
+        own_a = own_kernel_ms["stage_a"] if (two_stage and own_kernel_ms) else None
+        own_b = own_kernel_ms["build"] if own_kernel_ms else None
+        dom_ms = own_a if own_a else (stage_a_ms if two_stage else (rest_ms if rest_ms else fwd_ms))
         gbs = alg_bytes_fwd / (dom_ms * 1e-3) / 1e9
+        pmc, pmc_source = _pmc_traffic_c2() if c2 else ({}, None)
+        fwd_traffic = (sum(pmc.get(k, 0.0) for k in ("grid_build_kernel", "grid_stage_a_kernel", "grid_query_list_kernel"))
+                       if (two_stage and pmc) else None)
         out["roofline"] = {
             "bound": "hbm",
             "kernel": ("grid_stage_a_kernel (stage A of the search by tiles; dominant kernel of the step)" if two_stage
                        else "grid_query_wave_kernel (the search; dominant kernel of the step)"),
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            # FORWARD-level HBM-side traffic per step, all of the forward's launches (build + stage A + list kernel):
-            # rocprofv3 --pmc FETCH_SIZE (x2: 16-byte loads count half on gfx950, MI355X_MICROARCH.md) + WRITE_SIZE
-            # per launch, profiles/r3/pmc_summary.txt
-            "traffic": FWD_TRAFFIC_C2 if (c2 and two_stage) else None,
-            "kernel_ms": dom_ms, "build_kernel_ms": build_ms, "stage_a_kernel_ms": stage_a_ms, "rest_kernel_ms": rest_ms,
+            # FORWARD-level HBM-side traffic per step, all of the forward's launches (build + stage A + list kernel)
+            "traffic": fwd_traffic or None,
+            "traffic_dominant_kernel": pmc.get("grid_stage_a_kernel") if two_stage else None,
+            "kernel_ms": dom_ms,
+            "kernel_ms_source": ("the launch's own begin / end stamps (hipExtLaunchKernelGGL events)" if own_a
+                                 else "HIP events on the stream around the launch, less the events' own cost"),
+            "build_kernel_ms": own_b if own_b else build_ms,
+            "stage_a_kernel_ms": dom_ms if two_stage else None, "rest_kernel_ms": rest_ms,
             "backward_kernel_ms": bwd_ms,
             # the two bandwidth-shaped kernels of the step against the HBM roof (their counter bytes / their
-            # duration / 8 TB/s; launches issued back to back, events around the batch)
-            "build_frac_hbm": (BUILD_TRAFFIC_C2 / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (c2 and build_ms) else None,
-            "backward_frac_hbm": (BWD_TRAFFIC_C2 / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (c2 and bwd_ms) else None,
-            "kernel_ms_uncorrected": raw_kernel_ms, "kernel_event_overhead_ms": event_overhead_ms,
-            "traffic_source": ("recorded constant: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over the forward's launches, "
-                               "profiles/r4/pmc_summary.txt (the commit is named there)") if (c2 and two_stage) else None,
-            "note": "SURVEY.md §8(d): algorithmic forward bytes (%.0f) / the dominant kernel's average duration, HIP events "
-                    "on the launch stream around each of the forward's launches (pp_hip_debug.h), %d forwards after the "
-                    "timed region, each less the events' own cost (kernel_event_overhead_ms) so that build + stage A + rest "
-                    "= fwd_ms; 'traffic' is for the whole forward (every launch), not the dominant kernel alone. The "
-                    "search is bound by VALU issue and LDS bandwidth, not by HBM; 'bruteforce' carries the every-pair kernel "
-                    "with its VALU roofline" % (alg_bytes_fwd, 40)}
+            # duration / 8 TB/s) -- only where the summary's kernels are the ones this run timed
+            "build_frac_hbm": (pmc["grid_build_kernel"] / ((own_b or build_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                              if (pmc.get("grid_build_kernel") and (own_b or build_ms)) else None,
+            "backward_frac_hbm": (pmc["nmdist_bwd_lds64_kernel"] / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                 if (pmc.get("nmdist_bwd_lds64_kernel") and bwd_ms) else None,
+            "kernel_ms_stream_events": {"uncorrected": raw_kernel_ms, "event_overhead_ms": event_overhead_ms,
+                                        "corrected": {"build": build_ms, "stage_a": stage_a_ms, "rest": rest_ms}},
+            "traffic_source": pmc_source,
+            "note": "SURVEY.md §8(d): algorithmic forward bytes (%.0f) / the dominant kernel's average duration over %d "
+                    "forwards after the timed region; 'traffic' = 2 x FETCH_SIZE + WRITE_SIZE of the forward's launches "
+                    "(every launch, not the dominant kernel alone) from the rocprofv3 --pmc passes named in "
+                    "traffic_source. The search is bound by VALU issue and LDS bandwidth, not by HBM; 'bruteforce' "
+                    "carries the every-pair kernel with its VALU roofline" % (alg_bytes_fwd, 40)}
         sgbs = alg_bytes_step / (ms * 1e-3) / 1e9
         out["roofline_step"] = {"bound": "hbm", "achieved": sgbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": sgbs / HBM_PEAK_GBS,

@@ -74,6 +74,7 @@ int main(int argc, char** argv) {
   hipMemset(ws, 0, 256);
   hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   if (getenv("PP_PROBE_CHAIN")) pp_debug_set_fps_bucket_chain(atoi(getenv("PP_PROBE_CHAIN")));
+  if (getenv("PP_PROBE_SORT")) pp_debug_set_fps_bucket_sort(atoi(getenv("PP_PROBE_SORT")));
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int it = 0; it < 3; ++it) {
     hipMemcpy(temp, big.data(), big.size() * 4, hipMemcpyHostToDevice);

@@ -1,12 +1,12 @@
 #!/bin/bash
 # tools/run_regen_profiles.sh -- in the build container: build everything at HEAD, run tools/regen_profiles.sh on a GPU
-# box through gpurun, and copy what it produced into profiles/r<round>/ (round = $1, default 5; VERDICT r3 #7: one script regenerates every measured
+# box through gpurun, and copy what it produced into profiles/r<round>/ (round = $1, default 6; VERDICT r3 #7: one script regenerates every measured
 # file of the round from the final commit, the commit named in each).
 set -e
 cd "$(dirname "$0")/.."
 if [ -n "$(git status --porcelain -- pytorch_points_amd include bench.py tools oracle)" ]; then echo "commit first: the profiles name a commit"; exit 1; fi
 C=$(git rev-parse --short HEAD)
-R=${1:-5}
+R=${1:-6}
 python -c "import __graft_entry__ as g; g.build()"
 ./tools/build_fps_bucket_probes.sh > /dev/null 2>&1 || true
 rm -f tools/libpp_hip_*.so
