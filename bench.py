@@ -223,6 +223,13 @@ def _search_kernel_ms(fwd, n=40):
             bs.append(bm.value)
             aa.append(am.value)
             rr.append(rm.value)
+        on(2)   # the same forwards once more with the two launches stamped by their own begin and end
+        for _ in range(3):
+            fwd()
+        torch.cuda.synchronize()
+        for _ in range(n):
+            fwd()
+            bm, am = ctypes.c_float(0), ctypes.c_float(0)
             if own(ctypes.byref(bm), ctypes.byref(am)) == 0:
                 ob.append(bm.value)
                 oa.append(am.value)
@@ -261,6 +268,24 @@ def _distribution(kind, seed, B, N):
         x[:, 2 * q:3 * q, 0] = 0.3 * np.cos(th)
         x[:, 2 * q:3 * q, 1] = 0.3 * np.sin(th)
         return x.astype(np.float32)
+    # four adversarial families: what the pruning of the grid search is weakest on
+    if kind == "shells":          # concentric shells, r = 1 against r = 0.5: EVERY query is half a unit from every reference
+        x = rng.standard_normal((B, N, 3))
+        x /= np.linalg.norm(x, axis=-1, keepdims=True)
+        return (x * (1.0 if seed == 0 else 0.5)).astype(np.float32)
+    if kind == "shell_vs_core":   # a shell against a tight cluster at its centre (and back: the cluster's queries see a far shell)
+        x = rng.standard_normal((B, N, 3))
+        if seed == 0:
+            x /= np.linalg.norm(x, axis=-1, keepdims=True)
+        else:
+            x *= 1e-3
+        return x.astype(np.float32)
+    if kind == "identical":       # every point of a cloud the same point (all ties; one crowded cell)
+        return np.full((B, N, 3), 0.25 if seed == 0 else 0.75, np.float32)
+    if kind == "lattice":         # a 16^3 lattice against its half-cell shift: eight exactly equidistant neighbours everywhere
+        g = np.stack(np.meshgrid(*[np.arange(16, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3)
+        x = g[rng.integers(0, len(g), (B, N))]
+        return (x + (0.0 if seed == 0 else 0.5)).astype(np.float32)
     raise ValueError(kind)
 
 
@@ -735,7 +760,8 @@ def bench_chamfer(args, dist, world, rank, device):
     if rank == 0 and world == 1 and grid and args.launch == "all" and not args.no_extras:
         # other point distributions, forward only: same shapes, clouds that are not a sphere
         od = {}
-        for kind in ("cube", "gaussian", "blobs8", "two_scales", "shapenet_like", "disjoint"):
+        for kind in ("cube", "gaussian", "blobs8", "two_scales", "shapenet_like", "disjoint",
+                     "shells", "shell_vs_core", "identical", "lattice"):
             a = torch.from_numpy(_distribution(kind, 0, B, N)).to(device)
             b_ = torch.from_numpy(_distribution(kind, 1, B, N)).to(device)
             for _ in range(3):

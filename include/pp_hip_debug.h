@@ -38,8 +38,8 @@ int pp_debug_nmdistance_kernel_ms(float* build_ms, float* search_ms);
 /* the same with the search's two launches apart (stage A by tiles, then what it left); stage_a_ms = 0 without a stage-A kernel */
 int pp_debug_nmdistance_kernel_ms3(float* build_ms, float* stage_a_ms, float* rest_ms);
 
-/* ... and the build's and the stage-A kernel's OWN durations of the most recent timed forward (the launches' begin / end
- * stamps, hipExtLaunchKernelGGL: what rocprofv3 reports per dispatch) */
+/* ... and the build's and the stage-A kernel's OWN durations of the most recent forward timed with the knob at 2 (the
+ * launches' begin / end stamps, hipExtLaunchKernelGGL: what rocprofv3 reports per dispatch) */
 int pp_debug_nmdistance_kernel_own_ms(float* build_ms, float* stage_a_ms);
 
 /* unlabeled grid forward: queries its stage-A kernel left to the list kernel, per direction (2 B values; synchronises) */

@@ -2937,7 +2937,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   const int tile = g_tile != 0 ? (int)g_tile : tile_env;
   const Layout lay = make_layout(B, N, M, LAB);
   bool own = false;  // (timing: the two kernels' own begin / end stamps beside the stream events)
-  if (timing) {
+  if (g_time_kernels == 2) {  // (2: these instead of the stream events' figures, which the stamped launches would distort)
     std::lock_guard<std::mutex> lock(g_ev_mutex);
     own = own_events();
     g_evk_valid = false;

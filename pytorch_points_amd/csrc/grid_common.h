@@ -579,6 +579,65 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
     mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
     any_bad = !__builtin_isfinite(sm[3] + sm[4] + sm[5]);
   }
+  // Round 6 (the plain builds: ball_query, three_nn, knn_points): a point with a non-finite coordinate (or one whose
+  // square overflows) can never be anybody's neighbour -- its distance is NaN or +inf, never < anything, and where a
+  // search runs out of finite candidates it ends with the whole grid, rim cells included -- so it must not cost the
+  // batch element its grid (one NaN in one cloud: knn K = 8 0.18 -> 1.95 ms, the whole element every-pair).  The
+  // box and the moments once more over the finite points only; the others keep whatever cell cell_coord gives them
+  // (NaN -> 0, +-inf -> the rim).  The Chamfer build (REFINE) keeps the old rule: there the reference's "first point
+  // unconditionally" makes a non-finite point at index 0 selectable, which only the every-pair order reproduces.
+  float n_live = (float)nr;
+  if (!REFINE && !forced && any_bad) {  // (uniform)
+    mnx = __builtin_inff(); mny = mnx; mnz = mnx; mxx = -mnx; mxy = -mnx; mxz = -mnx;
+    float cnt = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) sm[e] = 0.0f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      if (nchunks > 1) load_chunk(ch * kBuildThreads * KP);
+#pragma unroll
+      for (int i = 0; i < KP; ++i) {
+        const float x = px[i], y = py[i], z = pz[i];
+        const bool ok = kidx(ch * kBuildThreads * KP, i) < nr && __builtin_isfinite(x * x + y * y + z * z);
+        mnx = ok ? fminf(mnx, x) : mnx; mny = ok ? fminf(mny, y) : mny; mnz = ok ? fminf(mnz, z) : mnz;
+        mxx = ok ? fmaxf(mxx, x) : mxx; mxy = ok ? fmaxf(mxy, y) : mxy; mxz = ok ? fmaxf(mxz, z) : mxz;
+        cnt += ok ? 1.0f : 0.0f;
+        sm[0] += ok ? x : 0.0f; sm[1] += ok ? y : 0.0f; sm[2] += ok ? z : 0.0f;
+        sm[3] += ok ? x * x : 0.0f; sm[4] += ok ? y * y : 0.0f; sm[5] += ok ? z * z : 0.0f;
+      }
+    }
+    if (nchunks > 1) load_chunk(0);  // (the passes below reload their chunks themselves, from the first)
+    float v[6] = {-mnx, -mny, -mnz, mxx, mxy, mxz};
+    float w[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]};
+    wave_reduce6_dpp<false, 6>(v);
+    wave_reduce6_dpp<true, 6>(w);
+    cnt = wave_reduce_dpp<true>(cnt);
+    __syncthreads();  // s_box was read above by every thread
+    if ((t & 63) == 63) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + e] = v[e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + 8 + e] = w[e];
+      s_box[(t >> 6) * 16 + 14] = cnt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 6; ++e) v[e] = s_box[(t & 15) * 16 + e];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) w[e] = s_box[(t & 15) * 16 + 8 + e];
+    float c2 = s_box[(t & 15) * 16 + 14];
+    wave_reduce6_dpp<false, 4>(v);
+    wave_reduce6_dpp<true, 4>(w);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) v[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), 15));
+#pragma unroll
+    for (int e = 0; e < 6; ++e) sm[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[e]), 15));
+    float csum = 0.0f;  // (sixteen partial counts: lanes 0..15 of a row hold them)
+    for (int l = 0; l < 16; ++l) csum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2), l));
+    mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
+    n_live = csum;
+    any_bad = !(csum > 0.0f) || !__builtin_isfinite(sm[3] + sm[4] + sm[5]);
+    __syncthreads();  // (s_box is written again below)
+  }
   PP_PHASE(2);
   // Outliers: a few points far from the bulk would stretch the box until the bulk sits in a handful of
   // cells.  Any box is valid -- cell_coord clamps, the points outside simply land in the boundary cells
@@ -587,7 +646,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   // every axis.  Uniform over the workgroup; clouds without outliers skip the second pass.
   bool trimmed = forced ? forced->trimmed != 0 : false;  // the box does not hold every point (the outliers sit in the rim cells)
   if (!any_bad && !forced) {
-    const float inv_n = 1.0f / (float)nr;
+    const float inv_n = 1.0f / n_live;
     const float mean[3] = {sm[0] * inv_n, sm[1] * inv_n, sm[2] * inv_n};
     float sig[3];
 #pragma unroll
@@ -1112,11 +1171,61 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
     mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
     any_bad = !__builtin_isfinite(sm[3] + sm[4] + sm[5]);
   }
+  // (plain builds) non-finite points are left out of the plan instead of costing the set its grid: the general path's
+  // rule and arithmetic (grid_build_set_impl, round 6)
+  float n_live = (float)nr;
+  if (!REFINE && any_bad) {  // (uniform)
+    mnx = __builtin_inff(); mny = mnx; mnz = mnx; mxx = -mnx; mxy = -mnx; mxz = -mnx;
+    float cnt = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) sm[e] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+      const float x = px[i], y = py[i], z = pz[i];
+      const bool ok = live[i >> 2] && __builtin_isfinite(x * x + y * y + z * z);
+      mnx = ok ? fminf(mnx, x) : mnx; mny = ok ? fminf(mny, y) : mny; mnz = ok ? fminf(mnz, z) : mnz;
+      mxx = ok ? fmaxf(mxx, x) : mxx; mxy = ok ? fmaxf(mxy, y) : mxy; mxz = ok ? fmaxf(mxz, z) : mxz;
+      cnt += ok ? 1.0f : 0.0f;
+      sm[0] += ok ? x : 0.0f; sm[1] += ok ? y : 0.0f; sm[2] += ok ? z : 0.0f;
+      sm[3] += ok ? x * x : 0.0f; sm[4] += ok ? y * y : 0.0f; sm[5] += ok ? z * z : 0.0f;
+    }
+    float v[6] = {-mnx, -mny, -mnz, mxx, mxy, mxz};
+    float w[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]};
+    wave_reduce6_dpp<false, 6>(v);
+    wave_reduce6_dpp<true, 6>(w);
+    cnt = wave_reduce_dpp<true>(cnt);
+    __syncthreads();  // s_box was read above by every thread
+    if (lane == 63) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) s_box[wave * 16 + e] = v[e];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) s_box[wave * 16 + 8 + e] = w[e];
+      s_box[wave * 16 + 14] = cnt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 6; ++e) v[e] = s_box[(t & 15) * 16 + e];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) w[e] = s_box[(t & 15) * 16 + 8 + e];
+    const float c2 = s_box[(t & 15) * 16 + 14];
+    wave_reduce6_dpp<false, 4>(v);
+    wave_reduce6_dpp<true, 4>(w);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) v[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), 15));
+#pragma unroll
+    for (int e = 0; e < 6; ++e) sm[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[e]), 15));
+    float csum = 0.0f;
+    for (int l = 0; l < 16; ++l) csum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2), l));
+    mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
+    n_live = csum;
+    any_bad = !(csum > 0.0f) || !__builtin_isfinite(sm[3] + sm[4] + sm[5]);
+    __syncthreads();  // (s_box is written again below)
+  }
   PP_PHASE(2);
   bool trimmed = false;
   float zmean = 0.0f, zsig = 0.0f;  // (for the slabs' balance below)
   if (!any_bad) {  // outliers: the box of the points within 4 sigma when the bounding box reaches beyond 6 (general path)
-    const float inv_n = 1.0f / (float)nr;
+    const float inv_n = 1.0f / n_live;
     const float mean[3] = {sm[0] * inv_n, sm[1] * inv_n, sm[2] * inv_n};
     float sig[3];
 #pragma unroll
