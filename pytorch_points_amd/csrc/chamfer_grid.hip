@@ -439,59 +439,19 @@ constexpr int kGroupBatch = 256;  // candidates per LDS batch of wave_group_sear
 // a blind seed's group: the open queries within this fraction of its candidate's distance (round 3: 1/4 made groups as
 // long as a row of the query grid -- 64 consecutive sorted queries run along x -- and the bound of a group is its
 // farthest member's: disjoint clouds examined 6000 candidates per query)
-#ifndef PP_BLIND_GROUP
-#define PP_BLIND_GROUP 0.25f
-#endif
-constexpr float kBlindGroup = PP_BLIND_GROUP;
-// (the macros below are A/B switches of the stages behind stage A: tools/build_variant_lib.sh <tag> -D<macro>=<value> builds a
-//  library with one of them changed, tools/job_r5ab.sh runs them all against the shipped values --
-//  profiles/r5/near_field_stages_ab.txt; the shipped library is compiled with the defaults written here)
-#ifndef PP_MEMBER_CUT_MIN
-#define PP_MEMBER_CUT_MIN 2  // (round 5: 2, was 8 -- disjoint clouds 0.225 -> 0.203 ms) candidates per member the pieces' cuts must leave in a block of rows for the member-by-member cut
-#endif
-#ifndef PP_SERIAL_MAX
-#define PP_SERIAL_MAX 24
-#endif
-#ifndef PP_LANE_STAGE_MIN
-#define PP_LANE_STAGE_MIN 6
-#endif
-#ifndef PP_LANE_BALL
-#define PP_LANE_BALL 1
-#endif
-#ifndef PP_BALL_MIN
-#define PP_BALL_MIN 6
-#endif
-#ifndef PP_BALL_RMAX
-#define PP_BALL_RMAX 2.5f
-#endif
-constexpr float kBallRmax = PP_BALL_RMAX;  // cells: the farthest candidate whose ball is walked (a box of at most 6 x 6 rows)
-#ifndef PP_POOLED_BALL
-#define PP_POOLED_BALL 1
-#endif
-#ifndef PP_POOLED_CUBE
-#define PP_POOLED_CUBE 1
-#endif
-#ifndef PP_POOL_CUBE_MIN
-#define PP_POOL_CUBE_MIN 1
-#endif
-constexpr int kPoolCubeMin = PP_POOL_CUBE_MIN;
-#ifndef PP_BALL_AFTER_CUBE
-#define PP_BALL_AFTER_CUBE 1
-#endif
-#ifndef PP_POOLED_LAB
-#define PP_POOLED_LAB 1  // labeled searches too (0: a lane per query, lane_ball_search)
-#endif
-#ifndef PP_POOL_MIN
-#define PP_POOL_MIN 1
-#endif
-constexpr int kPoolMin = PP_POOL_MIN;  // ... pooled over the wave (unlabeled searches)
-constexpr int kBallMin = PP_BALL_MIN;  // lanes with a candidate from which the ball around it is walked a lane per query
-#ifndef PP_SERIAL_FAR
-#define PP_SERIAL_FAR 8
-#endif
-constexpr int kSerialFar = PP_SERIAL_FAR;
-constexpr int kSerialMax = PP_SERIAL_MAX;  // open lanes of a wave from which the whole-wave cubes are skipped for the group search
-constexpr int kLaneStageMin = PP_LANE_STAGE_MIN;  // open lanes of a wave from which the cubes are searched a lane per query
+constexpr float kBlindGroup = 0.25f;
+// The constants of the stages behind stage A, as round 5's A/B runs settled them (each was a -D switch of a variant
+// library then: profiles/r5/near_field_stages_ab.txt; frozen in round 6).  The forms they chose between and that lost --
+// a lane per query instead of the pooled ball / cube, no ball after the cubes, a lane per query for labeled searches --
+// are gone from the dispatch; lane_ball_search remains for the wave slices below 384 points.
+constexpr int kMemberCutMin = 2;    // (round 5: 2, was 8 -- disjoint clouds 0.225 -> 0.203 ms) candidates per member the pieces' cuts must leave in a block of rows for the member-by-member cut
+constexpr float kBallRmax = 2.5f;   // cells: the farthest candidate whose ball is walked (a box of at most 6 x 6 rows)
+constexpr int kPoolCubeMin = 1;
+constexpr int kPoolMin = 1;         // ... pooled over the wave (unlabeled searches)
+constexpr int kBallMin = 6;         // lanes with a candidate from which the ball around it is walked a lane per query
+constexpr int kSerialFar = 8;
+constexpr int kSerialMax = 24;      // open lanes of a wave from which the whole-wave cubes are skipped for the group search
+constexpr int kLaneStageMin = 6;    // open lanes of a wave from which the cubes are searched a lane per query
 
 // distance (in cells) from a query at position f inside cell c to the nearer face of its 2-cell block along one
 // axis that has grid beyond it (s = -1: the block is cells c-1, c; +1: c, c+1; beyond the grid there is nothing)
@@ -1053,7 +1013,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
       const unsigned box_total = (unsigned)__builtin_amdgcn_readlane((int)pp::wave_scan_u32_dpp(len), 63);
       // (the member-by-member cut costs the wave ~30 instructions per member: it pays when the cut above left more
       //  candidates than that buys examined by every lane)
-      if (bounded && box_total > (unsigned)(PP_MEMBER_CUT_MIN) * (unsigned)__builtin_popcountll(members) && members != (1ull << seed)) {  // (wave-uniform)
+      if (bounded && box_total > (unsigned)kMemberCutMin * (unsigned)__builtin_popcountll(members) && members != (1ull << seed)) {  // (wave-uniform)
         // Member by member (round 3): the cut above measures from the BOX (its nearest face) with the LARGEST bound of
         // a piece -- between far clouds that is the box's diagonal too generous, thousands of candidates where every
         // member's own ball holds a handful.  A candidate of this row matters only if it lies within SOME member's own
@@ -2060,9 +2020,9 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
   bool ball_left = false;  // the ball gave up (rows through a crowded region): not for the lane cubes either
   auto ball_stage = [&]() {
     // (a candidate further than kBallRmax cells: a box of rows larger than the cubes' -- those lanes stay with the cubes)
-    const bool ball = PP_LANE_BALL && pend && !deferred && !ball_left &&
+    const bool ball = pend && !deferred && !ball_left &&
                       best * (g.invh * g.invh) <= kBallRmax * kBallRmax * kBoundSlack * 0.9999f;
-    constexpr bool kPooled = PP_POOLED_BALL && (PP_POOLED_LAB || !LAB) && CAPW >= 384;  // (the pooled form's lists need the slice of CAPW = 384)
+    constexpr bool kPooled = CAPW >= 384;  // (the pooled form's lists need the slice of CAPW = 384)
     if (__builtin_popcountll(__ballot(ball)) >= (kPooled ? kPoolMin : kBallMin)) {
       Found f;
       if constexpr (kPooled)
@@ -2082,7 +2042,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
   ball_stage();
   // the cubes of radius 1 and 2 for the lanes without a candidate: pooled over the wave like the balls (from kPoolCubeMin
   // lanes on), or a lane per query (from kLaneStageMin on)
-  constexpr bool kPooledCube = PP_POOLED_CUBE && PP_POOLED_BALL && (PP_POOLED_LAB || !LAB) && CAPW >= 384;
+  constexpr bool kPooledCube = CAPW >= 384;
   constexpr int kCubeMin = kPooledCube ? kPoolCubeMin : kLaneStageMin;
   auto cube_stage = [&](int rho, bool mine) {
     if constexpr (kPooledCube)
@@ -2107,7 +2067,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
       open_lane = true;
       pend = false;
     }
-    if (PP_BALL_AFTER_CUBE) ball_stage();
+    ball_stage();
     const bool mine2 = pend && !deferred && !ball_left && f.aux != 2.0f;
     if (__builtin_popcountll(__ballot(mine2)) >= kCubeMin) {
       f = cube_stage(2, mine2);

@@ -453,254 +453,11 @@ __global__ __launch_bounds__(512, 4) void group_points_lds_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// v3: the same staging, done by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write)
-// into a 2-deep ring of row buffers, one 1024-thread workgroup per CU.  Row c+1 is in flight during
-// the whole gather/store phase of row c; one barrier per channel.  Every wait is counted by hand:
-// the DMA pieces of row c are older than the V stores of channel c-1, and vector-memory operations
-// retire in issue order, so `vmcnt(V)` retires the DMA and leaves the stores in flight
-// (a __syncthreads() here would make hipcc drain the queue: the guide's "Pipelining across
-// barriers").  Used when 2 * row bytes fit the LDS and every position chunk is full.
-// ------------------------------------------------------------------------------------------------
-constexpr int kDmaThreads = 1024;
-constexpr int kDmaPieceF4 = kDmaThreads;  // float4 moved per workgroup pass (16 KiB)
-
-// PACK16: indices are < 65536, two per register -- twice the positions per workgroup in the same
-// register budget, i.e. half the row re-reads.
-template <int V, bool PACK16>
-__global__ __launch_bounds__(kDmaThreads) void group_points_dma_kernel(const float* __restrict__ points,
-                                                                       const int* __restrict__ idx,
-                                                                       float* __restrict__ out, int B, int C,
-                                                                       int N, long long P, int chunks,
-                                                                       int passes, int buf_floats,
-                                                                       int cgroups, int c_per_group, long long obs) {
-  extern __shared__ __attribute__((aligned(16))) float s_ring[];  // [2][buf_floats]
-  // (batch, position chunk, channel group); workgroups of one batch element share blockIdx % 8
-  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
-  const int per_b = chunks * cgroups;
-  const int b = x + 8 * (y / per_b);
-  const int rem = y % per_b;
-  const int chunk = rem / cgroups;
-  const int c_begin = (rem % cgroups) * c_per_group;
-  const int c_end = min(C, c_begin + c_per_group);
-  if (b >= B || c_begin >= c_end) return;
-  const int t = threadIdx.x;
-  const int wave = pp::wave_id_uniform();
-  const long long p0 = (long long)chunk * (kDmaThreads * 4 * V) + t * 4;
-  constexpr int IW = PACK16 ? 2 : 4;  // registers per index quad
-  unsigned ii[V][IW];
-#pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const pp::i4 q = *reinterpret_cast<const pp::i4*>(idx + (size_t)b * P + p0 + (long long)v * (kDmaThreads * 4));
-    if constexpr (PACK16) {
-      ii[v][0] = (unsigned)q.x | ((unsigned)q.y << 16);
-      ii[v][1] = (unsigned)q.z | ((unsigned)q.w << 16);
-    } else {
-      ii[v][0] = q.x; ii[v][1] = q.y; ii[v][2] = q.z; ii[v][3] = q.w;
-    }
-  }
-  const int n4 = N >> 2;
-  const pp::f4* __restrict__ row0 = reinterpret_cast<const pp::f4*>(points + (size_t)b * C * N);
-  float* __restrict__ out_b = out + (size_t)b * obs;
-
-  // one DMA instruction moves 64 lanes x 16 B to  lds_base(wave-uniform) + lane*16
-  auto issue_row = [&](int c, int slot) {
-    const pp::f4* __restrict__ row = row0 + (size_t)c * n4;
-    for (int k = 0; k < passes; ++k) {
-      const int e = k * kDmaPieceF4 + t;              // float4 index inside the row image
-      const int src = e < n4 ? e : n4 - 1;            // surplus lanes land in the pad of the image
-      float* dst = s_ring + (size_t)slot * buf_floats + (size_t)(k * kDmaPieceF4 + wave * 64) * 4;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(row + src),
-          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  };
-  issue_row(c_begin, 0);
-  for (int c = c_begin, it = 0; c < c_end; ++c, ++it) {
-    // retire this wave's DMA pieces of row c (older than the V stores issued after them)
-    if (it == 0)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(V) : "memory");
-    __builtin_amdgcn_s_barrier();  // every wave's pieces landed; every wave left row c-1
-    asm volatile("" ::: "memory");
-    if (c + 1 < c_end) issue_row(c + 1, (it + 1) & 1);
-    const float* cur = s_ring + (size_t)(it & 1) * buf_floats;
-    float* __restrict__ o = out_b + (size_t)c * P;
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      pp::f4 r;
-      if constexpr (PACK16) {
-        // the unpacked LDS addresses are loop-invariant; left alone the compiler keeps all 4 V of them
-        // in registers across the channel loop (and spills) -- the empty asm makes them per-row values
-        unsigned w0 = ii[v][0], w1 = ii[v][1];
-        asm volatile("" : "+v"(w0), "+v"(w1));
-        r.x = cur[w0 & 0xFFFFu];
-        r.y = cur[w0 >> 16];
-        r.z = cur[w1 & 0xFFFFu];
-        r.w = cur[w1 >> 16];
-      } else {
-        r.x = cur[ii[v][0]];
-        r.y = cur[ii[v][1]];
-        r.z = cur[ii[v][2]];
-        r.w = cur[ii[v][3]];
-      }
-      if constexpr (V >= 32) {
-        // wave-uniform base in SGPRs + one 32-bit lane offset for all V stores: with V separate 64-bit
-        // store addresses in VGPRs this instantiation spills
-        const float* base = o + (long long)chunk * (kDmaThreads * 4 * V) + (long long)v * (kDmaThreads * 4);
-        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(t * 16), "v"(r), "s"(base) : "memory");
-      } else {
-        *reinterpret_cast<pp::f4*>(o + p0 + (long long)v * (kDmaThreads * 4)) = r;
-      }
-    }
-  }
-}
-
-template <int V, bool PACK16 = false>
-bool launch_group_dma(const float* points, const int* idx, float* out, int B, int C, int N,
-                      long long P, long long obs, hipStream_t s) {
-  const long long per_block = (long long)kDmaThreads * 4 * V;
-  if (P % per_block != 0) return false;  // this form has no ragged-tail path
-  const long long chunks = P / per_block;
-  // every byte a CU moves (row re-reads from L2 included) shares one ~10 B/clk path, so the rows are
-  // re-read as rarely as the registers allow (V) and the channels are split only as far as needed
-  // to give every CU a workgroup
-  const long long base = 8LL * ((B + 7) / 8) * chunks;
-  int cgroups = 1;
-  while (base * cgroups < 256 && cgroups * 2 <= C) cgroups *= 2;
-  const int c_per_group = (C + cgroups - 1) / cgroups;
-  const long long blocks = base * cgroups;
-  const int n4 = N / 4;
-  const int passes = (n4 + kDmaPieceF4 - 1) / kDmaPieceF4;
-  const int buf_floats = passes * kDmaPieceF4 * 4;
-  const size_t lds = (size_t)2 * buf_floats * sizeof(float);
-  if (lds > 160 * 1024 || chunks > 0x7fffffLL || blocks > 0x7fffffffLL) return false;
-  if (PACK16 && N > 65536) return false;
-  static pp::DeviceFlags lds_ok;  // one set of flags per instantiation of this function template
-  if (pp::allow_big_lds(group_points_dma_kernel<V, PACK16>, 160 * 1024, lds_ok) != hipSuccess) return false;
-  group_points_dma_kernel<V, PACK16><<<dim3((unsigned)blocks), dim3(kDmaThreads), lds, s>>>(
-      points, idx, out, B, C, N, P, (int)chunks, passes, buf_floats, cgroups, c_per_group, obs);
-  return true;
-}
-
-// ------------------------------------------------------------------------------------------------
-// v6 (round 3): v3's ring of two row buffers WITHOUT its workgroup barrier per channel.  v3's sixteen waves issue one
-// channel's stores, meet, and restart together; the probes put the whole gap to the plain-store rate on
-// that lock step (0.90 ms for the stores with the barrier, 0.75 without).  Here the hand-over of a row is two counters
-// per slot in LDS: FULL (waves whose DMA pieces of the slot's row have landed) and DONE (waves that have finished
-// gathering from it).  A wave gathers row c as soon as FULL says every piece is there, and refills the other slot with
-// row c + 1 when DONE says every wave has left row c - 1 -- before its own gather if that is already so, else after
-// it -- so waves drift up to a channel apart instead of meeting at every channel.  Same bytes, same order of stores.
-template <int V>
-__global__ __launch_bounds__(kDmaThreads) void group_points_ring_kernel(const float* __restrict__ points,
-                                                                        const int* __restrict__ idx,
-                                                                        float* __restrict__ out, int B, int C, int N,
-                                                                        long long P, int chunks, int passes,
-                                                                        int buf_floats, int cgroups, int c_per_group,
-                                                                        long long obs) {
-  extern __shared__ __attribute__((aligned(16))) float s_ring6[];  // [2][buf_floats], then FULL[2], DONE[2]
-  const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
-  const int per_b = chunks * cgroups;
-  const int b = x + 8 * (y / per_b);
-  const int rem = y % per_b;
-  const int chunk = rem / cgroups;
-  const int c_begin = (rem % cgroups) * c_per_group;
-  const int c_end = min(C, c_begin + c_per_group);
-  if (b >= B || c_begin >= c_end) return;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = pp::wave_id_uniform();
-  constexpr unsigned kWaves = kDmaThreads / 64;
-  unsigned* s_cnt = reinterpret_cast<unsigned*>(s_ring6 + 2 * (size_t)buf_floats);
-  if (t < 4) s_cnt[t] = 0u;
-  const long long p0 = (long long)chunk * (kDmaThreads * 4 * V) + t * 4;
-  unsigned ii[V][4];
-#pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const pp::i4 q = *reinterpret_cast<const pp::i4*>(idx + (size_t)b * P + p0 + (long long)v * (kDmaThreads * 4));
-    ii[v][0] = q.x; ii[v][1] = q.y; ii[v][2] = q.z; ii[v][3] = q.w;
-  }
-  const int n4 = N >> 2;
-  const pp::f4* __restrict__ row0 = reinterpret_cast<const pp::f4*>(points + (size_t)b * C * N);
-  float* __restrict__ out_b = out + (size_t)b * obs;
-  auto issue_row = [&](int c, int slot) {
-    const pp::f4* __restrict__ row = row0 + (size_t)c * n4;
-    for (int k = 0; k < passes; ++k) {
-      const int e = k * kDmaPieceF4 + t;
-      const int src = e < n4 ? e : n4 - 1;
-      float* dst = s_ring6 + (size_t)slot * buf_floats + (size_t)(k * kDmaPieceF4 + wave * 64) * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + src),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  };
-  auto counter = [&](int i) { return __hip_atomic_load(&s_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-  __syncthreads();  // the counters are zero
-  issue_row(c_begin, 0);
-  bool early = true;  // the pieces of the row about to be waited for were issued BEFORE the previous channel's stores
-  for (int c = c_begin, it = 0; c < c_end; ++c, ++it) {
-    const int slot = it & 1;
-    const unsigned gen = (unsigned)(it >> 1) + 1u;  // rows this slot has held, this one included
-    // this wave's pieces of row c have landed: they are older than the previous channel's V stores when they were
-    // issued early, younger when they were issued after the gather
-    if (it == 0 || !early)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(V) : "memory");
-    if (lane == 0) __hip_atomic_fetch_add(&s_cnt[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    // refill the other slot now if every wave has left the row it held (row c - 1)
-    early = false;
-    if (c + 1 < c_end && (it == 0 || counter(2 + (slot ^ 1)) >= kWaves * (unsigned)((it - 1) / 2 + 1))) {
-      issue_row(c + 1, slot ^ 1);
-      early = true;
-    }
-    while (counter(slot) < kWaves * gen) __builtin_amdgcn_s_sleep(1);  // every wave's pieces of row c are there
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const float* cur = s_ring6 + (size_t)slot * buf_floats;
-    float* __restrict__ o = out_b + (size_t)c * P;
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      pp::f4 r;
-      r.x = cur[ii[v][0]];
-      r.y = cur[ii[v][1]];
-      r.z = cur[ii[v][2]];
-      r.w = cur[ii[v][3]];
-      __builtin_nontemporal_store(r, reinterpret_cast<pp::f4*>(o + p0 + (long long)v * (kDmaThreads * 4)));
-    }
-    // (the stores above needed the gathered values: this wave's reads of the row are complete)
-    if (lane == 0) __hip_atomic_fetch_add(&s_cnt[2 + slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (c + 1 < c_end && !early) {  // the refill that had to wait for the slowest wave of row c - 1
-      while (counter(2 + (slot ^ 1)) < kWaves * (unsigned)((it - 1) / 2 + 1)) __builtin_amdgcn_s_sleep(1);
-      issue_row(c + 1, slot ^ 1);
-    }
-  }
-}
-
-template <int V>
-bool launch_group_ring(const float* points, const int* idx, float* out, int B, int C, int N, long long P, long long obs,
-                       hipStream_t s) {
-  const long long per_block = (long long)kDmaThreads * 4 * V;
-  if (P % per_block != 0) return false;
-  const long long chunks = P / per_block;
-  const long long base = 8LL * ((B + 7) / 8) * chunks;
-  int cgroups = 1;
-  while (base * cgroups < 256 && cgroups * 2 <= C) cgroups *= 2;
-  const int c_per_group = (C + cgroups - 1) / cgroups;
-  const long long blocks = base * cgroups;
-  const int n4 = N / 4;
-  const int passes = (n4 + kDmaPieceF4 - 1) / kDmaPieceF4;
-  const int buf_floats = passes * kDmaPieceF4 * 4;
-  const size_t lds = (size_t)2 * buf_floats * sizeof(float) + 16;
-  if (lds > 160 * 1024 || chunks > 0x7fffffLL || blocks > 0x7fffffffLL) return false;
-  static pp::DeviceFlags lds_ok;
-  if (pp::allow_big_lds(group_points_ring_kernel<V>, 160 * 1024, lds_ok) != hipSuccess) return false;
-  group_points_ring_kernel<V><<<dim3((unsigned)blocks), dim3(kDmaThreads), lds, s>>>(
-      points, idx, out, B, C, N, P, (int)chunks, passes, buf_floats, cgroups, c_per_group, obs);
-  return hipGetLastError() == hipSuccess;
-}
-
-// ------------------------------------------------------------------------------------------------
-// v5: 512-thread workgroups with ONE row buffer each, two per CU: nothing overlaps inside a workgroup (DMA row c,
-// wait, barrier, gather + store, barrier); the two workgroups of a CU overlap each other and are not in step
-// (0.89 against 0.92 ms for v3 at config 4; the stores alone, without any barrier, would take 0.75 ms).
+// v5: the channel rows arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write) into ONE row
+// buffer per 512-thread workgroup, two workgroups per CU: nothing overlaps inside a workgroup (DMA row c, wait,
+// barrier, gather + store, barrier); the two workgroups of a CU overlap each other and are not in step (0.89 against
+// 0.92 ms at config 4 for the 1024-thread ring of two buffers it replaced -- tools/archive/group_points_dma_ring_r2_r3
+// -- ; the stores alone, without any barrier, would take 0.75 ms).  Full chunks of 512 * 4 * V positions only.
 // ------------------------------------------------------------------------------------------------
 constexpr int kDma1Threads = 512;
 template <int V, bool NT = false>
@@ -1500,27 +1257,19 @@ extern "C" int pp_group_points_strided_f32(const float* points, const int* idx, 
       (size_t)N * sizeof(float) <= 64 * 1024 && C >= 4 && (long long)B * P >= 256LL * 2048) {
     const long long per_cu = (long long)B * P / 512;  // positions per half-CU
     bool ok = false;
-    // DMA ring form: full chunks only, one 1024-thread workgroup per CU
-    if (g_group_variant == 132)  // 16-bit packed indices, 32 quads per thread: spills at 1024 threads (kept for tuning)
-      ok = launch_group_dma<32, true>(points, idx, out, B, C, N, P, obs, s);
-    // two 512-thread workgroups per CU, one row buffer each (v5): 3 % faster than the 1024-thread ring at config 4
-    // (the output is written with non-temporal stores: 4 GiB at config 4, nothing of it is read back from the
-    //  caches; 0.840 against 0.856 ms.  516: the same with ordinary stores)
-    if (g_group_variant == 216) ok = launch_group_ring<16>(points, idx, out, B, C, N, P, obs, s);
-    if (g_group_variant == 208) ok = launch_group_ring<8>(points, idx, out, B, C, N, P, obs, s);
-    if (g_group_variant == 516) ok = launch_group_dma1<16, false>(points, idx, out, B, C, N, P, obs, s);
-    if (!ok && (g_group_variant == 616 || (g_group_variant == 0 && C >= 8 && (long long)B * P * C >= 256LL * 1024 * 4 * 16 * 8)))
-      ok = launch_group_dma1<16, true>(points, idx, out, B, C, N, P, obs, s);
-    if (!ok && (g_group_variant == 116 || (g_group_variant == 0 && C >= 8 && (long long)B * P * C >= 256LL * 1024 * 4 * 16 * 8)))
-      ok = launch_group_dma<16>(points, idx, out, B, C, N, P, obs, s);
-    if (!ok && (g_group_variant == 108 || (g_group_variant == 0 && (long long)B * P >= 256LL * 1024 * 4 * 8)))
-      ok = launch_group_dma<8>(points, idx, out, B, C, N, P, obs, s);
-    else if (!ok && g_group_variant == 104)
-      ok = launch_group_dma<4>(points, idx, out, B, C, N, P, obs, s);
+    // the LDS-DMA form wherever the positions fill whole chunks (16, 8 or 4 index quads per thread): measured round 6
+    // at or ahead of every other form on every shape it can take (tools/group_shapes_time.py); the output is written
+    // with non-temporal stores (4 GiB at config 4, nothing of it is read back from the caches; 516: ordinary stores)
+    const int gv = g_group_variant;
+    if (gv == 516) ok = launch_group_dma1<16, false>(points, idx, out, B, C, N, P, obs, s);
+    if (!ok && (gv == 616 || gv == 0)) ok = launch_group_dma1<16, true>(points, idx, out, B, C, N, P, obs, s);
+    if (!ok && (gv == 608 || gv == 0)) ok = launch_group_dma1<8, true>(points, idx, out, B, C, N, P, obs, s);
+    if (!ok && (gv == 604 || gv == 0)) ok = launch_group_dma1<4, true>(points, idx, out, B, C, N, P, obs, s);
     if (ok) {
       PP_RETURN_IF_LAUNCH_FAILED();
       return PP_OK;
     }
+    // ragged chunks: the VGPR-staged form, 8 / 4 / 2 index quads per thread by the positions a CU gets
     if (g_group_variant == 8 || ((g_group_variant == 0 || g_group_variant > 100) && per_cu >= 512LL * 4 * 8))
       ok = launch_group_lds<8>(points, idx, out, B, C, N, P, obs, s);
     else if (g_group_variant == 4 || (g_group_variant == 0 && per_cu >= 512LL * 4 * 4))
@@ -1532,9 +1281,11 @@ extern "C" int pp_group_points_strided_f32(const float* points, const int* idx, 
       return PP_OK;
     }
   }
-  // unaligned shapes, or rows beyond 64 KiB: the 4-byte LDS-staged form
+  // unaligned shapes, or rows beyond 64 KiB: the 4-byte LDS-staged form -- from 2^28 output elements (measured round 6:
+  // 1.89 against 7.7 ms for the global gather at config 4 less one point and one sample, but 0.27 against 0.21 at a
+  // fifth of a GiB and 0.079 against 0.050 at 69 MB: tools/group_shapes_time.py)
   if (g_group_variant != 1 && (size_t)N * sizeof(float) <= 152 * 1024 && C >= 4 &&
-      (long long)B * P >= 256LL * 2048) {
+      (long long)B * P >= 256LL * 2048 && (g_group_variant != 0 || (long long)B * P * C >= (1LL << 28))) {
     constexpr int V = 16;
     const long long chunks = (P + 1024LL * V - 1) / (1024LL * V);
     const long long blocks = 8LL * ((B + 7) / 8) * chunks;

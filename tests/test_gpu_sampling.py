@@ -605,7 +605,7 @@ def test_group_points_grad_accumulating_and_overwriting_abi(cuda, b, c, n, npoin
     assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 8, 104, 108, 116, 132, 516, 616])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 8, 516, 604, 608, 616])
 @pytest.mark.parametrize("b,c,n,npoint,ns", [(9, 5, 1024, 600, 16), (2, 4, 16384, 2048, 64), (1, 7, 500, 4099, 32),
                                              (3, 9, 10000, 1024, 64), (2, 6, 20480, 512, 64), (2, 13, 4096, 2048, 32), (1, 16, 65536, 4096, 32),
                                              (4, 16, 16384, 4096, 64)])
