@@ -759,7 +759,9 @@ __global__ __launch_bounds__(1024) void group_points_grad_lds64_kernel(const flo
   };
   if constexpr (VEC) {
     long long e = t;
-    for (; e + 1024 * (U - 1) < p4; e += 1024 * U) {
+    // (the bound is the wave's LAST lane's: a wave enters the loop whole or not at all -- add4_merged's row shifts read
+    //  the neighbouring lanes -- and the quads of a wave that straddles the end go to the lane-by-lane loop below)
+    for (; (e | 63) + 1024 * (U - 1) < p4; e += 1024 * U) {
       pp::f4 g[U];
       pp::i4 i[U];
 #pragma unroll

@@ -582,7 +582,8 @@ def test_group_points_grad_ball_rows_and_split_columns(cuda, group_grad_path, b,
     assert np.allclose(got.cpu().numpy(), e, rtol=1e-5, atol=1e-4)   # the oracle sums in fp32 too
 
 
-@pytest.mark.parametrize("b,c,n,npoint,ns", [(2, 6, 4096, 512, 64), (3, 5, 1000, 77, 9), (1, 4, 30000, 2048, 32), (2, 3, 600, 10, 4)])
+@pytest.mark.parametrize("b,c,n,npoint,ns", [(2, 6, 4096, 512, 64), (3, 5, 1000, 77, 9), (1, 4, 30000, 2048, 32), (2, 3, 600, 10, 4),
+                                             (2, 8, 16384, 1875, 16), (1, 16, 8192, 4097, 20)])
 def test_group_points_grad_accumulating_and_overwriting_abi(cuda, b, c, n, npoint, ns):
     """the two contracts of the C ABI side by side: pp_group_points_grad_ws_f32 ACCUMULATES into the caller's tensor (the
     reference's: a zero-filled output it adds into, _ext/sampling.cpp:148-150), pp_group_points_grad_out_ws_f32 WRITES every
@@ -590,7 +591,8 @@ def test_group_points_grad_accumulating_and_overwriting_abi(cuda, b, c, n, npoin
     from pytorch_points_amd import _lib
     idx = _t((S.uniform01(47, (b, npoint, ns)).reshape(b, npoint, ns) * n).astype(np.int32), cuda)
     idx[:, 0, :] = n - 1                       # a run across a whole row
-    go = _t(S.normal(48, (b, c, npoint, ns)), cuda)
+    idx[:, -3:, :] = 5                         # ... and one over the last rows: where P / 4 is no multiple of 64
+    go = _t(S.normal(48, (b, c, npoint, ns)), cuda)   # the wave that straddles the end takes the lane-by-lane loop
     ref = torch.zeros(b, c, n, device=cuda, dtype=torch.float64)
     ref.scatter_add_(2, idx.long().reshape(b, 1, -1).expand(-1, c, -1), go.double().reshape(b, c, -1))
     L = _lib.lib()
@@ -767,6 +769,52 @@ def test_three_nn_grid_adversarial(cuda, tn_path):
         assert bad.size == 0, "case %d: %d rows differ, first %s got %s want %s" % (
             i, len(bad), bad[0], idx.cpu().numpy()[tuple(bad[0])], e_idx[tuple(bad[0])])
         assert np.array_equal(d2.cpu().numpy(), e_d2), "case %d distances" % i
+
+
+def _multi_round_cases():
+    """known / reference clouds on which a query's first round (a box of about one cell around it) finds fewer than the
+    neighbours it needs, so that the later rounds -- which walk only the BALL of the farthest neighbour found so far,
+    rows beyond it passed over, the others cut along x (round 5; ADVICE r5: untested) -- decide the answer: sparse
+    clouds, queries beside and far outside the known box, outliers (the grid trimmed to the bulk: rim cells open
+    outwards), clouds far from the origin, a handful of known points"""
+    rng = np.random.default_rng(91)
+    cases = []
+    sparse = (rng.random((1, 300, 3), dtype=np.float32) * np.float32(40.0))
+    cases.append(("sparse", (rng.random((1, 2500, 3), dtype=np.float32) * np.float32(40.0)), sparse))
+    beside = S.unit_sphere(92, 1, 2048)
+    q = S.unit_sphere(93, 1, 3000) * np.float32(0.3)
+    q[..., 0] += np.float32(4.0)                         # queries beside the known box, a few boxes away
+    q[0, ::7] *= np.float32(25.0)                        # ... and some far outside in every direction
+    cases.append(("beside_and_far", q, beside))
+    outl = S.unit_sphere(94, 1, 4096).copy()
+    outl[0, ::500] *= np.float32(300.0)                  # a few outliers: the box is trimmed to the bulk
+    qo = np.concatenate([S.unit_sphere(95, 1, 1500), outl[:, ::500] + np.float32(0.5), S.unit_sphere(96, 1, 500) * np.float32(120.0)], 1)
+    cases.append(("outliers_trimmed", qo, outl))
+    off = S.unit_sphere(97, 1, 700) * np.float32(3.0) + np.float32(1000.0)
+    cases.append(("offset_1e3_sparse", S.unit_sphere(98, 1, 2000) * np.float32(5.0) + np.float32(1000.0), off))
+    few = (rng.random((1, 5, 3), dtype=np.float32))
+    cases.append(("five_known", S.unit_sphere(99, 1, 1000) * np.float32(2.0), few))
+    return [(n, np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)) for n, a, b in cases]
+
+
+def test_three_nn_and_knn_multi_round_searches(cuda):
+    from pytorch_points_amd._ext import sampling
+    from pytorch_points_amd.ops import knn_points
+    for name, q, k in _multi_round_cases():
+        b, n, m = q.shape[0], q.shape[1], k.shape[1]
+        d2 = torch.empty(b, n, 3, device=cuda)
+        idx = torch.empty(b, n, 3, dtype=torch.int32, device=cuda)
+        sampling.three_nn_wrapper(b, n, m, _t(q, cuda), _t(k, cuda), d2, idx)
+        e_d2, e_idx = oracle.three_nn(q, k)
+        assert np.array_equal(idx.cpu().numpy(), e_idx), "three_nn %s" % name
+        assert np.array_equal(d2.cpu().numpy(), e_d2), "three_nn %s distances" % name
+        for K in (1, 4, 17, min(m, 64), m):             # (K near M: the last rounds take the whole grid)
+            if K > 128:
+                continue
+            out = knn_points(_t(q, cuda), _t(k, cuda), K=K)
+            e_d, e_i = oracle.knn(q, k, K)
+            assert np.array_equal(out.idx.cpu().numpy(), e_i), "knn %s K=%d" % (name, K)
+            assert np.array_equal(out.dists.cpu().numpy(), e_d), "knn %s K=%d distances" % (name, K)
 
 
 def test_three_interpolate_forward_backward(cuda):
