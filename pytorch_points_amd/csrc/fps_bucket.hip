@@ -232,7 +232,10 @@ __device__ __forceinline__ void axis_lut(const KeyPlan& kp, int a, int N, const 
     const int inc = wave_scan_incl(c);
     const unsigned below = (unsigned)(carry + inc - c) + (unsigned)c / 2u;
     carry += __builtin_amdgcn_readlane(inc, 63);
-    unsigned q = (unsigned)(((u64)below << nbits) / (u64)(N > 0 ? N : 1));
+    // (below < N <= 2^22 and at most ten bits: 32-bit arithmetic up to 2^21 points -- a 64-bit division is a hundred
+    //  instructions in each of the sixteen dependent rounds)
+    unsigned q = N <= (1 << 21) ? (below << nbits) / (unsigned)(N > 0 ? N : 1)
+                                : (unsigned)(((u64)below << nbits) / (u64)N);
     q = min(q, (1u << nbits) - 1u);
     int left = nbits;
     unsigned val = 0;
@@ -655,8 +658,11 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       if (redo) {  // (a key of this wave changed)
         unsigned top;
         row_max2_u32(khi, top, rsec);
-        const unsigned ml = row_max_u32(khi == top ? klo : 0u);  // (exact ties of the temp: the tie rank decides)
-        win = khi == top && klo == ml;  // one lane per row (every lane of a row of empty slots: they post the same zeros)
+        win = khi == top;
+        if (__builtin_popcountll(__ballot(win)) != 4) {  // (uniform) a temp shared inside a row -- or a row of empty
+          const unsigned ml = row_max_u32(win ? klo : 0u);  // slots: the tie rank decides (empty slots post the same zeros)
+          win = win && klo == ml;
+        }
       }
       if (win) {
         f4 r;
@@ -754,6 +760,8 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       cover &= accm;    // the picks (by candidate slot) that reach this lane's super-box
       u64 tm = 0ull;    // ... and this lane's bucket
       bool chg = false;
+      // (one pick of the lane's list per pass; two per pass on packed fp32 measured slower, round 6: 2.86 against 2.81 ms --
+      //  most lanes hold one pick or none, and the wider pass costs every lane)
       while (__ballot(cover != 0ull)) {
         const bool on = cover != 0ull;
         const int sl = on ? __builtin_ctzll(cover) : 0;
@@ -966,14 +974,20 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
 // same counting sort -- same plan, same cell tables, same keys -- as six short launches of kPre workgroups per
 // batch element, its tables in the workspace:
 //   box (a part per workgroup) -> per-axis fine histograms -> cell tables -> cell counts -> scan -> scatter.
-// The order of the points INSIDE a cell is whatever the atomics make it (it was in the one-workgroup form, too): any
-// order is correct, the boxes are computed from the points.
+// No atomic leaves a CU: a workgroup counts ITS share of the points in an LDS histogram and writes the histogram out as
+// a slab of its own; the scan turns the kPre slabs into kPre sets of cursors (cell-major, slab-minor); the scatter
+// loads its slab's cursors back into LDS.  (The first form had all kPre workgroups of an element add into ONE table with
+// device-scope atomics: 54 + 85 us for the two passes at config 3 -- those atomics execute at the memory side of the
+// eight L2s.)  The order of the points INSIDE a cell is by slab, then whatever the LDS atomics make it (as in the
+// one-workgroup form): any order is correct, the boxes are computed from the points.
 constexpr int kPre = 16;
 constexpr int kPreThreads = 1024;
+constexpr int kPreGroup = kBkBins / kPre;  // cells a workgroup of the scan owns
 struct PreTables {  // per batch element
-  float part[kPre][8];             // (-lo, hi) of every workgroup's share of the points
-  unsigned fine[3][kBkFine];       // per-axis histograms
-  unsigned cell[kBkBins];          // cell counts, then cursors
+  float part[kPre][8];              // (-lo, hi) of every workgroup's share of the points
+  unsigned fine[3][kBkFine];        // per-axis histograms, then the cell tables
+  unsigned gsum[kPre][kPre];        // [slab][group of kPreGroup cells]: points of the slab in the group
+  unsigned slab[kPre][kBkBins];     // cell counts of every workgroup's share, then its cursors
 };
 
 __device__ __forceinline__ void pre_range(int N, int& k0, int& k1) {
@@ -1000,7 +1014,7 @@ __global__ __launch_bounds__(kPreThreads) void fps_pre_box_kernel(const float* _
   const float* __restrict__ p = xyz + (size_t)blockIdx.y * N * 3;
   const int t = threadIdx.x, lane = t & 63;
   // (this element's tables of the later passes are cleared here: nothing reads them before the next launch)
-  for (int i = blockIdx.x * kPreThreads + t; i < 3 * kBkFine + kBkBins; i += kPre * kPreThreads) (&tb->fine[0][0])[i] = 0u;
+  for (int i = blockIdx.x * kPreThreads + t; i < 3 * kBkFine; i += kPre * kPreThreads) (&tb->fine[0][0])[i] = 0u;
   int k0, k1;
   pre_range(N, k0, k1);
   float v[6] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY};  // -lo, hi
@@ -1044,38 +1058,59 @@ __global__ __launch_bounds__(kPreThreads) void fps_pre_fine_kernel(const float* 
 
 // the per-axis histograms to cell tables, in place (a wave per axis: sixteen dependent scans, once per element)
 __global__ __launch_bounds__(192) void fps_pre_lut_kernel(int N, PreTables* tabs) {
+  __shared__ unsigned s_cnt[3][kBkFine];  // (the sixteen rounds read their counts from LDS: one trip to memory, not sixteen)
   PreTables* tb = tabs + blockIdx.x;
   const KeyPlan kp = pre_plan(tb);
   const int lane = threadIdx.x & 63, wave = pp::wave_id_uniform();
-  axis_lut(kp, wave, N, tb->fine[wave], tb->fine[wave], lane);
+  for (int i = lane; i < kBkFine; i += 64) s_cnt[wave][i] = tb->fine[wave][i];
+  axis_lut(kp, wave, N, s_cnt[wave], tb->fine[wave], lane);
 }
 
-// SCATTER = false: cell counts; true: the records to their places (after the scan)
+// SCATTER = false: this workgroup's cell counts, into its slab; true: its records to their places (after the scan).
+// Dynamic LDS: the kBkBins counters / cursors.
 template <bool SCATTER, bool REG>
 __global__ __launch_bounds__(kPreThreads) void fps_pre_cell_kernel(const float* __restrict__ xyz, const float* __restrict__ temp,
                                                                    int N, TieOrder order, BucketGeom geo, PreTables* tabs,
                                                                    f4* __restrict__ sorted_all, unsigned* __restrict__ aux_all) {
+  extern __shared__ unsigned s_cell[];  // kBkBins
   __shared__ unsigned s_lut[3][kBkFine];
   PreTables* tb = tabs + blockIdx.y;
+  unsigned* __restrict__ mine = tb->slab[blockIdx.x];
   const float* __restrict__ p = xyz + (size_t)blockIdx.y * N * 3;
   const int t = threadIdx.x;
   const KeyPlan kp = pre_plan(tb);
-  for (int i = t; i < 3 * kBkFine; i += kPreThreads) (&s_lut[0][0])[i] = (&tb->fine[0][0])[i];
+#pragma unroll
+  for (int i = 0; i < 3 * kBkFine / kPreThreads; ++i) (&s_lut[0][0])[i * kPreThreads + t] = (&tb->fine[0][0])[i * kPreThreads + t];
+#pragma unroll 8
+  for (int i = 4 * t; i < kBkBins; i += 4 * kPreThreads)
+    *reinterpret_cast<uint4*>(&s_cell[i]) = SCATTER ? *reinterpret_cast<const uint4*>(&mine[i]) : make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   int k0, k1;
   pre_range(N, k0, k1);
   if (!SCATTER) {
+#pragma unroll 4
     for (int k = k0 + t; k < k1; k += kPreThreads)
-      atomicAdd(&tb->cell[cell_key(kp, s_lut, p[3 * (size_t)k], p[3 * (size_t)k + 1], p[3 * (size_t)k + 2])], 1u);
+      atomicAdd(&s_cell[cell_key(kp, s_lut, p[3 * (size_t)k], p[3 * (size_t)k + 1], p[3 * (size_t)k + 2])], 1u);
+    __syncthreads();
+    // the slab, and its points per group of cells (what the scan's workgroups start from)
+    unsigned part = 0u;  // thread t: cells [32 t, 32 t + 32), all inside group t / (kPreGroup / 32)
+    for (int i = 0; i < kBkBins / kPreThreads; i += 4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(&s_cell[(kBkBins / kPreThreads) * t + i]);
+      *reinterpret_cast<uint4*>(&mine[(kBkBins / kPreThreads) * t + i]) = v;
+      part += v.x + v.y + v.z + v.w;
+    }
+    part = (unsigned)wave_scan_incl((int)part);  // (a wave = 2048 cells = one group)
+    if ((t & 63) == 63) tb->gsum[blockIdx.x][t >> 6] = part;
     return;
   }
   f4* __restrict__ sorted = sorted_all + (size_t)blockIdx.y * geo.npad;
   unsigned* __restrict__ rc = aux_all + (size_t)blockIdx.y * geo.naux;
   const float* __restrict__ tmp = temp ? temp + (size_t)blockIdx.y * N : nullptr;
+#pragma unroll 4
   for (int k = k0 + t; k < k1; k += kPreThreads) {
     f4 rec;
     rec.x = p[3 * (size_t)k]; rec.y = p[3 * (size_t)k + 1]; rec.z = p[3 * (size_t)k + 2];
-    const unsigned pos = atomicAdd(&tb->cell[cell_key(kp, s_lut, rec.x, rec.y, rec.z)], 1u);
+    const unsigned pos = atomicAdd(&s_cell[cell_key(kp, s_lut, rec.x, rec.y, rec.z)], 1u);
     const float t0 = tmp ? tmp[k] : 1e10f;  // (ref network/geo_operations.py:33: the caller's fill)
     if (REG) {
       rec.w = __uint_as_float(kRcMax - order.rank(k));
@@ -1095,28 +1130,41 @@ __global__ __launch_bounds__(kPreThreads) void fps_pre_cell_kernel(const float* 
     for (int pos = N + t; pos < geo.naux; pos += kPreThreads) rc[pos] = 0u;
   }
 }
+static_assert(kBkBins / kPreThreads == 32 && kPreGroup == 32 * 64 && kPreThreads / 64 == kPre, "a wave of the count = a group of the scan");
 
-// exclusive scan of an element's cell counts, in place (a wave per 2048 bins)
-__global__ __launch_bounds__(kBkThreads) void fps_pre_scan_kernel(PreTables* tabs) {
-  __shared__ int s_wsum[kBkWaves];
-  unsigned* __restrict__ h = tabs[blockIdx.x].cell;
-  const int lane = threadIdx.x & 63, wave = pp::wave_id_uniform();
-  constexpr int kRows = kBkBins / kBkWaves / 64;
-  int loc[kRows];
-  int carry = 0;
-  for (int r = 0; r < kRows; ++r) {
-    const int c = (int)h[wave * (kBkBins / kBkWaves) + 64 * r + lane];
-    const int inc = wave_scan_incl(c);
-    loc[r] = carry + inc - c;
-    carry += __builtin_amdgcn_readlane(inc, 63);
+// The slabs' counts into cursors: position of (cell, slab) = points of lower cells in every slab + points of this cell in
+// lower slabs.  Workgroup g of an element owns the cells [g kPreGroup, (g + 1) kPreGroup): two cells a thread.
+__global__ __launch_bounds__(kPreThreads) void fps_pre_scan_kernel(PreTables* tabs) {
+  __shared__ unsigned s_w[kPreThreads / 64];
+  PreTables* tb = tabs + blockIdx.y;
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned base = 0u;  // points of the groups below this one
+  for (int i = lane; i < kPre * kPre; i += 64) base += ((i % kPre) < g) ? (&tb->gsum[0][0])[i] : 0u;
+  base = (unsigned)__builtin_amdgcn_readlane(wave_scan_incl((int)base), 63);
+  const int c0 = g * kPreGroup + 2 * t;  // this thread's two cells
+  unsigned v[kPre][2];
+  unsigned tot = 0u;
+#pragma unroll
+  for (int s = 0; s < kPre; ++s) {
+    const uint2 q = *reinterpret_cast<const uint2*>(&tb->slab[s][c0]);
+    v[s][0] = q.x; v[s][1] = q.y;
+    tot += q.x + q.y;
   }
-  if (lane == 0) s_wsum[wave] = carry;
+  const unsigned inc = (unsigned)wave_scan_incl((int)tot);
+  if (lane == 63) s_w[wave] = inc;
   __syncthreads();
-  int base = 0;
-  for (int w = 0; w < wave; ++w) base += s_wsum[w];
-  for (int r = 0; r < kRows; ++r) h[wave * (kBkBins / kBkWaves) + 64 * r + lane] = (unsigned)(loc[r] + base);
+  unsigned run = base + inc - tot;
+  for (int w = 0; w < wave; ++w) run += s_w[w];
+  unsigned at0 = run, at1 = run;
+#pragma unroll
+  for (int s = 0; s < kPre; ++s) at1 += v[s][0];
+#pragma unroll
+  for (int s = 0; s < kPre; ++s) {
+    *reinterpret_cast<uint2*>(&tb->slab[s][c0]) = make_uint2(at0, at1);
+    at0 += v[s][0];
+    at1 += v[s][1];
+  }
 }
-
 
 pp::DeviceFlags g_bucket_lds[3];
 pp::Knob g_bucket_chain;  // 1: one pick per round (the round-4 chain)
@@ -1166,11 +1214,17 @@ int bucket_launch(const float* xyz, float* temp, int* idx, int B, int N, int npo
     fps_pre_box_kernel<<<grid, dim3(kPreThreads), 0, s>>>(xyz, N, tabs);
     fps_pre_fine_kernel<<<grid, dim3(kPreThreads), 0, s>>>(xyz, N, tabs);
     fps_pre_lut_kernel<<<dim3(B), dim3(192), 0, s>>>(N, tabs);
-    if (g.m == 1) fps_pre_cell_kernel<false, true><<<grid, dim3(kPreThreads), 0, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
-    else fps_pre_cell_kernel<false, false><<<grid, dim3(kPreThreads), 0, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
-    fps_pre_scan_kernel<<<dim3(B), dim3(kBkThreads), 0, s>>>(tabs);
-    if (g.m == 1) fps_pre_cell_kernel<true, true><<<grid, dim3(kPreThreads), 0, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
-    else fps_pre_cell_kernel<true, false><<<grid, dim3(kPreThreads), 0, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
+    static pp::DeviceFlags pre_lds[4];
+    hipError_t e = pp::allow_big_lds(fps_pre_cell_kernel<false, true>, kBkLdsBytes, pre_lds[0]);
+    if (e == hipSuccess) e = pp::allow_big_lds(fps_pre_cell_kernel<false, false>, kBkLdsBytes, pre_lds[1]);
+    if (e == hipSuccess) e = pp::allow_big_lds(fps_pre_cell_kernel<true, true>, kBkLdsBytes, pre_lds[2]);
+    if (e == hipSuccess) e = pp::allow_big_lds(fps_pre_cell_kernel<true, false>, kBkLdsBytes, pre_lds[3]);
+    if (e != hipSuccess) return (int)e;
+    if (g.m == 1) fps_pre_cell_kernel<false, true><<<grid, dim3(kPreThreads), kBkLdsBytes, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
+    else fps_pre_cell_kernel<false, false><<<grid, dim3(kPreThreads), kBkLdsBytes, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
+    fps_pre_scan_kernel<<<grid, dim3(kPreThreads), 0, s>>>(tabs);
+    if (g.m == 1) fps_pre_cell_kernel<true, true><<<grid, dim3(kPreThreads), kBkLdsBytes, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
+    else fps_pre_cell_kernel<true, false><<<grid, dim3(kPreThreads), kBkLdsBytes, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
   }
   // several picks per round from 32768 points (measured: 0.96 against 0.93 ms at 16 x 16384 -> 1024, 0.58 against 0.49
   // at 32 x 8192 -> 512: few buckets per lane, and the first hundred picks of any call come one per round)
