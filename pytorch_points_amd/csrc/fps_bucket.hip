@@ -629,8 +629,8 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     // super-box masks are the same for every wave (super-box l = lane l of each), so a lane only tests ITS bucket
     // against the picks that reach ITS super-box: each lane fetches its own pick (ds_bpermute), one pass serves
     // every pick of the round (a second only where two picks reach one super-box).
-    // The last picks are taken one per round (every candidate but the largest fails), so that the round that takes
-    // pick npoint-1 is known: temp ends as the minimum over every pick but the last (ref :203-205).
+    // The last pick is taken in a round of its own (every candidate but the largest fails; the rounds before it stop one
+    // short of it), so that it is never applied: temp ends as the minimum over every pick but the last (ref :203-205).
     bool win = false;    // this lane's bucket is its row's candidate
     unsigned rsec = 0u;  // the row's second-largest temp
     bool redo = true;
@@ -684,7 +684,10 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       // LDS only (see the one-pick chain below): no store's acknowledgement is waited for
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       PP_FPSB_MARK(2);
-      const bool single = npoint - j < 4 * kBkWaves + 2;
+      // The last pick is taken alone (a round whose every candidate but the largest fails) and never applied; a round
+      // before it takes at most npoint - 1 - j picks: a candidate with that many eligible keys above it fails.
+      const int room = npoint - 1 - j;
+      const bool last = room == 0;
       const u64 okey = s_key[buf][lane];  // a lane per candidate slot
       const f4 orec = s_rec[buf][lane];
       const unsigned bound = s_bound[buf];
@@ -717,8 +720,13 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
           // pick leaves behind in its own bucket could still be above it
           const bool lower = o_el && okey < mkey;
           const float dd = dist3(orec.x, orec.y, orec.z, mx, my, mz);
-          if (lower && (single || dd < __uint_as_float(ohi) || !(ohi > msec)))
+          if (lower && (last || dd < __uint_as_float(ohi) || !(ohi > msec)))
             __hip_atomic_fetch_max(&s_fail[buf], okey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (room < 4 * kBkWaves && !last) {  // (uniform; only the call's last rounds can run out of room)
+            const int rank = __builtin_popcountll(__ballot(o_el && okey > mkey));
+            if (rank >= room && lane == 0)
+              __hip_atomic_fetch_max(&s_fail[buf], mkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
           // the super-boxes the pick can reach: the box test with the super-box's box and its largest temp (>= every
           // member's: the test only ever says "visit" more often), a lane per super-box
           const float gx = fmaxf(fmaxf(sblox - mx, mx - sbhix), 0.0f);
@@ -751,7 +759,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       }
       j += k;
       buf ^= 1;
-      if (j >= npoint || k == 0) break;  // (a single round: its pick is the last one, never applied)
+      if (j >= npoint || k == 0) break;  // (the last round: its pick is never applied)
       // Which of my buckets can these picks change?  (Against the bucket's largest temp BEFORE the round: the test only
       // ever says "visit" more often than one pick at a time would.)  ... and does one of them lower the bucket's
       // BEST point?  Only then does the bucket's key change (every other temp only falls): a visit that leaves the
