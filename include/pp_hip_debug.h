@@ -28,6 +28,10 @@ void pp_debug_set_nmdistance_tile(int queries);
 /* grid search, unlabeled: the build of sets of at most 16384 aligned points: 0 = sorted through the LDS, a slab owning
  * whole z-layers (default), 1 = the general build always (tests and A/B timing) */
 void pp_debug_set_nmdistance_build(int general);
+/* grid search, unlabeled: directions no search can prune (every reference point at nearly one distance from the queries)
+ * are routed to the every-pair kernel, launched behind the search once an earlier call on the device has routed one:
+ * 0 = that, 1 = never (the search serves every direction), 2 = the every-pair launch always follows */
+void pp_debug_set_nmdistance_routing(int mode);
 /* labeled Chamfer brute force: 1 = the one-lane-per-query kernel */
 void pp_debug_set_labeled_variant(int variant);
 /* Chamfer backward: 1 LDS doubles, 2 CSR lists, 3 LDS fp32 columns, 4 global atomics, 5 deterministic */
@@ -48,7 +52,7 @@ int pp_debug_nmdistance_pending(const void* workspace, int B, int N, int M, unsi
 void pp_debug_set_fps_v1(int form); /* 0 = the library's choice, 1 = one workgroup per batch element over all points,
                                       * 2 = the CU cluster over all points, 3 = the bucketed kernel */
 /* the bucketed FPS kernel's serial chain (N <= 65536): 0 = the library's choice (several mutually independent picks
- * per barrier round from 32768 points, one pick per round below), 1 = one pick per round, 2 = several per round */
+ * per barrier round from 32768 points or 1024 picks, one pick per round below), 1 = one pick per round, 2 = several per round */
 void pp_debug_set_fps_bucket_chain(int form);
 /* the bucketed FPS kernel's sort: 0 = by the whole chip from 32768 points (six short launches in front of the kernel),
  * below that inside the kernel by its one workgroup; 1 = always inside the kernel */

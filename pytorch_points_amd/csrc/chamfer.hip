@@ -247,6 +247,26 @@ __global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_kernel(
                                  second ? r - tiles1 : r, label1, label2);
 }
 
+// The same tile for the directions the grid search has routed here (chamfer_grid.hip, round 6: a direction whose
+// queries see every reference point at nearly one distance cannot be pruned -- shell against a cluster at its centre,
+// identical points, a degenerate reference set -- and the search's in-kernel scans take twice this kernel's time).
+// routed[(2 b + direction) * stride] != 0: this kernel serves the direction; workgroups of the others leave at once.
+template <int Q, int G, bool PK>
+__global__ __launch_bounds__(kBlock) void nmdist_fwd_c3_routed_kernel(
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ dist1,
+    int* __restrict__ idx1, float* __restrict__ dist2, int* __restrict__ idx2, int N, int M,
+    int tiles1, int tiles2, int total, int per_xcd, const unsigned* __restrict__ routed, int stride) {
+  const int V = pp::xcd_virtual_block(blockIdx.x, per_xcd);
+  if (V >= total) return;  // uniform per workgroup
+  const int per_b = tiles1 + tiles2;
+  const int b = V / per_b;
+  const int r = V - b * per_b;
+  const bool second = r >= tiles1;
+  if (routed[(size_t)(2 * b + (second ? 1 : 0)) * stride] == 0u) return;
+  nmdist_tile<Q, G, PK, false, false>(xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, b, second,
+                                      second ? r - tiles1 : r, nullptr, nullptr);
+}
+
 // Generic point dimension (C != 3): one lane per query, reference point wave-uniform, plain
 // compare/select.  CT > 0: compile-time C, query in registers; CT == 0: run-time C, query re-read
 // from memory (L1) for every reference point.  Correctness path, not a tuned one.
@@ -960,6 +980,23 @@ int zero_outputs(float* dist1, int* idx1, float* dist2, int* idx2, int B, int N,
 // Tuning override for benchmarking variants in one process (bench.py --variant); 0 = automatic.
 static pp::Knob g_fwd_variant;
 extern "C" void pp_debug_set_nmdistance_variant(int v) { g_fwd_variant.set(v); }
+
+namespace pp {
+// (chamfer_grid.hip) the every-pair kernel over the directions marked in `routed` (device memory, one word every
+// `stride` words per (batch element, direction)); the other directions' workgroups leave at once
+int nmdist_forward_routed(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2, int* idx2, int B,
+                          int N, int M, const unsigned* routed, int stride, hipStream_t s) {
+  constexpr int Q = 4, G = 16, TQ = 64 * Q;
+  const int tiles1 = (N + TQ - 1) / TQ, tiles2 = (M + TQ - 1) / TQ;
+  const long long total = (long long)B * (tiles1 + tiles2);
+  if (total > 0x7fffff00LL) return PP_EINVAL;
+  const int per_xcd = (int)((total + 7) / 8);
+  nmdist_fwd_c3_routed_kernel<Q, G, true><<<dim3(per_xcd * 8), dim3(kBlock), 0, s>>>(
+      xyz1, xyz2, dist1, idx1, dist2, idx2, N, M, tiles1, tiles2, (int)total, per_xcd, routed, stride);
+  PP_RETURN_IF_LAUNCH_FAILED();
+  return PP_OK;
+}
+}  // namespace pp
 
 extern "C" int pp_nmdistance_forward_f32(const float* xyz1, const float* xyz2, float* dist1,
                                          int* idx1, float* dist2, int* idx2, int B, int N, int M,

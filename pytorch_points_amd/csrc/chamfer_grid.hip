@@ -2202,7 +2202,7 @@ __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_l
                                                                   float* __restrict__ dist1, int* __restrict__ idx1,
                                                                   float* __restrict__ dist2, int* __restrict__ idx2,
                                                                   unsigned char* __restrict__ ws, int B, int N, int M,
-                                                                  int waves_per_set, const Layout L) {
+                                                                  int waves_per_set, const Layout L, int routing) {
   static_assert((CAPW + 4) * 16 >= 1024 * 4, "the prefix sums of up to 1024 counts use the wave's slice");
   __shared__ pp::f4 s_pts[kListWgWaves][CAPW + 4];
   const int wave = pp::wave_id_uniform();
@@ -2291,6 +2291,8 @@ __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_l
   // nothing, or next to nothing, is left and the wave leaves here
   const unsigned total = (reinterpret_cast<const unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords)[pp::kLayerPending];
   if (total == 0u) return;
+  // (round 6) a direction the stage-A launch has routed to the every-pair kernel, when that kernel follows this launch
+  if (routing && (reinterpret_cast<const unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords)[pp::kLayerRouted] != 0u) return;
   const unsigned per_wave = min(64u, max(1u, (total + (unsigned)waves_per_set - 1) / (unsigned)waves_per_set));
   // ONE piece of per_wave entries per wave (the launch has a wave for every 64 queries of a direction, so a list of
   // every query still fits; no loop: state that lives across the search costs this kernel registers it does not have)
@@ -2411,13 +2413,48 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
                                                               float* __restrict__ dist2, int* __restrict__ idx2,
                                                               unsigned char* __restrict__ ws, int B, int N, int M,
                                                               int tiles1, int tiles2, int total, int per_xcd,
-                                                              const Layout L) {
+                                                              const Layout L, unsigned* __restrict__ routed_host,
+                                                              unsigned epoch) {
   static_assert(TQ % pp::kChunk == 0 && (CAP + 63) / 64 * 64 + 4 <= 4096 + 4, "");
   // PERSISTENT: the launch is a few workgroups per CU (a multiple of eight, so that a workgroup's tiles stay on its
   // XCD under the round-robin placement -- speed only); workgroup w takes the virtual tiles w, w + gridDim.x, ...
   const int nvt = per_xcd * 8;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = pp::wave_id_uniform();
+  if (!PERSIST && (int)blockIdx.x >= nvt) {
+    // Round 6: 2 B workgroups behind the tiles' (dispatched last, into the launch's tail), one per direction: is this
+    // a direction no search can prune?  Eight of its queries against 64 of its reference points (samples of the
+    // sorted clouds): where a query sees more than half of the samples within half a percent of its nearest one, every
+    // bound of the search is beaten by everybody -- a shell against a cluster at its centre, a cluster against a far
+    // shell -- and six of eight such queries ROUTE the direction to the every-pair kernel (kLayerRouted; launched behind
+    // the list kernel once the host has seen a routed direction: routed_host).  A degenerate reference set (identical
+    // points: no grid) is routed as it is.  A heuristic of speed only: both paths give the same bits.
+    const int set = (int)blockIdx.x - nvt;
+    if (set >= 2 * B || wave != 0) return;
+    const int b = set >> 1, dir = set & 1;
+    const GridSet* gs = reinterpret_cast<const GridSet*>(ws + L.sets);
+    const int r_useless = gs[set].useless, q_useless = gs[set ^ 1].useless;
+    const int nr = dir ? N : M, nq = dir ? M : N;
+    bool hopeless = r_useless != 0;
+    if (!r_useless && !q_useless && nr >= 64 && nq >= 16) {
+      const pp::f4* __restrict__ rs = reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
+      const pp::f4* __restrict__ qs = reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir ^ 1, N, M);
+      const pp::f4 r = rs[(size_t)lane * (size_t)nr / 64];
+      int votes = 0;
+      for (int i = 0; i < 8; ++i) {
+        const pp::f4 q = qs[(size_t)(2 * i + 1) * (size_t)nq / 16];  // (wave-uniform)
+        const float d = pp::chamfer_d3(r.x, r.y, r.z, q.x, q.y, q.z);
+        const float dmin = -pp::wave_reduce_dpp<false>(-d);
+        votes += __builtin_popcountll(__ballot(d <= dmin * 1.01f)) >= 32 ? 1 : 0;
+      }
+      hopeless = votes >= 6;
+    }
+    if (lane == 0) {
+      (reinterpret_cast<unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords)[pp::kLayerRouted] = hopeless ? 1u : 0u;
+      if (hopeless && routed_host) *reinterpret_cast<volatile unsigned*>(routed_host) = epoch;
+    }
+    return;
+  }
   constexpr int kW = TQ / 64;
   constexpr int kQueue = 64;  // leftovers of a tile served from the image (more than that stay for the list kernel)
   __shared__ pp::f4 s_img[(CAP + 63) / 64 * 64 + 4];  // (whole pieces of 64 points, then the padding)
@@ -2845,6 +2882,37 @@ static void record_timing_event(int i, hipStream_t s, bool two_stage = false) {
   }
 }
 
+namespace pp {
+int nmdist_forward_routed(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2, int* idx2, int B,
+                          int N, int M, const unsigned* routed, int stride, hipStream_t s);  // chamfer.hip
+}
+// Routing to the every-pair kernel (round 6).  Whether a direction is routed is decided on the device, by the stage-A
+// launch, call by call; whether the every-pair launch that serves routed directions FOLLOWS the list kernel is the
+// host's decision, and the host only knows what earlier calls found: a word of pinned host memory per device that a
+// stage-A launch sets to its call's number when it routes a direction.  A call issues the extra launch (a few
+// microseconds when nothing is routed: its workgroups leave at once) while that word names one of the last
+// kRouteMemory calls; without it the list kernel serves routed directions itself -- slower, the same bits.  So a stream
+// of ordinary clouds never pays for the launch, and a stream of adversarial ones pays the slow path once.
+constexpr unsigned kRouteMemory = 64;
+static std::atomic<unsigned> g_route_epoch{0};
+static std::atomic<unsigned*> g_route_word[64];  // per device: host pointer (mapped: the device writes through it)
+static unsigned* route_word(int dev) {
+  if (dev < 0 || dev >= 64) return nullptr;
+  unsigned* w = g_route_word[dev].load(std::memory_order_acquire);
+  if (w) return w;
+  unsigned* fresh = nullptr;
+  if (hipHostMalloc((void**)&fresh, 64, hipHostMallocMapped) != hipSuccess || !fresh) return nullptr;
+  *fresh = 0u;
+  unsigned* expected = nullptr;
+  if (!g_route_word[dev].compare_exchange_strong(expected, fresh, std::memory_order_acq_rel)) {
+    (void)hipHostFree(fresh);
+    return expected;
+  }
+  return fresh;
+}
+static pp::Knob g_route_mode;  // 0 automatic, 1 never route (the list kernel serves everything), 2 always issue the every-pair launch
+extern "C" void pp_debug_set_nmdistance_routing(int mode) { g_route_mode.set(mode); }
+
 // queries the stage-A kernel of the most recent unlabeled forward on this workspace left to the list kernel, per
 // direction (2 B numbers; synchronises the device): what fraction of the search ran outside stage A
 extern "C" int pp_debug_nmdistance_pending(const void* workspace, int B, int N, int M, unsigned* totals) {
@@ -2918,12 +2986,29 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   // (PP_NMDISTANCE_TILE: the debug knob's value from the environment, read once -- benchmarks of the forms in processes
   //  that do not call the knob)
   const bool two_stage = !LAB && tile != -1 && lay.chunks > 0;
+  bool routing = false;  // the every-pair launch for routed directions follows the list kernel
   if (two_stage) {  // stage A by tiles, then the whole-search kernel over what it left (LIST)
     const int tq = tile == 256 || tile == 1024 || tile == 513 ? tile : 512;
     const int tqq = tq == 513 ? 512 : tq;
     const int ta1 = (N + tqq - 1) / tqq, ta2 = (M + tqq - 1) / tqq;
     const long long ablocks = (long long)B * (ta1 + ta2);
     const int aper = (int)((ablocks + 7) / 8);
+    // routing (see route_word above): the stage-A launch decides per direction; the every-pair launch follows the list
+    // kernel when an earlier call on this device routed something
+    unsigned* route_dev = nullptr;  // the device's view of the pinned word
+    unsigned epoch = 0u;
+    if (g_route_mode != 1) {
+      int dev = 0;
+      unsigned* host = hipGetDevice(&dev) == hipSuccess ? route_word(dev) : nullptr;
+      if (host && hipHostGetDevicePointer((void**)&route_dev, host, 0) == hipSuccess && route_dev) {
+        epoch = g_route_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
+        if (epoch == 0u) epoch = g_route_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;  // (0 = "never")
+        const unsigned seen = *reinterpret_cast<volatile unsigned*>(host);
+        routing = g_route_mode == 2 || (seen != 0u && epoch - seen <= kRouteMemory);
+      } else {
+        route_dev = nullptr;
+      }
+    }
     // persistent: as many workgroups as stay resident (CUs x workgroups per CU by the image's size), a multiple of
     // eight, at most one per tile; each walks the tiles w, w + grid, ... with the next tile's front loads in flight
     static std::atomic<int> cus{0};
@@ -2940,14 +3025,16 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
     long long g_ = (long long)ncu * (PER_CU_);                                                                  \
     g_ = (g_ < (long long)aper * 8 ? g_ : (long long)aper * 8);                                                 \
     g_ = (g_ + 7) / 8 * 8;                                                                                      \
+    if ((PER_CU_) >= 1024 && route_dev != nullptr) g_ += 2 * B;  /* the routing workgroups, behind the tiles' */ \
     if (own) {                                                                                                  \
       hipExtLaunchKernelGGL((grid_stage_a_kernel<TQ_, CAP_, WPE_, ((PER_CU_) < 1024)>), dim3((unsigned)g_), dim3(TQ_), 0, s, \
-                            g_evk[2], g_evk[3], 0, dist1, idx1, dist2, idx2, ws, B, N, M, ta1, ta2, (int)ablocks, aper, lay); \
+                            g_evk[2], g_evk[3], 0, dist1, idx1, dist2, idx2, ws, B, N, M, ta1, ta2, (int)ablocks, aper, lay, \
+                            route_dev, epoch);                                                                    \
       std::lock_guard<std::mutex> lock(g_ev_mutex);                                                              \
       g_evk_valid = true;                                                                                        \
     } else                                                                                                       \
       grid_stage_a_kernel<TQ_, CAP_, WPE_, ((PER_CU_) < 1024)><<<dim3((unsigned)g_), dim3(TQ_), 0, s>>>(dist1, idx1, dist2, idx2, ws, B, N, M, ta1, \
-                                                                           ta2, (int)ablocks, aper, lay);         \
+                                                                           ta2, (int)ablocks, aper, lay, route_dev, epoch); \
   } while (0)
     switch (tq) {
       // (workgroups per CU: 1 << 20 = a workgroup per tile, not persistent -- measured as fast at config 2 (the front of
@@ -2972,7 +3059,14 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
     const int wps = ((N > M ? N : M) + 63) / 64;  // a wave for every 64 queries of a direction: as the whole-search kernel
     const long long lwaves = (long long)sets * wps;
     grid_query_list_kernel<384><<<dim3((unsigned)(((lwaves + kListWgWaves - 1) / kListWgWaves + 7) / 8 * 8)), dim3(64 * kListWgWaves), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2,
-                                                                                      ws, B, N, M, wps, lay);
+                                                                                      ws, B, N, M, wps, lay, routing ? 1 : 0);
+    if (routing) {
+      PP_RETURN_IF_LAUNCH_FAILED();
+      const int rc = pp::nmdist_forward_routed(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
+                                               reinterpret_cast<const unsigned*>(ws + lay.layers) + pp::kLayerRouted,
+                                               pp::kLayerWords, s);
+      if (rc != PP_OK) return rc;
+    }
   } else {
     switch (g_stage_cap) {
       case 320: PP_LAUNCH_W(320); break;

@@ -1234,10 +1234,11 @@ int bucket_launch(const float* xyz, float* temp, int* idx, int B, int N, int npo
     if (g.m == 1) fps_pre_cell_kernel<true, true><<<grid, dim3(kPreThreads), kBkLdsBytes, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
     else fps_pre_cell_kernel<true, false><<<grid, dim3(kPreThreads), kBkLdsBytes, s>>>(xyz, temp, N, order, g, tabs, sorted, aux);
   }
-  // several picks per round from 32768 points (measured: 0.96 against 0.93 ms at 16 x 16384 -> 1024, 0.58 against 0.49
-  // at 32 x 8192 -> 512: few buckets per lane, and the first hundred picks of any call come one per round)
+  // several picks per round from 32768 points or 1024 picks (measured round 6: 0.906 against 0.933 ms at 16 x 16384 ->
+  // 1024, 0.743 against 0.817 at 64 x 4096 -> 1024, but 0.508 against 0.490 at 32 x 8192 -> 512: the first fifty picks
+  // of any call come one per round, at two barriers each)
   const int chain = (int)g_bucket_chain;
-  if (g.m == 1 && (chain == 2 || (chain == 0 && N >= 32768))) {
+  if (g.m == 1 && (chain == 2 || (chain == 0 && (N >= 32768 || npoint >= 1024)))) {
     hipError_t e = pp::allow_big_lds(fps_bucket_kernel<true, true>, kBkLdsBytes, g_bucket_lds[2]);
     if (e != hipSuccess) return (int)e;
     fps_bucket_kernel<true, true><<<dim3(B), dim3(kBkThreads), kBkLdsBytes, s>>>(xyz, temp, idx, N, npoint, seed,

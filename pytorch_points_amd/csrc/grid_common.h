@@ -28,6 +28,7 @@ constexpr int kBuildSlabs = 4;  // workgroups that share the build of one set (e
 constexpr int kLayerWords = 40;
 constexpr int kLayerPending = 36;
 constexpr int kLayerCursor = 37;  // (zeroed by the build too) pieces of the pending list handed out so far: list kernel
+constexpr int kLayerRouted = 38;  // (zeroed by the build) 1: the stage-A kernel has routed the direction to the every-pair kernel (round 6)
 constexpr int kChunk = 256;
 constexpr int kChunkMax = 256;  // chunks per set the build can track (sets of up to 65536 points)
 __host__ __device__ inline int zkey(float z) {  // monotone in z for every non-NaN float
@@ -896,7 +897,7 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
         if (c >= 0 && c < nloc) layers[t] = s_cnt[sk(c)];
       }
       if (t == gz && slab == nslab - 1) layers[gz] = degenerate ? 0u : (unsigned)nr;
-      if ((t == kLayerPending || t == kLayerCursor) && slab == 0) layers[t] = 0u;
+      if ((t == kLayerPending || t == kLayerCursor || t == kLayerRouted) && slab == 0) layers[t] = 0u;
     }
   }
   __syncthreads();
@@ -1576,7 +1577,7 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
   }
   bool refined = false;
   if constexpr (REFINE) {
-    if ((t == kLayerPending || t == kLayerCursor) && slab == 0) layers[t] = 0u;
+    if ((t == kLayerPending || t == kLayerCursor || t == kLayerRouted) && slab == 0) layers[t] = 0u;
     for (int c = t; c < 2 * tz_chunks; c += kBuildThreads) tile_z[((size_t)(c >> 1) * nslab + slab) * 2 + (c & 1)] = s_tz[c];
     if (ncrowd > 0) {  // (uniform) second level: the general build's refinement of this slab's crowded cells, in place
       __threadfence_block();  // the copy-out's stores are read back

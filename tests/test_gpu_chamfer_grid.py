@@ -529,3 +529,44 @@ def test_ball_stage_sparse_reference_equal_brute_force(cuda, n, m):
     got = _run(cuda, x1, x2, 2)
     for g, e, what in zip(got, ref, ["dist1", "idx1", "dist2", "idx2"]):
         assert np.array_equal(g, e, equal_nan=True), "%d/%d: %s differs at %d places" % (n, m, what, int((g != e).sum()))
+
+
+# ---- round 6: directions no search can prune are routed to the every-pair kernel (the stage-A launch decides on the
+# device; the every-pair launch follows once the host has seen a routed direction).  Whatever is routed, and whichever
+# kernel serves it, the outputs are the every-pair kernel's, bit for bit.
+def _adversarial(name, b, n):
+    rng = np.random.default_rng(950)
+    if name == "shell_vs_core":
+        a = rng.standard_normal((b, n, 3)); a /= np.linalg.norm(a, axis=-1, keepdims=True)
+        return a.astype(np.float32), (rng.standard_normal((b, n, 3)) * 1e-3).astype(np.float32)
+    if name == "identical":
+        return np.full((b, n, 3), 0.25, np.float32), np.full((b, n, 3), 0.75, np.float32)
+    if name == "shells":
+        a = rng.standard_normal((b, n, 3)); a /= np.linalg.norm(a, axis=-1, keepdims=True)
+        c = rng.standard_normal((b, n, 3)); c /= np.linalg.norm(c, axis=-1, keepdims=True)
+        return a.astype(np.float32), (c * 0.5).astype(np.float32)
+    if name == "mixed":          # element 0 ordinary, element 1 a shell against its core: routed per direction
+        a = S.unit_sphere(951, b, n); c = S.unit_sphere(952, b, n)
+        c[1] = (rng.standard_normal((n, 3)) * 1e-3).astype(np.float32)
+        return a, c
+    return S.unit_sphere(953, b, n), S.unit_sphere(954, b, n)
+
+
+@pytest.mark.parametrize("name", ["shell_vs_core", "identical", "shells", "mixed", "sphere"])
+def test_routed_directions_equal_brute_force(cuda, name):
+    from pytorch_points_amd import _lib
+    route = _lib.lib().pp_debug_set_nmdistance_routing
+    route.argtypes = [ctypes.c_int]
+    route.restype = None
+    x1, x2 = _adversarial(name, 3, 8192)
+    ref = _run(cuda, x1, x2, 1)
+    try:
+        for mode, reps in ((1, 1), (2, 2), (0, 3)):      # never routed / the every-pair launch always / automatic (the
+            route(mode)                                   # launch follows from the second call on where something is routed)
+            for rep in range(reps):
+                got = _run(cuda, x1, x2, 2)
+                for g, e, what in zip(got, ref, ["dist1", "idx1", "dist2", "idx2"]):
+                    assert np.array_equal(g, e, equal_nan=True), "%s routing mode %d call %d: %s differs at %d places" % (
+                        name, mode, rep, what, int((g != e).sum()))
+    finally:
+        route(0)
