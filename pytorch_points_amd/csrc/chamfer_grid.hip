@@ -150,7 +150,7 @@ constexpr int kCellStride = kGridCells + 4;
 //                                  cloud's sorted order), 64 slots per wave of the stage-A kernel
 //   [.., +4*(T/64 + S + 1))        unsigned pend_cnt[...]   how many of a wave's 64 slots are filled
 struct Layout {
-  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, tile_z, layers, pend, pend_cnt, total;
+  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, tile_z, layers, pend, pend_cnt, routed, total;
   int chunks;  // chunk-table entries per set and slab (0: sets too large for the table)
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
@@ -170,7 +170,8 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   L.layers = ((L.tile_z + 4 * S * pp::kBuildSlabs * 2 * (size_t)L.chunks + 255) / 256) * 256;
   L.pend = L.layers + (L.chunks ? ((4 * S * pp::kLayerWords + 255) / 256) * 256 : 0);
   L.pend_cnt = L.pend + (L.chunks ? 4 * T : 0);
-  L.total = L.pend_cnt + (L.chunks ? ((4 * (T / 64 + S + 1) + 255) / 256) * 256 : 0);
+  L.routed = L.pend_cnt + (L.chunks ? ((4 * (T / 64 + S + 1) + 255) / 256) * 256 : 0);  // [S]: directions routed to the every-pair kernel before the build
+  L.total = L.routed + (L.chunks ? ((4 * S + 255) / 256) * 256 : 0);
   return L;
 }
 // second-level arrays of set (b, dir): first table entry / first descriptor
@@ -192,6 +193,42 @@ __host__ __device__ inline size_t set_point_offset(int b, int dir, int N, int M)
   return (size_t)b * ((size_t)N + M) + (dir ? (size_t)M : 0);  // references of (b,0) first (M), then (b,1) (N)
 }
 
+// Round 6: is a direction one no search can prune?  A wave per direction: eight of its queries against 64 of its reference
+// points; where a query sees more than half of the samples within half a percent of its nearest one, every bound of the
+// search is beaten by everybody -- a shell against a cluster at its centre, a cluster against a far shell, identical
+// points -- and six of eight such queries ROUTE the direction to the every-pair kernel.  A heuristic of speed only: both
+// paths give the same bits.  (The same test on samples of the sorted clouds runs in the stage-A launch's tail while the
+// host has not seen a routed direction: see grid_stage_a_kernel.)
+__device__ __forceinline__ bool direction_unprunable(const float* __restrict__ q, int nq, int qstride,
+                                                     const float* __restrict__ r, int nr, int rstride, int lane) {
+  if (nr < 64 || nq < 16) return false;
+  const float* rp = r + (size_t)((size_t)lane * (size_t)nr / 64) * rstride;
+  const float rx = rp[0], ry = rp[1], rz = rp[2];
+  int votes = 0;
+  for (int i = 0; i < 8; ++i) {
+    const float* qp = q + (size_t)((size_t)(2 * i + 1) * (size_t)nq / 16) * qstride;  // (wave-uniform)
+    const float d = pp::chamfer_d3(rx, ry, rz, qp[0], qp[1], qp[2]);
+    const float dmin = -pp::wave_reduce_dpp<false>(-d);
+    votes += __builtin_popcountll(__ballot(d <= dmin * 1.01f)) >= 32 ? 1 : 0;
+  }
+  return votes >= 6;
+}
+// ... in front of the build, on the clouds as they are given (the host has seen routed directions lately: the build, the
+// stage-A kernel and the list kernel then leave a routed direction alone from their first instruction)
+__global__ __launch_bounds__(64) void route_decide_kernel(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                          unsigned* __restrict__ routed, int B, int N, int M,
+                                                          unsigned* __restrict__ routed_host, unsigned epoch) {
+  const int set = blockIdx.x, b = set >> 1, dir = set & 1, lane = threadIdx.x;
+  const int nr = dir ? N : M, nq = dir ? M : N;  // dir 0: queries = cloud 1 (N), references = cloud 2 (M)
+  const float* r = (dir ? xyz1 : xyz2) + (size_t)b * nr * 3;
+  const float* q = (dir ? xyz2 : xyz1) + (size_t)b * nq * 3;
+  const bool hopeless = direction_unprunable(q, nq, 3, r, nr, 3, lane);
+  if (lane == 0) {
+    routed[set] = hopeless ? 1u : 0u;
+    if (hopeless && routed_host) *reinterpret_cast<volatile unsigned*>(routed_host) = epoch;
+  }
+}
+
 // kBuildSlabs workgroups per set: bounding box, cell histogram (LDS), exclusive scan, scatter
 // (grid_common.h).
 template <bool VEC>
@@ -200,13 +237,17 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
                                                                    unsigned char* __restrict__ ws, int B,
                                                                    int N, int M,
                                                                    const float* __restrict__ label1,
-                                                                   const float* __restrict__ label2, int fast) {
+                                                                   const float* __restrict__ label2, int fast,
+                                                                   const unsigned* __restrict__ pre_routed) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_cnt[];  // max(grid_build_lds_bytes(kBuildSlabs), grid_build_fast_lds_bytes())
   // a set is built on the XCD that will search it (the search kernel's set -> XCD mapping): its sorted
   // points and cell table are then already in that L2
   const int V = pp::xcd_virtual_block(blockIdx.x, (2 * B * pp::kBuildSlabs + 7) / 8);
   if (V >= 2 * B * pp::kBuildSlabs) return;
   const int set = V / pp::kBuildSlabs, slab = V % pp::kBuildSlabs;
+  // (round 6) both directions of the batch element routed to the every-pair kernel before this launch: neither grid
+  // is needed (a set is one direction's reference grid and the other's query order)
+  if (pre_routed != nullptr && pre_routed[set] != 0u && pre_routed[set ^ 1] != 0u) return;
   const int b = set >> 1, dir = set & 1;
   const int nr = dir ? N : M;
   const float* __restrict__ ref = (dir ? xyz1 : xyz2) + (size_t)b * nr * 3;
@@ -2202,7 +2243,8 @@ __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_l
                                                                   float* __restrict__ dist1, int* __restrict__ idx1,
                                                                   float* __restrict__ dist2, int* __restrict__ idx2,
                                                                   unsigned char* __restrict__ ws, int B, int N, int M,
-                                                                  int waves_per_set, const Layout L, int routing) {
+                                                                  int waves_per_set, const Layout L,
+                                                                  const unsigned* __restrict__ pre_routed) {
   static_assert((CAPW + 4) * 16 >= 1024 * 4, "the prefix sums of up to 1024 counts use the wave's slice");
   __shared__ pp::f4 s_pts[kListWgWaves][CAPW + 4];
   const int wave = pp::wave_id_uniform();
@@ -2248,6 +2290,9 @@ __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_l
   //  0.83 -> 0.78 -- but cost the clouds whose neighbouring waves share cells their cache hits: two_scales 0.316 -> 0.335,
   //  shapenet_like 0.21 -> 0.23.  Plain order.)
   if (set >= 2 * B) return;
+  // (round 6) a direction routed to the every-pair kernel in front of the build: nothing of it is here (its tables may
+  // not even have been built)
+  if (pre_routed != nullptr && pre_routed[set] != 0u) return;
   const int b = set >> 1, dir = set & 1;
   const int nq = dir ? M : N;
   const int nwq = (nq + 63) / 64;  // waves of the stage-A kernel in this direction (<= 1024)
@@ -2291,8 +2336,6 @@ __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_l
   // nothing, or next to nothing, is left and the wave leaves here
   const unsigned total = (reinterpret_cast<const unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords)[pp::kLayerPending];
   if (total == 0u) return;
-  // (round 6) a direction the stage-A launch has routed to the every-pair kernel, when that kernel follows this launch
-  if (routing && (reinterpret_cast<const unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords)[pp::kLayerRouted] != 0u) return;
   const unsigned per_wave = min(64u, max(1u, (total + (unsigned)waves_per_set - 1) / (unsigned)waves_per_set));
   // ONE piece of per_wave entries per wave (the launch has a wave for every 64 queries of a direction, so a list of
   // every query still fits; no loop: state that lives across the search costs this kernel registers it does not have)
@@ -2414,7 +2457,7 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
                                                               unsigned char* __restrict__ ws, int B, int N, int M,
                                                               int tiles1, int tiles2, int total, int per_xcd,
                                                               const Layout L, unsigned* __restrict__ routed_host,
-                                                              unsigned epoch) {
+                                                              unsigned epoch, const unsigned* __restrict__ pre_routed) {
   static_assert(TQ % pp::kChunk == 0 && (CAP + 63) / 64 * 64 + 4 <= 4096 + 4, "");
   // PERSISTENT: the launch is a few workgroups per CU (a multiple of eight, so that a workgroup's tiles stay on its
   // XCD under the round-robin placement -- speed only); workgroup w takes the virtual tiles w, w + gridDim.x, ...
@@ -2423,31 +2466,20 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   const int wave = pp::wave_id_uniform();
   if (!PERSIST && (int)blockIdx.x >= nvt) {
     // Round 6: 2 B workgroups behind the tiles' (dispatched last, into the launch's tail), one per direction: is this
-    // a direction no search can prune?  Eight of its queries against 64 of its reference points (samples of the
-    // sorted clouds): where a query sees more than half of the samples within half a percent of its nearest one, every
-    // bound of the search is beaten by everybody -- a shell against a cluster at its centre, a cluster against a far
-    // shell -- and six of eight such queries ROUTE the direction to the every-pair kernel (kLayerRouted; launched behind
-    // the list kernel once the host has seen a routed direction: routed_host).  A degenerate reference set (identical
-    // points: no grid) is routed as it is.  A heuristic of speed only: both paths give the same bits.
+    // a direction no search can prune (direction_unprunable, on samples of the sorted clouds)?  Then the host is told
+    // (routed_host): from its next calls on the decision is taken in front of the build (route_decide_kernel) and the
+    // every-pair kernel serves the routed directions.  This call's search serves them itself.
     const int set = (int)blockIdx.x - nvt;
     if (set >= 2 * B || wave != 0) return;
     const int b = set >> 1, dir = set & 1;
     const GridSet* gs = reinterpret_cast<const GridSet*>(ws + L.sets);
     const int r_useless = gs[set].useless, q_useless = gs[set ^ 1].useless;
     const int nr = dir ? N : M, nq = dir ? M : N;
-    bool hopeless = r_useless != 0;
-    if (!r_useless && !q_useless && nr >= 64 && nq >= 16) {
-      const pp::f4* __restrict__ rs = reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M);
-      const pp::f4* __restrict__ qs = reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir ^ 1, N, M);
-      const pp::f4 r = rs[(size_t)lane * (size_t)nr / 64];
-      int votes = 0;
-      for (int i = 0; i < 8; ++i) {
-        const pp::f4 q = qs[(size_t)(2 * i + 1) * (size_t)nq / 16];  // (wave-uniform)
-        const float d = pp::chamfer_d3(r.x, r.y, r.z, q.x, q.y, q.z);
-        const float dmin = -pp::wave_reduce_dpp<false>(-d);
-        votes += __builtin_popcountll(__ballot(d <= dmin * 1.01f)) >= 32 ? 1 : 0;
-      }
-      hopeless = votes >= 6;
+    bool hopeless = r_useless != 0;  // (a degenerate reference set -- identical points: no grid -- is routed as it is)
+    if (!r_useless && !q_useless) {
+      const float* rs = reinterpret_cast<const float*>(reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir, N, M));
+      const float* qs = reinterpret_cast<const float*>(reinterpret_cast<const pp::f4*>(ws + L.sorted) + set_point_offset(b, dir ^ 1, N, M));
+      hopeless = direction_unprunable(qs, nq, 4, rs, nr, 4, lane);
     }
     if (lane == 0) {
       (reinterpret_cast<unsigned*>(ws + L.layers) + (size_t)set * pp::kLayerWords)[pp::kLayerRouted] = hopeless ? 1u : 0u;
@@ -2491,6 +2523,14 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   const bool valid = f.valid;
   const int nq = dir ? M : N;
   const int set = 2 * b + dir;
+  if (pre_routed != nullptr && f.live && pre_routed[set] != 0u) {  // (uniform over the direction) served by the every-pair kernel
+    if constexpr (PERSIST) {
+      __syncthreads();
+      continue;
+    } else {
+      return;
+    }
+  }
   const pp::f4 qq = f.qq;
   const unsigned lay = f.lay;
   auto meta = [&](int l) { return __builtin_amdgcn_readlane((int)f.meta, l); };
@@ -2964,6 +3004,33 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   }();
   const int tile = g_tile != 0 ? (int)g_tile : tile_env;
   const Layout lay = make_layout(B, N, M, LAB);
+  const bool two_stage = !LAB && tile != -1 && lay.chunks > 0;
+  // routing (see route_word above): while the host has not seen a routed direction lately, the stage-A launch's tail
+  // tests every direction and tells the host; once it has, the test runs in front of the build (route_decide_kernel)
+  // and the every-pair kernel serves the routed directions behind the list kernel
+  unsigned* route_dev = nullptr;  // the device's view of the pinned word
+  unsigned epoch = 0u;
+  bool routing = false;
+  if (two_stage && g_route_mode != 1) {
+    int dev = 0;
+    unsigned* host = hipGetDevice(&dev) == hipSuccess ? route_word(dev) : nullptr;
+    if (host && hipHostGetDevicePointer((void**)&route_dev, host, 0) == hipSuccess && route_dev) {
+      epoch = g_route_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
+      if (epoch == 0u) epoch = g_route_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;  // (0 = "never")
+      const unsigned seen = *reinterpret_cast<volatile unsigned*>(host);
+      routing = g_route_mode == 2 || (seen != 0u && epoch - seen <= kRouteMemory);
+    } else {
+      route_dev = nullptr;
+    }
+  }
+  const unsigned* pre_routed = nullptr;
+  if (routing) {
+    route_decide_kernel<<<dim3(2 * B), dim3(64), 0, s>>>(xyz1, xyz2, reinterpret_cast<unsigned*>(ws + lay.routed), B, N, M,
+                                                         route_dev, epoch);
+    PP_RETURN_IF_LAUNCH_FAILED();
+    pre_routed = reinterpret_cast<const unsigned*>(ws + lay.routed);
+    route_dev = nullptr;  // (the stage-A launch's tail has nothing to decide)
+  }
   bool own = false;  // (timing: the two kernels' own begin / end stamps beside the stream events)
   if (g_time_kernels == 2) {  // (2: these instead of the stream events' figures, which the stamped launches would distort)
     std::lock_guard<std::mutex> lock(g_ev_mutex);
@@ -2973,10 +3040,10 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   if (own)
     hipExtLaunchKernelGGL((vec ? grid_build_kernel<true> : grid_build_kernel<false>), dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)),
                           dim3(kBuildThreads), lds, s, g_evk[0], g_evk[1], 0, xyz1, xyz2, ws, B, N, M,
-                          LAB ? label1 : nullptr, LAB ? label2 : nullptr, g_build_fast != 1 ? 1 : 0);
+                          LAB ? label1 : nullptr, LAB ? label2 : nullptr, g_build_fast != 1 ? 1 : 0, pre_routed);
   else
     (vec ? grid_build_kernel<true> : grid_build_kernel<false>)<<<dim3(8 * ((2 * B * pp::kBuildSlabs + 7) / 8)), dim3(kBuildThreads), lds, s>>>(
-        xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr, g_build_fast != 1 ? 1 : 0);
+        xyz1, xyz2, ws, B, N, M, LAB ? label1 : nullptr, LAB ? label2 : nullptr, g_build_fast != 1 ? 1 : 0, pre_routed);
   PP_RETURN_IF_LAUNCH_FAILED();
   if (timing) record_timing_event(1, s);
   const int tiles1 = (N + 255) / 256, tiles2 = (M + 255) / 256;
@@ -2985,30 +3052,12 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   const int per_xcd = (int)((blocks + 7) / 8);
   // (PP_NMDISTANCE_TILE: the debug knob's value from the environment, read once -- benchmarks of the forms in processes
   //  that do not call the knob)
-  const bool two_stage = !LAB && tile != -1 && lay.chunks > 0;
-  bool routing = false;  // the every-pair launch for routed directions follows the list kernel
   if (two_stage) {  // stage A by tiles, then the whole-search kernel over what it left (LIST)
     const int tq = tile == 256 || tile == 1024 || tile == 513 ? tile : 512;
     const int tqq = tq == 513 ? 512 : tq;
     const int ta1 = (N + tqq - 1) / tqq, ta2 = (M + tqq - 1) / tqq;
     const long long ablocks = (long long)B * (ta1 + ta2);
     const int aper = (int)((ablocks + 7) / 8);
-    // routing (see route_word above): the stage-A launch decides per direction; the every-pair launch follows the list
-    // kernel when an earlier call on this device routed something
-    unsigned* route_dev = nullptr;  // the device's view of the pinned word
-    unsigned epoch = 0u;
-    if (g_route_mode != 1) {
-      int dev = 0;
-      unsigned* host = hipGetDevice(&dev) == hipSuccess ? route_word(dev) : nullptr;
-      if (host && hipHostGetDevicePointer((void**)&route_dev, host, 0) == hipSuccess && route_dev) {
-        epoch = g_route_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
-        if (epoch == 0u) epoch = g_route_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;  // (0 = "never")
-        const unsigned seen = *reinterpret_cast<volatile unsigned*>(host);
-        routing = g_route_mode == 2 || (seen != 0u && epoch - seen <= kRouteMemory);
-      } else {
-        route_dev = nullptr;
-      }
-    }
     // persistent: as many workgroups as stay resident (CUs x workgroups per CU by the image's size), a multiple of
     // eight, at most one per tile; each walks the tiles w, w + grid, ... with the next tile's front loads in flight
     static std::atomic<int> cus{0};
@@ -3029,12 +3078,12 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
     if (own) {                                                                                                  \
       hipExtLaunchKernelGGL((grid_stage_a_kernel<TQ_, CAP_, WPE_, ((PER_CU_) < 1024)>), dim3((unsigned)g_), dim3(TQ_), 0, s, \
                             g_evk[2], g_evk[3], 0, dist1, idx1, dist2, idx2, ws, B, N, M, ta1, ta2, (int)ablocks, aper, lay, \
-                            route_dev, epoch);                                                                    \
+                            route_dev, epoch, pre_routed);                                                        \
       std::lock_guard<std::mutex> lock(g_ev_mutex);                                                              \
       g_evk_valid = true;                                                                                        \
     } else                                                                                                       \
       grid_stage_a_kernel<TQ_, CAP_, WPE_, ((PER_CU_) < 1024)><<<dim3((unsigned)g_), dim3(TQ_), 0, s>>>(dist1, idx1, dist2, idx2, ws, B, N, M, ta1, \
-                                                                           ta2, (int)ablocks, aper, lay, route_dev, epoch); \
+                                                                           ta2, (int)ablocks, aper, lay, route_dev, epoch, pre_routed); \
   } while (0)
     switch (tq) {
       // (workgroups per CU: 1 << 20 = a workgroup per tile, not persistent -- measured as fast at config 2 (the front of
@@ -3059,12 +3108,10 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
     const int wps = ((N > M ? N : M) + 63) / 64;  // a wave for every 64 queries of a direction: as the whole-search kernel
     const long long lwaves = (long long)sets * wps;
     grid_query_list_kernel<384><<<dim3((unsigned)(((lwaves + kListWgWaves - 1) / kListWgWaves + 7) / 8 * 8)), dim3(64 * kListWgWaves), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2,
-                                                                                      ws, B, N, M, wps, lay, routing ? 1 : 0);
+                                                                                      ws, B, N, M, wps, lay, pre_routed);
     if (routing) {
       PP_RETURN_IF_LAUNCH_FAILED();
-      const int rc = pp::nmdist_forward_routed(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M,
-                                               reinterpret_cast<const unsigned*>(ws + lay.layers) + pp::kLayerRouted,
-                                               pp::kLayerWords, s);
+      const int rc = pp::nmdist_forward_routed(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, pre_routed, 1, s);
       if (rc != PP_OK) return rc;
     }
   } else {
