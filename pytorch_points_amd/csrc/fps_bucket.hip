@@ -666,7 +666,12 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       }
       if (win) {
         f4 r;
-        r.x = ax; r.y = ay; r.z = az; r.w = __uint_as_float(bsec);
+        // (what this pick leaves behind in its bucket is also at most its distance to the box's farthest corner: dist3 of
+        //  the pick and any point of the box, in dist3's own monotone arithmetic, is no larger -- early in a call, while
+        //  every temp is far above a bucket's size, that is the bound that lets a second candidate through)
+        const float ex = fmaxf(ax - lox, hix - ax), ey = fmaxf(ay - loy, hiy - ay), ez = fmaxf(az - loz, hiz - az);
+        const unsigned diag = __float_as_uint(__builtin_fmaf(ez, ez, __builtin_fmaf(ex, ex, ey * ey)));
+        r.x = ax; r.y = ay; r.z = az; r.w = __uint_as_float(bsec < diag ? bsec : diag);
         s_key[buf][myslot] = bkey;
         s_rec[buf][myslot] = r;
       }
@@ -691,10 +696,10 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       const u64 okey = s_key[buf][lane];  // a lane per candidate slot
       const f4 orec = s_rec[buf][lane];
       const unsigned bound = s_bound[buf];
-      if (t < 64) {  // (the other half of the tables: read for the last time before this round's first barrier)
-        if (t == 0) s_fail[buf ^ 1] = 0ull;
-        s_sbmax[buf ^ 1][t] = 0u;
-        s_cover[buf ^ 1][t] = 0ull;
+      if (wave == kBkWaves - 1) {  // (the other half of the tables: read for the last time before this round's first
+        if (lane == 0) s_fail[buf ^ 1] = 0ull;  // barrier; by the wave that is dealt the fewest candidates to test)
+        s_sbmax[buf ^ 1][lane] = 0u;
+        s_cover[buf ^ 1][lane] = 0ull;
       }
       const unsigned ohi = (unsigned)(okey >> 32);
       bool o_el = okey != 0ull && ohi > bound;
