@@ -2935,17 +2935,28 @@ int nmdist_forward_routed(const float* xyz1, const float* xyz2, float* dist1, in
 // of ordinary clouds never pays for the launch, and a stream of adversarial ones pays the slow path once.
 constexpr unsigned kRouteMemory = 64;
 static std::atomic<unsigned> g_route_epoch{0};
-static std::atomic<unsigned*> g_route_word[64];  // per device: host pointer (mapped: the device writes through it)
-static unsigned* route_word(int dev) {
+struct RouteWord {
+  unsigned* host;    // pinned, mapped: the host reads it, a launch writes through `dev`
+  unsigned* dev;
+};
+static std::atomic<RouteWord*> g_route_word[64];  // per device; allocated once, never freed
+static const RouteWord* route_word(int dev) {
   if (dev < 0 || dev >= 64) return nullptr;
-  unsigned* w = g_route_word[dev].load(std::memory_order_acquire);
+  RouteWord* w = g_route_word[dev].load(std::memory_order_acquire);
   if (w) return w;
-  unsigned* fresh = nullptr;
-  if (hipHostMalloc((void**)&fresh, 64, hipHostMallocMapped) != hipSuccess || !fresh) return nullptr;
-  *fresh = 0u;
-  unsigned* expected = nullptr;
+  unsigned* host = nullptr;
+  unsigned* devp = nullptr;
+  if (hipHostMalloc((void**)&host, 64, hipHostMallocMapped) != hipSuccess || !host) return nullptr;
+  *host = 0u;
+  if (hipHostGetDevicePointer((void**)&devp, host, 0) != hipSuccess || !devp) {
+    (void)hipHostFree(host);
+    return nullptr;
+  }
+  RouteWord* fresh = new RouteWord{host, devp};
+  RouteWord* expected = nullptr;
   if (!g_route_word[dev].compare_exchange_strong(expected, fresh, std::memory_order_acq_rel)) {
-    (void)hipHostFree(fresh);
+    (void)hipHostFree(host);
+    delete fresh;
     return expected;
   }
   return fresh;
@@ -3013,14 +3024,13 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
   bool routing = false;
   if (two_stage && g_route_mode != 1) {
     int dev = 0;
-    unsigned* host = hipGetDevice(&dev) == hipSuccess ? route_word(dev) : nullptr;
-    if (host && hipHostGetDevicePointer((void**)&route_dev, host, 0) == hipSuccess && route_dev) {
+    const RouteWord* rw = hipGetDevice(&dev) == hipSuccess ? route_word(dev) : nullptr;
+    if (rw) {
+      route_dev = rw->dev;
       epoch = g_route_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;
       if (epoch == 0u) epoch = g_route_epoch.fetch_add(1u, std::memory_order_relaxed) + 1u;  // (0 = "never")
-      const unsigned seen = *reinterpret_cast<volatile unsigned*>(host);
+      const unsigned seen = *reinterpret_cast<volatile unsigned*>(rw->host);
       routing = g_route_mode == 2 || (seen != 0u && epoch - seen <= kRouteMemory);
-    } else {
-      route_dev = nullptr;
     }
   }
   const unsigned* pre_routed = nullptr;
