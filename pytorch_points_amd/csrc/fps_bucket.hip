@@ -43,6 +43,7 @@
 #define PP_FPSB_MARK(n)
 #define PP_FPSB_TOUCHED(mask)
 #define PP_FPSB_PICKS(k)
+#define PP_FPSB_AT(j)
 #define PP_FPSB_END()
 #endif
 
@@ -654,6 +655,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
     int j = 1;
     while (j < npoint) {
       PP_FPSB_MARK(0);
+      PP_FPSB_AT(j);
       const unsigned khi = (unsigned)(bkey >> 32), klo = (unsigned)bkey;
       if (redo) {  // (a key of this wave changed)
         unsigned top;

@@ -8,11 +8,13 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Iinclude -Ipytorch_points_amd/csrc tools/fps_bucket_probe.hip -o tools/fps_bucket_probe
 #include <hip/hip_runtime.h>
 __device__ unsigned long long g_probe[16][32];
+__device__ unsigned long long g_at[16];
 #ifdef PP_FPSB_NOMARKS  // timing only (with -DPP_FPSB_DOUBLE=<bits>: what one more copy of a link of the chain costs)
 #define PP_FPSB_PROBE_DECL
 #define PP_FPSB_MARK(n)
 #define PP_FPSB_TOUCHED(mask)
 #define PP_FPSB_PICKS(k)
+#define PP_FPSB_AT(j)
 #define PP_FPSB_END()
 #else
 // pr_acc: 0..5 phase clocks, 6 touched buckets, 12 rounds; pr_hist (LDS: indexed by a run-time value -- a register
@@ -21,6 +23,7 @@ __device__ unsigned long long g_probe[16][32];
 #define PP_FPSB_PROBE_DECL                                   \
   unsigned long long pr_t[7] = {0, 0, 0, 0, 0, 0, 0};        \
   unsigned long long pr_acc[13] = {0};                       \
+  unsigned long long pr_first = 0; int pr_next = 3;          \
   __shared__ unsigned pr_hist[16][32];                       \
   if (lane < 32) pr_hist[wave][lane] = 0u;
 #define PP_FPSB_MARK(n)                                                            \
@@ -36,6 +39,15 @@ __device__ unsigned long long g_probe[16][32];
     pr_acc[12] += 1;                                         \
   } while (0)
 #define PP_FPSB_PICKS(k) do { if (lane == 0) pr_hist[wave][8 + ((k) > 17 ? 17 : (k))] += 1u; } while (0)
+// the clock when the chain reaches pick 2^e (e = 3 .. 12), wave 0 of workgroup 0: where in the call the time goes
+#define PP_FPSB_AT(j)                                                                                 \
+  do {                                                                                                \
+    if (pr_first == 0) pr_first = pr_t[0];                                                            \
+    while (pr_next <= 12 && (j) >= (1 << pr_next)) {                                                   \
+      if (blockIdx.x == 0 && t == 0) g_at[pr_next] = pr_t[0] - pr_first;                              \
+      ++pr_next;                                                                                      \
+    }                                                                                                 \
+  } while (0)
 #define PP_FPSB_END()                                                         \
   do {                                                                        \
     if (blockIdx.x == 0 && lane == 0) {                                       \
@@ -89,6 +101,11 @@ int main(int argc, char** argv) {
     continue;
 #endif
     if (it < 2) continue;
+    unsigned long long at[16];
+    hipMemcpyFromSymbol(at, HIP_SYMBOL(g_at), sizeof(at));
+    printf(" cycles from the chain's start to pick 2^e:");
+    for (int e = 3; e <= 12; ++e) printf(" %d:%llu", 1 << e, at[e]);
+    printf("\n");
     const double rounds = (double)pr[0][12];
     printf(" %.0f rounds for %d picks: %.2f picks per round; rounds with k picks:", rounds, npoint - 1, (npoint - 1) / rounds);
     for (int k = 0; k <= 17; ++k)
