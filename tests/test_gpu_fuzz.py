@@ -171,9 +171,17 @@ def test_fuzz_furthest_sampling(cuda, seed):
     from pytorch_points_amd._ext import sampling
     rng = np.random.default_rng(7000 + seed)
     b = int(rng.integers(1, 4))
-    n = int(rng.choice([300, 1024, 2048, 2049, 3000, 4096, 5003, 8192, 12000, 16384, 20000]))
-    m = int(rng.choice([1, 5, 31, 32, 33, 64, 200, 513]))
+    n = int(rng.choice([300, 1024, 2048, 2049, 3000, 4096, 5003, 8192, 12000, 16384, 20000, 33000, 40000]))
+    m = int(rng.choice([1, 5, 31, 32, 33, 64, 200, 513, 1024, 1700]))
     m = min(m, n)
+    # the bucketed kernel's chain: the library's choice (several picks per round from 32768 points or 1024 picks), or
+    # several picks per round wherever the bucketed kernel runs (round 6)
+    import ctypes
+    from pytorch_points_amd import _lib
+    chain = _lib.lib().pp_debug_set_fps_bucket_chain
+    chain.argtypes = [ctypes.c_int]
+    chain.restype = None
+    force_batched = bool(rng.integers(0, 2))
     x = _cloud(rng, b, n, int(rng.integers(0, 8)))
     start = int(rng.integers(0, n))
     t0 = None
@@ -183,8 +191,12 @@ def test_fuzz_furthest_sampling(cuda, seed):
     idx = torch.empty(b, m, dtype=torch.int32, device=cuda)
     temp = torch.from_numpy(t0).to(cuda) if t0 is not None else torch.full((b, n), 1e10, dtype=torch.float32, device=cuda)
     pts = torch.empty(b, m, 3, device=cuda)
-    sampling.furthest_sampling(m, start, torch.from_numpy(x).to(cuda), temp, idx, pts, False)
-    assert np.array_equal(idx.cpu().numpy(), e_idx), (b, n, m, start)
+    chain(2 if force_batched else 0)
+    try:
+        sampling.furthest_sampling(m, start, torch.from_numpy(x).to(cuda), temp, idx, pts, False)
+    finally:
+        chain(0)
+    assert np.array_equal(idx.cpu().numpy(), e_idx), (b, n, m, start, force_batched)
     assert np.array_equal(temp.cpu().numpy(), e_temp), (b, n, m, start)
     assert np.array_equal(pts.cpu().numpy(), np.take_along_axis(x, e_idx[..., None].astype(np.int64), 1))
 
