@@ -32,6 +32,9 @@ void pp_debug_set_nmdistance_build(int general);
  * are routed to the every-pair kernel, launched behind the search once an earlier call on the device has routed one:
  * 0 = that, 1 = never (the search serves every direction), 2 = the every-pair launch always follows */
 void pp_debug_set_nmdistance_routing(int mode);
+/* grid search, unlabeled: the far-field (group) search of the list kernel skips the cell rows that hold no points by a
+ * per-set row bitmap written in the stage-A launch's tail: 0 = that (default), 1 = every row is looked up (tests, A/B) */
+void pp_debug_set_nmdistance_row_bitmap(int off);
 /* labeled Chamfer brute force: 1 = the one-lane-per-query kernel */
 void pp_debug_set_labeled_variant(int variant);
 /* Chamfer backward: 1 LDS doubles, 2 CSR lists, 3 LDS fp32 columns, 4 global atomics, 5 deterministic */

@@ -64,6 +64,8 @@ __device__ unsigned g_qwave[kQWaves][10];
 __device__ unsigned g_qstart[kQWaves][2];    // a wave's first and last stamp (10 ns units, low 32 bits of the clock)
 __device__ unsigned long long g_qgroup[8];  // group search: calls, groups, blind groups, candidates of the row cuts, max of them in one call, rows of the
                                              // boxes, rows listed by pass 1, candidates the whole wave walked
+__device__ unsigned g_qgw[kQWaves][16];       // group search, per wave: groups, blind groups, candidates of the row cuts, candidates walked, rows listed, batches
+extern "C" int pp_debug_read_query_wave_groups(void* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qgw), sizeof(g_qgw)); }
 __device__ unsigned long long g_qgt[8];      // group search: time (10 ns) in sampling, grouping, row listing, row cuts + spans, candidate fetch + sift, walk
 extern "C" int pp_debug_read_query_group_times(void* out, int reset) {
   int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qgt), sizeof(g_qgt));
@@ -73,6 +75,10 @@ extern "C" int pp_debug_read_query_group_times(void* out, int reset) {
   }
   return rc;
 }
+#ifdef PP_QUERY_PROBE_NO_GROUP_STATS  // (the waves' phase stamps only: the group search's own clocks and counters cost it a factor)
+#define PP_GT_DECL
+#define PP_GT(i)
+#else
 #define PP_GT_DECL unsigned long long pp_gtp = wall_clock64(), pp_gt[6] = {0, 0, 0, 0, 0, 0}
 #define PP_GT(i)                                   \
   do {                                             \
@@ -80,6 +86,7 @@ extern "C" int pp_debug_read_query_group_times(void* out, int reset) {
     pp_gt[i] += pp_n - pp_gtp;                     \
     pp_gtp = pp_n;                                 \
   } while (0)
+#endif
 extern "C" int pp_debug_read_query_phases(void* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qphase), sizeof(g_qphase));
 }
@@ -149,8 +156,11 @@ constexpr int kCellStride = kGridCells + 4;
 //   [.., +4*T)                     int pend[T]        unlabeled searches: the queries stage A left (positions in the query
 //                                  cloud's sorted order), 64 slots per wave of the stage-A kernel
 //   [.., +4*(T/64 + S + 1))        unsigned pend_cnt[...]   how many of a wave's 64 slots are filled
+//   [.., +4*S)                     unsigned routed[S]       directions routed to the every-pair kernel in front of the build
+//   [.., +128*S)                   unsigned rowbits[S][32]  bit (y + gy z) of a set: its cell row (y, z) holds points; written by
+//                                  the stage-A launch's tail workgroups for the group search of the list kernel (round 6)
 struct Layout {
-  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, tile_z, layers, pend, pend_cnt, routed, total;
+  size_t sets, cell_start, sorted, sub_start, sub_desc, sorted2, slab, slab2, tile_z, layers, pend, pend_cnt, routed, rowbits, total;
   int chunks;  // chunk-table entries per set and slab (0: sets too large for the table)
 };
 __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled = false) {
@@ -171,7 +181,8 @@ __host__ __device__ inline Layout make_layout(int B, int N, int M, bool labeled 
   L.pend = L.layers + (L.chunks ? ((4 * S * pp::kLayerWords + 255) / 256) * 256 : 0);
   L.pend_cnt = L.pend + (L.chunks ? 4 * T : 0);
   L.routed = L.pend_cnt + (L.chunks ? ((4 * (T / 64 + S + 1) + 255) / 256) * 256 : 0);  // [S]: directions routed to the every-pair kernel before the build
-  L.total = L.routed + (L.chunks ? ((4 * S + 255) / 256) * 256 : 0);
+  L.rowbits = L.routed + (L.chunks ? ((4 * S + 255) / 256) * 256 : 0);  // [S][32]: which cell rows of a set hold points (bit y + gy z)
+  L.total = L.rowbits + (L.chunks ? 128 * S : 0);
   return L;
 }
 // second-level arrays of set (b, dir): first table entry / first descriptor
@@ -480,7 +491,7 @@ constexpr int kGroupBatch = 256;  // candidates per LDS batch of wave_group_sear
 // a blind seed's group: the open queries within this fraction of its candidate's distance (round 3: 1/4 made groups as
 // long as a row of the query grid -- 64 consecutive sorted queries run along x -- and the bound of a group is its
 // farthest member's: disjoint clouds examined 6000 candidates per query)
-constexpr float kBlindGroup = 0.25f;
+constexpr float kBlindGroup = 0.35f;  // (round 6, with the nearest-first parts below: 0.25 -> 0.35 blobs8 0.468 -> 0.455, disjoint +1 %)
 // The constants of the stages behind stage A, as round 5's A/B runs settled them (each was a -D switch of a variant
 // library then: profiles/r5/near_field_stages_ab.txt; frozen in round 6).  The forms they chose between and that lost --
 // a lane per query instead of the pooled ball / cube, no ball after the cubes, a lane per query for labeled searches --
@@ -492,6 +503,7 @@ constexpr int kPoolMin = 1;         // ... pooled over the wave (unlabeled searc
 constexpr int kBallMin = 6;         // lanes with a candidate from which the ball around it is walked a lane per query
 constexpr int kSerialFar = 8;
 constexpr int kSerialMax = 24;      // open lanes of a wave from which the whole-wave cubes are skipped for the group search
+constexpr int kOpenJoin = 16;       // open lanes of a wave from which its pending lanes go to the group search with them
 constexpr int kLaneStageMin = 6;    // open lanes of a wave from which the cubes are searched a lane per query
 
 // distance (in cells) from a query at position f inside cell c to the nearer face of its 2-cell block along one
@@ -798,7 +810,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
                                                              const float* __restrict__ slab, float qx, float qy,
                                                              float qz, float ql, float best, int bidx, unsigned open_lo,
                                                              unsigned open_hi, lds_f4_wptr lw, lds_f_wptr lwl,
-                                                             int row_room) {
+                                                             int row_room, const unsigned* __restrict__ rowbits) {
   const lds_f4_ptr lr = (lds_f4_ptr)lw;
   const lds_f_ptr lrl = (lds_f_ptr)lwl;
   const int lane = threadIdx.x & 63;
@@ -822,6 +834,18 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
                 hi = (c == gdim - 1 && rim_open) ? inf : mn + (float)(c + 1) * g.h;
     return fmaxf(fmaxf(lo - bhi, blo - hi) - slack, 0.0f);
   };
+  // Round 6: the set's row bitmap (bit y + gy z: the cell row (y, z) holds points; nullptr: not available, every row
+  // counts).  Between clusters a group's box is hundreds of rows of which a handful hold anything: the sampling, the row
+  // list and the cuts below take the non-empty ones only.  Lane l holds word l & 31.
+  // (used where at most half of the rows hold points: on a filled grid the lookups cost a Gaussian 3 % and skip nothing)
+  const unsigned rbw = rowbits != nullptr ? rowbits[lane & 31] : 0xffffffffu;
+  const unsigned rb_pc = lane < 32 ? (unsigned)__builtin_popcount(rbw) : 0u;
+  const unsigned rb_incl = pp::wave_scan_u32_dpp(rb_pc);
+  const int rb_rows = __builtin_amdgcn_readlane((int)rb_incl, 63);
+  const bool have_rb = rowbits != nullptr && 2 * rb_rows <= g.gy * g.gz;  // (wave-uniform)
+  auto row_has_points = [&](int row) {  // row = y + gy z (any lane, any row < 1024)
+    return ((unsigned)__shfl((int)rbw, row >> 5) >> (row & 31)) & 1u;
+  };
 #ifdef PP_QUERY_PROBE
   unsigned long long pp_ngroups = 0, pp_nblind = 0, pp_ncand = 0, pp_nrows = 0, pp_nwalk = 0, pp_nlist = 0;
 #endif
@@ -838,18 +862,44 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     if (blind) {
       // one sample per non-empty cell row -- the first point at or after the seed's cell along x, else the row's last
       // point -- kSmp chunks of rows in flight; the nearest sample bounds the seed's neighbour
-      const int nall = g.gy * g.gz;
       const int cxs = cell_coord(sx, g.minx, g.invh, g.gx);
       float u1 = inf;
       float smx = 0.0f, smy = 0.0f, smz = 0.0f;  // this lane's nearest sample
       constexpr int kSmp = 6;  // chunks of 64 rows in flight (676 rows of a 26^3 grid: two rounds of two dependent loads)
+      // (the rows by rank among the non-empty ones: the word by bisection over the words' prefix counts, the bit by halving)
+      const int nall = have_rb ? rb_rows : g.gy * g.gz;
+      const bool rb_select = have_rb;
+      auto kth_row = [&](int k) {  // k < nall
+        int lo = 0, hi = 31;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+          const int mid = (lo + hi + 1) >> 1;
+          const unsigned before = (unsigned)__shfl((int)(rb_incl - rb_pc), mid);  // set bits in the words before `mid`
+          const bool ge = before <= (unsigned)k;
+          lo = ge ? mid : lo;
+          hi = ge ? hi : mid - 1;
+        }
+        unsigned v = (unsigned)__shfl((int)rbw, lo);
+        int rnk = k - (int)(unsigned)__shfl((int)(rb_incl - rb_pc), lo), pos = 0;
+#pragma unroll
+        for (int wdt = 16; wdt >= 1; wdt >>= 1) {
+          const int c = __builtin_popcount(v & ((1u << wdt) - 1u));
+          const bool up = rnk >= c;
+          rnk -= up ? c : 0;
+          v = up ? v >> wdt : v;
+          pos += up ? wdt : 0;
+        }
+        return lo * 32 + pos;
+      };
       for (int r0 = 0; r0 < nall; r0 += 64 * kSmp) {
         unsigned rs[kSmp], rm[kSmp], re[kSmp];
 #pragma unroll
         for (int u = 0; u < kSmp; ++u) {
-          const int r = r0 + u * 64 + lane;
-          const bool ok = r < nall;
-          const int base = (ok ? r : 0) * g.gx;
+          const int rk = r0 + u * 64 + lane;
+          const bool ok = rk < nall;
+          int r = ok ? rk : 0;
+          if (rb_select && r0 + u * 64 < nall) r = kth_row(r);  // (wave-uniform condition: whole chunks beyond the last row skip it)
+          const int base = r * g.gx;
           rs[u] = cell_start[base];
           rm[u] = cell_start[base + cxs];
           re[u] = ok ? cell_start[base + g.gx] : rs[u];
@@ -947,6 +997,20 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     }
     ub = pp::wave_reduce_dpp<false>(ub);
     float U = ub * 1.0001f;
+#ifdef PP_QUERY_PROBE
+    {
+      const unsigned pp_w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+      if (lane == 0 && pp_w < (unsigned)kQWaves && pp_ngroups == 1) {
+        g_qgw[pp_w][6] = __float_as_uint(bhx - blx);
+        g_qgw[pp_w][7] = __float_as_uint(bhy - bly);
+        g_qgw[pp_w][8] = __float_as_uint(bhz - blz);
+        g_qgw[pp_w][9] = __float_as_uint(sqrtf(us));
+        g_qgw[pp_w][10] = __float_as_uint(sqrtf(U));
+        g_qgw[pp_w][11] = (unsigned)__builtin_popcountll(members);
+        g_qgw[pp_w][12] = __float_as_uint(g.h);
+      }
+    }
+#endif
     // the rows within sqrt(U) of the box (cell coordinates are monotonic in the coordinate: exact)
     const bool bounded = U < inf;
     const float R = bounded ? fast_sqrt(U) * 1.0001f + slack : 0.0f;
@@ -965,7 +1029,10 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     auto piece_cut = [&](int rr, int cy, int cz, float& xlo, float& xhi) {
       xlo = inf;
       xhi = -inf;
-      if (rr >= nrows) return;
+      // (the bitmap's words travel through ds_bpermute: looked up by EVERY lane before the lanes part -- a disabled lane's
+      //  word reads as zero -- and for a row inside the table whatever rr is)
+      const bool has_points = row_has_points((cy + g.gy * cz) & (pp::kGridMax * pp::kGridMax - 1)) != 0u;
+      if (rr >= nrows || !has_points) return;
       const float gy_ = axis_gap(bly, bhy, g.miny, cy, g.gy), gz_ = axis_gap(blz, bhz, g.minz, cz, g.gz);
       const float gyz = __builtin_fmaf(gz_, gz_, gy_ * gy_) * 0.9999f;
       if (!bounded) {
@@ -1028,9 +1095,14 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         for (int k = 0; k < kSub; ++k) su[k] = fminf(su[k], U);
         ubm = fminf(ubm, best * 1.0001f);
       }
-      const int rr = r0 + lane < nq ? (listed ? (int)rowq[r0 + lane] : r0 + lane) : nrows;
-      const int dz = (int)(((float)rr + 0.5f) * inv_ny);
-      const int cz = z0 + dz, cy = y0 + (rr - dz * ny);
+      int rr = r0 + lane < nq ? (listed ? (int)rowq[r0 + lane] : r0 + lane) : nrows;  // (travels with the row's span below)
+      int cy, cz;
+      auto row_coords = [&]() {
+        const int dz = (int)(((float)rr + 0.5f) * inv_ny);
+        cz = z0 + dz;
+        cy = y0 + (rr - dz * ny);
+      };
+      row_coords();
       unsigned cs = 0u, len = 0u;
       float xlo, xhi;  // the row's cut along x
       piece_cut(rr, cy, cz, xlo, xhi);
@@ -1049,17 +1121,12 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
           len = cell_start[base + x1 + 1] - cs;
         }
       };
-      load_span();
-      // candidates of the pieces' cuts in these rows
-      const unsigned box_total = (unsigned)__builtin_amdgcn_readlane((int)pp::wave_scan_u32_dpp(len), 63);
-      // (the member-by-member cut costs the wave ~30 instructions per member: it pays when the cut above left more
-      //  candidates than that buys examined by every lane)
-      if (bounded && box_total > (unsigned)kMemberCutMin * (unsigned)__builtin_popcountll(members) && members != (1ull << seed)) {  // (wave-uniform)
-        // Member by member (round 3): the cut above measures from the BOX (its nearest face) with the LARGEST bound of
-        // a piece -- between far clouds that is the box's diagonal too generous, thousands of candidates where every
-        // member's own ball holds a handful.  A candidate of this row matters only if it lies within SOME member's own
-        // bound: the hull of the members' own cuts, intersected with the cut above.
-        // (the slack folded into the row's faces: gap = max3(lo' - q, q - hi', 0))
+      // Member by member (round 3): the cut above measures from the BOX (its nearest face) with the LARGEST bound of
+      // a piece -- between far clouds that is the box's diagonal too generous, thousands of candidates where every
+      // member's own ball holds a handful.  A candidate of this row matters only if it lies within SOME member's own
+      // bound: the hull of the members' own cuts, intersected with the cut above.
+      // (the slack folded into the row's faces: gap = max3(lo' - q, q - hi', 0))
+      auto member_cut = [&]() {
         const float ylo = ((cy == 0 && rim_open) ? -inf : g.miny + (float)cy * g.h) - slack,
                     yhi = ((cy == g.gy - 1 && rim_open) ? inf : g.miny + (float)(cy + 1) * g.h) + slack;
         const float zlo = ((cz == 0 && rim_open) ? -inf : g.minz + (float)cz * g.h) - slack,
@@ -1081,6 +1148,15 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         xlo = fmaxf(xlo, mlo);
         xhi = fminf(xhi, mhi);
         if (!rim_open && (xhi < box_x0 || xlo > box_x1)) xhi = -inf;  // (no member reaches the box in this row)
+      };
+      load_span();
+      // candidates of the pieces' cuts in these rows
+      const unsigned box_total = (unsigned)__builtin_amdgcn_readlane((int)pp::wave_scan_u32_dpp(len), 63);
+      // (the member-by-member cut costs the wave ~30 instructions per member: it pays when the cut above left more
+      //  candidates than that buys examined by every lane)
+      const bool by_member = bounded && members != (1ull << seed);  // (wave-uniform)
+      if (by_member && box_total > (unsigned)kMemberCutMin * (unsigned)__builtin_popcountll(members)) {  // (wave-uniform)
+        member_cut();
         load_span();
       }
       if (__ballot(len != 0u) == 0ull) {  // wave-uniform: nothing in these rows
@@ -1088,9 +1164,49 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         continue;
       }
       dirty = true;
-      const unsigned incl = pp::wave_scan_u32_dpp(len);
-      const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-      const unsigned excl = incl - len;
+      unsigned incl = pp::wave_scan_u32_dpp(len);
+      unsigned rows_total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+      // Round 6: the rows of a block NEAREST FIRST (by the distance from the seed to the middle point of the row's span)
+      // where they hold more than one batch, and a block of more than kSplitMin candidates IN PARTS: the nearest rows
+      // that hold two batches first, then the rows still to come are cut again, member by member, by what the members
+      // have found -- a group between clusters meets its neighbours' cluster in its first batches, and the other clusters
+      // in reach of the first, crude bound (the nearest of one sample per row) are then out of every member's own reach,
+      // whole rows of them.  In cell order, cut once, the waves that decide the length of blobs8's launch walked 7000
+      // candidates of four clusters, every lane every point.  The order of the candidates does not matter to the result:
+      // the minimum is the exact (distance, index) one.
+      constexpr unsigned kSplitMin = 4u * (unsigned)kGroupBatch;  // (from 2 / 3 batches on, parts of 1 batch: blobs8 +1..4 %)
+      bool ordered = false;
+      {
+        const unsigned long long nzr = __ballot(len != 0u);
+        if (rows_total > (unsigned)kGroupBatch && (nzr & (nzr - 1ull)) != 0ull) {  // (wave-uniform)
+          const pp::f4 mp = sorted[cs + (len >> 1)];  // (an empty row reads sorted[0]: its key is not used)
+          const unsigned key = (unsigned)__float_as_int(pp::chamfer_d3(mp.x, mp.y, mp.z, sx, sy, sz));  // (bits: a total order)
+          unsigned rank = 0u;
+          for (unsigned long long m = nzr; m; m &= m - 1ull) {
+            const int jn = (int)__builtin_ctzll(m);
+            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, jn);
+            rank += (kj < key || (kj == key && jn < lane)) ? 1u : 0u;
+          }
+          const unsigned long long zr = ~nzr;  // the empty rows behind the others, in lane order: a permutation of the lanes
+          const unsigned zrank = (unsigned)__builtin_popcountll(nzr) +
+                                 __builtin_amdgcn_mbcnt_hi((unsigned)(zr >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)zr, 0u));
+          rank = len != 0u ? rank : zrank;
+          cs = (unsigned)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)cs);
+          len = (unsigned)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)len);
+          rr = __builtin_amdgcn_ds_permute((int)(rank << 2), rr);
+          incl = pp::wave_scan_u32_dpp(len);
+          ordered = true;
+        }
+      }
+      unsigned done_rows = 0u;  // lanes (rows, in their order after the sort) examined so far
+      for (;;) {                // wave-uniform: the block's parts
+      unsigned upto = 64u;
+      if (ordered && by_member && rows_total > kSplitMin)  // the leading rows that hold two batches (incl counts the rows not yet examined)
+        upto = (unsigned)__builtin_ctzll(__ballot(incl >= 2u * (unsigned)kGroupBatch)) + 1u;
+      const unsigned plen = ((unsigned)lane >= done_rows && (unsigned)lane < upto) ? len : 0u;
+      const unsigned pincl = upto == 64u ? incl : pp::wave_scan_u32_dpp(plen);
+      const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)pincl, 63);
+      const unsigned excl = pincl - plen;
       const unsigned shift = cs - excl;  // candidate c of this lane's row sits at sorted[c + shift]
 #ifdef PP_QUERY_PROBE
       pp_ncand += total;
@@ -1230,8 +1346,37 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
       }
+      done_rows = upto;
+      if (done_rows >= 64u) break;
+      // the rows still to come, cut again by the bounds as they are now
+      U = fminf(U, pp::wave_reduce_dpp<false>(member ? best : 0.0f) * 1.0001f);
+#pragma unroll
+      for (int k = 0; k < kSub; ++k) su[k] = fminf(su[k], U);
+      ubm = fminf(ubm, best * 1.0001f);
+      row_coords();
+      piece_cut(rr, cy, cz, xlo, xhi);
+      member_cut();
+      load_span();
+      len = (unsigned)lane >= done_rows ? len : 0u;
+      incl = pp::wave_scan_u32_dpp(len);
+      rows_total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+      if (rows_total == 0u) break;
+      }
     }
   }
+#ifdef PP_QUERY_PROBE
+  {
+    const unsigned pp_w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (lane == 0 && pp_w < (unsigned)kQWaves) {
+      g_qgw[pp_w][0] = (unsigned)pp_ngroups;
+      g_qgw[pp_w][1] = (unsigned)pp_nblind;
+      g_qgw[pp_w][2] = (unsigned)pp_ncand;
+      g_qgw[pp_w][3] = (unsigned)pp_nwalk;
+      g_qgw[pp_w][4] = (unsigned)pp_nlist;
+      g_qgw[pp_w][5] = (unsigned)__builtin_popcountll(((unsigned long long)open_hi << 32) | open_lo);
+    }
+  }
+#endif
 #if defined(PP_QUERY_PROBE) && !defined(PP_QUERY_PROBE_NO_GROUP_STATS)  // (same-address atomics: they distort p7)
   if (lane == 0) {
     atomicAdd(&g_qgroup[0], 1ull);
@@ -1687,7 +1832,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
                                                const float* __restrict__ label1, const float* __restrict__ label2,
                                                const Layout& L, const int b, const int dir, const int jj,
                                                const bool valid, const bool skip_a, lds_f4_wptr s_pts_w,
-                                               lds_f_wptr s_lab_w) {
+                                               lds_f_wptr s_lab_w, const unsigned* __restrict__ rowbits = nullptr) {
   PP_QPHASE_DECL;
   PP_SPHASE(0);
   const int lane = threadIdx.x & 63;
@@ -2138,7 +2283,11 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
       pending &= ~farish;
     }
   }
-  if (__builtin_popcountll(pending) >= kSerialMax) {
+  // (round 6) ... or where the group search runs anyway for many lanes: the pending lanes join its groups for next to
+  // nothing -- the walk is paid per group, not per member -- where one after the other they cost the wave ~9 us each
+  // (blobs8 0.625 -> 0.49 ms; from 1, 4, 8 or 32 open lanes on: the same)
+  if (__builtin_popcountll(pending) >= kSerialMax ||
+      (pending != 0ull && __builtin_popcountll(open) >= kOpenJoin)) {
     // many (next to crowded cells, typically: every one of them would scan those cells by itself, ~ 0.8 wave
     // instructions per candidate and query against ~ 13 per candidate for all of them in the group search)
     open |= pending;
@@ -2166,7 +2315,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     const unsigned long long todo = open & __ballot(finite);
     if (todo) {
       const Found f = wave_group_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, best, bidx, (unsigned)todo,
-                                             (unsigned)(todo >> 32), s_pts_w, s_lab_w, (CAPW + 4 - kGroupBatch) * 8);
+                                             (unsigned)(todo >> 32), s_pts_w, s_lab_w, (CAPW + 4 - kGroupBatch) * 8, rowbits);
       if ((todo >> lane) & 1ull) {
         const bool none = f.bidx == 0x7fffffff;  // (labeled: nobody carries this label -- ref nmdistance_cuda.cu:110-113)
         od[j] = (LAB && none) ? 0.0f : f.best;
@@ -2244,7 +2393,8 @@ __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_l
                                                                   float* __restrict__ dist2, int* __restrict__ idx2,
                                                                   unsigned char* __restrict__ ws, int B, int N, int M,
                                                                   int waves_per_set, const Layout L,
-                                                                  const unsigned* __restrict__ pre_routed) {
+                                                                  const unsigned* __restrict__ pre_routed,
+                                                                  const unsigned* __restrict__ rowbits) {
   static_assert((CAPW + 4) * 16 >= 1024 * 4, "the prefix sums of up to 1024 counts use the wave's slice");
   __shared__ pp::f4 s_pts[kListWgWaves][CAPW + 4];
   const int wave = pp::wave_id_uniform();
@@ -2369,7 +2519,8 @@ __global__ __launch_bounds__(64 * kListWgWaves, PP_LIST_WAVES) void grid_query_l
       skip_a = __all(!valid || (entry & kPendTried) != 0);
     }
     search_queries<false, CAPW, PP_LIST_WAVES>(xyz1, xyz2, dist1, idx1, dist2, idx2, ws, B, N, M, nullptr, nullptr, L, b, dir,
-                                entry & ~kPendTried, valid, skip_a, (lds_f4_wptr)(&s_pts[wave][0]), (lds_f_wptr) nullptr);
+                                entry & ~kPendTried, valid, skip_a, (lds_f4_wptr)(&s_pts[wave][0]), (lds_f_wptr) nullptr,
+                                rowbits != nullptr ? rowbits + (size_t)set * 32 : nullptr);
   }
 }
 
@@ -2470,9 +2621,28 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
     // (routed_host): from its next calls on the decision is taken in front of the build (route_decide_kernel) and the
     // every-pair kernel serves the routed directions.  This call's search serves them itself.
     const int set = (int)blockIdx.x - nvt;
-    if (set >= 2 * B || wave != 0) return;
-    const int b = set >> 1, dir = set & 1;
+    if (set >= 2 * B) return;
     const GridSet* gs = reinterpret_cast<const GridSet*>(ws + L.sets);
+    // ... and which cell rows of the set's grid hold points at all (rowbits): between clusters the group search's boxes
+    // are hundreds of rows of which a handful are not empty (blobs8: 236 rows listed per group, ~6 with points)
+    if (pre_routed == nullptr || pre_routed[set] == 0u) {  // (a routed direction's tables may not have been built)
+      const GridSet g = gs[set];
+      const int gx = min(max(g.gx, 1), pp::kGridMax);
+      const int nall = g.useless ? 0 : min(max(g.gy, 1), pp::kGridMax) * min(max(g.gz, 1), pp::kGridMax);
+      const unsigned* __restrict__ cs = reinterpret_cast<const unsigned*>(ws + L.cell_start) + (size_t)set * kCellStride;
+      unsigned* __restrict__ rb = reinterpret_cast<unsigned*>(ws + L.rowbits) + (size_t)set * 32;
+      for (int r0 = wave * 64; r0 < pp::kGridMax * pp::kGridMax; r0 += TQ) {  // (wave-uniform)
+        const int r = r0 + lane;
+        const bool ne = r < nall && cs[(r + 1) * gx] != cs[r * gx];
+        const unsigned long long bal = __ballot(ne);
+        if (lane == 0) {
+          rb[r0 >> 5] = (unsigned)bal;
+          rb[(r0 >> 5) + 1] = (unsigned)(bal >> 32);
+        }
+      }
+    }
+    if (wave != 0 || routed_host == nullptr) return;
+    const int b = set >> 1, dir = set & 1;
     const int r_useless = gs[set].useless, q_useless = gs[set ^ 1].useless;
     const int nr = dir ? N : M, nq = dir ? M : N;
     bool hopeless = r_useless != 0;  // (a degenerate reference set -- identical points: no grid -- is routed as it is)
@@ -2961,6 +3131,8 @@ static const RouteWord* route_word(int dev) {
   }
   return fresh;
 }
+static pp::Knob g_rowbits_mode;  // 0: the group search skips the empty cell rows by the set's row bitmap; 1: it does not (A/B, tests)
+extern "C" void pp_debug_set_nmdistance_row_bitmap(int v) { g_rowbits_mode.set(v); }
 static pp::Knob g_route_mode;  // 0 automatic, 1 never route (the list kernel serves everything), 2 always issue the every-pair launch
 extern "C" void pp_debug_set_nmdistance_routing(int mode) { g_route_mode.set(mode); }
 
@@ -3084,7 +3256,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
     long long g_ = (long long)ncu * (PER_CU_);                                                                  \
     g_ = (g_ < (long long)aper * 8 ? g_ : (long long)aper * 8);                                                 \
     g_ = (g_ + 7) / 8 * 8;                                                                                      \
-    if ((PER_CU_) >= 1024 && route_dev != nullptr) g_ += 2 * B;  /* the routing workgroups, behind the tiles' */ \
+    if ((PER_CU_) >= 1024) g_ += 2 * B;  /* a workgroup per direction behind the tiles': routing test, row bitmap */ \
     if (own) {                                                                                                  \
       hipExtLaunchKernelGGL((grid_stage_a_kernel<TQ_, CAP_, WPE_, ((PER_CU_) < 1024)>), dim3((unsigned)g_), dim3(TQ_), 0, s, \
                             g_evk[2], g_evk[3], 0, dist1, idx1, dist2, idx2, ws, B, N, M, ta1, ta2, (int)ablocks, aper, lay, \
@@ -3117,8 +3289,10 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
     const int sets = 2 * B;
     const int wps = ((N > M ? N : M) + 63) / 64;  // a wave for every 64 queries of a direction: as the whole-search kernel
     const long long lwaves = (long long)sets * wps;
+    // (the row bitmaps are written by the tail workgroups of the stage-A launch: the non-persistent forms)
+    const unsigned* rowbits = (tile != 513 && g_rowbits_mode != 1) ? reinterpret_cast<const unsigned*>(ws + lay.rowbits) : nullptr;
     grid_query_list_kernel<384><<<dim3((unsigned)(((lwaves + kListWgWaves - 1) / kListWgWaves + 7) / 8 * 8)), dim3(64 * kListWgWaves), 0, s>>>(xyz1, xyz2, dist1, idx1, dist2, idx2,
-                                                                                      ws, B, N, M, wps, lay, pre_routed);
+                                                                                      ws, B, N, M, wps, lay, pre_routed, rowbits);
     if (routing) {
       PP_RETURN_IF_LAUNCH_FAILED();
       const int rc = pp::nmdist_forward_routed(xyz1, xyz2, dist1, idx1, dist2, idx2, B, N, M, pre_routed, 1, s);

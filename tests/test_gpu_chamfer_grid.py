@@ -570,3 +570,52 @@ def test_routed_directions_equal_brute_force(cuda, name):
                         name, mode, rep, what, int((g != e).sum()))
     finally:
         route(0)
+
+
+# ---- round 6: the group search takes the non-empty cell rows only (a per-set row bitmap written in the stage-A launch's
+# tail).  Clouds whose grids are mostly empty rows -- clusters at different places, a line, a few outliers that stretch
+# the box -- searched with the bitmap (default) and without it: both are the every-pair kernel's bits.
+def _sparse_row_cases():
+    c = {}
+    rng = np.random.default_rng(77)
+
+    def blobs(seed, b, n, k, sigma, span):
+        r = np.random.default_rng(seed)
+        cen = r.random((b, k, 3), dtype=np.float32) * np.float32(span)
+        pick = r.integers(0, k, n)
+        return (cen[:, pick] + r.standard_normal((b, n, 3)).astype(np.float32) * np.float32(sigma)).astype(np.float32)
+
+    c["blobs8_other_places"] = (blobs(1, 3, 16384, 8, 0.02, 2.0), blobs(2, 3, 16384, 8, 0.02, 2.0))
+    c["blobs3_vs_blobs40"] = (blobs(3, 2, 9000, 3, 0.01, 1.0), blobs(4, 2, 12000, 40, 0.005, 1.0))
+    c["one_blob_vs_far_blob"] = (blobs(5, 2, 8192, 1, 0.03, 1.0), blobs(6, 2, 8192, 1, 0.03, 1.0) + np.float32(3.0))
+    line = np.zeros((2, 8192, 3), np.float32)
+    line[..., 0] = rng.random((2, 8192), dtype=np.float32)
+    line[..., 1] = line[..., 0] * np.float32(0.5)
+    c["diagonal_line_vs_blobs"] = (line, blobs(7, 2, 10000, 5, 0.02, 1.5))
+    stretched = blobs(8, 2, 8192, 2, 0.01, 0.3)
+    stretched[:, :6] = rng.random((2, 6, 3), dtype=np.float32) * np.float32(4.0)
+    c["two_blobs_and_six_outliers"] = (blobs(9, 2, 8192, 4, 0.02, 2.0) + np.float32(1.0), stretched)
+    c["ragged_blobs"] = (blobs(10, 1, 16383, 6, 0.02, 2.0), blobs(11, 1, 8195, 6, 0.02, 2.0))
+    return c
+
+
+SPARSE_ROWS = _sparse_row_cases()
+
+
+@pytest.mark.parametrize("name", sorted(SPARSE_ROWS))
+def test_group_search_row_bitmap_equals_brute_force(cuda, name):
+    from pytorch_points_amd import _lib
+    knob = _lib.lib().pp_debug_set_nmdistance_row_bitmap
+    knob.argtypes = [ctypes.c_int]
+    knob.restype = None
+    x1, x2 = [np.ascontiguousarray(a) for a in SPARSE_ROWS[name]]
+    ref = _run(cuda, x1, x2, 1)
+    try:
+        for off in (0, 1, 0):
+            knob(off)
+            got = _run(cuda, x1, x2, 2)
+            for g, e, what in zip(got, ref, ["dist1", "idx1", "dist2", "idx2"]):
+                assert np.array_equal(g, e), "%s (row bitmap %s): %s differs at %d places" % (
+                    name, "off" if off else "on", what, int((g != e).sum()))
+    finally:
+        knob(0)

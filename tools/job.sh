@@ -8,6 +8,7 @@
 #   shard     the batch-sharded exchange: one-rank RCCL paths, the distributed bench line's logic
 #   exchange  the exchange forms on a one-rank RCCL group, 300 steps each (profiles/r<N>/exchange_one_rank_runs.txt)
 #   benchline the default bench line once more (the eager number follows the host)
+#   chamfer   the grid search's parity tests, then the forward on the other clouds (tools/far_time.py)
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -69,5 +70,9 @@ d = json.loads(open("gpurun_out/benchline/bench_chamfer_n1.json").read().strip()
 print("eager %.4f ext %.4f host_bound %s" % (d["ms_per_step"], d["launch_modes_ms_per_step"]["ext"], d.get("host_bound")))
 PY
   ;;
-*) echo "usage: tools/job.sh final|tests|fuzz|fps|fpsquick|shard|exchange|benchline"; exit 2 ;;
+chamfer)
+  timeout 2400 python -m pytest tests/test_gpu_chamfer_grid.py tests/test_gpu_chamfer.py -m gpu -x -q > gpurun_out/pytest_chamfer.log 2>&1
+  tail -5 gpurun_out/pytest_chamfer.log
+  timeout 600 python tools/far_time.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/far_time.txt ;;
+*) echo "usage: tools/job.sh final|tests|fuzz|fps|fpsquick|shard|exchange|benchline|chamfer"; exit 2 ;;
 esac

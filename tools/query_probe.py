@@ -65,6 +65,28 @@ for mode in [int(a) for a in sys.argv[1:]] or [0]:
               " ".join("%d:%d" % (tt, int(((st <= tt) & (en > tt) & ok).sum())) for tt in range(0, int(en[ok].max()) + 1, max(1, int(en[ok].max()) // 12))))
         order = np.argsort(-life)[:12]
         print("   longest waves: " + " ".join("w%d[%.0f-%.0f]" % (w, st[w], en[w]) for w in order))
+        gw = None
+        if hasattr(L, "pp_debug_read_query_wave_groups"):
+            gw = np.zeros((1 << 17, 16), np.uint32)
+            rgw = L.pp_debug_read_query_wave_groups; rgw.argtypes = [ctypes.c_void_p]; rgw.restype = ctypes.c_int
+            assert rgw(gw.ctypes.data) == 0
+        for w in order:
+            print("      w%d phases (us): " % w + " ".join("p%d %.0f" % (k, wv[w, k]) for k in range(9)) +
+                  ("" if gw is None else "   group search: open lanes %d groups %d blind %d candidates %d walked %d rows listed %d" % (
+                      gw[w, 5], gw[w, 0], gw[w, 1], gw[w, 2], gw[w, 3], gw[w, 4]) +
+                   " | first group: %d members, box %.3f x %.3f x %.3f, sqrt(us) %.3f sqrt(U) %.3f, h %.3f" % (
+                      gw[w, 11], *[float(x) for x in gw[w, 6:11].view(np.float32)], float(gw[w, 12:13].view(np.float32)[0]))))
+        if gw is not None:
+            g = gw[:nw].astype(np.float64)
+            p7 = wv[:, 7]
+            for lo, hi in ((0, 20), (20, 50), (50, 100), (100, 200), (200, 1e9)):
+                sel = (p7 >= lo) & (p7 < hi)
+                if sel.any():
+                    print("      waves with p7 in [%g, %g) us: %d; mean open lanes %.1f groups %.1f blind %.1f candidates %.0f walked %.0f rows listed %.1f" % (
+                        lo, hi, int(sel.sum()), g[sel, 5].mean(), g[sel, 0].mean(), g[sel, 1].mean(), g[sel, 2].mean(), g[sel, 3].mean(), g[sel, 4].mean()))
+        lf = life[ok]
+        print("   wave life (us): mean %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f; sum over waves / (CUs x 1 us): %.1f" % (
+            lf.mean(), np.percentile(lf, 50), np.percentile(lf, 90), np.percentile(lf, 99), lf.max(), lf.sum() / 256.0))
         # which waves end last
         order = np.argsort(-en)[:12]
         print("   last to end:   " + " ".join("w%d[%.0f-%.0f]" % (w, st[w], en[w]) for w in order))
