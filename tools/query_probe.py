@@ -79,6 +79,18 @@ for mode in [int(a) for a in sys.argv[1:]] or [0]:
         if gw is not None:
             g = gw[:nw].astype(np.float64)
             p7 = wv[:, 7]
+            ext = gw[:nw, 6:9].copy().view(np.float32).max(1).astype(np.float64)   # largest extent of the first group's box
+            mem = g[:, 11]
+            lifes = wv.sum(1)
+            for lo, hi in ((0, 0.02), (0.02, 0.04), (0.04, 0.06), (0.06, 0.08), (0.08, 0.12), (0.12, 1e9)):
+                sel = (ext >= lo) & (ext < hi) & (g[:, 0] > 0)
+                if sel.any():
+                    print("      first group's box extent in [%g, %g): %d waves; life mean %.1f p90 %.1f max %.1f us; members %.1f groups %.1f" % (
+                        lo, hi, int(sel.sum()), lifes[sel].mean(), np.percentile(lifes[sel], 90), lifes[sel].max(), mem[sel].mean(), g[sel, 0].mean()))
+            for lo, hi in ((1, 2), (2, 3), (3, 4), (4, 99)):
+                sel = (g[:, 0] >= lo) & (g[:, 0] < hi)
+                if sel.any():
+                    print("      groups in [%d, %d): %d waves; life mean %.1f p90 %.1f max %.1f us" % (lo, hi, int(sel.sum()), lifes[sel].mean(), np.percentile(lifes[sel], 90), lifes[sel].max()))
             for lo, hi in ((0, 20), (20, 50), (50, 100), (100, 200), (200, 1e9)):
                 sel = (p7 >= lo) & (p7 < hi)
                 if sel.any():
