@@ -10,6 +10,7 @@ R=${1:-6}
 python -c "import __graft_entry__ as g; g.build()"
 ./tools/build_fps_bucket_probes.sh > /dev/null 2>&1 || true
 rm -f tools/libpp_hip_*.so
+PP_PROBE_FLAGS=-DPP_QUERY_PROBE_NO_GROUP_STATS PP_PROBE_OUT=tools/libpp_hip_probe_light.so bash tools/build_probe_lib.sh > /dev/null 2>&1 || true
 /usr/local/graft/bin/gpurun --timeout 3000 -- "PP_COMMIT=$C PP_ROUND=$R bash tools/regen_profiles.sh"
 mkdir -p profiles/r$R
 cp gpurun_out/r$R/* profiles/r$R/
