@@ -2379,11 +2379,13 @@ constexpr int kPendTried = 1 << 30;
 #define PP_LIST_WAVES 5  // waves per SIMD the kernel and its out-of-line stages are compiled for (96 registers)
 #endif
 #ifndef PP_LIST_WG_WAVES
-#define PP_LIST_WG_WAVES 4  // waves per workgroup of the list kernel (independent waves: only the dispatch sees the difference)
+#define PP_LIST_WG_WAVES 2  // waves per workgroup of the list kernel (independent waves; round 6: 4 -> 2 -- a workgroup's LDS and wave
+                            // slots are free when its LAST wave ends, and a long wave held three finished ones': blobs8 0.458 ->
+                            // 0.440 ms, 1: the same with the sphere's empty launch +1 %, 8 / 16: 0.49 / 0.62)
 #endif
 constexpr int kListWgWaves = PP_LIST_WG_WAVES;
 #ifndef PP_LIST_RIM_UNITS
-#define PP_LIST_RIM_UNITS 2
+#define PP_LIST_RIM_UNITS 4
 #endif
 constexpr int kListRimUnits = PP_LIST_RIM_UNITS;  // workgroups from either end of a set's tiles that the launch starts first
 template <int CAPW>
