@@ -1888,7 +1888,28 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
   float best = __builtin_inff();
   int bidx = 0x7fffffff;
   float thr = 0.0f;  // (nothing settles below it: skip_a leaves every query to the stages after stage A)
-  if (!skip_a) {  // (wave-uniform)
+  // Round 6: a query in the void -- by the set's row bitmap (list kernel, sets with crowded cells; words of ones where it
+  // was not made) the nine cell rows (y +- 1, z +- 1) around its cell hold nothing, so neither does its block nor its cube
+  // of radius 1: straight to the group search, which is where the cubes sent it after finding them empty, two dependent
+  // round trips per four rows later (blobs8: 10 us of a wave's 64 in the cubes, 7 in a stage A over empty rows).  A wave
+  // all of whose queries are such skips stage A.  A choice of route only: the group search is complete.
+  bool void_around = false;
+  if (rowbits != nullptr && pp::grid_refined(g)) {  // (wave-uniform; every lane takes part in the lookups: ds_bpermute)
+    const unsigned rbw = rowbits[lane & 31];
+    const int vy = cell_coord(qy, g.miny, g.invh, g.gy), vz = cell_coord(qz, g.minz, g.invh, g.gz);
+    unsigned any = 0u;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+      const int y = vy + e % 3 - 1, z = vz + e / 3 - 1;
+      const bool in = y >= 0 && y < g.gy && z >= 0 && z < g.gz;
+      const int row = in ? y + g.gy * z : 0;
+      // (no short-circuit: a lane that sat a lookup out would hand its word out as zero)
+      const unsigned w = (unsigned)__shfl((int)rbw, row >> 5);
+      any |= in ? (w >> (row & 31)) & 1u : 0u;
+    }
+    void_around = any == 0u;
+  }
+  if (!skip_a && !__all(void_around || !valid)) {  // (wave-uniform)
   // Stage A: the 2x2x2 block of cells nearest to q' (own cell + the neighbour on the side of the cell q' lies
   // in, per axis).  A point outside that block is beyond the far face of q''s cell along some axis (>= h/2
   // away) or beyond the neighbour (>= h away).  The block is four rows (y, z) of one or two cells (x0..x1).
@@ -2196,7 +2217,7 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
   const float out_x = fmaxf(g.minx - qx, qx - (g.minx + (float)g.gx * g.h)), out_y = fmaxf(g.miny - qy, qy - (g.miny + (float)g.gy * g.h)),
               out_z = fmaxf(g.minz - qz, qz - (g.minz + (float)g.gz * g.h));
   const bool far_out = fmaxf(out_x, fmaxf(out_y, out_z)) > 3.0f * g.h;
-  if (pend && far_out && !deferred) {
+  if (pend && (far_out || void_around) && !deferred) {
     open_lane = true;
     pend = false;
   }
@@ -2315,7 +2336,8 @@ __device__ __forceinline__ void search_queries(const float* __restrict__ xyz1, c
     const unsigned long long todo = open & __ballot(finite);
     if (todo) {
       const Found f = wave_group_search<LAB, W>(g, cell_start, sorted, slab, qx, qy, qz, ql, best, bidx, (unsigned)todo,
-                                             (unsigned)(todo >> 32), s_pts_w, s_lab_w, (CAPW + 4 - kGroupBatch) * 8, rowbits);
+                                             (unsigned)(todo >> 32), s_pts_w, s_lab_w, (CAPW + 4 - kGroupBatch) * 8,
+                                             refined_set ? rowbits : nullptr);  // (only such sets have a bitmap)
       if ((todo >> lane) & 1ull) {
         const bool none = f.bidx == 0x7fffffff;  // (labeled: nobody carries this label -- ref nmdistance_cuda.cu:110-113)
         od[j] = (LAB && none) ? 0.0f : f.best;
@@ -2617,12 +2639,16 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   const int nvt = per_xcd * 8;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = pp::wave_id_uniform();
-  if (!PERSIST && (int)blockIdx.x >= nvt) {
+  // (the per-direction workgroups come FIRST in the launch -- 2 B of them rounded up to a multiple of eight, so that the
+  //  tiles keep their XCDs: behind the tiles they started last and a launch whose tiles all decline waited 2-3 us for them)
+  const int head = PERSIST ? 0 : (2 * B + 7) / 8 * 8;
+  const int bid = (int)blockIdx.x - head;  // the tile's workgroup
+  if (!PERSIST && bid < 0) {
     // Round 6: 2 B workgroups behind the tiles' (dispatched last, into the launch's tail), one per direction: is this
     // a direction no search can prune (direction_unprunable, on samples of the sorted clouds)?  Then the host is told
     // (routed_host): from its next calls on the decision is taken in front of the build (route_decide_kernel) and the
     // every-pair kernel serves the routed directions.  This call's search serves them itself.
-    const int set = (int)blockIdx.x - nvt;
+    const int set = (int)blockIdx.x;
     if (set >= 2 * B) return;
     const GridSet* gs = reinterpret_cast<const GridSet*>(ws + L.sets);
     // ... and which cell rows of the set's grid hold points at all (rowbits): between clusters the group search's boxes
@@ -2672,7 +2698,7 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   __shared__ unsigned s_tot;  // queries of the tile left pending
   PP_QPHASE_DECL;
   StageAFront<TQ> nx;
-  stage_a_issue<TQ>(nx, (int)blockIdx.x, per_xcd, total, tiles1, tiles2, N, M, ws, L, t, lane);
+  stage_a_issue<TQ>(nx, bid, per_xcd, total, tiles1, tiles2, N, M, ws, L, t, lane);
   // A tile's results are stored at the top of the NEXT iteration, behind that iteration's wait for its front: the
   // wait below must be vmcnt(0) (the asm load), and scattered 4-byte stores issued just before it would make every
   // tile wait for them to retire.
@@ -2680,7 +2706,7 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
   int sv_i = 0, sv_off = 0, sv_dir = 0;
   bool sv_ok = false;
   // (!PERSIST: a workgroup per tile, the loop is one pass and the compiler knows it: no state lives across it)
-  for (int it = (int)blockIdx.x; it < (PERSIST ? nvt : (int)blockIdx.x + 1); it += (PERSIST ? (int)gridDim.x : 1)) {  // workgroup-uniform
+  for (int it = bid; it < (PERSIST ? nvt : bid + 1); it += (PERSIST ? (int)gridDim.x : 1)) {  // workgroup-uniform
   PP_APHASE(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's front has landed (the asm load of the query too)
   if (sv_ok) {
@@ -3262,7 +3288,7 @@ static int grid_forward(const float* xyz1, const float* xyz2, const float* label
     long long g_ = (long long)ncu * (PER_CU_);                                                                  \
     g_ = (g_ < (long long)aper * 8 ? g_ : (long long)aper * 8);                                                 \
     g_ = (g_ + 7) / 8 * 8;                                                                                      \
-    if ((PER_CU_) >= 1024) g_ += 2 * B;  /* a workgroup per direction behind the tiles': routing test, row bitmap */ \
+    if ((PER_CU_) >= 1024) g_ += (2 * B + 7) / 8 * 8;  /* a workgroup per direction in front of the tiles': routing test, row bitmap */ \
     if (own) {                                                                                                  \
       hipExtLaunchKernelGGL((grid_stage_a_kernel<TQ_, CAP_, WPE_, ((PER_CU_) < 1024)>), dim3((unsigned)g_), dim3(TQ_), 0, s, \
                             g_evk[2], g_evk[3], 0, dist1, idx1, dist2, idx2, ws, B, N, M, ta1, ta2, (int)ablocks, aper, lay, \
