@@ -303,9 +303,6 @@ __global__ __launch_bounds__(kBuildThreads) void grid_build_kernel(const float* 
 // PIPE = true (serve_long_scans): four steps per round, their loads issued together: with one dependent load per step
 // a scan of thousands of candidates costs its length in memory round trips.
 constexpr unsigned kScanInline = 512;
-#ifndef PP_SCAN_ONE_ROW
-#define PP_SCAN_ONE_ROW 1
-#endif
 template <bool LAB, bool PIPE>
 __device__ __forceinline__ unsigned long long wave_scan_rows(int nrows, unsigned rs, unsigned re,
                                                              const pp::f4* __restrict__ sorted,
@@ -347,7 +344,7 @@ __device__ __forceinline__ unsigned long long wave_scan_rows(int nrows, unsigned
       // row is thousands of candidates long -- needs no search for its candidates' rows: two ballots find that out and
       // the row (the search is 3 nrows instructions per candidate against 12 for its distance)
       const bool mine = lane < nrows && len > 0u;
-      if (PP_SCAN_ONE_ROW && __ballot(mine && excl > c0 && excl < c0 + 256u) == 0ull) {  // (wave-uniform)
+      if (__ballot(mine && excl > c0 && excl < c0 + 256u) == 0ull) {  // (wave-uniform)
         const unsigned long long upto = __ballot(mine && excl <= c0);
         const unsigned sh = (unsigned)__builtin_amdgcn_readlane((int)shift, 63 - (int)__builtin_clzll(upto | 1ull));
 #pragma unroll
@@ -1057,14 +1054,10 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
     typedef unsigned short __attribute__((address_space(3))) * lds_u16_ptr;
     const lds_u16_ptr rowq = (lds_u16_ptr)(lw + kGroupBatch);
     int nq = 0;
-#ifdef PP_NO_ROWLIST
-    const bool listed = false;
-#else
     // (a box of at most 64 rows is one block anyway: no list; row_room: the two-byte entries the wave's slice holds
     //  behind the candidate batch -- 1056 for slices of 384 points, the default; a smaller slice lists smaller boxes only)
     const bool listed = nrows > 64 && nrows <= row_room;
-#endif
-    if (!listed) nq = nrows;  // PP_NO_ROWLIST: every block of rows
+    if (!listed) nq = nrows;  // every block of rows
     for (int r0 = 0; listed && r0 < nrows; r0 += 64) {  // wave-uniform
       const int rr = r0 + lane;
       // (rr < 2^11, ny < 2^6: the rounded product is the exact quotient)
@@ -1248,11 +1241,7 @@ __device__ __attribute__((noinline)) Found wave_group_search(const GridSet g, co
         // operations instead of eight by each of the 64.)  The survivors are packed; the tail up to a multiple of four
         // is filled with points at infinity.
         unsigned cnt = 0u;
-#ifdef PP_NO_SIFT
-        const bool sift = false;
-#else
         const bool sift = bounded && total - t0 > 64u;  // (wave-uniform; a few candidates are cheaper examined than sifted)
-#endif
 #pragma unroll
         for (int u = 0; u < kGroupBatch / 64; ++u) {
           const pp::f4 c4 = pt[u];
