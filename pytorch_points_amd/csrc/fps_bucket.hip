@@ -43,6 +43,7 @@
 #define PP_FPSB_MARK(n)
 #define PP_FPSB_TOUCHED(mask)
 #define PP_FPSB_PICKS(k)
+#define PP_FPSB_ELIG(e, k)
 #define PP_FPSB_AT(j)
 #define PP_FPSB_END()
 #endif
@@ -752,6 +753,7 @@ __global__ __launch_bounds__(kBkThreads) void fps_bucket_kernel(
       const u64 accm = __ballot(o_el && okey > fail);
       const int k = __builtin_popcountll(accm);
       PP_FPSB_PICKS(k);
+      PP_FPSB_ELIG(__builtin_popcountll(elm), k);
       // this wave's own candidates among the picks: stored at their positions -- the number of eligible keys above --
       // as ~tie rank (turned into the index after the loop)
       for (unsigned own = (unsigned)(accm >> (4 * wave)) & 15u; own; own &= own - 1u) {

@@ -7,13 +7,14 @@
 // (the one-pick chain, PP_PROBE_CHAIN=1: 0->1 best bucket + post, 1->2 barrier, 2->3 pick read, 3->4 box test, 4->5 visits)
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Iinclude -Ipytorch_points_amd/csrc tools/fps_bucket_probe.hip -o tools/fps_bucket_probe
 #include <hip/hip_runtime.h>
-__device__ unsigned long long g_probe[16][32];
+__device__ unsigned long long g_probe[16][40];
 __device__ unsigned long long g_at[16];
 #ifdef PP_FPSB_NOMARKS  // timing only (with -DPP_FPSB_DOUBLE=<bits>: what one more copy of a link of the chain costs)
 #define PP_FPSB_PROBE_DECL
 #define PP_FPSB_MARK(n)
 #define PP_FPSB_TOUCHED(mask)
 #define PP_FPSB_PICKS(k)
+#define PP_FPSB_ELIG(e, k)
 #define PP_FPSB_AT(j)
 #define PP_FPSB_END()
 #else
@@ -39,6 +40,8 @@ __device__ unsigned long long g_at[16];
     pr_acc[12] += 1;                                         \
   } while (0)
 #define PP_FPSB_PICKS(k) do { if (lane == 0) pr_hist[wave][8 + ((k) > 17 ? 17 : (k))] += 1u; } while (0)
+// eligible candidates of the round (above BOUND) against the picks it took: summed, and the rounds that took them all
+#define PP_FPSB_ELIG(e, k) do { pr_acc[7] += (e); pr_acc[8] += ((k) == (e)) ? 1 : 0; } while (0)
 // the clock when the chain reaches pick 2^e (e = 3 .. 12), wave 0 of workgroup 0: where in the call the time goes
 #define PP_FPSB_AT(j)                                                                                 \
   do {                                                                                                \
@@ -53,6 +56,7 @@ __device__ unsigned long long g_at[16];
     if (blockIdx.x == 0 && lane == 0) {                                       \
       for (int i__ = 0; i__ < 7; ++i__) g_probe[wave][i__] = pr_acc[i__];     \
       g_probe[wave][12] = pr_acc[12];                                         \
+      g_probe[wave][32] = pr_acc[7]; g_probe[wave][33] = pr_acc[8];           \
       for (int i__ = 0; i__ < 5; ++i__) g_probe[wave][7 + i__] = pr_hist[wave][i__];   \
       for (int i__ = 0; i__ < 18; ++i__) g_probe[wave][13 + i__] = pr_hist[wave][8 + i__]; \
     }                                                                         \
@@ -94,7 +98,7 @@ int main(int argc, char** argv) {
     const int rc = pp_furthest_sampling_f32(x, temp, idx, B, N, npoint, 0, ws, wsb, nullptr);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
-    unsigned long long pr[16][32];
+    unsigned long long pr[16][40];
     hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_probe), sizeof(pr));
     printf("rc %d: %.3f ms = %.3f us/pick (events)\n", rc, ms, ms * 1e3 / (npoint - 1));
 #ifdef PP_FPSB_NOMARKS
@@ -111,6 +115,8 @@ int main(int argc, char** argv) {
     for (int k = 0; k <= 17; ++k)
       if (pr[0][13 + k]) printf(" %d:%llu", k, pr[0][13 + k]);
     printf("\n");
+    printf(" eligible candidates per round (above BOUND): %.2f; rounds that took every eligible one: %.3f of the rounds\n",
+           pr[0][32] / rounds, pr[0][33] / rounds);
     for (int w = 0; w < 16; ++w) {
       printf(" wave %2d cycles/round:", w);
       double tot = 0;
