@@ -414,6 +414,66 @@ struct BuildPlan {
   int trimmed;
 };
 
+// Round 6 (the plain builds: ball_query, three_nn, knn_points): a point with a non-finite coordinate (or one whose
+// square overflows) can never be anybody's neighbour -- its distance is NaN or +inf, never < anything, and where a
+// search runs out of finite candidates it ends with the whole grid, rim cells included -- so it must not cost the
+// batch element its grid (one NaN in one cloud: knn K = 8 0.18 -> 1.95 ms, the whole element every-pair).  The box
+// and the moments once more over the finite points only; the others keep whatever cell cell_coord gives them
+// (NaN -> 0, +-inf -> the rim).  The Chamfer build (REFINE) keeps the old rule: there the reference's "first point
+// unconditionally" makes a non-finite point at index 0 selectable, which only the every-pair order reproduces.
+// OUT OF LINE, the points read again from memory: inlined -- the same arithmetic on the points the builds hold in
+// registers -- it cost every build 350 bytes of scratch per thread on the path that never takes it (bq_build_kernel
+// 19.8 -> 24.7 us).  Called by every thread of the workgroup; leaves in s_box: [0..2] -min, [3..5] max, [8..13] the
+// sums of x, y, z, x^2, y^2, z^2, [14] the number of finite points (the same values in every workgroup of the set: the
+// slabs' plans must agree, and they do -- same data, same order).  The caller reads them and meets a barrier.
+__device__ __attribute__((noinline)) void plain_finite_plan(const float* __restrict__ ref, int nr, float* s_box) {
+  const int t = threadIdx.x;
+  const float inf = __builtin_inff();
+  float v[6] = {-inf, -inf, -inf, -inf, -inf, -inf};  // -min, max
+  float w[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  float cnt = 0.0f;
+  for (int i = t; i < nr; i += kBuildThreads) {
+    const float x = ref[3 * (size_t)i], y = ref[3 * (size_t)i + 1], z = ref[3 * (size_t)i + 2];
+    if (__builtin_isfinite(x * x + y * y + z * z)) {
+      v[0] = fmaxf(v[0], -x); v[1] = fmaxf(v[1], -y); v[2] = fmaxf(v[2], -z);
+      v[3] = fmaxf(v[3], x);  v[4] = fmaxf(v[4], y);  v[5] = fmaxf(v[5], z);
+      cnt += 1.0f;
+      w[0] += x; w[1] += y; w[2] += z;
+      w[3] += x * x; w[4] += y * y; w[5] += z * z;
+    }
+  }
+  wave_reduce6_dpp<false, 6>(v);
+  wave_reduce6_dpp<true, 6>(w);
+  cnt = wave_reduce_dpp<true>(cnt);
+  __syncthreads();  // s_box was read by every thread before the call
+  if ((t & 63) == 63) {
+#pragma unroll
+    for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + e] = v[e];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + 8 + e] = w[e];
+    s_box[(t >> 6) * 16 + 14] = cnt;
+  }
+  __syncthreads();
+  if (t < 64) {  // one wave folds the sixteen partials, in a fixed order
+    float fv[6], fw[6], fc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { fv[e] = -inf; fw[e] = 0.0f; }
+    for (int k = 0; k < kBuildThreads / 64; ++k) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { fv[e] = fmaxf(fv[e], s_box[k * 16 + e]); fw[e] += s_box[k * 16 + 8 + e]; }
+      fc += s_box[k * 16 + 14];
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();  // (every lane has read the partials before lane 0 overwrites the first row)
+    if (t == 0) {
+#pragma unroll
+      for (int e = 0; e < 6; ++e) { s_box[e] = fv[e]; s_box[8 + e] = fw[e]; }
+      s_box[14] = fc;
+    }
+  }
+  __syncthreads();
+}
+
 template <bool MORTON, bool VEC, bool REFINE>
 __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ ref, int nr, GridSet* gs,
                                                unsigned* __restrict__ cell_start, f4* __restrict__ sorted,
@@ -588,56 +648,17 @@ __device__ __forceinline__ void grid_build_set_impl(const float* __restrict__ re
   // (NaN -> 0, +-inf -> the rim).  The Chamfer build (REFINE) keeps the old rule: there the reference's "first point
   // unconditionally" makes a non-finite point at index 0 selectable, which only the every-pair order reproduces.
   float n_live = (float)nr;
-  if (!REFINE && !forced && any_bad) {  // (uniform)
-    mnx = __builtin_inff(); mny = mnx; mnz = mnx; mxx = -mnx; mxy = -mnx; mxz = -mnx;
-    float cnt = 0.0f;
+  if (!REFINE && !forced && any_bad) {  // (uniform; out of line: see plain_finite_plan)
+    plain_finite_plan(ref, nr, s_box);
+    // (wave-uniform values, as the ones they replace: through readfirstlane)
+    auto uni = [&](int e) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_box[e]))); };
+    mnx = -uni(0); mny = -uni(1); mnz = -uni(2); mxx = uni(3); mxy = uni(4); mxz = uni(5);
 #pragma unroll
-    for (int e = 0; e < 6; ++e) sm[e] = 0.0f;
-    for (int ch = 0; ch < nchunks; ++ch) {
-      if (nchunks > 1) load_chunk(ch * kBuildThreads * KP);
-#pragma unroll
-      for (int i = 0; i < KP; ++i) {
-        const float x = px[i], y = py[i], z = pz[i];
-        const bool ok = kidx(ch * kBuildThreads * KP, i) < nr && __builtin_isfinite(x * x + y * y + z * z);
-        mnx = ok ? fminf(mnx, x) : mnx; mny = ok ? fminf(mny, y) : mny; mnz = ok ? fminf(mnz, z) : mnz;
-        mxx = ok ? fmaxf(mxx, x) : mxx; mxy = ok ? fmaxf(mxy, y) : mxy; mxz = ok ? fmaxf(mxz, z) : mxz;
-        cnt += ok ? 1.0f : 0.0f;
-        sm[0] += ok ? x : 0.0f; sm[1] += ok ? y : 0.0f; sm[2] += ok ? z : 0.0f;
-        sm[3] += ok ? x * x : 0.0f; sm[4] += ok ? y * y : 0.0f; sm[5] += ok ? z * z : 0.0f;
-      }
-    }
-    if (nchunks > 1) load_chunk(0);  // (the passes below reload their chunks themselves, from the first)
-    float v[6] = {-mnx, -mny, -mnz, mxx, mxy, mxz};
-    float w[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]};
-    wave_reduce6_dpp<false, 6>(v);
-    wave_reduce6_dpp<true, 6>(w);
-    cnt = wave_reduce_dpp<true>(cnt);
-    __syncthreads();  // s_box was read above by every thread
-    if ((t & 63) == 63) {
-#pragma unroll
-      for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + e] = v[e];
-#pragma unroll
-      for (int e = 0; e < 6; ++e) s_box[(t >> 6) * 16 + 8 + e] = w[e];
-      s_box[(t >> 6) * 16 + 14] = cnt;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 6; ++e) v[e] = s_box[(t & 15) * 16 + e];
-#pragma unroll
-    for (int e = 0; e < 6; ++e) w[e] = s_box[(t & 15) * 16 + 8 + e];
-    float c2 = s_box[(t & 15) * 16 + 14];
-    wave_reduce6_dpp<false, 4>(v);
-    wave_reduce6_dpp<true, 4>(w);
-#pragma unroll
-    for (int e = 0; e < 6; ++e) v[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), 15));
-#pragma unroll
-    for (int e = 0; e < 6; ++e) sm[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[e]), 15));
-    float csum = 0.0f;  // (sixteen partial counts: lanes 0..15 of a row hold them)
-    for (int l = 0; l < 16; ++l) csum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2), l));
-    mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
-    n_live = csum;
-    any_bad = !(csum > 0.0f) || !__builtin_isfinite(sm[3] + sm[4] + sm[5]);
+    for (int e = 0; e < 6; ++e) sm[e] = uni(8 + e);
+    n_live = uni(14);
+    any_bad = !(n_live > 0.0f) || !__builtin_isfinite(sm[3] + sm[4] + sm[5]);
     __syncthreads();  // (s_box is written again below)
+    if (nchunks > 1) load_chunk(0);  // (the passes below reload their chunks themselves, from the first)
   }
   PP_PHASE(2);
   // Outliers: a few points far from the bulk would stretch the box until the bulk sits in a handful of
@@ -1175,51 +1196,15 @@ __device__ __forceinline__ int grid_build_set_fast(const float* __restrict__ ref
   // (plain builds) non-finite points are left out of the plan instead of costing the set its grid: the general path's
   // rule and arithmetic (grid_build_set_impl, round 6)
   float n_live = (float)nr;
-  if (!REFINE && any_bad) {  // (uniform)
-    mnx = __builtin_inff(); mny = mnx; mnz = mnx; mxx = -mnx; mxy = -mnx; mxz = -mnx;
-    float cnt = 0.0f;
+  if (!REFINE && any_bad) {  // (uniform; out of line: see plain_finite_plan)
+    plain_finite_plan(ref, nr, s_box);
+    // (wave-uniform values, as the ones they replace: through readfirstlane)
+    auto uni = [&](int e) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_box[e]))); };
+    mnx = -uni(0); mny = -uni(1); mnz = -uni(2); mxx = uni(3); mxy = uni(4); mxz = uni(5);
 #pragma unroll
-    for (int e = 0; e < 6; ++e) sm[e] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < KP; ++i) {
-      const float x = px[i], y = py[i], z = pz[i];
-      const bool ok = live[i >> 2] && __builtin_isfinite(x * x + y * y + z * z);
-      mnx = ok ? fminf(mnx, x) : mnx; mny = ok ? fminf(mny, y) : mny; mnz = ok ? fminf(mnz, z) : mnz;
-      mxx = ok ? fmaxf(mxx, x) : mxx; mxy = ok ? fmaxf(mxy, y) : mxy; mxz = ok ? fmaxf(mxz, z) : mxz;
-      cnt += ok ? 1.0f : 0.0f;
-      sm[0] += ok ? x : 0.0f; sm[1] += ok ? y : 0.0f; sm[2] += ok ? z : 0.0f;
-      sm[3] += ok ? x * x : 0.0f; sm[4] += ok ? y * y : 0.0f; sm[5] += ok ? z * z : 0.0f;
-    }
-    float v[6] = {-mnx, -mny, -mnz, mxx, mxy, mxz};
-    float w[6] = {sm[0], sm[1], sm[2], sm[3], sm[4], sm[5]};
-    wave_reduce6_dpp<false, 6>(v);
-    wave_reduce6_dpp<true, 6>(w);
-    cnt = wave_reduce_dpp<true>(cnt);
-    __syncthreads();  // s_box was read above by every thread
-    if (lane == 63) {
-#pragma unroll
-      for (int e = 0; e < 6; ++e) s_box[wave * 16 + e] = v[e];
-#pragma unroll
-      for (int e = 0; e < 6; ++e) s_box[wave * 16 + 8 + e] = w[e];
-      s_box[wave * 16 + 14] = cnt;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 6; ++e) v[e] = s_box[(t & 15) * 16 + e];
-#pragma unroll
-    for (int e = 0; e < 6; ++e) w[e] = s_box[(t & 15) * 16 + 8 + e];
-    const float c2 = s_box[(t & 15) * 16 + 14];
-    wave_reduce6_dpp<false, 4>(v);
-    wave_reduce6_dpp<true, 4>(w);
-#pragma unroll
-    for (int e = 0; e < 6; ++e) v[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), 15));
-#pragma unroll
-    for (int e = 0; e < 6; ++e) sm[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w[e]), 15));
-    float csum = 0.0f;
-    for (int l = 0; l < 16; ++l) csum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c2), l));
-    mnx = -v[0]; mny = -v[1]; mnz = -v[2]; mxx = v[3]; mxy = v[4]; mxz = v[5];
-    n_live = csum;
-    any_bad = !(csum > 0.0f) || !__builtin_isfinite(sm[3] + sm[4] + sm[5]);
+    for (int e = 0; e < 6; ++e) sm[e] = uni(8 + e);
+    n_live = uni(14);
+    any_bad = !(n_live > 0.0f) || !__builtin_isfinite(sm[3] + sm[4] + sm[5]);
     __syncthreads();  // (s_box is written again below)
   }
   PP_PHASE(2);
