@@ -11,7 +11,9 @@ from pytorch_points_amd import synthetic as S
 from pytorch_points_amd._ext import sampling, losses
 dev = torch.device("cuda:0")
 def t(fn, n=5):
-    fn(); torch.cuda.synchronize()
+    n = max(n, 4) * 4   # (5 calls untimed, 4 n timed: three calls after one were the clocks settling as much as the op)
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n): fn()
@@ -45,6 +47,7 @@ ms = t(lambda: sampling.gather_forward(B, C, N, M, f2, gi, go)); print("gather_f
 gg = torch.zeros(B, C, N, device=dev)
 ms = t(lambda: sampling.gather_backward(B, C, N, M, go, gi, gg)); print("gather_backward: %.3f ms" % ms)
 x1 = torch.from_numpy(S.unit_sphere(2, B, N)).to(dev); x2 = torch.from_numpy(S.unit_sphere(3, B, N)).to(dev)
+torch.manual_seed(3)
 l1 = torch.randint(0, 4, (B, N), device=dev).float(); l2 = torch.randint(0, 4, (B, N), device=dev).float()
 dd1 = torch.empty(B, N, device=dev); dd2 = torch.empty(B, N, device=dev)
 ii1 = torch.empty(B, N, dtype=torch.int32, device=dev); ii2 = torch.empty(B, N, dtype=torch.int32, device=dev)
