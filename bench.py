@@ -938,6 +938,11 @@ def bench_ball_group(args, dist, world, rank, device):
 
     with torch.no_grad():
         qg_fused_ms = time_it(lambda: qg(x, centres, feats))
+        # ball_query by itself, call after call (ball_query_ms is taken between two events INSIDE the step, behind a
+        # group_points that has just pushed 4 GiB through the caches, and carries the events' own ~3 us)
+        for _ in range(5):
+            ball_query(r, ns, x, centres)
+        bq_alone_ms = time_it(lambda: ball_query(r, ns, x, centres), 20)
         qg_unfused_ms = time_it(lambda: qg.forward_unfused(x, centres, feats))
     gp_bytes = 4.0 * B * C * N + 4.0 * B * npoint * ns + 4.0 * B * C * npoint * ns
     gbs = gp_bytes / (gp_ms * 1e-3) / 1e9
@@ -975,7 +980,7 @@ def bench_ball_group(args, dist, world, rank, device):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ball_query r=%.2f nsample=%d + group_points B=%d N=%d npoint=%d C=%d"
                                    % (r, ns, B, N, npoint, C), "parallelism": "batch-shard x%d" % world},
-            "ball_query_ms": bq_ms, "group_points_ms": gp_ms, "group_points_grad_ms": gpg_ms,
+            "ball_query_ms": bq_ms, "ball_query_alone_ms": bq_alone_ms, "group_points_ms": gp_ms, "group_points_grad_ms": gpg_ms,
             "query_and_group_fused_ms": qg_fused_ms, "query_and_group_composed_ms": qg_unfused_ms,
             "ball_query_pairs_per_s": float(B) * npoint * N / (bq_ms * 1e-3),
             "roofline": {"bound": "hbm", "kernel": "group_points_dma1_kernel", "achieved": gbs, "peak": HBM_PEAK_GBS,
