@@ -2855,6 +2855,16 @@ __global__ __launch_bounds__(TQ, WPE) void grid_stage_a_kernel(float* __restrict
                      a3 = ((s3 - tb0) << 4) - (T3 << 6);
       const unsigned endb = ns << 4;  // the padding
       const int kmax = (int)pp::wave_reduce_dpp<false>((float)T4);
+#ifdef PP_QUERY_PROBE_WALK  // (diagnostic: how full the walk's iterations are -- groups of the lanes against 64 x the wave's longest)
+      {
+        const float tsum = pp::wave_reduce_dpp<true>((float)T4);
+        if (lane == 63) {
+          atomicAdd(&g_qgroup[0], (unsigned long long)tsum);
+          atomicAdd(&g_qgroup[1], 64ull * (unsigned long long)kmax);
+          atomicAdd(&g_qgroup[2], 1ull);
+        }
+      }
+#endif
       PP_APHASE(2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the image have landed
       // the padding: four points that can never be taken (their distance is NaN); lanes whose rows are finished, and
