@@ -91,3 +91,42 @@ def test_nonfinite_ball_three_nn_knn(cuda, name, qbad, rbad):
     finally:
         k(0)
     assert _eq(out[0][0], out[1][0]) and _eq(out[0][1], out[1][1]), "%s: three_nn differs" % name
+
+
+# Round 6: non-finite points no longer cost a set its grid (the plain builds recompute box and moments over the finite
+# points, out of line): larger sets -- the LDS-sorted build (16384 aligned points), the general build in one chunk
+# (unaligned) and in several chunks (40001 points) -- with a handful of NaN / inf points among the references AND the
+# queries; the grid paths against the scan kernels, bit for bit, and the grid really used (no fallback to the scan).
+@pytest.mark.parametrize("nref,nq", [(16384, 4096), (16383, 3001), (40001, 5000)])
+def test_nonfinite_points_keep_the_grid_larger_sets(cuda, nref, nq):
+    from pytorch_points_amd._ext import sampling
+    from pytorch_points_amd.ops import knn_points
+    q = _poison(S.unit_sphere(310, 2, nq), 5, [np.nan, np.inf])
+    r = _poison(S.unit_sphere(311, 2, nref), 6, [np.nan, -np.inf, np.inf])
+    tq, tr = torch.from_numpy(q).to(cuda), torch.from_numpy(r).to(cuda)
+    for knob, fn in (("pp_debug_set_ball_query_search", lambda: (sampling.ball_query(tq, tr, 0.08, 16),)),
+                     ("pp_debug_set_knn_search", lambda: knn_points(tq, tr, K=5)[:2])):
+        k = _knob(knob)
+        out = []
+        try:
+            for m in (2 if "ball" in knob else 0, 1):
+                k(m)
+                out.append(fn())
+                torch.cuda.synchronize()
+        finally:
+            k(0)
+        for a, b in zip(out[0], out[1]):
+            assert _eq(a, b), "%d refs: %s differs between grid and scan" % (nref, knob)
+    k = _knob("pp_debug_set_three_nn_search")
+    out = []
+    try:
+        for m in (0, 1):
+            k(m)
+            d2 = torch.empty(2, nq, 3, device=cuda)
+            idx = torch.empty(2, nq, 3, dtype=torch.int32, device=cuda)
+            sampling.three_nn_wrapper(2, nq, nref, tq, tr, d2, idx)
+            torch.cuda.synchronize()
+            out.append((d2, idx))
+    finally:
+        k(0)
+    assert _eq(out[0][0], out[1][0]) and _eq(out[0][1], out[1][1]), "%d refs: three_nn differs" % nref
