@@ -53,7 +53,7 @@ using pp::kBuildThreads;
 
 constexpr int kBqMaxCells = 3;   // cell-box half-extent the grid path accepts
 #ifndef PP_BQ_CAP
-#define PP_BQ_CAP 512
+#define PP_BQ_CAP 448  // (round 6: 512 -> 448, 11.2 KB of LDS a wave, 14 waves a CU: 0.0960 -> 0.0944 ms at config 4; 384 / 416 / 480: 0.0950 / 0.0955 / 0.0972)
 #endif
 constexpr int kBqCap = PP_BQ_CAP;  // candidates staged per pass (16 bytes each)
 constexpr int kBqMaxN = 524288;  // point bitmap <= 64 KiB
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
   IT* myrow = s_rows + (size_t)ci * stride;
   int cnt = valid ? 0 : nsample;  // hits of the centre so far (same in its LPC lanes); idle lanes count as full
   const float r2v = radius2;
-  static_assert(kBqCap % (32 * LPC) == 0, "a pass is whole 32-candidate blocks for every lane of a centre");
-  constexpr int NB = kBqCap / 32 / LPC;  // 32-candidate blocks a lane scans per pass, at most
+  static_assert(kBqCap % 32 == 0, "a pass is whole 32-candidate blocks");
+  constexpr int NB = (kBqCap / 32 + LPC - 1) / LPC;  // 32-candidate blocks a lane scans per pass, at most
   for (int base = 0; base < total; base += kBqCap) {
     const int ncand = min(kBqCap, total - base);
     // 3a. indices of the candidates of this pass, ascending
@@ -375,6 +375,29 @@ __global__ __launch_bounds__(64) void bq_query_kernel(const float* __restrict__ 
   __syncthreads();
   const bool pow2 = (nsample & (nsample - 1)) == 0;  // (uniform) a shift instead of a division per output word
   const int lg = __builtin_ctz((unsigned)nsample);
+  // (round 6) four consecutive words of a row per lane and store where the rows allow it (nsample a multiple of four, the
+  // output 16-byte aligned): 4 stores of 1 KB a wave for 16 rows of 64 instead of 16 of 256 bytes -- the step was 11 of the
+  // kernel's 80 us
+  if ((nsample & 3) == 0 && (reinterpret_cast<uintptr_t>(gout) & 15) == 0) {  // (uniform)
+    for (int f0 = 0; f0 < total_out; f0 += 256) {
+      const int f = f0 + 4 * lane;
+      if (f < total_out) {
+        const int row = pow2 ? (f >> lg) : f / nsample;
+        const int slot = f - row * nsample;
+        const int rc = s_rowinfo[3 * row], rf = s_rowinfo[3 * row + 1], ro = s_rowinfo[3 * row + 2];
+        const IT* __restrict__ src = s_rows + (size_t)row * stride + slot;
+        int4 v;
+        v.x = slot < rc ? (int)src[0] : rf;
+        v.y = slot + 1 < rc ? (int)src[1] : rf;
+        v.z = slot + 2 < rc ? (int)src[2] : rf;
+        v.w = slot + 3 < rc ? (int)src[3] : rf;
+        {  // (non-temporal: nothing of the 33 MB is read again by this launch -- 0.0981 -> 0.0960 ms)
+          const pp::i4 nv = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(nv, reinterpret_cast<pp::i4*>(gout + (size_t)ro * nsample + slot));
+        }
+      }
+    }
+  } else
 #pragma unroll 4
   for (int f0 = 0; f0 < total_out; f0 += 64) {
     const int f = min(f0 + lane, total_out - 1);
