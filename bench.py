@@ -814,6 +814,12 @@ def bench_chamfer(args, dist, world, rank, device):
                     trial.drain()
             else:
                 out["exchange_modes_ms"] = {exchange_mode: ms, "p2p": None}
+        except BaseException as exc:   # noqa: BLE001 -- a failure of the untried form on any rank must not cost the line: the
+            # native line stands; this rank leaves (the others either fail the same way or are let go by their watchdogs)
+            sys.stderr.write("bench: the p2p trial failed on rank %d (%s: %s): the native line stands\n" % (rank, type(exc).__name__, exc))
+            native_line["exchange_trial_note"] = "the p2p trial failed (%s): the native line stands" % type(exc).__name__
+            dog.cancel()
+            give_up()
         finally:
             dog.cancel()
     torch.autograd.set_multithreading_enabled(engine_threads_default)
